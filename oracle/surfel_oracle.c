@@ -1,0 +1,914 @@
+/*
+ * surfel_oracle.c -- CPU restatement of the reference Gaussian-surfel (2DGS) rasterizer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (vidu4d_amd/, include/) may link, import
+ * or call this file.  It is used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * as the checker / the timed CPU baseline, never as the thing shipped.
+ *
+ * What it restates (file:line in /root/reference/gs/submodules/diff-surfel-rasterization/):
+ *   oracle_preprocess        cuda_rasterizer/forward.cu:166-260 (preprocessCUDA), :75-128
+ *                            (computeTransMat), :133-163 (computeAABB), :20-71 (computeColorFromSH),
+ *                            auxiliary.h:64-74 (getRect), :160-185 (in_frustum), :188-210 (quat_to_rotmat)
+ *   oracle_inclusive_scan    rasterizer_impl.cu:278 (cub::DeviceScan::InclusiveSum, by specification)
+ *   oracle_emit_keys         rasterizer_impl.cu:70-111 (duplicateWithKeys)
+ *   oracle_higher_msb        rasterizer_impl.cu:35-50 (getHigherMsb)
+ *   oracle_sort_pairs        rasterizer_impl.cu:304-309 (cub::DeviceRadixSort::SortPairs on bits
+ *                            [0, 32+bit): "stable ascending sort", by specification)
+ *   oracle_tile_ranges       rasterizer_impl.cu:311-319, :116-138 (memset + identifyTileRanges)
+ *   oracle_render_forward    forward.cu:265-463 (renderCUDA fwd)
+ *   oracle_render_backward   backward.cu:143-449 (renderCUDA bwd)
+ *   oracle_aabb_backward     backward.cu:599-649 (computeAABB bwd, incl. the dL_dmean2D "hack")
+ *   oracle_preprocess_backward backward.cu:533-597, :451-529 (computeTransMat vjp), :20-139 (SH bwd),
+ *                            auxiliary.h:125-135 (dnormvdv), :213-257 (quat_to_rotmat_vjp)
+ *   oracle_mark_visible      rasterizer_impl.cu:54-66 (checkFrustum)
+ *
+ * Numeric conventions (DESIGN.md "Numeric conventions"; SURVEY.md §8a trap 10):
+ *   - all arithmetic fp32, evaluated in the order written, NO fused multiply-add (build with
+ *     -ffp-contract=off); the HIP kernels follow the same order for everything that feeds the
+ *     integer binning outputs (radii, rects, keys), so those compare bit-exactly.
+ *   - the reference's rsqrtf (auxiliary.h:190) is restated as 1.0f / sqrtf(x) (both correctly
+ *     rounded on CPU and on gfx950; an approximate rsq differs per vendor).
+ *   - radius = ceil(3.f * max(max(ext.x, ext.y), FilterSize)) is evaluated in fp64 exactly as the
+ *     reference's double-typed macro forces (forward.cu:239, auxiliary.h:20).
+ *   - rho2d = FilterInvSquare * (dx*dx+dy*dy): the fp64 product 1/(F*F)*(float) rounds to exactly
+ *     2.0f*(dx*dx+dy*dy) in fp32, which is what is computed here.
+ *   - depth < NEAR_PLANE (double 0.2) is equivalent to the fp32 test depth < 0.2f.
+ *   - mapped_depth / dmd_dd (fp64 sub-expressions in the reference) are evaluated in fp32 here.
+ *   - float->int conversions saturate and map NaN to 0 (what both NVIDIA cvt.rzi and gfx950
+ *     v_cvt_i32_f32 do), instead of C's undefined behaviour.
+ *   - backward accumulations (the reference's fp32 atomicAdd in arbitrary order) are summed in
+ *     fp64 in list order and rounded once: the "ideal" value any atomic order is close to.
+ *
+ * Parity status: the reference ships no tests or golden vectors for this path; the
+ * oracle is pinned against outputs of the reference's own .cu files compiled for gfx950
+ * (oracle/ref_build -> oracle/_ref, fixtures in tests/golden/), see DESIGN.md "Oracle".
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BLOCK_X 16
+#define BLOCK_Y 16
+#define BLOCK_SIZE (BLOCK_X * BLOCK_Y)
+
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+#define FILTER_SIZE_D 0.7071067811865476 /* auxiliary.h:20 (double literal) */
+#define NEAR_PLANE_F 0.2f                /* auxiliary.h:35 */
+#define FAR_PLANE_F 100.0f               /* auxiliary.h:36 */
+
+int oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
+/* float -> int conversion with GPU semantics (saturating, NaN -> 0). */
+static int f2i_sat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* auxiliary.h:64-74 */
+static void get_rect(float px, float py, int max_radius, int grid_x, int grid_y, uint32_t rmin[2],
+                     uint32_t rmax[2])
+{
+    const float r = (float)max_radius;
+    rmin[0] = (uint32_t)imin(grid_x, imax(0, f2i_sat((px - r) / (float)BLOCK_X)));
+    rmin[1] = (uint32_t)imin(grid_y, imax(0, f2i_sat((py - r) / (float)BLOCK_Y)));
+    rmax[0] = (uint32_t)imin(grid_x, imax(0, f2i_sat((px + r + (float)BLOCK_X - 1.0f) / (float)BLOCK_X)));
+    rmax[1] = (uint32_t)imin(grid_y, imax(0, f2i_sat((py + r + (float)BLOCK_Y - 1.0f) / (float)BLOCK_Y)));
+}
+
+/* auxiliary.h:188-210.  R is row-major: R[3*r + c]. */
+static void quat_to_rotmat(const float q[4], float R[9])
+{
+    const float inv = 1.0f / sqrtf(q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+    R[0] = 1.f - 2.f * (y * y + z * z);
+    R[3] = 2.f * (x * y + w * z);
+    R[6] = 2.f * (x * z - w * y);
+    R[1] = 2.f * (x * y - w * z);
+    R[4] = 1.f - 2.f * (x * x + z * z);
+    R[7] = 2.f * (y * z + w * x);
+    R[2] = 2.f * (x * z + w * y);
+    R[5] = 2.f * (y * z - w * x);
+    R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+/* (W v)_r with W taken from the 4x4 view matrix stored as in the reference (forward.cu:79-83). */
+static void view_rot(const float* vm, const float v[3], float out[3])
+{
+    for (int r = 0; r < 3; r++) out[r] = vm[r] * v[0] + vm[4 + r] * v[1] + vm[8 + r] * v[2];
+}
+/* (W^T v)_r (backward.cu:502-507). */
+static void view_rot_t(const float* vm, const float v[3], float out[3])
+{
+    for (int r = 0; r < 3; r++) out[r] = vm[4 * r + 0] * v[0] + vm[4 * r + 1] * v[1] + vm[4 * r + 2] * v[2];
+}
+/* auxiliary.h:76-84 */
+static void transform_point_4x3(const float* m, const float p[3], float out[3])
+{
+    for (int r = 0; r < 3; r++) out[r] = m[r] * p[0] + m[4 + r] * p[1] + m[8 + r] * p[2] + m[12 + r];
+}
+
+/* forward.cu:20-71 */
+static void sh_to_rgb(int deg, const float pos[3], const float campos[3], const float* sh /* [M][3] */,
+                      float rgb[3], uint8_t clamped[3])
+{
+    float dir[3] = {pos[0] - campos[0], pos[1] - campos[1], pos[2] - campos[2]};
+    const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    dir[0] = dir[0] / len;
+    dir[1] = dir[1] / len;
+    dir[2] = dir[2] / len;
+    const float x = dir[0], y = dir[1], z = dir[2];
+    for (int c = 0; c < 3; c++) {
+#define SH(k) sh[3 * (k) + c]
+        float result = SH_C0 * SH(0);
+        if (deg > 0) {
+            result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z;
+                const float xy = x * y, yz = y * z, xz = x * z;
+                result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) +
+                         SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) + SH_C2[3] * xz * SH(7) +
+                         SH_C2[4] * (xx - yy) * SH(8);
+                if (deg > 2) {
+                    result = result + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                             SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                             SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                             SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+                             SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        result += 0.5f;
+        clamped[c] = (uint8_t)(result < 0);
+        rgb[c] = result > 0.0f ? result : 0.0f;
+    }
+}
+
+/* forward.cu:75-128.  Returns 0 when the surfel is culled (cos == 0). */
+static int compute_transmat(const float p_world[3], const float quat[4], const float scale[2], const float* vm,
+                            float fx, float fy, float cx, float cy, float T[9], float normal[3])
+{
+    float R[9];
+    quat_to_rotmat(quat, R);
+    float p_view[3];
+    {
+        float t[3];
+        view_rot(vm, p_world, t);
+        for (int r = 0; r < 3; r++) p_view[r] = t[r] + vm[12 + r];
+    }
+    const float rs0[3] = {R[0] * scale[0], R[3] * scale[0], R[6] * scale[0]};
+    const float rs1[3] = {R[1] * scale[1], R[4] * scale[1], R[7] * scale[1]};
+    const float r2[3] = {R[2], R[5], R[8]};
+    float M0[3], M1[3], tn[3];
+    view_rot(vm, rs0, M0);
+    view_rot(vm, rs1, M1);
+    view_rot(vm, r2, tn);
+    const float cosv = -tn[0] * p_view[0] + -tn[1] * p_view[1] + -tn[2] * p_view[2];
+    if (cosv == 0.0f) return 0;
+    const float mult = cosv > 0 ? 1.f : -1.f;
+    T[0] = fx * M0[0] + cx * M0[2];
+    T[1] = fx * M1[0] + cx * M1[2];
+    T[2] = fx * p_view[0] + cx * p_view[2];
+    T[3] = fy * M0[1] + cy * M0[2];
+    T[4] = fy * M1[1] + cy * M1[2];
+    T[5] = fy * p_view[1] + cy * p_view[2];
+    T[6] = M0[2];
+    T[7] = M1[2];
+    T[8] = p_view[2];
+    normal[0] = tn[0] * mult;
+    normal[1] = tn[1] * mult;
+    normal[2] = tn[2] * mult;
+    return 1;
+}
+
+/* forward.cu:133-163 */
+static int compute_aabb(const float T[9], float center[2], float extent[2])
+{
+    const float* Tu = T;
+    const float* Tv = T + 3;
+    const float* Tw = T + 6;
+    const float d = Tw[0] * Tw[0] + Tw[1] * Tw[1] + -1.0f * (Tw[2] * Tw[2]);
+    if (d == 0.0f) return 0;
+    const float r = 1.0f / d;
+    const float f[3] = {r, r, -1.0f * r};
+    const float px = f[0] * (Tu[0] * Tw[0]) + f[1] * (Tu[1] * Tw[1]) + f[2] * (Tu[2] * Tw[2]);
+    const float py = f[0] * (Tv[0] * Tw[0]) + f[1] * (Tv[1] * Tw[1]) + f[2] * (Tv[2] * Tw[2]);
+    const float h0x = px * px - (f[0] * (Tu[0] * Tu[0]) + f[1] * (Tu[1] * Tu[1]) + f[2] * (Tu[2] * Tu[2]));
+    const float h0y = py * py - (f[0] * (Tv[0] * Tv[0]) + f[1] * (Tv[1] * Tv[1]) + f[2] * (Tv[2] * Tv[2]));
+    center[0] = px;
+    center[1] = py;
+    extent[0] = sqrtf(h0x > 0.0f ? h0x : 0.0f);
+    extent[1] = sqrtf(h0y > 0.0f ? h0y : 0.0f);
+    return 1;
+}
+
+/*
+ * forward.cu:166-260.  All per-surfel outputs are dense arrays of length P (the reference carves
+ * them from geomBuffer, rasterizer_impl.cu:155-170).  Entries of culled surfels (radii == 0) are
+ * zero here; the reference leaves them uninitialised and never reads them.
+ * shs may be NULL iff colors_precomp != NULL.
+ */
+void oracle_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
+                       const float* opacities, const float* shs, const float* colors_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H,
+                       float tan_fovx, float tan_fovy, int32_t* radii, float* means2D /*P*2*/,
+                       float* depths /*P*/, float* transMats /*P*9*/, float* rgb /*P*3*/,
+                       float* normal_opacity /*P*4*/, uint8_t* clamped /*P*3*/, uint32_t* tiles_touched)
+{
+    (void)projmatrix; /* only feeds a value the reference computes and discards (auxiliary.h:170-175) */
+    const float focal_y = H / (2.0f * tan_fovy); /* rasterizer_impl.cu:223-224 */
+    const float focal_x = W / (2.0f * tan_fovx);
+    const float cx = (float)((double)(float)W / 2.0); /* forward.cu:208 */
+    const float cy = (float)((double)(float)H / 2.0);
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        radii[idx] = 0;
+        tiles_touched[idx] = 0;
+        means2D[2 * idx] = means2D[2 * idx + 1] = 0.f;
+        depths[idx] = 0.f;
+        for (int k = 0; k < 9; k++) transMats[9 * idx + k] = 0.f;
+        for (int k = 0; k < 3; k++) rgb[3 * idx + k] = 0.f;
+        for (int k = 0; k < 4; k++) normal_opacity[4 * idx + k] = 0.f;
+        for (int k = 0; k < 3; k++) clamped[3 * idx + k] = 0;
+
+        const float* p_world = means3D + 3 * idx;
+        float p_view[3];
+        transform_point_4x3(viewmatrix, p_world, p_view);
+        if (p_view[2] <= 0.2f) continue; /* auxiliary.h:175 */
+
+        float T[9], normal[3];
+        if (!compute_transmat(p_world, rotations + 4 * idx, scales + 2 * idx, viewmatrix, focal_x, focal_y, cx, cy,
+                              T, normal))
+            continue;
+        for (int k = 0; k < 9; k++) transMats[9 * idx + k] = T[k]; /* written before the later early-outs */
+
+        float center[2], extent[2];
+        if (!compute_aabb(T, center, extent)) continue;
+
+        /* forward.cu:237-239: fp64 because FilterSize is a double literal */
+        const float emax = extent[0] > extent[1] ? extent[0] : extent[1];
+        const double em = (double)emax > FILTER_SIZE_D ? (double)emax : FILTER_SIZE_D;
+        const float radius = (float)ceil((double)3.f * em);
+
+        uint32_t rmin[2], rmax[2];
+        get_rect(center[0], center[1], f2i_sat(radius), grid_x, grid_y, rmin, rmax);
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
+
+        if (colors_precomp == NULL) {
+            sh_to_rgb(D, p_world, campos, shs + (size_t)idx * M * 3, rgb + 3 * idx, clamped + 3 * idx);
+        }
+        depths[idx] = p_view[2];
+        radii[idx] = f2i_sat(radius);
+        means2D[2 * idx] = center[0];
+        means2D[2 * idx + 1] = center[1];
+        normal_opacity[4 * idx + 0] = normal[0];
+        normal_opacity[4 * idx + 1] = normal[1];
+        normal_opacity[4 * idx + 2] = normal[2];
+        normal_opacity[4 * idx + 3] = opacities[idx];
+        tiles_touched[idx] = (rmax[1] - rmin[1]) * (rmax[0] - rmin[0]);
+    }
+}
+
+/* rasterizer_impl.cu:54-66 */
+void oracle_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present)
+{
+    for (int idx = 0; idx < P; idx++) {
+        float p_view[3];
+        transform_point_4x3(viewmatrix, means3D + 3 * idx, p_view);
+        present[idx] = (uint8_t)!(p_view[2] <= 0.2f);
+    }
+}
+
+/* rasterizer_impl.cu:278.  Returns the total (num_rendered, :282). */
+uint32_t oracle_inclusive_scan(int P, const uint32_t* in, uint32_t* out)
+{
+    uint32_t s = 0;
+    for (int i = 0; i < P; i++) {
+        s += in[i];
+        out[i] = s;
+    }
+    return s;
+}
+
+/* rasterizer_impl.cu:70-111 */
+void oracle_emit_keys(int P, const float* means2D, const float* depths, const uint32_t* offsets,
+                      const int32_t* radii, int W, int H, uint64_t* keys, uint32_t* values)
+{
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
+    for (int idx = 0; idx < P; idx++) {
+        if (radii[idx] > 0) {
+            uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
+            uint32_t rmin[2], rmax[2];
+            get_rect(means2D[2 * idx], means2D[2 * idx + 1], radii[idx], grid_x, grid_y, rmin, rmax);
+            uint32_t dbits;
+            memcpy(&dbits, depths + idx, 4);
+            for (uint32_t y = rmin[1]; y < rmax[1]; y++)
+                for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
+                    uint64_t key = (uint64_t)(y * (uint32_t)grid_x + x);
+                    key <<= 32;
+                    key |= dbits;
+                    keys[off] = key;
+                    values[off] = (uint32_t)idx;
+                    off++;
+                }
+        }
+    }
+}
+
+/* rasterizer_impl.cu:35-50 */
+uint32_t oracle_higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb)
+            msb += step;
+        else
+            msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/*
+ * Stable ascending sort of (key, value) pairs on key bits [0, end_bit) -- the specification of
+ * cub::DeviceRadixSort::SortPairs(..., 0, 32 + bit) (rasterizer_impl.cu:304-309).  Implemented as a
+ * bottom-up merge sort (stable by construction), deliberately NOT a radix sort so that it is
+ * independent of the device implementation it checks.
+ */
+void oracle_sort_pairs(uint32_t L, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                       uint32_t* vals_out, int end_bit)
+{
+    const uint64_t mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
+    if (L == 0) return;
+    uint64_t* ka = (uint64_t*)malloc((size_t)L * 8);
+    uint32_t* va = (uint32_t*)malloc((size_t)L * 4);
+    uint64_t* kb = (uint64_t*)malloc((size_t)L * 8);
+    uint32_t* vb = (uint32_t*)malloc((size_t)L * 4);
+    memcpy(ka, keys_in, (size_t)L * 8);
+    memcpy(va, vals_in, (size_t)L * 4);
+    for (uint64_t width = 1; width < L; width *= 2) {
+        for (uint64_t lo = 0; lo < L; lo += 2 * width) {
+            uint64_t mid = lo + width < L ? lo + width : L;
+            uint64_t hi = lo + 2 * width < L ? lo + 2 * width : L;
+            uint64_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                if ((ka[j] & mask) < (ka[i] & mask)) {
+                    kb[k] = ka[j];
+                    vb[k++] = va[j++];
+                } else {
+                    kb[k] = ka[i];
+                    vb[k++] = va[i++];
+                }
+            }
+            while (i < mid) {
+                kb[k] = ka[i];
+                vb[k++] = va[i++];
+            }
+            while (j < hi) {
+                kb[k] = ka[j];
+                vb[k++] = va[j++];
+            }
+        }
+        uint64_t* tk = ka;
+        ka = kb;
+        kb = tk;
+        uint32_t* tv = va;
+        va = vb;
+        vb = tv;
+    }
+    memcpy(keys_out, ka, (size_t)L * 8);
+    memcpy(vals_out, va, (size_t)L * 4);
+    free(ka);
+    free(va);
+    free(kb);
+    free(vb);
+}
+
+/* rasterizer_impl.cu:311-319 + :116-138.  ranges is [num_tiles][2], zero-filled first. */
+void oracle_tile_ranges(uint32_t L, const uint64_t* sorted_keys, int num_tiles, uint32_t* ranges)
+{
+    memset(ranges, 0, (size_t)num_tiles * 8);
+    for (uint32_t idx = 0; idx < L; idx++) {
+        const uint32_t currtile = (uint32_t)(sorted_keys[idx] >> 32);
+        if (idx == 0)
+            ranges[2 * currtile] = 0;
+        else {
+            const uint32_t prevtile = (uint32_t)(sorted_keys[idx - 1] >> 32);
+            if (currtile != prevtile) {
+                ranges[2 * prevtile + 1] = idx;
+                ranges[2 * currtile] = idx;
+            }
+        }
+        if (idx == L - 1) ranges[2 * currtile + 1] = L;
+    }
+}
+
+/* The per-(pixel, surfel) evaluation shared by forward and backward (forward.cu:358-399,
+ * backward.cu:282-323).  Returns 0 if the pair is skipped. */
+typedef struct {
+    float sx, sy;     /* s: hit point in splat space */
+    float pz;         /* p.z of the plane intersection */
+    float kx, ky, kz; /* k, l planes */
+    float lx, ly, lz;
+    float dx, dy; /* xy - pixf */
+    float rho3d, rho2d;
+    float depth;
+    float G, alpha;
+} pair_eval;
+
+static int eval_pair(const float* Tu, const float* Tv, const float* Tw, const float* xy, float opacity, float pixx,
+                     float pixy, pair_eval* e)
+{
+    e->kx = -Tu[0] + pixx * Tw[0];
+    e->ky = -Tu[1] + pixx * Tw[1];
+    e->kz = -Tu[2] + pixx * Tw[2];
+    e->lx = -Tv[0] + pixy * Tw[0];
+    e->ly = -Tv[1] + pixy * Tw[1];
+    e->lz = -Tv[2] + pixy * Tw[2];
+    const float px = e->ky * e->lz - e->kz * e->ly; /* auxiliary.h:152-158 */
+    const float py = e->kz * e->lx - e->kx * e->lz;
+    const float pz = e->kx * e->ly - e->ky * e->lx;
+    if (pz == 0.0f) return 0;
+    e->pz = pz;
+    e->sx = px / pz;
+    e->sy = py / pz;
+    e->rho3d = e->sx * e->sx + e->sy * e->sy;
+    e->dx = xy[0] - pixx;
+    e->dy = xy[1] - pixy;
+    e->rho2d = 2.0f * (e->dx * e->dx + e->dy * e->dy);
+    const float rho = e->rho3d < e->rho2d ? e->rho3d : e->rho2d; /* min(rho3d, rho2d) */
+    e->depth = (e->rho3d <= e->rho2d) ? (e->sx * Tw[0] + e->sy * Tw[1]) + Tw[2] : Tw[2];
+    if (e->depth < NEAR_PLANE_F) return 0;
+    const float power = -0.5f * rho;
+    if (power > 0.0f) return 0;
+    e->G = expf(power);
+    const float a = opacity * e->G;
+    e->alpha = a < 0.99f ? a : 0.99f;
+    if (e->alpha < 1.0f / 255.0f) return 0;
+    return 1;
+}
+
+static float map_depth(float depth)
+{
+    return (FAR_PLANE_F * depth - FAR_PLANE_F * NEAR_PLANE_F) / ((FAR_PLANE_F - NEAR_PLANE_F) * depth);
+}
+
+/*
+ * forward.cu:265-463.  final_T is [3][H*W] (T, dist1, dist2), n_contrib is [2][H*W] (last, median),
+ * out_color [3][H*W], out_others [8][H*W].  Also returns per-pixel work statistics if pairs != NULL:
+ * pairs[0] += list entries visited, pairs[1] += entries that contributed.
+ */
+void oracle_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                           const float* features /*P*3*/, const float* transMats, const float* normal_opacity,
+                           const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
+                           float* out_others, uint64_t* pairs)
+{
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const size_t HW = (size_t)H * W;
+    uint64_t visited = 0, contributed = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : visited, contributed)
+    for (int tile = 0; tile < grid_x * grid_y; tile++) {
+        const int tx = tile % grid_x, ty = tile / grid_x;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                if (pxi >= W || pyi >= H) continue;
+                const size_t pix_id = (size_t)W * pyi + pxi;
+                const float pixx = (float)pxi + 0.5f, pixy = (float)pyi + 0.5f;
+                float T = 1.0f;
+                uint32_t contributor = 0, last_contributor = 0;
+                float C[3] = {0, 0, 0};
+                float D = 0, N[3] = {0, 0, 0}, dist1 = 0, dist2 = 0, distortion = 0;
+                float median_depth = 0, median_weight = 0, median_contributor = -1.0f;
+                for (uint32_t i = r0; i < r1; i++) {
+                    contributor++;
+                    visited++;
+                    const uint32_t id = point_list[i];
+                    const float* Tm = transMats + 9 * (size_t)id;
+                    const float* no = normal_opacity + 4 * (size_t)id;
+                    pair_eval e;
+                    if (!eval_pair(Tm, Tm + 3, Tm + 6, means2D + 2 * (size_t)id, no[3], pixx, pixy, &e)) continue;
+                    const float alpha = e.alpha, depth = e.depth;
+                    const float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) break; /* done = true */
+                    contributed++;
+                    const float A = 1 - T;
+                    const float m = map_depth(depth);
+                    const float error = m * m * A + dist2 - 2 * m * dist1;
+                    distortion += error * alpha * T;
+                    if (T > 0.5f) {
+                        median_depth = depth;
+                        median_weight = alpha * T;
+                        median_contributor = (float)contributor;
+                    }
+                    for (int ch = 0; ch < 3; ch++) N[ch] += no[ch] * alpha * T;
+                    D += depth * alpha * T;
+                    dist1 += m * alpha * T;
+                    dist2 += m * m * alpha * T;
+                    for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * (size_t)id + ch] * alpha * T;
+                    T = test_T;
+                    last_contributor = contributor;
+                }
+                final_T[pix_id] = T;
+                n_contrib[pix_id] = last_contributor;
+                for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix_id] = C[ch] + T * bg[ch];
+                /* float -> uint32 store of median_contributor (-1 saturates to 0, SURVEY trap 7) */
+                n_contrib[pix_id + HW] = median_contributor < 0 ? 0u : (uint32_t)median_contributor;
+                final_T[pix_id + HW] = dist1;
+                final_T[pix_id + 2 * HW] = dist2;
+                out_others[pix_id + 0 * HW] = D;
+                out_others[pix_id + 1 * HW] = 1 - T;
+                for (int ch = 0; ch < 3; ch++) out_others[pix_id + (2 + ch) * HW] = N[ch];
+                out_others[pix_id + 5 * HW] = median_depth;
+                out_others[pix_id + 6 * HW] = distortion;
+                out_others[pix_id + 7 * HW] = median_weight;
+            }
+    }
+    if (pairs) {
+        pairs[0] += visited;
+        pairs[1] += contributed;
+    }
+}
+
+/*
+ * backward.cu:143-449.  Accumulators are fp64 arrays (see header): dL_dtransMat [P*9],
+ * dL_dmean2D [P*3] (x,y used), dL_dnormal3D [P*3], dL_dopacity [P], dL_dcolors [P*3]; the caller
+ * zero-fills them and rounds to fp32 afterwards (oracle_round_f64_to_f32).
+ */
+void oracle_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+                            const float* means2D, const float* normal_opacity, const float* transMats,
+                            const float* colors, const float* final_Ts, const uint32_t* n_contrib,
+                            const float* dL_dpixels /*3*HW*/, const float* dL_depths /*8*HW*/, double* dL_dtransMat,
+                            double* dL_dmean2D, double* dL_dnormal3D, double* dL_dopacity, double* dL_dcolors)
+{
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < grid_x * grid_y; tile++) {
+        const int tx = tile % grid_x, ty = tile / grid_x;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        const uint32_t toDo = r1 - r0;
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                if (pxi >= W || pyi >= H) continue;
+                const size_t pix_id = (size_t)W * pyi + pxi;
+                const float pixx = (float)pxi + 0.5f, pixy = (float)pyi + 0.5f;
+
+                const float T_final = final_Ts[pix_id];
+                float T = T_final;
+                uint32_t contributor = toDo;
+                const int last_contributor = (int)n_contrib[pix_id];
+                float accum_rec[3] = {0, 0, 0};
+                float dL_dpixel[3];
+                const float dL_ddepth = dL_depths[0 * HW + pix_id];
+                const float dL_daccum = dL_depths[1 * HW + pix_id];
+                const float dL_dreg = dL_depths[6 * HW + pix_id];
+                float dL_dnormal2D[3];
+                for (int i = 0; i < 3; i++) dL_dnormal2D[i] = dL_depths[(2 + i) * HW + pix_id];
+                const int median_contributor = (int)n_contrib[pix_id + HW];
+                const float dL_dmedian_depth = dL_depths[5 * HW + pix_id];
+                const float dL_dmax_dweight = dL_depths[7 * HW + pix_id];
+                float last_depth = 0, last_normal[3] = {0, 0, 0};
+                float accum_depth_rec = 0, accum_alpha_rec = 0, accum_normal_rec[3] = {0, 0, 0};
+                const float final_D = final_Ts[pix_id + HW];
+                const float final_D2 = final_Ts[pix_id + 2 * HW];
+                const float final_A = 1 - T_final;
+                float last_dL_dT = 0;
+                for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * HW + pix_id];
+                float last_alpha = 0, last_color[3] = {0, 0, 0};
+                float bg_dot_dpixel = 0;
+                for (int i = 0; i < 3; i++) bg_dot_dpixel += bg[i] * dL_dpixel[i];
+
+                for (uint32_t it = 0; it < toDo; it++) {
+                    contributor--;
+                    if ((int64_t)contributor >= (int64_t)last_contributor) continue;
+                    const uint32_t id = point_list[r1 - it - 1];
+                    const float* Tm = transMats + 9 * (size_t)id;
+                    const float* Tw = Tm + 6;
+                    const float* no = normal_opacity + 4 * (size_t)id;
+                    pair_eval e;
+                    if (!eval_pair(Tm, Tm + 3, Tw, means2D + 2 * (size_t)id, no[3], pixx, pixy, &e)) continue;
+                    const float alpha = e.alpha, G = e.G, c_d = e.depth;
+
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float c = colors[3 * (size_t)id + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        const float dL_dchannel = dL_dpixel[ch];
+                        dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+#pragma omp atomic
+                        dL_dcolors[3 * (size_t)id + ch] += (double)(dchannel_dcolor * dL_dchannel);
+                    }
+                    float dL_dz = 0.0f;
+                    float dL_dweight = 0;
+                    const float m_d = map_depth(c_d);
+                    const float dmd_dd =
+                        (FAR_PLANE_F * NEAR_PLANE_F) / ((FAR_PLANE_F - NEAR_PLANE_F) * c_d * c_d);
+                    if ((int64_t)contributor == (int64_t)median_contributor - 1) {
+                        dL_dz += dL_dmedian_depth;
+                        dL_dweight += dL_dmax_dweight;
+                    }
+                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                    dL_dz += dL_dmd * dmd_dd;
+
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = c_d;
+                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                    for (int ch = 0; ch < 3; ch++) {
+                        accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                        last_normal[ch] = no[ch];
+                        dL_dalpha += (no[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
+#pragma omp atomic
+                        dL_dnormal3D[3 * (size_t)id + ch] += (double)(alpha * T * dL_dnormal2D[ch]);
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+                    const float dL_dG = no[3] * dL_dalpha;
+                    dL_dz += alpha * T * dL_ddepth;
+
+                    if (e.rho3d <= e.rho2d) {
+                        const float dL_dsx = dL_dG * -G * e.sx + dL_dz * Tw[0];
+                        const float dL_dsy = dL_dG * -G * e.sy + dL_dz * Tw[1];
+                        const float dz_dTw[3] = {e.sx, e.sy, 1.0f};
+                        const float dsx_pz = dL_dsx / e.pz;
+                        const float dsy_pz = dL_dsy / e.pz;
+                        const float dp[3] = {dsx_pz, dsy_pz, -(dsx_pz * e.sx + dsy_pz * e.sy)};
+                        /* dL_dk = cross(l, dL_dp); dL_dl = cross(dL_dp, k) */
+                        const float dk[3] = {e.ly * dp[2] - e.lz * dp[1], e.lz * dp[0] - e.lx * dp[2],
+                                             e.lx * dp[1] - e.ly * dp[0]};
+                        const float dl[3] = {dp[1] * e.kz - dp[2] * e.ky, dp[2] * e.kx - dp[0] * e.kz,
+                                             dp[0] * e.ky - dp[1] * e.kx};
+                        double* g = dL_dtransMat + 9 * (size_t)id;
+                        for (int c = 0; c < 3; c++) {
+                            const float dTw = pixx * dk[c] + pixy * dl[c] + dL_dz * dz_dTw[c];
+#pragma omp atomic
+                            g[c] += (double)(-dk[c]);
+#pragma omp atomic
+                            g[3 + c] += (double)(-dl[c]);
+#pragma omp atomic
+                            g[6 + c] += (double)dTw;
+                        }
+                    } else {
+                        const float dG_ddelx = -G * 2.0f * e.dx;
+                        const float dG_ddely = -G * 2.0f * e.dy;
+#pragma omp atomic
+                        dL_dmean2D[3 * (size_t)id + 0] += (double)(dL_dG * dG_ddelx);
+#pragma omp atomic
+                        dL_dmean2D[3 * (size_t)id + 1] += (double)(dL_dG * dG_ddely);
+#pragma omp atomic
+                        dL_dtransMat[9 * (size_t)id + 8] += (double)dL_dz;
+                    }
+#pragma omp atomic
+                    dL_dopacity[id] += (double)(G * dL_dalpha);
+                }
+            }
+    }
+}
+
+void oracle_round_f64_to_f32(size_t n, const double* in, float* out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = (float)in[i];
+}
+
+/* backward.cu:599-649.  Operates in place on fp32 arrays (dL_dmean2Ds [P*3], dL_dtransMats [P*9]). */
+void oracle_aabb_backward(int P, const int32_t* radii, float Wh, float Hh, const float* transMats,
+                          float* dL_dmean2Ds, float* dL_dtransMats)
+{
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0)) continue;
+        const float* T0 = transMats + 9 * (size_t)idx;
+        const float* T1 = T0 + 3;
+        const float* T3 = T0 + 6;
+        const float gx = dL_dmean2Ds[3 * idx], gy = dL_dmean2Ds[3 * idx + 1];
+        const float d = T3[0] * T3[0] + T3[1] * T3[1] + -1.0f * (T3[2] * T3[2]);
+        const float r = 1.0f / d;
+        const float f[3] = {r, r, -1.0f * r};
+        const float sgn[3] = {1.0f, 1.0f, -1.0f};
+        float dT0[3], dT1[3], dT3[3], df[3];
+        for (int c = 0; c < 3; c++) {
+            dT0[c] = gx * f[c] * T3[c];
+            dT1[c] = gy * f[c] * T3[c];
+            dT3[c] = gx * f[c] * T0[c] + gy * f[c] * T1[c];
+            df[c] = (gx * T0[c] * T3[c]) + (gy * T1[c] * T3[c]);
+        }
+        const float dL_dd = (float)((double)(df[0] * f[0] + df[1] * f[1] + df[2] * f[2]) * (-1.0 / (double)d));
+        for (int c = 0; c < 3; c++) {
+            const float dd_dT3 = sgn[c] * T3[c] * 2.0f;
+            dT3[c] += dL_dd * dd_dT3;
+        }
+        float* g = dL_dtransMats + 9 * (size_t)idx;
+        for (int c = 0; c < 3; c++) {
+            g[c] += dT0[c];
+            g[3 + c] += dT1[c];
+            g[6 + c] += dT3[c];
+        }
+        const float z = T0[8];
+        dL_dmean2Ds[3 * idx + 0] = g[2] * z * Wh;
+        dL_dmean2Ds[3 * idx + 1] = g[5] * z * Hh;
+    }
+}
+
+/* auxiliary.h:125-135 */
+static void dnormvdv3(const float v[3], const float dv[3], float out[3])
+{
+    const float sum2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    out[0] = ((+sum2 - v[0] * v[0]) * dv[0] - v[1] * v[0] * dv[1] - v[2] * v[0] * dv[2]) * invsum32;
+    out[1] = (-v[0] * v[1] * dv[0] + (sum2 - v[1] * v[1]) * dv[1] - v[2] * v[1] * dv[2]) * invsum32;
+    out[2] = (-v[0] * v[2] * dv[0] - v[1] * v[2] * dv[1] + (sum2 - v[2] * v[2]) * dv[2]) * invsum32;
+}
+
+/* backward.cu:20-139.  dL_dcolor is the (already accumulated) gradient w.r.t. the clamped RGB. */
+static void sh_backward(int deg, int max_coeffs, const float pos[3], const float campos[3], const float* sh,
+                        const uint8_t clamped[3], const float dL_dcolor[3], float dL_dmean[3] /* += */,
+                        float* dL_dsh /* [M][3] */)
+{
+    const float dir_orig[3] = {pos[0] - campos[0], pos[1] - campos[1], pos[2] - campos[2]};
+    const float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
+    const float x = dir_orig[0] / len, y = dir_orig[1] / len, z = dir_orig[2] / len;
+    float dRGB[3];
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[c] * (clamped[c] ? 0.f : 1.f);
+    float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+    (void)max_coeffs;
+#define SH(k) sh[3 * (k) + c]
+#define DSH(k) dL_dsh[3 * (k) + c]
+    for (int c = 0; c < 3; c++) {
+        DSH(0) = SH_C0 * dRGB[c];
+        if (deg > 0) {
+            DSH(1) = (-SH_C1 * y) * dRGB[c];
+            DSH(2) = (SH_C1 * z) * dRGB[c];
+            DSH(3) = (-SH_C1 * x) * dRGB[c];
+            dx[c] = -SH_C1 * SH(3);
+            dy[c] = -SH_C1 * SH(1);
+            dz[c] = SH_C1 * SH(2);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z;
+                const float xy = x * y, yz = y * z, xz = x * z;
+                DSH(4) = (SH_C2[0] * xy) * dRGB[c];
+                DSH(5) = (SH_C2[1] * yz) * dRGB[c];
+                DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * dRGB[c];
+                DSH(7) = (SH_C2[3] * xz) * dRGB[c];
+                DSH(8) = (SH_C2[4] * (xx - yy)) * dRGB[c];
+                dx[c] += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) +
+                         SH_C2[4] * 2.f * x * SH(8);
+                dy[c] += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) +
+                         SH_C2[4] * 2.f * -y * SH(8);
+                dz[c] += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+                if (deg > 2) {
+                    DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * dRGB[c];
+                    DSH(10) = (SH_C3[1] * xy * z) * dRGB[c];
+                    DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB[c];
+                    DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB[c];
+                    DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB[c];
+                    DSH(14) = (SH_C3[5] * z * (xx - yy)) * dRGB[c];
+                    DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * dRGB[c];
+                    dx[c] += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz +
+                              SH_C3[2] * SH(11) * -2.f * xy + SH_C3[3] * SH(12) * -3.f * 2.f * xz +
+                              SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * SH(14) * 2.f * xz +
+                              SH_C3[6] * SH(15) * 3.f * (xx - yy));
+                    dy[c] += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+                              SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                              SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
+                              SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                    dz[c] += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                              SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                              SH_C3[5] * SH(14) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    const float ddir[3] = {dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2],
+                           dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2],
+                           dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2]};
+    float dmean[3];
+    dnormvdv3(dir_orig, ddir, dmean);
+    for (int c = 0; c < 3; c++) dL_dmean[c] += dmean[c];
+}
+
+/*
+ * backward.cu:533-597 (+ :451-529, auxiliary.h:213-257).  Outputs are zero-filled by the caller
+ * (rasterize_points.cu:194-202); surfels with radii == 0 are skipped and keep zeros.
+ * shs may be NULL (colors_precomp path): then dL_dsh is untouched.
+ */
+void oracle_preprocess_backward(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
+                                const uint8_t* clamped, const float* scales, const float* rotations,
+                                const float* viewmatrix, float focal_x, float focal_y, float tan_fovx,
+                                float tan_fovy, const float* campos, const float* dL_dtransMats,
+                                const float* dL_dnormal3Ds, const float* dL_dcolors, float* dL_dshs,
+                                float* dL_dmean3Ds, float* dL_dscales, float* dL_drots)
+{
+    const float fx = focal_x, fy = focal_y;
+    const float cx = focal_x * tan_fovx, cy = focal_y * tan_fovy; /* backward.cu:570 */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0)) continue;
+        const float* dT = dL_dtransMats + 9 * (size_t)idx;
+        const float* dN = dL_dnormal3Ds + 3 * (size_t)idx;
+        const float* p_world = means3D + 3 * (size_t)idx;
+        const float* quat = rotations + 4 * (size_t)idx;
+        const float sx = scales[2 * idx], sy = scales[2 * idx + 1];
+        const float* vm = viewmatrix;
+
+        float R[9];
+        quat_to_rotmat(quat, R);
+        float p_view[3];
+        {
+            float t[3];
+            view_rot(vm, p_world, t);
+            for (int r = 0; r < 3; r++) p_view[r] = t[r] + vm[12 + r];
+        }
+        /* dL_dM columns j=0..2: (fx*dTu[j], fy*dTv[j], cx*dTu[j] + cy*dTv[j] + dTw[j]) */
+        float dM[3][3];
+        for (int j = 0; j < 3; j++) {
+            dM[j][0] = fx * dT[j];
+            dM[j][1] = fy * dT[3 + j];
+            dM[j][2] = cx * dT[j] + cy * dT[3 + j] + dT[6 + j];
+        }
+        float dRS0[3], dRS1[3], dpw[3];
+        view_rot_t(vm, dM[0], dRS0);
+        view_rot_t(vm, dM[1], dRS1);
+        view_rot_t(vm, dM[2], dpw);
+        float dtn[3];
+        view_rot_t(vm, dN, dtn);
+        {
+            const float r2[3] = {R[2], R[5], R[8]};
+            float tn[3];
+            view_rot(vm, r2, tn);
+            const float cosv = -tn[0] * p_view[0] + -tn[1] * p_view[1] + -tn[2] * p_view[2];
+            const float mult = cosv > 0 ? 1.f : -1.f;
+            for (int c = 0; c < 3; c++) dtn[c] *= mult;
+        }
+        /* v_R[c][r] column-major: column 0 = dRS0*sx, 1 = dRS1*sy, 2 = dtn */
+        float vR[3][3];
+        for (int r = 0; r < 3; r++) {
+            vR[0][r] = dRS0[r] * sx;
+            vR[1][r] = dRS1[r] * sy;
+            vR[2][r] = dtn[r];
+        }
+        {
+            const float inv = 1.0f / sqrtf(quat[3] * quat[3] + quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2]);
+            const float w = quat[0] * inv, x = quat[1] * inv, y = quat[2] * inv, z = quat[3] * inv;
+            float* dq = dL_drots + 4 * (size_t)idx;
+            dq[0] = 2.f * (x * (vR[1][2] - vR[2][1]) + y * (vR[2][0] - vR[0][2]) + z * (vR[0][1] - vR[1][0]));
+            dq[1] = 2.f * (-2.f * x * (vR[1][1] + vR[2][2]) + y * (vR[0][1] + vR[1][0]) + z * (vR[0][2] + vR[2][0]) +
+                           w * (vR[1][2] - vR[2][1]));
+            dq[2] = 2.f * (x * (vR[0][1] + vR[1][0]) - 2.f * y * (vR[0][0] + vR[2][2]) + z * (vR[1][2] + vR[2][1]) +
+                           w * (vR[2][0] - vR[0][2]));
+            dq[3] = 2.f * (x * (vR[0][2] + vR[2][0]) + y * (vR[1][2] + vR[2][1]) - 2.f * z * (vR[0][0] + vR[1][1]) +
+                           w * (vR[0][1] - vR[1][0]));
+        }
+        dL_dscales[2 * idx + 0] = dRS0[0] * R[0] + dRS0[1] * R[3] + dRS0[2] * R[6];
+        dL_dscales[2 * idx + 1] = dRS1[0] * R[1] + dRS1[1] * R[4] + dRS1[2] * R[7];
+        float* dmean = dL_dmean3Ds + 3 * (size_t)idx;
+        dmean[0] = dpw[0];
+        dmean[1] = dpw[1];
+        dmean[2] = dpw[2];
+        if (shs)
+            sh_backward(D, M, p_world, campos, shs + (size_t)idx * M * 3, clamped + 3 * (size_t)idx,
+                        dL_dcolors + 3 * (size_t)idx, dmean, dL_dshs + (size_t)idx * M * 3);
+    }
+}
