@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- train images/s (fwd+bwd raster) of the MI355X-native surfel rasterizer.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json's headline configuration (configs[2]: Stage-3 gs-bob op, 200 000 surfels,
+512x512, SH degree 3, 120 frames), synthetic seeded surfels, inputs resident in HBM.
+A *step* is one optimizer step's worth of raster work on a rank: FRAMES_PER_STEP (= 2, the frame
+pair `imgs_per_gpu=1` gives the reference, lab4d/engine/trainer.py:439-476) frames, each
+forward + backward through the public `GaussianRasterizer` autograd op with upstream gradients on
+the colour image and all 8 auxiliary planes.  Frames are sharded one-frame-per-GPU-per-slot across
+ranks (rank r renders frames r, r+N, ...: frame-parallel, weak scaling); with N > 1 every step ends
+with ONE RCCL all-reduce of the flat canonical-surfel gradient buffer (58 floats per surfel), the
+only exchange the path has.  value = N * K * FRAMES_PER_STEP / max-over-ranks time.
+
+Extra objects on the JSON line: "roofline" (dominant kernel: algorithmic bytes per launch /
+its average launch duration, measured with HIP events on the launch stream inside the timed
+region) and "cpu_baseline" (the CPU oracle timed on this box's host cores, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FRAMES_PER_STEP = 2
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); 6.29 TB/s measured copy
+GRAD_FLOATS_PER_SURFEL = 3 + 1 + 2 + 4 + 48  # means3D, opacity, scales, rotations, SH
+
+
+def stage_bytes(stage: str, N: int, R: float, P: int, T: int, K: int) -> float:
+    """Algorithmic bytes of one launch of a stage (DESIGN.md 'Measurement')."""
+    return {
+        "preprocess_fwd": N * (232 + 87),
+        "scan": N * 8,
+        "emit_keys": N * 20 + R * 12,
+        "radix_sort": R * 24 * K,
+        "tile_ranges": R * 8 + T * 8,
+        "blend_fwd": T * 8 + R * 76 + P * 64,
+        "bwd_zero": N * 80,
+        "blend_bwd": T * 8 + R * 76 + P * 108 + N * 76,
+        "preprocess_bwd": N * (347 + 276),
+    }[stage]
+
+
+def higher_msb(n: int) -> int:
+    """Bits the reference sorts the tile id on (getHigherMsb, rasterizer_impl.cu:35-50)."""
+    msb = step = 16
+    while step > 1:
+        step //= 2
+        msb = msb + step if (n >> msb) else msb - step
+    return msb + 1 if (n >> msb) else msb
+
+
+def total_bytes(N, R, P, T, K):
+    return N * 1046 + R * (172 + 24 * K) + P * 172 + T * 24
+
+
+def cpu_baseline(scene, n_images: int):
+    """The CPU oracle (oracle/surfel_oracle.c, OpenMP over tiles/surfels) on the same workload."""
+    from oracle import surfel_oracle as so
+    from vidu4d_amd.synthetic import frame_motion, make_upstream_grads
+    cores = so.set_threads(os.cpu_count() or 1)
+    dc, do = make_upstream_grads(scene.width, scene.height)
+    t_fwd = t_all = 0.0
+    for f in range(n_images + 1):
+        sc = frame_motion(scene, f, 120)
+        t0 = time.perf_counter()
+        st = so.forward(sc.means3D, sc.opacities, sc.scales, sc.rotations, sc.viewmatrix, sc.projmatrix, sc.campos,
+                        sc.bg, sc.width, sc.height, sc.tanfovx, sc.tanfovy, sc.sh_degree, shs=sc.shs)
+        t1 = time.perf_counter()
+        so.backward(st, dc, do)
+        t2 = time.perf_counter()
+        if f > 0:  # first image is the warm-up
+            t_fwd += t1 - t0
+            t_all += t2 - t0
+    return {"value": n_images / t_all, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n_images} frames fwd+bwd of the same {scene.num_surfels}-surfel {scene.width}x{scene.height} "
+                      f"workload (1 warm-up frame untimed), C oracle with OpenMP",
+            "fwd_only_images_per_s": n_images / t_fwd}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--surfels", type=int, default=200_000)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=120)
+    ap.add_argument("--cpu-images", type=int, default=6, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-stage-timers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import diff_surfel_rasterization as dsr
+    from vidu4d_amd import _lib
+    from vidu4d_amd.synthetic import frame_motion, make_scene, make_upstream_grads
+
+    N, W = args.surfels, args.res
+    scene_cpu = make_scene(N, W, seed=1234)
+    scene = scene_cpu.to(dev)
+    H = scene.height
+    dc, do = (t.to(dev) for t in make_upstream_grads(W, H))
+    # this rank's frames, resident in HBM before the timed region
+    my_frames = list(range(rank, args.frames, world))
+    frames = [frame_motion(scene, f, args.frames) for f in my_frames]
+    means = [f.means3D for f in frames]
+    rots = [f.rotations for f in frames]
+    rs = dsr.GaussianRasterizationSettings(H, W, scene.tanfovx, scene.tanfovy, scene.bg, 1.0, scene.viewmatrix,
+                                           scene.projmatrix, scene.sh_degree, scene.campos, False, False)
+    rast = dsr.GaussianRasterizer(rs)
+    opac = scene.opacities.clone().requires_grad_(True)
+    scales = scene.scales.clone().requires_grad_(True)
+    shs = scene.shs.clone().requires_grad_(True)
+    flat = torch.empty(N * GRAD_FLOATS_PER_SURFEL, device=dev) if world > 1 else None
+    counter = {"slot": 0, "R": 0.0, "n": 0}
+
+    def step():
+        for t in (opac, scales, shs):
+            t.grad = None
+        g_means = g_rot = None
+        for _ in range(FRAMES_PER_STEP):
+            i = counter["slot"] % len(frames)
+            counter["slot"] += 1
+            m = means[i].detach().requires_grad_(True)
+            r = rots[i].detach().requires_grad_(True)
+            m2d = torch.zeros_like(m, requires_grad=True)
+            color, radii, allmap = rast(means3D=m, means2D=m2d, opacities=opac, shs=shs, scales=scales, rotations=r)
+            torch.autograd.backward([color, allmap], [dc, do])
+            g_means = m.grad if g_means is None else g_means + m.grad
+            g_rot = r.grad if g_rot is None else g_rot + r.grad
+        if world > 1:  # the path's only exchange: canonical-surfel gradients, once per optimizer step
+            torch.cat([g_means.reshape(-1), opac.grad.reshape(-1), scales.grad.reshape(-1), g_rot.reshape(-1),
+                       shs.grad.reshape(-1)], out=flat)
+            dist.all_reduce(flat)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if not args.no_stage_timers:
+        _lib.profile_read(reset=True)
+        _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    images = world * args.steps * FRAMES_PER_STEP
+    value = images / elapsed
+    out = {
+        "metric": "train images/sec (fwd+bwd raster) @200k surfels, 512^2" if (N, W) == (200_000, 512)
+        else f"train images/sec (fwd+bwd raster) @{N} surfels, {W}x{H}",
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[2] op-level: Stage-3 gs-bob rasterizer fwd+bwd, {N} surfels, "
+                               f"{W}x{H}, SH degree 3, {args.frames} frames sharded one-frame-per-GPU, "
+                               f"{FRAMES_PER_STEP} frames per step per GPU",
+                   "surfels": N, "width": W, "height": H, "frames": args.frames, "frames_per_step": FRAMES_PER_STEP,
+                   "parallelism": f"frame-parallel x{world}" + (" + RCCL all-reduce of surfel grads" if world > 1 else "")},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (live HIP-event stage timers of the timed region)
+        from vidu4d_amd import _C
+        # num_rendered of this rank's frames (read once, outside the timed region)
+        Rs = []
+        with torch.no_grad():
+            for i in range(min(len(frames), 4)):
+                o = _C.rasterize_gaussians(scene.bg, means[i], torch.empty(0, device=dev), scene.opacities,
+                                           scene.scales, rots[i], 1.0, torch.empty(0, device=dev), scene.viewmatrix,
+                                           scene.projmatrix, scene.tanfovx, scene.tanfovy, H, W, scene.shs, 3,
+                                           scene.campos, False, False)
+                Rs.append(o[0])
+        R = sum(Rs) / len(Rs)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        K = (32 + higher_msb(T) + 7) // 8  # 8-bit radix passes over the (tile | depth) key
+        out["config"]["num_rendered_mean"] = R
+        out["config"]["algorithmic_bytes_per_image"] = total_bytes(N, R, W * H, T, K)
+        out["algorithmic_GBps_whole_op"] = total_bytes(N, R, W * H, T, K) * (images / world) / elapsed / 1e9
+        if not args.no_stage_timers:
+            prof = _lib.profile_read(reset=True)
+            stages = {k: {"ms_total": ms, "launches": n, "ms_avg": (ms / n if n else None)} for k, (ms, n) in prof.items()}
+            out["stage_ms_avg"] = {k: (round(v["ms_avg"], 4) if v["ms_avg"] is not None else None) for k, v in stages.items()}
+            dom = max((k for k in stages if stages[k]["launches"]), key=lambda k: stages[k]["ms_total"])
+            avg_s = stages[dom]["ms_avg"] * 1e-3
+            ach = stage_bytes(dom, N, R, W * H, T, K) / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                               "avg_launch_ms": stages[dom]["ms_avg"],
+                               "algorithmic_bytes_per_launch": stage_bytes(dom, N, R, W * H, T, K)}
+        if world == 1 and args.cpu_images > 0:
+            out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+// host_emul.cpp -- TEST INFRASTRUCTURE.  Compiles the product's arithmetic header
+// (vidu4d_amd/csrc/surfel_math.h) for the host and runs it through sequential loops that stand in
+// for the kernels' thread grids, so that the formulas can be checked against the oracle on a box
+// without a GPU.  It is never loaded by the product package; it is not a fallback.
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#include "../../vidu4d_amd/csrc/surfel_math.h"
+
+using namespace surfel;
+
+static Camera make_cam(const float* view, const float* campos, int W, int H, float tfx, float tfy, int D, int M)
+{
+    Camera c;
+    memcpy(c.view, view, sizeof(c.view));
+    memcpy(c.campos, campos, sizeof(c.campos));
+    c.W = W; c.H = H;
+    c.grid_x = (W + TILE - 1) / TILE; c.grid_y = (H + TILE - 1) / TILE;
+    c.tan_fovx = tfx; c.tan_fovy = tfy;
+    c.focal_y = H / (2.0f * tfy); c.focal_x = W / (2.0f * tfx);
+    c.cx = (float)((double)(float)W / 2.0); c.cy = (float)((double)(float)H / 2.0);
+    c.sh_degree = D; c.sh_coeffs = M;
+    return c;
+}
+
+extern "C" void emul_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
+                                const float* opacities, const float* shs, const float* colors_precomp,
+                                const float* view, const float* campos, int W, int H, float tfx, float tfy,
+                                int32_t* radii, uint32_t* tiles, float* rec)
+{
+    const Camera cam = make_cam(view, campos, W, H, tfx, tfy, D, M);
+    for (int i = 0; i < P; i++) {
+        Projected o;
+        radii[i] = 0; tiles[i] = 0;
+        for (int k = 0; k < REC_FLOATS; k++) rec[(size_t)i * REC_FLOATS + k] = 0.f;
+        if (!project_surfel(cam, means3D + 3 * i, rotations + 4 * i, scales + 2 * i, o)) continue;
+        float rgb[3]; uint32_t mask = 0;
+        if (colors_precomp) { for (int c = 0; c < 3; c++) rgb[c] = colors_precomp[3 * i + c]; }
+        else sh_forward(D, means3D + 3 * i, cam.campos, shs + (size_t)i * M * 3, rgb, mask);
+        float* r = rec + (size_t)i * REC_FLOATS;
+        for (int k = 0; k < 9; k++) r[k] = o.T[k];
+        r[R_CX] = o.center[0]; r[R_CY] = o.center[1]; r[R_OPAC] = opacities[i];
+        for (int k = 0; k < 3; k++) { r[R_NX + k] = o.normal[k]; r[R_RGB + k] = rgb[k]; }
+        r[R_DEPTH] = o.depth;
+        memcpy(&r[R_CLAMP], &mask, 4);
+        radii[i] = o.radius; tiles[i] = o.tiles;
+    }
+}
+
+extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec,
+                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
+                                float* out_others)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const size_t HW = (size_t)W * H;
+    for (int tile = 0; tile < gx * gy; tile++)
+        for (int l = 0; l < TILE * TILE; l++) {
+            const int px = (tile % gx) * TILE + l % TILE, py = (tile / gx) * TILE + l / TILE;
+            if (px >= W || py >= H) continue;
+            const float pixx = px + 0.5f, pixy = py + 0.5f;
+            FwdPixel s;
+            const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            for (uint32_t i = r0; i < r1; i++) {
+                const float* r = rec + (size_t)point_list[i] * REC_FLOATS;
+                PairEval e;
+                if (!eval_pair(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
+                if (!fwd_accumulate(s, e, r + R_NX, r + R_RGB, i - r0 + 1)) break;
+            }
+            const size_t pid = (size_t)py * W + px;
+            final_T[pid] = s.T; final_T[pid + HW] = s.dist1; final_T[pid + 2 * HW] = s.dist2;
+            n_contrib[pid] = s.last_contributor; n_contrib[pid + HW] = s.median_contributor;
+            for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pid] = s.C[ch] + s.T * bg[ch];
+            out_others[pid] = s.D; out_others[pid + HW] = 1.0f - s.T;
+            for (int ch = 0; ch < 3; ch++) out_others[pid + (2 + ch) * HW] = s.N[ch];
+            out_others[pid + 5 * HW] = s.median_depth; out_others[pid + 6 * HW] = s.distortion;
+            out_others[pid + 7 * HW] = s.median_weight;
+        }
+}
+
+extern "C" void emul_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec,
+                                const float* bg, const float* final_T, const uint32_t* n_contrib,
+                                const float* dL_dcolor, const float* dL_dothers, double* acc /*[P][20]*/)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const size_t HW = (size_t)W * H;
+    for (int tile = 0; tile < gx * gy; tile++)
+        for (int l = 0; l < TILE * TILE; l++) {
+            const int px = (tile % gx) * TILE + l % TILE, py = (tile / gx) * TILE + l / TILE;
+            if (px >= W || py >= H) continue;
+            const float pixx = px + 0.5f, pixy = py + 0.5f;
+            const size_t pid = (size_t)py * W + px;
+            BwdPixel s;
+            s.T_final = final_T[pid]; s.final_D = final_T[pid + HW]; s.final_D2 = final_T[pid + 2 * HW];
+            s.last_contributor = n_contrib[pid]; s.median_contributor = n_contrib[pid + HW];
+            for (int c = 0; c < 3; c++) s.dL_dpixel[c] = dL_dcolor[c * HW + pid];
+            s.dL_ddepth = dL_dothers[pid]; s.dL_daccum = dL_dothers[pid + HW];
+            for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = dL_dothers[pid + (2 + c) * HW];
+            s.dL_dmedian_depth = dL_dothers[pid + 5 * HW]; s.dL_dreg = dL_dothers[pid + 6 * HW];
+            s.dL_dmax_dweight = dL_dothers[pid + 7 * HW];
+            s.T = s.T_final; s.final_A = 1.0f - s.T_final;
+            s.bg_dot_dpixel = bg[0] * s.dL_dpixel[0] + bg[1] * s.dL_dpixel[1] + bg[2] * s.dL_dpixel[2];
+            const uint32_t r0 = ranges[2 * tile];
+            for (int ci = (int)s.last_contributor - 1; ci >= 0; ci--) {
+                const uint32_t id = point_list[r0 + ci];
+                const float* r = rec + (size_t)id * REC_FLOATS;
+                PairEval e;
+                if (!eval_pair(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
+                float g[ACC_FLOATS];
+                bwd_pair(s, e, r + 6, r[R_OPAC], r + R_NX, r + R_RGB, pixx, pixy,
+                         (uint32_t)ci + 1 == s.median_contributor, g);
+                for (int k = 0; k < ACC_FLOATS; k++) acc[(size_t)id * ACC_FLOATS + k] += (double)g[k];
+            }
+        }
+}
+
+extern "C" void emul_preprocess_bwd(int P, int D, int M, const float* means3D, const float* scales,
+                                    const float* rotations, const float* shs, const float* view, const float* campos,
+                                    int W, int H, float tfx, float tfy, const int32_t* radii, const float* rec,
+                                    const float* acc, float* dmeans3D, float* dmeans2D, float* dcolors, float* dopacity,
+                                    float* dtransMat, float* dsh, float* dscales, float* drot)
+{
+    const Camera cam = make_cam(view, campos, W, H, tfx, tfy, D, M);
+    for (int i = 0; i < P; i++) {
+        if (!(radii[i] > 0)) continue;  // outputs pre-zeroed by the caller
+        const float* r = rec + (size_t)i * REC_FLOATS;
+        const float* a = acc + (size_t)i * ACC_FLOATS;
+        SurfelGrads o;
+        surfel_backward(cam, means3D + 3 * i, rotations + 4 * i, scales + 2 * i, r, a, o);
+        float dmean[3] = {o.dmean3D[0], o.dmean3D[1], o.dmean3D[2]};
+        const float dcol[3] = {a[A_RGB], a[A_RGB + 1], a[A_RGB + 2]};
+        uint32_t mask; memcpy(&mask, &r[R_CLAMP], 4);
+        if (shs) sh_backward(D, M, means3D + 3 * i, cam.campos, shs + (size_t)i * M * 3, mask, dcol, dsh + (size_t)i * M * 3, dmean);
+        for (int k = 0; k < 3; k++) { dmeans3D[3 * i + k] = dmean[k]; dmeans2D[3 * i + k] = o.dmean2D[k]; dcolors[3 * i + k] = dcol[k]; }
+        dopacity[i] = a[A_OPAC];
+        for (int k = 0; k < 9; k++) dtransMat[9 * i + k] = o.dT[k];
+        dscales[2 * i] = o.dscale[0]; dscales[2 * i + 1] = o.dscale[1];
+        for (int k = 0; k < 4; k++) drot[4 * i + k] = o.drot[k];
+    }
+}

@@ -1,0 +1,33 @@
+"""The product's arithmetic header (vidu4d_amd/csrc/surfel_math.h), compiled for the host by
+tests/host_emul, against the oracle: the formulas every HIP kernel inlines are checked on the CPU."""
+import numpy as np
+import pytest
+
+from oracle import surfel_oracle as so
+from tests.host_emul import emul
+from tests.util import DIST_ATOL, assert_close, make_case, oracle_forward
+from vidu4d_amd.synthetic import make_upstream_grads
+
+
+@pytest.mark.parametrize("case", ["tiny", "ragged", "deg0", "deg2", "subpixel", "huge", "init_opacity"])
+def test_header_math_matches_oracle(case):
+    sc = make_case(case)
+    st = oracle_forward(sc)
+    dc, do = make_upstream_grads(sc.width, sc.height)
+    g = so.backward(st, dc, do)
+    e = emul.run(st, dc.numpy(), do.numpy())
+    # EXACT functions: bit-identical binning inputs
+    vis = st["radii"] > 0
+    assert np.array_equal(e["radii"], st["radii"])
+    assert np.array_equal(e["tiles"], st["tiles_touched"])
+    assert np.array_equal(e["rec"][vis, 0:9], st["transMat"][vis])
+    assert np.array_equal(e["rec"][vis, 9:11], st["means2D"][vis])
+    assert np.array_equal(e["rec"][vis, 15], st["depths"][vis])
+    assert_close("rgb", e["rec"][vis, 16:19], st["rgb"][vis], rtol=1e-6)
+    assert np.array_equal(e["n_contrib"], st["n_contrib"])
+    assert_close("color", e["color"], st["color"])
+    for i in range(8):
+        assert_close(f"others[{i}]", e["others"][i], st["others"][i], atol=DIST_ATOL if i == 6 else 0.0)
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dsh", "dL_dscales",
+              "dL_drotations"):
+        assert_close(k, e["grads"][k], g[k])

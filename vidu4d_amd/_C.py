@@ -1,0 +1,237 @@
+"""Drop-in for the reference's native module `diff_surfel_rasterization._C`.
+
+Same three functions, same positional arguments and return tuples as the pybind module
+(/root/reference/gs/submodules/diff-surfel-rasterization/ext.cpp:15-19, rasterize_points.cu:39-60,
+:143-166, :242-261); the body marshals torch tensors to raw device pointers and calls the C ABI
+(include/vidu4d_surfel.h) on torch's current HIP stream.  There is no CPU path: tensors must live
+on a GPU and the HIP library must load.
+
+Difference that a caller can observe only through timing: `rasterize_gaussians` does not stall the
+GPU in the middle of the forward to read `num_rendered`.  The binning buffer is sized from the
+previous call's count (+25 %), all kernels are queued, and the host waits only for the tile-count
+scan; if the guess was too small the tail of the forward is queued again with an exact buffer.
+Set VIDU4D_SURFEL_EXACT=1 to size exactly first (one host sync before the sort, as upstream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+
+_EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
+_capacity_hint: dict = {}
+_pinned: dict = {}
+
+
+def _ptr(t):
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t.contiguous()
+
+
+def _check_cuda(*ts):
+    for t in ts:
+        if t is not None and t.numel() and not t.is_cuda:
+            raise RuntimeError("diff_surfel_rasterization: all tensors must be CUDA/HIP tensors "
+                               "(there is no CPU path in the MI355X build)")
+
+
+def _pinned_slot(device):
+    key = str(device)
+    if key not in _pinned:
+        _pinned[key] = torch.zeros(2, dtype=torch.int32).pin_memory()
+    return _pinned[key]
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """-> (num_rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer)"""
+    lib = _lib.load()
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if scales.ndim != 2 or scales.shape[1] != 2:
+        raise RuntimeError("scales must have dimensions (num_points, 2)")
+    if rotations.ndim != 2 or rotations.shape[1] != 4:
+        raise RuntimeError("rotations must have dimensions (num_points, 4)")
+    _check_cuda(background, means3D, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, sh,
+                campos)
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    means3D = _f32c(means3D, "means3D")
+    scales = _f32c(scales, "scales")
+    rotations = _f32c(rotations, "rotations")
+    opacity = _f32c(opacity, "opacity")
+    background = _f32c(background, "background")
+    viewmatrix = _f32c(viewmatrix, "viewmatrix")
+    projmatrix = _f32c(projmatrix, "projmatrix")
+    campos = _f32c(campos, "campos")
+    M = 0
+    if sh.numel():
+        sh = _f32c(sh, "sh")
+        M = sh.shape[1]
+    if colors.numel():
+        colors = _f32c(colors, "colors")
+
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    out_others = torch.empty((8, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty((lib.vidu4d_surfel_geom_bytes(P),), dtype=torch.uint8, device=dev)
+    img = torch.empty((lib.vidu4d_surfel_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+
+    a = _lib.ForwardArgs()
+    a.P, a.D, a.M, a.width, a.height = P, int(degree), M, W, H
+    a.tan_fovx, a.tan_fovy = float(tan_fovx), float(tan_fovy)
+    a.scale_modifier = float(scale_modifier)
+    a.prefiltered, a.debug = int(bool(prefiltered)), int(bool(debug))
+    a.background, a.means3D, a.shs, a.colors_precomp = _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors)
+    a.opacities, a.scales, a.rotations = _ptr(opacity), _ptr(scales), _ptr(rotations)
+    a.transMat_precomp = _ptr(transMat_precomp)
+    a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
+    a.out_color, a.out_others, a.radii = out_color.data_ptr(), out_others.data_ptr(), _ptr(radii)
+    a.geom_buffer, a.geom_bytes = geom.data_ptr(), geom.numel()
+    a.image_buffer, a.image_bytes = img.data_ptr(), img.numel()
+    stream = _stream(dev)
+
+    if P == 0:  # rasterize_points.cu:105: nothing is launched, outputs are zeros
+        out_color.zero_()
+        out_others.zero_()
+        binning = torch.empty((0,), dtype=torch.uint8, device=dev)
+        return 0, out_color, out_others, radii, geom, binning, img
+
+    _lib.check(lib.vidu4d_surfel_forward_plan(C.byref(a), stream), "surfel forward (plan)")
+    key = (P, W, H, str(dev))
+    hint = _capacity_hint.get(key)
+    R = C.c_int64(0)
+    if _EXACT or hint is None or debug:
+        _lib.check(lib.vidu4d_surfel_num_rendered(C.byref(a), stream, C.byref(R)), "surfel forward (count)")
+        cap = max(int(R.value), 1)
+        binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
+        _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
+                   "surfel forward (run)")
+        num_rendered = int(R.value)
+    else:
+        cap = hint
+        binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
+        slot = _pinned_slot(dev)
+        slot.copy_(geom[:8].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
+                   "surfel forward (run)")
+        ev.synchronize()  # waits for preprocess + scan only; sort and blend keep running
+        num_rendered = int(slot[0])
+        if num_rendered > cap:  # guess too small: queue the tail again with an exact buffer
+            cap = num_rendered
+            binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
+            _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
+                       "surfel forward (re-run)")
+    _capacity_hint[key] = max(int(num_rendered * 1.25) + 4096, 4096)
+    # the capacity the buffers were carved with travels to backward inside the buffer tensor
+    binning._vidu4d_capacity = cap
+    return num_rendered, out_color, out_others, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                                 binning_capacity=None):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations)"""
+    lib = _lib.load()
+    _check_cuda(background, means3D, radii, colors, scales, rotations, viewmatrix, projmatrix, sh, campos, geomBuffer,
+                binningBuffer, imageBuffer)
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    M = sh.shape[1] if sh.numel() else 0
+    opt = dict(dtype=torch.float32, device=dev)
+    dL_dmeans3D = torch.empty((P, 3), **opt)
+    dL_dmeans2D = torch.empty((P, 3), **opt)
+    dL_dcolors = torch.empty((P, 3), **opt)
+    dL_dopacity = torch.empty((P, 1), **opt)
+    dL_dtransMat = torch.empty((P, 9), **opt)
+    dL_dsh = torch.empty((P, M, 3), **opt)
+    dL_dscales = torch.empty((P, 2), **opt)
+    dL_drotations = torch.empty((P, 4), **opt)
+    if P == 0:
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+    if binning_capacity is None:
+        binning_capacity = getattr(binningBuffer, "_vidu4d_capacity", None)
+    if binning_capacity is None:
+        binning_capacity = max(int(R), 1)
+    ws = torch.empty((lib.vidu4d_surfel_backward_workspace_bytes(P),), dtype=torch.uint8, device=dev)
+    means3D = _f32c(means3D, "means3D")
+    scales = _f32c(scales, "scales")
+    rotations = _f32c(rotations, "rotations")
+    dL_dout_color = _f32c(dL_dout_color, "dL_dout_color")
+    dL_dout_others = _f32c(dL_dout_others, "dL_dout_others")
+    background = _f32c(background, "background")
+    viewmatrix = _f32c(viewmatrix, "viewmatrix")
+    projmatrix = _f32c(projmatrix, "projmatrix")
+    campos = _f32c(campos, "campos")
+    if sh.numel():
+        sh = _f32c(sh, "sh")
+    if colors.numel():
+        colors = _f32c(colors, "colors")
+
+    b = _lib.BackwardArgs()
+    b.P, b.D, b.M, b.width, b.height = P, int(degree), M, W, H
+    b.tan_fovx, b.tan_fovy, b.scale_modifier, b.debug = float(tan_fovx), float(tan_fovy), float(scale_modifier), int(
+        bool(debug))
+    b.background, b.means3D, b.radii = _ptr(background), _ptr(means3D), _ptr(radii)
+    b.shs, b.colors_precomp, b.scales, b.rotations = _ptr(sh), _ptr(colors), _ptr(scales), _ptr(rotations)
+    b.transMat_precomp = _ptr(transMat_precomp)
+    b.viewmatrix, b.projmatrix, b.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
+    b.dL_dout_color, b.dL_dout_others = dL_dout_color.data_ptr(), dL_dout_others.data_ptr()
+    b.geom_buffer, b.binning_buffer, b.image_buffer = geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr()
+    b.binning_capacity = int(binning_capacity)
+    b.workspace, b.workspace_bytes = ws.data_ptr(), ws.numel()
+    b.dL_dmeans2D, b.dL_dcolors, b.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dcolors.data_ptr(), dL_dopacity.data_ptr()
+    b.dL_dmeans3D, b.dL_dtransMat, b.dL_dsh = dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh)
+    b.dL_dscales, b.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
+    _lib.check(lib.vidu4d_surfel_backward(C.byref(b), _stream(dev)), "surfel backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool (P,) (rasterize_points.cu:242-261)"""
+    lib = _lib.load()
+    _check_cuda(means3D, viewmatrix, projmatrix)
+    P = means3D.shape[0]
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P:
+        m = _f32c(means3D, "means3D")
+        v = _f32c(viewmatrix, "viewmatrix")
+        pj = _f32c(projmatrix, "projmatrix")
+        _lib.check(lib.vidu4d_surfel_mark_visible(P, m.data_ptr(), v.data_ptr(), pj.data_ptr(), present.data_ptr(),
+                                                  _stream(means3D.device)), "mark_visible")
+    return present
+
+
+def read_state(what: str, fwd_inputs: dict, geomBuffer, binningBuffer, imgBuffer, P, W, H, dtype, max_count):
+    """Test helper: copies one internal array (see _lib.STATE) to a host tensor."""
+    lib = _lib.load()
+    a = _lib.ForwardArgs()
+    a.P, a.width, a.height = P, W, H
+    a.geom_buffer, a.geom_bytes = geomBuffer.data_ptr(), geomBuffer.numel()
+    a.image_buffer, a.image_bytes = imgBuffer.data_ptr(), imgBuffer.numel()
+    cap = getattr(binningBuffer, "_vidu4d_capacity", 0)
+    dst = torch.empty((max(max_count, 1),), dtype=dtype)
+    n = C.c_int64(0)
+    _lib.check(lib.vidu4d_surfel_state_read(C.byref(a), _ptr(binningBuffer), cap, _lib.STATE[what], dst.data_ptr(),
+                                            dst.numel() * dst.element_size(), C.byref(n),
+                                            _stream(geomBuffer.device)), f"state_read({what})")
+    return dst[: n.value].clone()

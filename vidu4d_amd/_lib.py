@@ -1,0 +1,123 @@
+"""ctypes binding of libvidu4d_surfel.so (C ABI in include/vidu4d_surfel.h).
+
+The product path has NO fallback: if the shared object is missing it is built with hipcc, and if
+that fails (or the symbols are missing) importing a symbol raises.  Nothing here touches oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
+
+ABI_VERSION = 1
+
+
+class ForwardArgs(C.Structure):
+    """struct Vidu4dSurfelForwardArgs"""
+    _fields_ = [
+        ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("width", C.c_int), ("height", C.c_int),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float),
+        ("prefiltered", C.c_int), ("debug", C.c_int),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+        ("transMat_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("campos", C.c_void_p), ("out_color", C.c_void_p), ("out_others", C.c_void_p), ("radii", C.c_void_p),
+        ("geom_buffer", C.c_void_p), ("geom_bytes", C.c_size_t), ("image_buffer", C.c_void_p),
+        ("image_bytes", C.c_size_t),
+    ]
+
+
+class BackwardArgs(C.Structure):
+    """struct Vidu4dSurfelBackwardArgs"""
+    _fields_ = [
+        ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("width", C.c_int), ("height", C.c_int),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float), ("debug", C.c_int),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("radii", C.c_void_p), ("shs", C.c_void_p),
+        ("colors_precomp", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+        ("transMat_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("campos", C.c_void_p), ("dL_dout_color", C.c_void_p), ("dL_dout_others", C.c_void_p),
+        ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("binning_capacity", C.c_int64),
+        ("image_buffer", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dL_dmeans2D", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dopacity", C.c_void_p),
+        ("dL_dmeans3D", C.c_void_p), ("dL_dtransMat", C.c_void_p), ("dL_dsh", C.c_void_p),
+        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
+    ]
+
+
+# every symbol include/vidu4d_surfel.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "vidu4d_surfel_abi_version": (C.c_int, []),
+    "vidu4d_last_error": (C.c_char_p, []),
+    "vidu4d_surfel_geom_bytes": (C.c_size_t, [C.c_int]),
+    "vidu4d_surfel_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vidu4d_surfel_binning_bytes": (C.c_size_t, [C.c_int64]),
+    "vidu4d_surfel_backward_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "vidu4d_surfel_forward_plan": (C.c_int, [C.POINTER(ForwardArgs), _P]),
+    "vidu4d_surfel_num_rendered": (C.c_int, [C.POINTER(ForwardArgs), _P, C.POINTER(C.c_int64)]),
+    "vidu4d_surfel_forward_run": (C.c_int, [C.POINTER(ForwardArgs), _P, C.c_size_t, C.c_int64, _P]),
+    "vidu4d_surfel_backward": (C.c_int, [C.POINTER(BackwardArgs), _P]),
+    "vidu4d_surfel_mark_visible": (C.c_int, [C.c_int, _P, _P, _P, _P, _P]),
+    "vidu4d_surfel_state_read": (C.c_int, [C.POINTER(ForwardArgs), _P, C.c_int64, C.c_int, _P, C.c_size_t,
+                                           C.POINTER(C.c_int64), _P]),
+    "vidu4d_surfel_profile_enable": (C.c_int, [C.c_int]),
+    "vidu4d_surfel_profile_stage_count": (C.c_int, []),
+    "vidu4d_surfel_profile_stage_name": (C.c_char_p, [C.c_int]),
+    "vidu4d_surfel_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
+    "vidu4d_quaternion_mul": (C.c_int, [C.c_int64, _P, C.c_int, _P, C.c_int, _P, _P]),
+    "vidu4d_quaternion_mul_backward": (C.c_int, [C.c_int64, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "vidu4d_quaternion_mul_backward_backward": (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P,
+                                                          _P, _P]),
+    "vidu4d_quaternion_conjugate": (C.c_int, [C.c_int64, _P, _P, _P]),
+}
+
+STATE = dict(num_rendered=0, records=1, tiles_touched=2, point_list=3, sorted_keys=4, ranges=5, final_T=6,
+             n_contrib=7, unsorted_keys=8, unsorted_values=9)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads (building first if needed) the HIP library; raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.vidu4d_surfel_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libvidu4d_surfel.so ABI {got} != expected {ABI_VERSION}: rebuild (python -m vidu4d_amd.build)")
+    _lib = lib
+    return lib
+
+
+class SurfelError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().vidu4d_last_error()
+        raise SurfelError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def profile_enable(on: bool):
+    load().vidu4d_surfel_profile_enable(int(on))
+
+
+def profile_read(reset: bool = True) -> dict:
+    """{stage name: (total milliseconds, launch-span count)} since the last reset."""
+    lib = load()
+    n = lib.vidu4d_surfel_profile_stage_count()
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    check(lib.vidu4d_surfel_profile_read(ms, cnt, int(reset)), "profile_read")
+    return {lib.vidu4d_surfel_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}

@@ -1,0 +1,294 @@
+// blend.hip -- per-tile front-to-back alpha blending (forward) and the per-pixel gradient scatter
+// (backward) of the surfel rasterizer.  gfx950 only.
+//
+// Reference behaviour: renderCUDA forward (/root/reference/gs/submodules/diff-surfel-rasterization/
+// cuda_rasterizer/forward.cu:265-463) and renderCUDA backward (backward.cu:143-449).
+//
+// MI355X design (DESIGN.md "blend kernels"):
+//   * one 256-thread workgroup (4 wave64) per 16x16 tile; each wave owns an 8x8 pixel quadrant
+//     (compact footprint, 32-byte row segments on output);
+//   * workgroup -> tile mapping is XCD-aware: workgroup b is dispatched to XCD b % 8, so XCD x gets
+//     the contiguous band of tiles [x*per, (x+1)*per); neighbouring tiles, which share most of
+//     their surfels, then hit the same 4 MiB L2;
+//   * the tile's depth-sorted surfel list is staged 256 entries at a time into LDS as 80-byte
+//     records (five ds_write_b128 per lane, conflict-free at a 20-dword stride) and read back with
+//     wave-uniform (broadcast) ds_read_b128;
+//   * backward: all 64 lanes of a wave work on the same list entry, so the 18 gradient components
+//     are first reduced across the wave with a DPP reduce-scatter butterfly (row_mirror,
+//     row_half_mirror, quad_perm: 15 DPP adds for 16 values instead of 96), then combined across the
+//     4 waves with LDS float atomics, and only one global atomic per (entry, component) is issued
+//     per 256-entry batch.  The reference issues up to 16 global atomics per (pixel, entry).
+#include "surfel_state.h"
+
+namespace surfel {
+
+constexpr int BLEND_BATCH = 256;
+
+struct TileCoord {
+    int tile, tx, ty;
+    bool valid;
+};
+
+__device__ __forceinline__ TileCoord xcd_tile(int grid_x, int grid_y)
+{
+    const int ntiles = grid_x * grid_y;
+    const int per = (ntiles + 7) >> 3;
+    TileCoord t;
+    t.tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    t.valid = t.tile < ntiles;
+    t.tx = t.tile % grid_x;
+    t.ty = t.tile / grid_x;
+    return t;
+}
+inline int xcd_grid(int grid_x, int grid_y) { return ((grid_x * grid_y + 7) >> 3) * 8; }
+
+__device__ __forceinline__ void stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
+{
+    const float4* src = reinterpret_cast<const float4*>(rec + (size_t)id * REC_FLOATS);
+    const float4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    float4* dst = s_rec + slot * 5;
+    dst[0] = a;
+    dst[1] = b;
+    dst[2] = c;
+    dst[3] = d;
+    dst[4] = e;
+}
+
+__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y,
+                                                       const uint32_t* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ point_list,
+                                                       const float* __restrict__ rec, const float* __restrict__ bg,
+                                                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                       float* __restrict__ out_color, float* __restrict__ out_others)
+{
+    __shared__ float4 s_rec[BLEND_BATCH * 5];
+    const TileCoord tc = xcd_tile(grid_x, grid_y);
+    if (!tc.valid) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
+    const uint32_t r0 = ranges[2 * tc.tile], r1 = ranges[2 * tc.tile + 1];
+    int todo = (int)(r1 - r0);
+
+    FwdPixel s;
+    bool done = !inside;
+    for (int base = 0; todo > 0; base += BLEND_BATCH, todo -= BLEND_BATCH) {
+        if (__syncthreads_count(done) == 256) break;
+        if ((int)threadIdx.x < todo) stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        __syncthreads();
+        const int cnt = todo < BLEND_BATCH ? todo : BLEND_BATCH;
+        for (int j = 0; !done && j < cnt; j++) {
+            const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+            const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
+            PairEval e;
+            if (!eval_pair(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e)) continue;
+            const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+            const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+            if (!fwd_accumulate(s, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
+        }
+    }
+    if (inside) {
+        const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
+        final_T[pid] = s.T;
+        final_T[pid + HW] = s.dist1;
+        final_T[pid + 2 * HW] = s.dist2;
+        n_contrib[pid] = s.last_contributor;
+        n_contrib[pid + HW] = s.median_contributor;
+        for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pid] = s.C[ch] + s.T * bg[ch];
+        out_others[pid] = s.D;
+        out_others[pid + HW] = 1.0f - s.T;
+        out_others[pid + 2 * HW] = s.N[0];
+        out_others[pid + 3 * HW] = s.N[1];
+        out_others[pid + 4 * HW] = s.N[2];
+        out_others[pid + 5 * HW] = s.median_depth;
+        out_others[pid + 6 * HW] = s.distortion;
+        out_others[pid + 7 * HW] = s.median_weight;
+    }
+}
+
+void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const uint32_t* point_list,
+                      const float* background, float* out_color, float* out_others, hipStream_t stream)
+{
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(cam.grid_x, cam.grid_y)), dim3(256), 0, stream, cam.W, cam.H,
+                       cam.grid_x, cam.grid_y, img.ranges, point_list, g.rec, background, img.final_T, img.n_contrib,
+                       out_color, out_others);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DPP lane exchanges (GFX9 encodings): all are involutions inside a row of 16 lanes.
+constexpr int DPP_QUAD_XOR1 = 0xB1;    // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;    // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_MIRROR = 0x140;  // lane i <-> 15 - i
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <-> 7 - i inside each 8
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// One halving step of the reduce-scatter: `hi` lanes keep v[N/2..N), the others v[0..N/2); every
+// kept value receives the partner lane's copy of it.
+template <int CTRL, int N>
+__device__ __forceinline__ void halve(float (&v)[16], bool hi)
+{
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) {
+        const float keep = hi ? v[i + N / 2] : v[i];
+        const float send = hi ? v[i] : v[i + N / 2];
+        v[i] = keep + dpp_xchg<CTRL>(send);
+    }
+}
+
+// Sums 16 per-lane values over each row of 16 lanes; on return lane L holds the row total of
+// component (L & 15).
+__device__ __forceinline__ float row_reduce_scatter16(float (&v)[16], int lane)
+{
+    halve<DPP_ROW_MIRROR, 16>(v, (lane & 8) != 0);
+    halve<DPP_ROW_HALF_MIRROR, 8>(v, (lane & 4) != 0);
+    halve<DPP_QUAD_XOR2, 4>(v, (lane & 2) != 0);
+    halve<DPP_QUAD_XOR1, 2>(v, (lane & 1) != 0);
+    return v[0];
+}
+
+// Same for 2 values: lane L holds the row total of component ((L >> 3) & 1).
+__device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
+{
+    const bool hi = (lane & 8) != 0;
+    float v = (hi ? b : a) + dpp_xchg<DPP_ROW_MIRROR>(hi ? a : b);
+    v += dpp_xchg<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_xchg<DPP_QUAD_XOR2>(v);
+    v += dpp_xchg<DPP_QUAD_XOR1>(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y,
+                                                       const uint32_t* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ point_list,
+                                                       const float* __restrict__ rec, const float* __restrict__ bg,
+                                                       const float* __restrict__ final_T,
+                                                       const uint32_t* __restrict__ n_contrib,
+                                                       const float* __restrict__ dL_dcolor,
+                                                       const float* __restrict__ dL_dothers, float* __restrict__ acc)
+{
+    __shared__ float4 s_rec[BLEND_BATCH * 5];
+    __shared__ float s_acc[BLEND_BATCH * ACC_FLOATS];
+    __shared__ uint32_t s_id[BLEND_BATCH];
+    __shared__ uint32_t s_max;
+    const TileCoord tc = xcd_tile(grid_x, grid_y);
+    if (!tc.valid) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
+    const uint32_t r0 = ranges[2 * tc.tile];
+    const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
+
+    BwdPixel s;
+    s.last_contributor = 0;
+    s.median_contributor = 0;
+    s.T_final = 0.f;
+    s.final_D = s.final_D2 = 0.f;
+    s.dL_ddepth = s.dL_daccum = s.dL_dreg = s.dL_dmedian_depth = s.dL_dmax_dweight = 0.f;
+    for (int c = 0; c < 3; c++) s.dL_dpixel[c] = s.dL_dnormal2D[c] = 0.f;
+    if (inside) {
+        s.T_final = final_T[pid];
+        s.final_D = final_T[pid + HW];
+        s.final_D2 = final_T[pid + 2 * HW];
+        s.last_contributor = n_contrib[pid];
+        s.median_contributor = n_contrib[pid + HW];
+        for (int c = 0; c < 3; c++) s.dL_dpixel[c] = dL_dcolor[c * HW + pid];
+        s.dL_ddepth = dL_dothers[pid];
+        s.dL_daccum = dL_dothers[pid + HW];
+        for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = dL_dothers[pid + (2 + c) * HW];
+        s.dL_dmedian_depth = dL_dothers[pid + 5 * HW];
+        s.dL_dreg = dL_dothers[pid + 6 * HW];
+        s.dL_dmax_dweight = dL_dothers[pid + 7 * HW];
+    }
+    s.T = s.T_final;
+    s.final_A = 1.0f - s.T_final;
+    s.bg_dot_dpixel = bg[0] * s.dL_dpixel[0] + bg[1] * s.dL_dpixel[1] + bg[2] * s.dL_dpixel[2];
+
+    // entries at or beyond every pixel's last contributor never matter: skip them wholesale
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    {
+        uint32_t m = s.last_contributor;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)m, d, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) atomicMax(&s_max, m);
+    }
+    __syncthreads();
+    const int n_used = (int)s_max;
+
+    // accumulator slot handled by this lane after the row reduce-scatter
+    const int c16 = lane & 15;
+    const int slot16 = c16 < 9 ? c16 : (c16 == 9 ? A_OPAC : (c16 < 13 ? c16 + 2 : c16 + 3));
+    const int slot2 = A_M2D + ((lane >> 3) & 1);
+
+    for (int hi = n_used; hi > 0; hi -= BLEND_BATCH) {
+        const int cnt = hi < BLEND_BATCH ? hi : BLEND_BATCH;
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)];
+            s_id[threadIdx.x] = id;
+            stage_record(s_rec, threadIdx.x, rec, id);
+        }
+#pragma unroll
+        for (int k = 0; k < ACC_FLOATS / 4; k++)
+            reinterpret_cast<float4*>(s_acc)[threadIdx.x * (ACC_FLOATS / 4) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t contributor = (uint32_t)(hi - 1 - j);
+            const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+            const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
+            PairEval e;
+            const bool ok = inside && contributor < s.last_contributor &&
+                            eval_pair(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e);
+            if (!__any(ok)) continue;
+            float g[ACC_FLOATS];
+#pragma unroll
+            for (int k = 0; k < ACC_FLOATS; k++) g[k] = 0.f;
+            if (ok) {
+                const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                bwd_pair(s, e, Tw, q2.w, nrm, rgb, pixx, pixy, contributor + 1 == s.median_contributor, g);
+            }
+            float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
+                           g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
+            const float r16 = row_reduce_scatter16(v, lane);
+            if (r16 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot16], r16);
+            if (__any(g[A_M2D] != 0.f || g[A_M2D + 1] != 0.f)) {
+                const float r2 = row_reduce_scatter2(g[A_M2D], g[A_M2D + 1], lane);
+                if ((lane & 7) == 0 && r2 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot2], r2);
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            float* dst = acc + (size_t)s_id[threadIdx.x] * ACC_FLOATS;
+            const float* src = s_acc + threadIdx.x * ACC_FLOATS;
+#pragma unroll
+            for (int k = 0; k < ACC_FLOATS; k++) {
+                if (k == 15 || k == 19) continue;
+                const float val = src[k];
+                if (val != 0.f) atomicAdd(dst + k, val);
+            }
+        }
+    }
+}
+
+void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(xcd_grid(a.cam.grid_x, a.cam.grid_y)), dim3(256), 0, stream, a.cam.W,
+                       a.cam.H, a.cam.grid_x, a.cam.grid_y, a.img.ranges, a.point_list, a.geom.rec, a.background,
+                       a.img.final_T, a.img.n_contrib, a.dL_dcolor, a.dL_dothers, a.acc);
+}
+
+}  // namespace surfel

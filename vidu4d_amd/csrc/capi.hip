@@ -1,0 +1,366 @@
+// capi.hip -- the extern "C" boundary declared in include/vidu4d_surfel.h.
+// Argument validation, scratch carving and launch orchestration; no device code here.
+//
+// Orchestration mirrors CudaRasterizer::Rasterizer::forward / ::backward
+// (/root/reference/gs/submodules/diff-surfel-rasterization/cuda_rasterizer/rasterizer_impl.cu:
+// 198-342, :346-448) with the host synchronisation taken out of the middle.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/vidu4d_surfel.h"
+#include "surfel_state.h"
+
+using namespace surfel;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(VIDU4D_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg).
+// Disabled by default: zero overhead (one branch) per stage.
+enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BWD_ZERO, ST_BLEND_BWD,
+             ST_PREPROCESS_BWD, ST_COUNT };
+static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "emit_keys", "radix_sort", "tile_ranges",
+                                                   "blend_fwd", "bwd_zero", "blend_bwd", "preprocess_bwd"};
+struct StageSpan {
+    hipEvent_t a, b;
+    int stage;
+};
+static bool g_prof_on = false;
+static std::vector<StageSpan> g_spans;      // recorded, not yet harvested
+static std::vector<StageSpan> g_span_pool;  // reusable event pairs
+static double g_stage_ms[ST_COUNT];
+static long long g_stage_n[ST_COUNT];
+
+struct StageTimer {
+    StageSpan sp;
+    hipStream_t stream;
+    bool on;
+    StageTimer(int stage, hipStream_t s) : stream(s), on(g_prof_on)
+    {
+        if (!on) return;
+        if (!g_span_pool.empty()) {
+            sp = g_span_pool.back();
+            g_span_pool.pop_back();
+        } else {
+            hipEventCreate(&sp.a);
+            hipEventCreate(&sp.b);
+        }
+        sp.stage = stage;
+        hipEventRecord(sp.a, stream);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        hipEventRecord(sp.b, stream);
+        g_spans.push_back(sp);
+    }
+};
+
+extern "C" int vidu4d_surfel_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+    return VIDU4D_OK;
+}
+extern "C" int vidu4d_surfel_profile_stage_count(void) { return ST_COUNT; }
+extern "C" const char* vidu4d_surfel_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+// Waits for the recorded events, adds them to the per-stage totals and returns the totals
+// (milliseconds, launch-span counts).  reset != 0 clears the totals afterwards.
+extern "C" int vidu4d_surfel_profile_read(double* total_ms, long long* count, int reset)
+{
+    for (const StageSpan& sp : g_spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            g_stage_ms[sp.stage] += ms;
+            g_stage_n[sp.stage] += 1;
+        }
+        g_span_pool.push_back(sp);
+    }
+    g_spans.clear();
+    for (int i = 0; i < ST_COUNT; i++) {
+        if (total_ms) total_ms[i] = g_stage_ms[i];
+        if (count) count[i] = g_stage_n[i];
+        if (reset) {
+            g_stage_ms[i] = 0;
+            g_stage_n[i] = 0;
+        }
+    }
+    return VIDU4D_OK;
+}
+
+// debug != 0 reproduces the reference's CHECK_CUDA(.., debug): synchronise + check after a stage.
+#define STAGE_CHECK(debug, stream, what)                                                                    \
+    do {                                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                                  \
+        if (e_ == hipSuccess && (debug)) e_ = hipStreamSynchronize(stream);                                 \
+        if (e_ != hipSuccess) return fail(VIDU4D_E_HIP, "stage '%s' failed: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int vidu4d_surfel_abi_version(void) { return VIDU4D_SURFEL_ABI; }
+extern "C" const char* vidu4d_last_error(void) { return g_err; }
+
+extern "C" size_t vidu4d_surfel_geom_bytes(int P)
+{
+    GeomState g;
+    return carve_geom(nullptr, P < 0 ? 0 : P, g);
+}
+extern "C" size_t vidu4d_surfel_image_bytes(int width, int height)
+{
+    ImageState s;
+    return carve_image(nullptr, width < 0 ? 0 : width, height < 0 ? 0 : height, s);
+}
+extern "C" size_t vidu4d_surfel_binning_bytes(int64_t capacity)
+{
+    BinState b;
+    return carve_binning(nullptr, capacity, b);
+}
+extern "C" size_t vidu4d_surfel_backward_workspace_bytes(int P)
+{
+    return (size_t)(P < 0 ? 0 : P) * ACC_FLOATS * sizeof(float) + 256;
+}
+
+static int check_forward(const Vidu4dSurfelForwardArgs* a)
+{
+    if (!a) return fail(VIDU4D_E_INVALID, "args is NULL");
+    if (a->P < 0 || a->width <= 0 || a->height <= 0) return fail(VIDU4D_E_INVALID, "bad sizes P=%d W=%d H=%d", a->P, a->width, a->height);
+    if (a->transMat_precomp)
+        return fail(VIDU4D_E_UNSUPPORTED,
+                    "cov3D_precomp/transMat_precomp is not supported: the reference path leaves the normal "
+                    "uninitialised (forward.cu:214-224) and its backward dereferences scales/rotations anyway");
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr) && a->P > 0)
+        return fail(VIDU4D_E_INVALID, "provide exactly one of shs / colors_precomp");
+    if (a->shs && (a->M <= 0 || a->M > 16 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M))
+        return fail(VIDU4D_E_INVALID, "bad SH configuration D=%d M=%d", a->D, a->M);
+    if (!(a->tan_fovx > 0.f) || !(a->tan_fovy > 0.f)) return fail(VIDU4D_E_INVALID, "tan_fov must be > 0");
+    if (!a->out_color || !a->out_others || !a->background) return fail(VIDU4D_E_INVALID, "output/background pointer is NULL");
+    if (a->P > 0 && (!a->means3D || !a->opacities || !a->scales || !a->rotations || !a->radii || !a->viewmatrix || !a->campos))
+        return fail(VIDU4D_E_INVALID, "an input pointer is NULL");
+    if (!a->geom_buffer || a->geom_bytes < vidu4d_surfel_geom_bytes(a->P)) return fail(VIDU4D_E_BUFFER, "geom_buffer too small");
+    if (!a->image_buffer || a->image_bytes < vidu4d_surfel_image_bytes(a->width, a->height)) return fail(VIDU4D_E_BUFFER, "image_buffer too small");
+    return VIDU4D_OK;
+}
+
+extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_forward(a);
+    if (rc) return rc;
+    GeomState g;
+    ImageState img;
+    carve_geom((char*)a->geom_buffer, a->P, g);
+    carve_image((char*)a->image_buffer, a->width, a->height, img);
+    PreprocessArgs pa;
+    pa.cam = make_camera_params(a->viewmatrix, a->campos, a->width, a->height, a->tan_fovx, a->tan_fovy, a->D, a->M);
+    pa.P = a->P;
+    pa.means3D = a->means3D;
+    pa.scales = a->scales;
+    pa.rotations = a->rotations;
+    pa.opacities = a->opacities;
+    pa.shs = a->shs;
+    pa.colors_precomp = a->colors_precomp;
+    pa.radii = a->radii;
+    pa.geom = g;
+    {
+        StageTimer t(ST_PREPROCESS, stream);
+        launch_preprocess_fwd(pa, stream);
+    }
+    STAGE_CHECK(a->debug, stream, "preprocess");
+    {
+        StageTimer t(ST_SCAN, stream);
+        launch_scan_blocks(g, a->P, img.ranges, pa.cam.grid_x * pa.cam.grid_y, stream);
+    }
+    STAGE_CHECK(a->debug, stream, "scan");
+    return VIDU4D_OK;
+}
+
+extern "C" int vidu4d_surfel_num_rendered(const Vidu4dSurfelForwardArgs* a, void* stream_, int64_t* out)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a || !out || !a->geom_buffer) return fail(VIDU4D_E_INVALID, "NULL argument");
+    GeomState g;
+    carve_geom((char*)a->geom_buffer, a->P, g);
+    uint32_t r = 0;
+    HIP_TRY(hipMemcpyAsync(&r, &g.hdr->num_rendered, sizeof(r), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *out = (int64_t)r;
+    return VIDU4D_OK;
+}
+
+extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void* binning, size_t binning_bytes,
+                                         int64_t capacity, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_forward(a);
+    if (rc) return rc;
+    if (capacity < 0) return fail(VIDU4D_E_INVALID, "negative capacity");
+    if (capacity > 0 && (!binning || binning_bytes < vidu4d_surfel_binning_bytes(capacity)))
+        return fail(VIDU4D_E_BUFFER, "binning_buffer too small for capacity %lld", (long long)capacity);
+    if (capacity > 0xFFFFFFFFll) return fail(VIDU4D_E_INVALID, "capacity exceeds the 32-bit pair index of the reference");
+    GeomState g;
+    ImageState img;
+    BinState b;
+    carve_geom((char*)a->geom_buffer, a->P, g);
+    carve_image((char*)a->image_buffer, a->width, a->height, img);
+    carve_binning((char*)binning, capacity, b);
+    const CameraParams cam =
+        make_camera_params(a->viewmatrix, a->campos, a->width, a->height, a->tan_fovx, a->tan_fovy, a->D, a->M);
+    const uint32_t* point_list = nullptr;
+    if (capacity > 0) {
+        {
+            StageTimer t(ST_EMIT, stream);
+            launch_emit_keys(cam, a->P, a->radii, g, b, capacity, stream);
+        }
+        STAGE_CHECK(a->debug, stream, "emit_keys");
+        const int passes = sort_passes(cam.grid_x, cam.grid_y);
+        int side;
+        {
+            StageTimer t(ST_SORT, stream);
+            side = launch_radix_sort(g, b, capacity, passes, stream);
+        }
+        STAGE_CHECK(a->debug, stream, "radix_sort");
+        {
+            StageTimer t(ST_RANGES, stream);
+            launch_tile_ranges(g, b.keys[side], capacity, img.ranges, stream);
+        }
+        STAGE_CHECK(a->debug, stream, "tile_ranges");
+        point_list = b.vals[side];
+    }
+    {
+        StageTimer t(ST_BLEND_FWD, stream);
+        launch_blend_fwd(cam, g, img, point_list, a->background, a->out_color, a->out_others, stream);
+    }
+    STAGE_CHECK(a->debug, stream, "blend_forward");
+    return VIDU4D_OK;
+}
+
+extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a) return fail(VIDU4D_E_INVALID, "args is NULL");
+    if (a->P < 0 || a->width <= 0 || a->height <= 0) return fail(VIDU4D_E_INVALID, "bad sizes");
+    if (a->transMat_precomp) return fail(VIDU4D_E_UNSUPPORTED, "transMat_precomp is not supported (see forward)");
+    if (a->P == 0) return VIDU4D_OK;
+    if (!a->geom_buffer || !a->image_buffer || !a->workspace || !a->dL_dout_color || !a->dL_dout_others ||
+        !a->means3D || !a->radii || !a->scales || !a->rotations || !a->viewmatrix || !a->campos || !a->background)
+        return fail(VIDU4D_E_INVALID, "an input pointer is NULL");
+    if (!a->dL_dmeans2D || !a->dL_dcolors || !a->dL_dopacity || !a->dL_dmeans3D || !a->dL_dtransMat ||
+        !a->dL_dscales || !a->dL_drotations || (a->shs && !a->dL_dsh))
+        return fail(VIDU4D_E_INVALID, "an output pointer is NULL");
+    if (a->workspace_bytes < vidu4d_surfel_backward_workspace_bytes(a->P)) return fail(VIDU4D_E_BUFFER, "workspace too small");
+    if (a->binning_capacity > 0 && !a->binning_buffer) return fail(VIDU4D_E_INVALID, "binning_buffer is NULL");
+
+    BackwardArgs ba;
+    ba.cam = make_camera_params(a->viewmatrix, a->campos, a->width, a->height, a->tan_fovx, a->tan_fovy, a->D, a->M);
+    BinState b;
+    carve_geom((char*)a->geom_buffer, a->P, ba.geom);
+    carve_image((char*)a->image_buffer, a->width, a->height, ba.img);
+    carve_binning((char*)a->binning_buffer, a->binning_capacity, b);
+    const int side = sort_passes(ba.cam.grid_x, ba.cam.grid_y) & 1;
+    ba.point_list = a->binning_capacity > 0 ? b.vals[side] : nullptr;
+    ba.P = a->P;
+    ba.background = a->background;
+    ba.means3D = a->means3D;
+    ba.radii = a->radii;
+    ba.shs = a->shs;
+    ba.colors_precomp = a->colors_precomp;
+    ba.scales = a->scales;
+    ba.rotations = a->rotations;
+    ba.dL_dcolor = a->dL_dout_color;
+    ba.dL_dothers = a->dL_dout_others;
+    uintptr_t ws = ((uintptr_t)a->workspace + 255) & ~(uintptr_t)255;
+    ba.acc = (float*)ws;
+    ba.dL_dmeans2D = a->dL_dmeans2D;
+    ba.dL_dcolors = a->dL_dcolors;
+    ba.dL_dopacity = a->dL_dopacity;
+    ba.dL_dmeans3D = a->dL_dmeans3D;
+    ba.dL_dtransMat = a->dL_dtransMat;
+    ba.dL_dsh = a->dL_dsh;
+    ba.dL_dscales = a->dL_dscales;
+    ba.dL_drotations = a->dL_drotations;
+
+    {
+        StageTimer t(ST_BWD_ZERO, stream);
+        HIP_TRY(hipMemsetAsync(ba.acc, 0, (size_t)a->P * ACC_FLOATS * sizeof(float), stream));
+    }
+    {
+        StageTimer t(ST_BLEND_BWD, stream);
+        launch_blend_bwd(ba, stream);
+    }
+    STAGE_CHECK(a->debug, stream, "blend_backward");
+    {
+        StageTimer t(ST_PREPROCESS_BWD, stream);
+        launch_preprocess_bwd(ba, stream);
+    }
+    STAGE_CHECK(a->debug, stream, "preprocess_backward");
+    return VIDU4D_OK;
+}
+
+extern "C" int vidu4d_surfel_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                          uint8_t* present, void* stream_)
+{
+    (void)projmatrix;
+    if (P < 0) return fail(VIDU4D_E_INVALID, "negative P");
+    if (P == 0) return VIDU4D_OK;
+    if (!means3D || !viewmatrix || !present) return fail(VIDU4D_E_INVALID, "NULL pointer");
+    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_);
+    STAGE_CHECK(0, (hipStream_t)stream_, "mark_visible");
+    return VIDU4D_OK;
+}
+
+extern "C" int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* a, const void* binning, int64_t capacity,
+                                        int what, void* dst, size_t dst_bytes, int64_t* count, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a || !dst || !count) return fail(VIDU4D_E_INVALID, "NULL argument");
+    GeomState g;
+    ImageState img;
+    BinState b;
+    carve_geom((char*)a->geom_buffer, a->P, g);
+    carve_image((char*)a->image_buffer, a->width, a->height, img);
+    carve_binning((char*)binning, capacity, b);
+    const int gx = (a->width + TILE - 1) / TILE, gy = (a->height + TILE - 1) / TILE;
+    const int side = sort_passes(gx, gy) & 1;
+    uint32_t R = 0;
+    HIP_TRY(hipMemcpyAsync(&R, &g.hdr->num_rendered, sizeof(R), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const size_t hw = (size_t)a->width * a->height;
+    const void* src = nullptr;
+    size_t n = 0, esz = 4;
+    switch (what) {
+        case VIDU4D_STATE_NUM_RENDERED: src = &g.hdr->num_rendered; n = 1; break;
+        case VIDU4D_STATE_RECORDS: src = g.rec; n = (size_t)a->P * REC_FLOATS; break;
+        case VIDU4D_STATE_TILES_TOUCHED: src = g.tiles_touched; n = (size_t)a->P; break;
+        case VIDU4D_STATE_POINT_LIST: src = b.vals[side]; n = R; break;
+        case VIDU4D_STATE_SORTED_KEYS: src = b.keys[side]; n = R; esz = 8; break;
+        case VIDU4D_STATE_RANGES: src = img.ranges; n = (size_t)gx * gy * 2; break;
+        case VIDU4D_STATE_FINAL_T: src = img.final_T; n = 3 * hw; break;
+        case VIDU4D_STATE_N_CONTRIB: src = img.n_contrib; n = 2 * hw; break;
+        case VIDU4D_STATE_UNSORTED_KEYS: src = b.keys[0]; n = R; esz = 8; break;
+        case VIDU4D_STATE_UNSORTED_VALUES: src = b.vals[0]; n = R; break;
+        default: return fail(VIDU4D_E_INVALID, "unknown state array %d", what);
+    }
+    if ((what == VIDU4D_STATE_POINT_LIST || what == VIDU4D_STATE_SORTED_KEYS || what >= VIDU4D_STATE_UNSORTED_KEYS) &&
+        (int64_t)R > capacity)
+        return fail(VIDU4D_E_BUFFER, "num_rendered %u exceeds capacity %lld", R, (long long)capacity);
+    *count = (int64_t)n;
+    if (n * esz > dst_bytes) return fail(VIDU4D_E_BUFFER, "dst too small: need %zu bytes", n * esz);
+    if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * esz, hipMemcpyDefault, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return VIDU4D_OK;
+}

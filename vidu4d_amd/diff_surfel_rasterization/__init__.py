@@ -1,0 +1,135 @@
+"""MI355X-native `diff_surfel_rasterization`: the operator boundary of Vidu4D Stage-3.
+
+Public surface = the reference package's
+(/root/reference/gs/submodules/diff-surfel-rasterization/diff_surfel_rasterization/__init__.py):
+
+    GaussianRasterizationSettings   NamedTuple, 12 fields in the reference order (:158-170)
+    GaussianRasterizer              nn.Module: __init__(raster_settings), markVisible(positions),
+                                    forward(means3D, means2D, opacities, shs=None, colors_precomp=None,
+                                            scales=None, rotations=None, cov3D_precomp=None)
+                                    -> (color (3,H,W), radii (N,) int32, allmap (8,H,W))   (:172-222)
+    rasterize_gaussians             functional form (:21-42)
+    _RasterizeGaussians             the autograd.Function (:44-156); backward returns 9 entries
+                                    (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, None)
+
+so `from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer`
+(gs/gaussian_renderer/__init__.py:14) keeps working.  The native module behind it is
+`vidu4d_amd._C` (hand-written HIP through a C ABI) instead of the CUDA pybind extension.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from .. import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU copies of the call arguments, written to snapshot_{fw,bw}.dump when a debug call fails
+    (same file names and format as upstream, :83-90, :133-140)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
+                       cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                       rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        if rs.debug:
+            saved = _snapshot(native_args)
+            try:
+                out = _C.rasterize_gaussians(*native_args)
+            except Exception:
+                torch.save(saved, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _C.rasterize_gaussians(*native_args)
+        num_rendered, color, others, radii, geom_buf, binning_buf, img_buf = out
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.binning_capacity = getattr(binning_buf, "_vidu4d_capacity", max(num_rendered, 1))
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf,
+                              binning_buf, img_buf)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, others
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf,
+         img_buf) = ctx.saved_tensors
+        native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                       rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh,
+                       rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
+        if rs.debug:
+            saved = _snapshot(native_args)
+            try:
+                grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity)
+            except Exception:
+                torch.save(saved, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity)
+        (g_means2D, g_colors_precomp, g_opacities, g_means3D, g_cov3Ds_precomp, g_sh, g_scales,
+         g_rotations) = grads
+        return (g_means3D, g_means2D, g_sh, g_colors_precomp, g_opacities, g_scales, g_rotations, g_cov3Ds_precomp,
+                None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points in front of the near plane (z_view > 0.2)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        have_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (have_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        def absent():
+            return torch.empty(0, dtype=torch.float32, device=means3D.device)
+
+        shs = absent() if shs is None else shs
+        colors_precomp = absent() if colors_precomp is None else colors_precomp
+        scales = absent() if scales is None else scales
+        rotations = absent() if rotations is None else rotations
+        cov3D_precomp = absent() if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)
