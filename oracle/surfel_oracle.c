@@ -34,6 +34,9 @@
  *     2.0f*(dx*dx+dy*dy) in fp32, which is what is computed here.
  *   - depth < NEAR_PLANE (double 0.2) is equivalent to the fp32 test depth < 0.2f.
  *   - mapped_depth / dmd_dd (fp64 sub-expressions in the reference) are evaluated in fp32 here.
+ *   - the ray/splat intersection (eval_pair) uses explicit fused multiply-adds in a fixed sequence
+ *     (what nvcc's default contraction does to the reference in an unspecified way): its cross
+ *     product cancels catastrophically, so the rounding of its inputs decides threshold tests.
  *   - float->int conversions saturate and map NaN to 0 (what both NVIDIA cvt.rzi and gfx950
  *     v_cvt_i32_f32 do), instead of C's undefined behaviour.
  *   - backward accumulations (the reference's fp32 atomicAdd in arbitrary order) are summed in
@@ -445,28 +448,31 @@ typedef struct {
     float G, alpha;
 } pair_eval;
 
+/* The operation sequence (explicit fmaf, no other contraction) is part of the parity contract:
+ * vidu4d_amd/csrc/surfel_math.h eval_pair states the identical sequence, see the comment there. */
 static int eval_pair(const float* Tu, const float* Tv, const float* Tw, const float* xy, float opacity, float pixx,
                      float pixy, pair_eval* e)
 {
-    e->kx = -Tu[0] + pixx * Tw[0];
-    e->ky = -Tu[1] + pixx * Tw[1];
-    e->kz = -Tu[2] + pixx * Tw[2];
-    e->lx = -Tv[0] + pixy * Tw[0];
-    e->ly = -Tv[1] + pixy * Tw[1];
-    e->lz = -Tv[2] + pixy * Tw[2];
-    const float px = e->ky * e->lz - e->kz * e->ly; /* auxiliary.h:152-158 */
-    const float py = e->kz * e->lx - e->kx * e->lz;
-    const float pz = e->kx * e->ly - e->ky * e->lx;
+    e->kx = fmaf(pixx, Tw[0], -Tu[0]);
+    e->ky = fmaf(pixx, Tw[1], -Tu[1]);
+    e->kz = fmaf(pixx, Tw[2], -Tu[2]);
+    e->lx = fmaf(pixy, Tw[0], -Tv[0]);
+    e->ly = fmaf(pixy, Tw[1], -Tv[1]);
+    e->lz = fmaf(pixy, Tw[2], -Tv[2]);
+    const float px = fmaf(e->ky, e->lz, -(e->kz * e->ly)); /* auxiliary.h:152-158 */
+    const float py = fmaf(e->kz, e->lx, -(e->kx * e->lz));
+    const float pz = fmaf(e->kx, e->ly, -(e->ky * e->lx));
     if (pz == 0.0f) return 0;
     e->pz = pz;
-    e->sx = px / pz;
-    e->sy = py / pz;
-    e->rho3d = e->sx * e->sx + e->sy * e->sy;
+    const float ipz = 1.0f / pz;
+    e->sx = px * ipz;
+    e->sy = py * ipz;
+    e->rho3d = fmaf(e->sx, e->sx, e->sy * e->sy);
     e->dx = xy[0] - pixx;
     e->dy = xy[1] - pixy;
-    e->rho2d = 2.0f * (e->dx * e->dx + e->dy * e->dy);
+    e->rho2d = 2.0f * fmaf(e->dx, e->dx, e->dy * e->dy);
     const float rho = e->rho3d < e->rho2d ? e->rho3d : e->rho2d; /* min(rho3d, rho2d) */
-    e->depth = (e->rho3d <= e->rho2d) ? (e->sx * Tw[0] + e->sy * Tw[1]) + Tw[2] : Tw[2];
+    e->depth = (e->rho3d <= e->rho2d) ? fmaf(e->sx, Tw[0], fmaf(e->sy, Tw[1], Tw[2])) : Tw[2];
     if (e->depth < NEAR_PLANE_F) return 0;
     const float power = -0.5f * rho;
     if (power > 0.0f) return 0;

@@ -16,7 +16,7 @@ def lib():
         src = os.path.join(_HERE, "host_emul.cpp")
         hdr = os.path.join(_HERE, "..", "..", "vidu4d_amd", "csrc", "surfel_math.h")
         if (not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
-            subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+            subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-mfma",
                                    "-Wno-unknown-pragmas", "-o", _LIB, src])
         _lib = C.CDLL(_LIB)
     return _lib

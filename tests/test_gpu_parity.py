@@ -31,7 +31,7 @@ def _state(what, out, sc, dtype, count):
     return _C.read_state(what, None, geom, binning, img, sc.num_surfels, sc.width, sc.height, dtype, count).numpy()
 
 
-def _check_forward(sc, st, out):
+def _check_forward(sc, st, out, colors=None):
     R, color, others, radii, geom, binning, img = out
     P, W, H = sc.num_surfels, sc.width, sc.height
     gx, gy = st["grid"]
@@ -43,7 +43,8 @@ def _check_forward(sc, st, out):
     assert np.array_equal(rec[vis, 0:9], st["transMat"][vis]), "homography must be bit-exact (feeds the binning)"
     assert np.array_equal(rec[vis, 9:11], st["means2D"][vis])
     assert np.array_equal(rec[vis, 15], st["depths"][vis])
-    assert_close("rgb", rec[vis, 16:19], st["rgb"][vis], rtol=1e-6, outlier_fraction=0)
+    want_rgb = st["rgb"] if colors is None else to_np(colors)
+    assert_close("rgb", rec[vis, 16:19], want_rgb[vis], rtol=1e-6, outlier_fraction=0)
     keys = _state("sorted_keys", out, sc, torch.int64, max(R, 1)).view(np.uint64)
     assert np.array_equal(keys, st["point_list_keys"]), "sorted keys differ"
     plist = _state("point_list", out, sc, torch.int32, max(R, 1)).view(np.uint32)
@@ -106,7 +107,7 @@ def test_colors_precomp_path(gpu_device):
     cols = torch.rand(sc.num_surfels, 3, generator=g)
     st = oracle_forward(sc, colors_precomp=cols)
     d, shs, colsd, out = _native_forward(sc, gpu_device, colors_precomp=cols)
-    _check_forward(sc, st, out)
+    _check_forward(sc, st, out, colors=cols)
     _check_backward(sc, st, d, shs, colsd, out, gpu_device)
 
 

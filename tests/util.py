@@ -29,7 +29,8 @@ def to_np(x):
     return np.asarray(x)
 
 
-def assert_close(name, got, want, rtol=RTOL, atol=0.0, outlier_fraction=OUTLIER_FRACTION, outlier_rtol=OUTLIER_RTOL):
+def assert_close(name, got, want, rtol=RTOL, atol=0.0, outlier_fraction=OUTLIER_FRACTION, outlier_rtol=OUTLIER_RTOL,
+                 min_outliers=None):
     got = to_np(got).astype(np.float64)
     want = to_np(want).astype(np.float64)
     assert got.shape == want.shape, f"{name}: shape {got.shape} != {want.shape}"
@@ -40,8 +41,20 @@ def assert_close(name, got, want, rtol=RTOL, atol=0.0, outlier_fraction=OUTLIER_
     bad = err > tol
     frac = bad.mean() if bad.size else 0.0
     worst = err.max() / (scale + 1e-30) if err.size else 0.0
-    assert frac <= outlier_fraction, (f"{name}: {bad.sum()} of {bad.size} entries ({frac:.2e}) exceed rtol {rtol:g} "
-                                      f"(scale {scale:.3e}, worst {worst:.3e})")
+    # one flipped (pixel, surfel) pair touches one pixel of an image plane, or one surfel's row of a
+    # per-surfel tensor: that many entries are always tolerated when the fraction budget is non-zero
+    if min_outliers is None:
+        if got.ndim == 3 and got.shape[0] <= 8:      # (C,H,W) image: one pixel
+            min_outliers = got.shape[0]
+        elif got.ndim == 2 and got.shape[1] > 64:    # (H,W) plane
+            min_outliers = 1
+        elif got.ndim >= 2:                          # per-surfel tensor: one row
+            min_outliers = int(np.prod(got.shape[1:]))
+        else:
+            min_outliers = 1
+    allowed = max(int(np.ceil(outlier_fraction * bad.size)), min_outliers) if outlier_fraction > 0 else 0
+    assert bad.sum() <= allowed, (f"{name}: {bad.sum()} of {bad.size} entries ({frac:.2e}) exceed rtol {rtol:g} "
+                                  f"(scale {scale:.3e}, worst {worst:.3e}, allowed {allowed})")
     assert (err <= outlier_rtol * scale + atol).all(), f"{name}: worst error {worst:.3e} beyond the outlier bound"
     return worst
 

@@ -84,6 +84,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles the HIP runtime (libamdhip64) that owns the device memory and
+    # streams we are handed; loading ours first would bring a second runtime into the process.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()

@@ -159,6 +159,7 @@ static int check_forward(const Vidu4dSurfelForwardArgs* a)
 extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();  // a stale error of an unrelated earlier HIP call must not be blamed on us
     int rc = check_forward(a);
     if (rc) return rc;
     GeomState g;
@@ -206,6 +207,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
                                          int64_t capacity, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();  // a stale error of an unrelated earlier HIP call must not be blamed on us
     int rc = check_forward(a);
     if (rc) return rc;
     if (capacity < 0) return fail(VIDU4D_E_INVALID, "negative capacity");
@@ -252,6 +254,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
 extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();  // a stale error of an unrelated earlier HIP call must not be blamed on us
     if (!a) return fail(VIDU4D_E_INVALID, "args is NULL");
     if (a->P < 0 || a->width <= 0 || a->height <= 0) return fail(VIDU4D_E_INVALID, "bad sizes");
     if (a->transMat_precomp) return fail(VIDU4D_E_UNSUPPORTED, "transMat_precomp is not supported (see forward)");
@@ -318,6 +321,7 @@ extern "C" int vidu4d_surfel_mark_visible(int P, const float* means3D, const flo
     if (P < 0) return fail(VIDU4D_E_INVALID, "negative P");
     if (P == 0) return VIDU4D_OK;
     if (!means3D || !viewmatrix || !present) return fail(VIDU4D_E_INVALID, "NULL pointer");
+    (void)hipGetLastError();
     launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_);
     STAGE_CHECK(0, (hipStream_t)stream_, "mark_visible");
     return VIDU4D_OK;

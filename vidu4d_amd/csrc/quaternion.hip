@@ -91,7 +91,11 @@ int done(void)
 {
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
-unsigned blocks(int64_t B) { return (unsigned)((B + 255) / 256); }
+unsigned blocks(int64_t B)
+{
+    (void)hipGetLastError();  // drop stale errors of unrelated earlier HIP calls
+    return (unsigned)((B + 255) / 256);
+}
 
 }  // namespace
 

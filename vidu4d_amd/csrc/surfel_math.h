@@ -388,29 +388,37 @@ SURFEL_HD float fast_rcp(float x)
 }
 
 // Tu,Tv,Tw: homography rows; (cx,cy): projected centre; returns false when the pair is skipped.
+//
+// THRESHOLD-EXACT: the ray/splat intersection is a cross product of two large, nearly parallel
+// plane vectors, so a different rounding of its inputs (FMA contraction or not) moves rho3d by
+// ~1e-5 relative and flips the alpha >= 1/255, rho3d <= rho2d and T < 1e-4 decisions for a few
+// pixels per image.  To keep the GPU and the CPU oracle on the same side of every threshold the
+// operation sequence below is fixed -- explicit fmaf, contraction off -- and oracle/surfel_oracle.c
+// (eval_pair) states the identical sequence.  Only rcp and exp differ (<= 2 ulp).
 SURFEL_HD bool eval_pair(const float Tu[3], const float Tv[3], const float Tw[3], float cx, float cy, float opacity,
                          float pixx, float pixy, PairEval& e)
 {
-    e.kx = pixx * Tw[0] - Tu[0];
-    e.ky = pixx * Tw[1] - Tu[1];
-    e.kz = pixx * Tw[2] - Tu[2];
-    e.lx = pixy * Tw[0] - Tv[0];
-    e.ly = pixy * Tw[1] - Tv[1];
-    e.lz = pixy * Tw[2] - Tv[2];
-    const float px = e.ky * e.lz - e.kz * e.ly;
-    const float py = e.kz * e.lx - e.kx * e.lz;
-    const float pz = e.kx * e.ly - e.ky * e.lx;
+#pragma clang fp contract(off)
+    e.kx = fmaf(pixx, Tw[0], -Tu[0]);
+    e.ky = fmaf(pixx, Tw[1], -Tu[1]);
+    e.kz = fmaf(pixx, Tw[2], -Tu[2]);
+    e.lx = fmaf(pixy, Tw[0], -Tv[0]);
+    e.ly = fmaf(pixy, Tw[1], -Tv[1]);
+    e.lz = fmaf(pixy, Tw[2], -Tv[2]);
+    const float px = fmaf(e.ky, e.lz, -(e.kz * e.ly));
+    const float py = fmaf(e.kz, e.lx, -(e.kx * e.lz));
+    const float pz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
     if (pz == 0.0f) return false;
     e.pz = pz;
     const float ipz = fast_rcp(pz);
     e.sx = px * ipz;
     e.sy = py * ipz;
-    e.rho3d = e.sx * e.sx + e.sy * e.sy;
+    e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
     e.dx = cx - pixx;
     e.dy = cy - pixy;
-    e.rho2d = 2.0f * (e.dx * e.dx + e.dy * e.dy);  // FilterInvSquare == 2 (auxiliary.h:20-21)
+    e.rho2d = 2.0f * fmaf(e.dx, e.dx, e.dy * e.dy);  // FilterInvSquare == 2 (auxiliary.h:20-21)
     const float rho = fminf(e.rho3d, e.rho2d);
-    e.depth = (e.rho3d <= e.rho2d) ? (e.sx * Tw[0] + e.sy * Tw[1]) + Tw[2] : Tw[2];
+    e.depth = (e.rho3d <= e.rho2d) ? fmaf(e.sx, Tw[0], fmaf(e.sy, Tw[1], Tw[2])) : Tw[2];
     if (e.depth < NEAR_PLANE) return false;
     const float power = -0.5f * rho;
     if (power > 0.0f) return false;
@@ -421,6 +429,7 @@ SURFEL_HD bool eval_pair(const float Tu[3], const float Tv[3], const float Tw[3]
 
 SURFEL_HD float map_depth(float depth)
 {
+#pragma clang fp contract(off)
     return (FAR_PLANE * depth - FAR_PLANE * NEAR_PLANE) * fast_rcp((FAR_PLANE - NEAR_PLANE) * depth);
 }
 
@@ -439,23 +448,24 @@ struct FwdPixel {
 SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal[3], const float rgb[3],
                               uint32_t contributor)
 {
-    const float test_T = s.T * (1.0f - e.alpha);
+#pragma clang fp contract(off)
+    const float test_T = s.T * (1.0f - e.alpha);  // THRESHOLD-EXACT (same two roundings as the oracle)
     if (test_T < T_EPS) return false;
     const float w = e.alpha * s.T;
     const float A = 1.0f - s.T;
     const float m = map_depth(e.depth);
-    const float error = m * m * A + s.dist2 - 2.0f * m * s.dist1;
-    s.distortion += error * w;
+    const float error = fmaf(m * m, A, fmaf(-2.0f * m, s.dist1, s.dist2));
+    s.distortion = fmaf(error, w, s.distortion);
     if (s.T > 0.5f) {
         s.median_depth = e.depth;
         s.median_weight = w;
         s.median_contributor = contributor;
     }
-    for (int ch = 0; ch < 3; ch++) s.N[ch] += normal[ch] * w;
-    s.D += e.depth * w;
-    s.dist1 += m * w;
-    s.dist2 += m * m * w;
-    for (int ch = 0; ch < 3; ch++) s.C[ch] += rgb[ch] * w;
+    for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(normal[ch], w, s.N[ch]);
+    s.D = fmaf(e.depth, w, s.D);
+    s.dist1 = fmaf(m, w, s.dist1);
+    s.dist2 = fmaf(m * m, w, s.dist2);
+    for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(rgb[ch], w, s.C[ch]);
     s.T = test_T;
     s.last_contributor = contributor;
     return true;
