@@ -108,3 +108,24 @@ def test_golden_fixtures():
             assert_close(f"{f}:{k}", st[k], z[k], rtol=1e-6, outlier_fraction=0)
         for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh"):
             assert_close(f"{f}:{k}", g[k], z[k], rtol=1e-6, outlier_fraction=0)
+
+
+def test_reference_golden_fixtures_pin_the_oracle():
+    """tests/golden/ref_*.npz were produced BY THE REFERENCE ITSELF -- its own rasterizer sources
+    compiled for gfx950 and run on an MI355X (oracle/ref_build/make_ref_golden.py).  The oracle must
+    reproduce them: integers bit-for-bit, floats to 1e-4 of scale.  This is what pins the oracle."""
+    files = sorted(f for f in os.listdir(GOLDEN) if f.startswith("ref_") and f.endswith(".npz"))
+    assert files, "no reference-generated fixtures committed"
+    for f in files:
+        z = np.load(os.path.join(GOLDEN, f))
+        st = so.forward(z["means3D"], z["opacities"], z["scales"], z["rotations"], z["viewmatrix"], z["projmatrix"],
+                        z["campos"], z["bg"], int(z["W"]), int(z["H"]), float(z["tanfovx"]), float(z["tanfovy"]),
+                        int(z["sh_degree"]), shs=z["shs"])
+        g = so.backward(st, z["dL_dcolor"], z["dL_dothers"])
+        for k in ("radii", "point_list", "ranges"):
+            assert np.array_equal(st[k], z[k]), (f, k)
+        assert (st["n_contrib"] != z["n_contrib"]).mean() <= 2e-3
+        for k in ("color", "others"):
+            assert_close(f"{f}:{k}", st[k], z[k], atol=2e-6, outlier_fraction=2e-3)
+        for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh"):
+            assert_close(f"{f}:{k}", g[k], z[k], outlier_fraction=2e-3)
