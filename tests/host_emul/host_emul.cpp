@@ -44,13 +44,14 @@ extern "C" void emul_preprocess(int P, int D, int M, const float* means3D, const
         for (int k = 0; k < 3; k++) { r[R_NX + k] = o.normal[k]; r[R_RGB + k] = rgb[k]; }
         r[R_DEPTH] = o.depth;
         memcpy(&r[R_CLAMP], &mask, 4);
+        contribution_box(o.T, o.center[0], o.center[1], opacities[i], r + R_BOX);
         radii[i] = o.radius; tiles[i] = o.tiles;
     }
 }
 
 extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec,
                                 const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                                float* out_others)
+                                float* out_others, int cull)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const size_t HW = (size_t)W * H;
@@ -64,7 +65,8 @@ extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint
             for (uint32_t i = r0; i < r1; i++) {
                 const float* r = rec + (size_t)point_list[i] * REC_FLOATS;
                 PairEval e;
-                if (!eval_pair(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
+                if (cull && (pixx < r[R_BOX] || pixx > r[R_BOX + 2] || pixy < r[R_BOX + 1] || pixy > r[R_BOX + 3])) continue;
+                if (!eval_pair_flat(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
                 if (!fwd_accumulate(s, e, r + R_NX, r + R_RGB, i - r0 + 1)) break;
             }
             const size_t pid = (size_t)py * W + px;
@@ -80,7 +82,7 @@ extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint
 
 extern "C" void emul_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib,
-                                const float* dL_dcolor, const float* dL_dothers, double* acc /*[P][20]*/)
+                                const float* dL_dcolor, const float* dL_dothers, double* acc /*[P][20]*/, int cull)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const size_t HW = (size_t)W * H;
@@ -105,7 +107,8 @@ extern "C" void emul_render_bwd(int W, int H, const uint32_t* ranges, const uint
                 const uint32_t id = point_list[r0 + ci];
                 const float* r = rec + (size_t)id * REC_FLOATS;
                 PairEval e;
-                if (!eval_pair(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
+                if (cull && (pixx < r[R_BOX] || pixx > r[R_BOX + 2] || pixy < r[R_BOX + 1] || pixy > r[R_BOX + 3])) continue;
+                if (!eval_pair_flat(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
                 float g[ACC_FLOATS];
                 bwd_pair(s, e, r + 6, r[R_OPAC], r + R_NX, r + R_RGB, pixx, pixy,
                          (uint32_t)ci + 1 == s.median_contributor, g);

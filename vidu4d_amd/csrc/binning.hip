@@ -42,30 +42,35 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint32_t* n
 }
 
 // Exclusive scan of counts[RADIX * nblocks] in place (digit-major), one 1024-thread workgroup.
+// Coalesced: the array is walked in 1024-wide strips, each strip scanned with wave64 shuffles +
+// a 16-entry LDS step, and a running carry links the strips (total <= 256 * 1024 entries at 4M
+// pairs, i.e. <= 256 strips).
 __global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t* counts, int total)
 {
     __shared__ uint32_t s_part[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = (total + 1023) / 1024;
-    const int lo = threadIdx.x * chunk;
-    const int hi = lo + chunk < total ? lo + chunk : total;
-    uint32_t sum = 0;
-    for (int i = lo; i < hi; i++) sum += counts[i];
-    uint32_t inc = sum;
+    uint32_t carry = 0;
+    for (int base = 0; base < total; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < total ? counts[i] : 0;
+        uint32_t inc = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) s_part[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; w++) base += s_part[w];
-    uint32_t run = base + inc - sum;
-    for (int i = lo; i < hi; i++) {
-        const uint32_t c = counts[i];
-        counts[i] = run;
-        run += c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_part[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = s_part[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        if (i < total) counts[i] = carry + wbase + inc - v;
+        carry += tot;
+        __syncthreads();
     }
 }
 

@@ -10,9 +10,14 @@
 //   * workgroup -> tile mapping is XCD-aware: workgroup b is dispatched to XCD b % 8, so XCD x gets
 //     the contiguous band of tiles [x*per, (x+1)*per); neighbouring tiles, which share most of
 //     their surfels, then hit the same 4 MiB L2;
-//   * the tile's depth-sorted surfel list is staged 256 entries at a time into LDS as 80-byte
-//     records (five ds_write_b128 per lane, conflict-free at a 20-dword stride) and read back with
-//     wave-uniform (broadcast) ds_read_b128;
+//   * the tile's depth-sorted surfel list is staged 256 (forward) / 128 (backward) entries at a
+//     time into LDS as 80-byte records (five ds_write_b128 per lane, conflict-free at a 20-dword
+//     stride) and read back with wave-uniform (broadcast) ds_read_b128;
+//   * while staging, every thread tests its entry's conservative contribution box against the four
+//     quadrants; wave64 ballots turn that into one 64-bit mask per (quadrant, staging wave), and each
+//     wave then iterates only over the set bits with scalar bit tricks (s_ff1 / s_and): list entries
+//     that cannot reach a wave's 64 pixels are never evaluated.  The pair evaluation itself is
+//     branch-free; the only branches in the loop are wave-uniform;
 //   * backward: all 64 lanes of a wave work on the same list entry, so the 18 gradient components
 //     are first reduced across the wave with a DPP reduce-scatter butterfly (row_mirror,
 //     row_half_mirror, quad_perm: 15 DPP adds for 16 values instead of 96), then combined across the
@@ -22,7 +27,8 @@
 
 namespace surfel {
 
-constexpr int BLEND_BATCH = 256;
+constexpr int FWD_BATCH = 256;  // list entries staged per round (one per thread)
+constexpr int BWD_BATCH = 128;
 
 struct TileCoord {
     int tile, tx, ty;
@@ -42,16 +48,42 @@ __device__ __forceinline__ TileCoord xcd_tile(int grid_x, int grid_y)
 }
 inline int xcd_grid(int grid_x, int grid_y) { return ((grid_x * grid_y + 7) >> 3) * 8; }
 
-__device__ __forceinline__ void stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
+// Stages one surfel record (q0..q4) into LDS slot `slot` and returns q5, the contribution box.
+__device__ __forceinline__ float4 stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
 {
     const float4* src = reinterpret_cast<const float4*>(rec + (size_t)id * REC_FLOATS);
-    const float4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    const float4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], box = src[5];
     float4* dst = s_rec + slot * 5;
     dst[0] = a;
     dst[1] = b;
     dst[2] = c;
     dst[3] = d;
     dst[4] = e;
+    return box;
+}
+
+// Per-wave cull masks.  Thread t staged list entry t of the batch and knows its contribution box;
+// for each of the four 8x8 pixel quadrants of the tile (one per wave) a wave64 ballot says which
+// of the 64 entries this wave staged can touch that quadrant.  s_mask[q][w] = entries 64w..64w+63
+// relevant to quadrant q.  Afterwards wave q walks only the set bits: entries that cannot
+// contribute to its pixels cost nothing.
+__device__ __forceinline__ void publish_cull_masks(unsigned long long (*s_mask)[4], bool valid, float4 box, int tile_x0,
+                                                   int tile_y0, int wave, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float rx0 = (float)(tile_x0 + (q & 1) * 8) + 0.5f, ry0 = (float)(tile_y0 + (q >> 1) * 8) + 0.5f;
+        const bool hit = valid && !(box.z < rx0 || box.x > rx0 + 7.0f || box.w < ry0 || box.y > ry0 + 7.0f);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_mask[q][wave] = m;
+    }
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y,
@@ -61,7 +93,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                        float* __restrict__ out_color, float* __restrict__ out_others)
 {
-    __shared__ float4 s_rec[BLEND_BATCH * 5];
+    __shared__ float4 s_rec[FWD_BATCH * 5];
+    __shared__ unsigned long long s_mask[4][4];
     const TileCoord tc = xcd_tile(grid_x, grid_y);
     if (!tc.valid) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,19 +107,31 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
 
     FwdPixel s;
     bool done = !inside;
-    for (int base = 0; todo > 0; base += BLEND_BATCH, todo -= BLEND_BATCH) {
+    for (int base = 0; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
         if (__syncthreads_count(done) == 256) break;
-        if ((int)threadIdx.x < todo) stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        const bool have = (int)threadIdx.x < todo;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) box = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
         __syncthreads();
-        const int cnt = todo < BLEND_BATCH ? todo : BLEND_BATCH;
-        for (int j = 0; !done && j < cnt; j++) {
-            const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-            const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
-            PairEval e;
-            if (!eval_pair(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e)) continue;
-            const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-            const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-            if (!fwd_accumulate(s, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
+        if (__all(done)) continue;  // this wave's 64 pixels are saturated; it keeps helping to stage
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            unsigned long long m = uniform_u64(s_mask[wave][k]);
+            while (m) {
+                const int j = k * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+                const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
+                PairEval e;
+                const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && !done;
+                if (!__any(ok)) continue;
+                if (ok) {
+                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                    const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                    if (!fwd_accumulate(s, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
+                }
+            }
         }
     }
     if (inside) {
@@ -173,9 +218,10 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
                                                        const float* __restrict__ dL_dcolor,
                                                        const float* __restrict__ dL_dothers, float* __restrict__ acc)
 {
-    __shared__ float4 s_rec[BLEND_BATCH * 5];
-    __shared__ float s_acc[BLEND_BATCH * ACC_FLOATS];
-    __shared__ uint32_t s_id[BLEND_BATCH];
+    __shared__ float4 s_rec[BWD_BATCH * 5];
+    __shared__ float s_acc[BWD_BATCH * ACC_FLOATS];
+    __shared__ uint32_t s_id[BWD_BATCH];
+    __shared__ unsigned long long s_mask[4][4];
     __shared__ uint32_t s_max;
     const TileCoord tc = xcd_tile(grid_x, grid_y);
     if (!tc.valid) return;
@@ -213,17 +259,17 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     s.bg_dot_dpixel = bg[0] * s.dL_dpixel[0] + bg[1] * s.dL_dpixel[1] + bg[2] * s.dL_dpixel[2];
 
     // entries at or beyond every pixel's last contributor never matter: skip them wholesale
+    // (per wave for the inner loop, per workgroup for the staging)
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
-    {
-        uint32_t m = s.last_contributor;
+    uint32_t wave_last = s.last_contributor;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)m, d, 64);
-            m = o > m ? o : m;
-        }
-        if (lane == 0) atomicMax(&s_max, m);
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)wave_last, d, 64);
+        wave_last = o > wave_last ? o : wave_last;
     }
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+    if (lane == 0) atomicMax(&s_max, wave_last);
     __syncthreads();
     const int n_used = (int)s_max;
 
@@ -232,53 +278,68 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     const int slot16 = c16 < 9 ? c16 : (c16 == 9 ? A_OPAC : (c16 < 13 ? c16 + 2 : c16 + 3));
     const int slot2 = A_M2D + ((lane >> 3) & 1);
 
-    for (int hi = n_used; hi > 0; hi -= BLEND_BATCH) {
-        const int cnt = hi < BLEND_BATCH ? hi : BLEND_BATCH;
+    for (int hi = n_used; hi > 0; hi -= BWD_BATCH) {
+        const int cnt = hi < BWD_BATCH ? hi : BWD_BATCH;
         __syncthreads();
-        if ((int)threadIdx.x < cnt) {
-            const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)];
-            s_id[threadIdx.x] = id;
-            stage_record(s_rec, threadIdx.x, rec, id);
+        {
+            // threads 0..127 stage (back to front: slot t <-> list entry hi-1-t), all zero the accumulators
+            const bool have = (int)threadIdx.x < cnt;
+            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (have) {
+                const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)];
+                s_id[threadIdx.x] = id;
+                box = stage_record(s_rec, threadIdx.x, rec, id);
+            }
+            if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
+            for (int i = threadIdx.x; i < BWD_BATCH * ACC_FLOATS / 4; i += 256)
+                reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#pragma unroll
-        for (int k = 0; k < ACC_FLOATS / 4; k++)
-            reinterpret_cast<float4*>(s_acc)[threadIdx.x * (ACC_FLOATS / 4) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
 
-        for (int j = 0; j < cnt; j++) {
-            const uint32_t contributor = (uint32_t)(hi - 1 - j);
-            const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-            const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
-            PairEval e;
-            const bool ok = inside && contributor < s.last_contributor &&
-                            eval_pair(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e);
-            if (!__any(ok)) continue;
-            float g[ACC_FLOATS];
+#pragma unroll 1
+        for (int k = 0; k < BWD_BATCH / 64; k++) {
+            unsigned long long m = uniform_u64(s_mask[wave][k]);
+            while (m) {
+                const int j = k * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t contributor = (uint32_t)(hi - 1 - j);
+                if (contributor >= wave_last) continue;  // wave-uniform
+                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+                const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
+                PairEval e;
+                const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) &&
+                                contributor < s.last_contributor;  // (outside pixels have last_contributor 0)
+                if (!__any(ok)) continue;
+                float g[ACC_FLOATS];
 #pragma unroll
-            for (int k = 0; k < ACC_FLOATS; k++) g[k] = 0.f;
-            if (ok) {
-                const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-                const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                bwd_pair(s, e, Tw, q2.w, nrm, rgb, pixx, pixy, contributor + 1 == s.median_contributor, g);
-            }
-            float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
-                           g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
-            const float r16 = row_reduce_scatter16(v, lane);
-            if (r16 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot16], r16);
-            if (__any(g[A_M2D] != 0.f || g[A_M2D + 1] != 0.f)) {
-                const float r2 = row_reduce_scatter2(g[A_M2D], g[A_M2D + 1], lane);
-                if ((lane & 7) == 0 && r2 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot2], r2);
+                for (int i = 0; i < ACC_FLOATS; i++) g[i] = 0.f;
+                if (ok) {
+                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                    const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                    bwd_pair(s, e, Tw, q2.w, nrm, rgb, pixx, pixy, contributor + 1 == s.median_contributor, g);
+                }
+                float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
+                               g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
+                const float r16 = row_reduce_scatter16(v, lane);
+                if (r16 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot16], r16);
+                if (__any(g[A_M2D] != 0.f || g[A_M2D + 1] != 0.f)) {
+                    const float r2 = row_reduce_scatter2(g[A_M2D], g[A_M2D + 1], lane);
+                    if ((lane & 7) == 0 && r2 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot2], r2);
+                }
             }
         }
         __syncthreads();
-        if ((int)threadIdx.x < cnt) {
-            float* dst = acc + (size_t)s_id[threadIdx.x] * ACC_FLOATS;
-            const float* src = s_acc + threadIdx.x * ACC_FLOATS;
+        // flush: 2 threads per entry, 10 slots each
+        {
+            const int ent = threadIdx.x >> 1, half = threadIdx.x & 1;
+            if (ent < cnt) {
+                float* dst = acc + (size_t)s_id[ent] * ACC_FLOATS + half * 10;
+                const float* src = s_acc + ent * ACC_FLOATS + half * 10;
 #pragma unroll
-            for (int k = 0; k < ACC_FLOATS; k++) {
-                if (k == 15 || k == 19) continue;
-                const float val = src[k];
-                if (val != 0.f) atomicAdd(dst + k, val);
+                for (int i = 0; i < 10; i++) {
+                    const float val = src[i];
+                    if (val != 0.f) atomicAdd(dst + i, val);
+                }
             }
         }
     }

@@ -75,6 +75,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(PreprocessArg
             rec[2] = make_float4(o.T[8], o.center[0], o.center[1], a.opacities[idx]);
             rec[3] = make_float4(o.normal[0], o.normal[1], o.normal[2], o.depth);
             rec[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
+            float box[4];
+            contribution_box(o.T, o.center[0], o.center[1], a.opacities[idx], box);
+            rec[5] = make_float4(box[0], box[1], box[2], box[3]);
         }
         a.radii[idx] = radius;
         a.geom.tiles_touched[idx] = tiles;

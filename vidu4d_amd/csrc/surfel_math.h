@@ -31,12 +31,15 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_EPS = 0.0001f;
 
-// Per-surfel record written by preprocess and gathered by the blend kernels (5 x float4 = 80 B).
+// Per-surfel record written by preprocess and gathered by the blend kernels (6 x float4 = 96 B).
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z cx cy opacity
 //   q3 = n.x n.y n.z depth   | q4 = r g b clampmask(bits)
-constexpr int REC_FLOATS = 20;
+//   q5 = conservative pixel-space box outside which the surfel cannot contribute (x0 y0 x1 y1)
+constexpr int REC_FLOATS = 24;
+constexpr int REC_LDS_FLOATS = 20;  // q0..q4 are staged in LDS; q5 only feeds the per-wave cull masks
 enum RecSlot {
-    R_TU = 0, R_TV = 3, R_TW = 6, R_CX = 9, R_CY = 10, R_OPAC = 11, R_NX = 12, R_DEPTH = 15, R_RGB = 16, R_CLAMP = 19
+    R_TU = 0, R_TV = 3, R_TW = 6, R_CX = 9, R_CY = 10, R_OPAC = 11, R_NX = 12, R_DEPTH = 15, R_RGB = 16, R_CLAMP = 19,
+    R_BOX = 20
 };
 
 // Per-surfel gradient accumulator filled by the backward blend (20 floats = 80 B):
@@ -425,6 +428,91 @@ SURFEL_HD bool eval_pair(const float Tu[3], const float Tv[3], const float Tw[3]
     e.G = fast_exp(power);
     e.alpha = fminf(ALPHA_MAX, opacity * e.G);
     return e.alpha >= ALPHA_MIN;
+}
+
+// Same arithmetic as eval_pair (bit-identical values), without early returns: every lane of a wave
+// runs the full sequence and the skip conditions come back as one predicate.  The conditions are
+// the negations the reference writes (`if (x) continue`), so NaNs take the same side.
+SURFEL_HD bool eval_pair_flat(const float Tu[3], const float Tv[3], const float Tw[3], float cx, float cy,
+                              float opacity, float pixx, float pixy, PairEval& e)
+{
+#pragma clang fp contract(off)
+    e.kx = fmaf(pixx, Tw[0], -Tu[0]);
+    e.ky = fmaf(pixx, Tw[1], -Tu[1]);
+    e.kz = fmaf(pixx, Tw[2], -Tu[2]);
+    e.lx = fmaf(pixy, Tw[0], -Tv[0]);
+    e.ly = fmaf(pixy, Tw[1], -Tv[1]);
+    e.lz = fmaf(pixy, Tw[2], -Tv[2]);
+    const float px = fmaf(e.ky, e.lz, -(e.kz * e.ly));
+    const float py = fmaf(e.kz, e.lx, -(e.kx * e.lz));
+    const float pz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
+    e.pz = pz;
+    const float ipz = fast_rcp(pz);
+    e.sx = px * ipz;
+    e.sy = py * ipz;
+    e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
+    e.dx = cx - pixx;
+    e.dy = cy - pixy;
+    e.rho2d = 2.0f * fmaf(e.dx, e.dx, e.dy * e.dy);
+    const float rho = fminf(e.rho3d, e.rho2d);
+    e.depth = (e.rho3d <= e.rho2d) ? fmaf(e.sx, Tw[0], fmaf(e.sy, Tw[1], Tw[2])) : Tw[2];
+    const float power = -0.5f * rho;
+    e.G = fast_exp(power);
+    e.alpha = fminf(ALPHA_MAX, opacity * e.G);
+    return (pz != 0.0f) & !(e.depth < NEAR_PLANE) & !(power > 0.0f) & !(e.alpha < ALPHA_MIN);
+}
+
+// Conservative pixel-space box of the pixels a surfel can contribute to.  A pair contributes only if
+// alpha = min(0.99, o*exp(-rho/2)) >= 1/255 with rho = min(rho3d, rho2d), i.e. only if
+// rho3d <= rc or rho2d <= rc with rc = 2 ln(255 o).  {rho2d <= rc} is a disc of radius sqrt(rc/2)
+// around the projected centre; {rho3d <= rc} is the projection of the splat-space disc of radius
+// sqrt(rc), whose exact screen AABB follows from the homography like the reference's 1-sigma box
+// (forward.cu:133-163) with the first two columns scaled by sqrt(rc) -- evaluated relative to the
+// projected centre so that fp32 cancellation stays far below the safety margin.  If that conic is
+// not an ellipse in front of the camera plane the box is unbounded.  Margin: 1 px + 0.2 %.
+// This only prunes work: pixels inside the box still run the exact per-pixel test.
+SURFEL_HD void contribution_box(const float T[9], float cx, float cy, float opacity, float box[4])
+{
+    const float BIG = 3.0e38f;
+    const float oa = opacity * 255.0f;
+    if (!(oa >= 1.0f)) {  // can never reach alpha >= 1/255 (also catches NaN)
+        box[0] = box[1] = BIG;
+        box[2] = box[3] = -BIG;
+        return;
+    }
+    const float rc = 2.0f * logf(oa) * 1.0001f + 1e-4f;
+    const float r2 = sqrtf(0.5f * rc);
+    float x0 = cx - r2, x1 = cx + r2, y0 = cy - r2, y1 = cy + r2;
+    // centred homography rows: screen coordinates relative to (cx, cy)
+    const float Tw0 = T[6], Tw1 = T[7], Tw2 = T[8];
+    const float Ux = T[0] - cx * Tw0, Uy = T[1] - cx * Tw1, Uz = T[2] - cx * Tw2;
+    const float Vx = T[3] - cy * Tw0, Vy = T[4] - cy * Tw1, Vz = T[5] - cy * Tw2;
+    const float d = rc * (Tw0 * Tw0 + Tw1 * Tw1) - Tw2 * Tw2;
+    if (d < -1e-3f * Tw2 * Tw2) {
+        const float f = 1.0f / d;
+        const float ex = f * (rc * (Ux * Tw0 + Uy * Tw1) - Uz * Tw2);
+        const float ey = f * (rc * (Vx * Tw0 + Vy * Tw1) - Vz * Tw2);
+        const float hx2 = ex * ex - f * (rc * (Ux * Ux + Uy * Uy) - Uz * Uz);
+        const float hy2 = ey * ey - f * (rc * (Vx * Vx + Vy * Vy) - Vz * Vz);
+        const float hx = sqrtf(fmaxf(hx2, 0.f)), hy = sqrtf(fmaxf(hy2, 0.f));
+        if (hx == hx && hy == hy && ex == ex && ey == ey) {
+            x0 = fminf(x0, cx + ex - hx);
+            x1 = fmaxf(x1, cx + ex + hx);
+            y0 = fminf(y0, cy + ey - hy);
+            y1 = fmaxf(y1, cy + ey + hy);
+        } else {
+            x0 = y0 = -BIG;
+            x1 = y1 = BIG;
+        }
+    } else {
+        x0 = y0 = -BIG;
+        x1 = y1 = BIG;
+    }
+    const float mx = 1.0f + 2e-3f * (x1 - x0), my = 1.0f + 2e-3f * (y1 - y0);
+    box[0] = x0 - mx;
+    box[1] = y0 - my;
+    box[2] = x1 + mx;
+    box[3] = y1 + my;
 }
 
 SURFEL_HD float map_depth(float depth)
