@@ -42,10 +42,10 @@ def stage_bytes(stage: str, N: int, R: float, P: int, T: int, K: int) -> float:
     """Algorithmic bytes of one launch of a stage (DESIGN.md 'Measurement')."""
     return {
         "preprocess_fwd": N * (232 + 87),
-        "scan": N * 8,
+        "tile_scan": T * 12,
         "emit_keys": N * 20 + R * 12,
-        "radix_sort": R * 24 * K,
-        "tile_ranges": R * 8 + T * 8,
+        "tile_sort": R * 20,
+        
         "blend_fwd": T * 8 + R * 76 + P * 64,
         "bwd_zero": N * 80,
         "blend_bwd": T * 8 + R * 76 + P * 108 + N * 76,
@@ -63,6 +63,9 @@ def higher_msb(n: int) -> int:
 
 
 def total_bytes(N, R, P, T, K):
+    """The reference algorithm's bytes per image (K 8-bit radix passes over 24-byte pairs).
+    This is the figure the roofline fraction of the whole op is quoted against; our own pipeline moves
+    fewer (the tile-binned sort touches each 8-byte pair three times instead of 2K times)."""
     return N * 1046 + R * (172 + 24 * K) + P * 172 + T * 24
 
 

@@ -16,9 +16,9 @@
  * the reference solves this with a std::function<char*(size_t)> resize callback and a blocking
  * cudaMemcpy (rasterizer_impl.cu:282-286).  Here the forward is split in two calls instead:
  *
- *     vidu4d_surfel_forward_plan(args, stream)          preprocess + tile-count scan
+ *     vidu4d_surfel_forward_plan(args, stream)          preprocess + per-tile count scan (tile ranges)
  *     vidu4d_surfel_num_rendered(args, stream, &R)      (optional) blocking read of num_rendered
- *     vidu4d_surfel_forward_run(args, binning, cap,...) key emit + radix sort + ranges + blend
+ *     vidu4d_surfel_forward_run(args, binning, cap,...) pair emit + in-tile radix sort + blend
  *
  * A caller that wants the reference's exact behaviour calls all three (one host sync, exact
  * buffer).  A caller that wants no host sync passes a capacity guess straight to _run: every
@@ -153,13 +153,10 @@ enum Vidu4dSurfelStateArray {
     VIDU4D_STATE_RECORDS = 1,       /* float[P][24]  (layout: vidu4d_amd/csrc/surfel_math.h) */
     VIDU4D_STATE_TILES_TOUCHED = 2, /* uint32[P] */
     VIDU4D_STATE_POINT_LIST = 3,    /* uint32[num_rendered] sorted surfel ids (binning.point_list) */
-    VIDU4D_STATE_SORTED_KEYS = 4,   /* uint64[num_rendered] */
+    VIDU4D_STATE_SORTED_KEYS = 4,   /* uint64[num_rendered] (tile << 32 | depth bits); dst must be HOST memory */
     VIDU4D_STATE_RANGES = 5,        /* uint32[tiles][2] */
     VIDU4D_STATE_FINAL_T = 6,       /* float[3][H*W]: T, dist1, dist2 */
-    VIDU4D_STATE_N_CONTRIB = 7,     /* uint32[2][H*W]: last, median */
-    VIDU4D_STATE_UNSORTED_KEYS = 8, /* uint64[num_rendered] as emitted (only valid before the sort
-                                       reuses the buffer: debug builds of the tests re-emit) */
-    VIDU4D_STATE_UNSORTED_VALUES = 9
+    VIDU4D_STATE_N_CONTRIB = 7      /* uint32[2][H*W]: last, median */
 };
 int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* args, const void* binning_buffer, int64_t capacity,
                              int what, void* dst, size_t dst_bytes, int64_t* count, void* stream);

@@ -57,8 +57,9 @@ def _compare(tag, st, g, rf, rg, sc):
         assert (ncon != st["n_contrib"]).mean() <= REF_OUTLIERS, f"{tag}: n_contrib"
     assert_close(f"{tag}:color", rf["color"], st["color"], outlier_fraction=budget)
     for i in range(8):
+        # planes 5 / 7 (median depth / weight) are selections: a T > 0.5 flip swaps in another sample
         assert_close(f"{tag}:others[{i}]", rf["others"][i], st["others"][i], atol=DIST_ATOL if i == 6 else 0.0,
-                     outlier_fraction=budget)
+                     outlier_fraction=budget, outlier_rtol=1.0 if i in (5, 7) else 5e-2)
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dtransMat",
               "dL_dcolors"):
         assert_close(f"{tag}:{k}", rg[k], g[k], outlier_fraction=budget)
@@ -105,7 +106,7 @@ def test_product_matches_real_reference_headline(gpu_device):
     assert_close("color", color, rf["color"], outlier_fraction=budget)
     for i in range(8):
         assert_close(f"others[{i}]", allmap[i], rf["others"][i], atol=DIST_ATOL if i == 6 else 0.0,
-                     outlier_fraction=budget)
+                     outlier_fraction=budget, outlier_rtol=1.0 if i in (5, 7) else 5e-2)
     for t, k in zip(leaves + [m2d], ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh",
                                       "dL_dmeans2D")):
         assert_close(k, t.grad, rg[k], outlier_fraction=budget)

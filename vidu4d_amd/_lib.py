@@ -74,7 +74,7 @@ SYMBOLS = {
 }
 
 STATE = dict(num_rendered=0, records=1, tiles_touched=2, point_list=3, sorted_keys=4, ranges=5, final_T=6,
-             n_contrib=7, unsorted_keys=8, unsorted_values=9)
+             n_contrib=7)
 
 _lib = None
 

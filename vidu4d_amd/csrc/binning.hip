@@ -1,190 +1,321 @@
-// binning.hip -- on-device stable LSD radix sort of the (tile | depth) keys and tile-range
-// identification.  gfx950 only.
+// binning.hip -- tile binning and in-tile depth ordering of the (surfel, tile) pairs.  gfx950 only.
 //
-// Replaces cub::DeviceRadixSort::SortPairs(keys, values, R, 0, 32 + bit) and identifyTileRanges
-// (/root/reference/gs/submodules/diff-surfel-rasterization/cuda_rasterizer/rasterizer_impl.cu:
-// 304-309, :116-138).  The result must be the *stable* ascending order on the low 32+bit key bits:
-// ties (same tile, identical depth bits) keep emission order, i.e. ascending surfel id.
+// What the reference computes (/root/reference/gs/submodules/diff-surfel-rasterization/
+// cuda_rasterizer/rasterizer_impl.cu): InclusiveSum over tiles_touched (:278), duplicateWithKeys
+// (:70-111) emitting 64-bit (tile << 32 | depth bits) keys in surfel-id order, a stable
+// cub::DeviceRadixSort over 32+ceil(log2 tiles) bits (:304-309) and identifyTileRanges (:116-138).
+// Result: point_list = surfel ids grouped by tile, ascending depth bits inside a tile, ties in
+// ascending surfel id; ranges[tile] = [start, end).
 //
-// Structure per 8-bit pass (three launches, all sized from the buffer capacity and guarded by the
-// device-side element count so that no host sync is needed):
-//   hist     each 256-thread workgroup counts the digits of its 4096-key tile in LDS
-//   scan     one workgroup turns the [digit][workgroup] counts into global offsets (digit-major
-//            exclusive scan)
-//   scatter  each wave64 ranks its keys with ballot-based digit matching: for every 64 consecutive
-//            keys the lanes holding the same digit are found with 8 ballots, the lane's rank inside
-//            that group is a popcount of the lower lanes, and a per-wave LDS counter carries the
-//            running count across the 16 rounds.  Waves own consecutive key ranges, so
-//            offset(digit, workgroup) + sum(lower waves) + rank is the stable destination.
+// The same result, arranged for the MI355X (six 8-bit passes over a ~0.6M-pair list are ~18
+// dependent launches of mostly launch latency, and every pass drags all pairs through HBM):
+//   1. preprocess counts pairs per tile.  Device-scope atomics on MI355X are served at the memory
+//      side of the fabric (the XCD L2s are not coherent), ~0.25 ns each at best and far worse on a hot
+//      address, so the default "grouped" path uses none: a 1024-thread workgroup histograms the pairs
+//      of its <= 4096 consecutive surfels in LDS and writes one row of per-(group, tile) counts; a
+//      column prefix over the <= 256 groups then gives every group its private sub-range of every
+//      tile segment.  (Images with more than 16k tiles fall back to sliced global atomics.);
+//   2. tile_scan (one workgroup): exclusive scan over the tiles -> ranges, total -> num_rendered.
+//      This IS the most-significant-digit pass of the reference's sort, done as a counting sort;
+//   3. emit: every pair is written once, straight into its tile's segment, as (depth bits << 32 | id);
+//      the order inside a segment is whatever the atomics give;
+//   4. tile_sort: one workgroup per tile orders its segment by (depth bits, surfel id) with an LSD
+//      radix sort held entirely in LDS (8-bit digits; ranks from wave64 ballot digit matching +
+//      popcount prefix, as in a device-wide radix sort, but the ping-pong buffers are LDS arrays).
+//      Passes whose digit is identical for the whole segment (upper id bytes, the depth exponent
+//      byte) are detected from the histogram and skipped.  Segments longer than TILE_SORT_CAP run
+//      the same code with the ping-pong in global memory.
+// Ordering by (depth, id) equals the reference's stable sort because a surfel is emitted at most
+// once per tile, in id order.  No pass ever moves a pair across tiles, so pairs cross HBM three
+// times (emit, sort in, sort out) instead of thirteen.
 #include "surfel_state.h"
+#include "wave_utils.h"
 
 namespace surfel {
 
-__device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift) { return (uint32_t)(key >> shift) & (RADIX - 1); }
-
-__global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint32_t* num_ptr, int64_t capacity,
-                                                               const uint64_t* keys, uint32_t* counts, int nblocks,
-                                                               int shift)
-{
-    __shared__ uint32_t s_hist[RADIX];
-    int64_t n = (int64_t)*num_ptr;
-    if (n > capacity) n = 0;
-    s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
-#pragma unroll 4
-    for (int k = 0; k < SORT_ITEMS; k++) {
-        const int64_t i = base + (int64_t)k * SORT_BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&s_hist[digit_of(keys[i], shift)], 1u);
-    }
-    __syncthreads();
-    counts[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
-}
-
-// Exclusive scan of counts[RADIX * nblocks] in place (digit-major), one 1024-thread workgroup.
-// Coalesced: the array is walked in 1024-wide strips, each strip scanned with wave64 shuffles +
-// a 16-entry LDS step, and a running carry links the strips (total <= 256 * 1024 entries at 4M
-// pairs, i.e. <= 256 strips).
-__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t* counts, int total)
+// Exclusive scan over the (tile, slice) counters in tile-major order, 16 per thread (one tile).
+__global__ __launch_bounds__(1024) void tile_scan_kernel(GeomState g, ImageState img, int num_tiles)
 {
     __shared__ uint32_t s_part[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (int base = 0; base < total; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < total ? counts[i] : 0;
-        uint32_t inc = v;
+    for (int base = 0; base < num_tiles; base += 1024) {
+        const int t = base + threadIdx.x;
+        uint32_t cnt[TILE_SLICES];
+        uint32_t c = 0;
+        if (t < num_tiles) {
+            const uint4* p = reinterpret_cast<const uint4*>(img.tile_count + (size_t)t * TILE_SLICES);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
+            for (int k = 0; k < TILE_SLICES / 4; k++) {
+                const uint4 v = p[k];
+                cnt[4 * k] = v.x;
+                cnt[4 * k + 1] = v.y;
+                cnt[4 * k + 2] = v.z;
+                cnt[4 * k + 3] = v.w;
+                c += v.x + v.y + v.z + v.w;
+            }
         }
+        const uint32_t inc = wave_inclusive_scan(c, lane);
         if (lane == 63) s_part[wave] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < 16; w++) {
-            const uint32_t t = s_part[w];
-            if (w < wave) wbase += t;
-            tot += t;
+            const uint32_t v = s_part[w];
+            if (w < wave) wbase += v;
+            tot += v;
         }
-        if (i < total) counts[i] = carry + wbase + inc - v;
+        if (t < num_tiles) {
+            const uint32_t start = carry + wbase + inc - c;
+            // empty tiles keep the reference's memset value (0, 0) (rasterizer_impl.cu:311)
+            img.ranges[2 * t] = c ? start : 0u;
+            img.ranges[2 * t + 1] = c ? start + c : 0u;
+            uint32_t run = start;
+#pragma unroll
+            for (int k = 0; k < TILE_SLICES; k++) {
+                img.tile_base[(size_t)t * TILE_SLICES + k] = run;
+                run += cnt[k];
+                img.tile_count[(size_t)t * TILE_SLICES + k] = 0;  // becomes the emit cursor
+            }
+        }
         carry += tot;
         __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        g.hdr->num_rendered = carry;
+        g.hdr->overflow = 0;
+    }
 }
 
-__global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(const uint32_t* num_ptr, int64_t capacity,
-                                                                  const uint64_t* keys_in, const uint32_t* vals_in,
-                                                                  uint64_t* keys_out, uint32_t* vals_out,
-                                                                  const uint32_t* offsets, int nblocks, int shift)
+// Grouped path, step 1: one thread per tile turns its column group_counts[*][t] into an exclusive
+// prefix over the groups (in place) and leaves the tile's total in tile_count[t].
+__global__ __launch_bounds__(256) void group_prefix_kernel(ImageState img, int num_tiles, int groups)
 {
-    __shared__ uint32_t s_cnt[4][RADIX];   // running / final per-wave digit counts
-    __shared__ uint32_t s_base[4][RADIX];  // destination base per (wave, digit)
-    int64_t n = (int64_t)*num_ptr;
-    if (n > capacity) n = 0;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= num_tiles) return;
+    uint32_t run = 0;
+    int g = 0;
+    for (; g + 8 <= groups; g += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = img.group_counts[(size_t)(g + k) * num_tiles + t];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            img.group_counts[(size_t)(g + k) * num_tiles + t] = run;
+            run += c[k];
+        }
+    }
+    for (; g < groups; g++) {
+        const uint32_t c = img.group_counts[(size_t)g * num_tiles + t];
+        img.group_counts[(size_t)g * num_tiles + t] = run;
+        run += c;
+    }
+    img.tile_count[t] = run;
+}
+
+// Grouped path, step 2: exclusive scan of the tile totals -> ranges, total -> num_rendered.
+__global__ __launch_bounds__(1024) void tile_totals_scan_kernel(GeomState g, ImageState img, int num_tiles)
+{
+    __shared__ uint32_t s_part[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
-    __syncthreads();
+    uint32_t carry = 0;
+    for (int base = 0; base < num_tiles; base += 1024) {
+        const int t = base + threadIdx.x;
+        const uint32_t c = t < num_tiles ? img.tile_count[t] : 0;
+        const uint32_t inc = wave_inclusive_scan(c, lane);
+        if (lane == 63) s_part[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t v = s_part[w];
+            if (w < wave) wbase += v;
+            tot += v;
+        }
+        if (t < num_tiles) {
+            const uint32_t start = carry + wbase + inc - c;
+            img.ranges[2 * t] = c ? start : 0u;  // empty tiles: the reference's memset (0, 0)
+            img.ranges[2 * t + 1] = c ? start + c : 0u;
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        g.hdr->num_rendered = carry;
+        g.hdr->overflow = 0;
+    }
+}
 
-    // wave w owns keys [base + w*1024, base + (w+1)*1024), 64 consecutive keys per round
-    const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (SORT_TILE / 4);
-    uint64_t key[SORT_ITEMS];
-    uint32_t val[SORT_ITEMS];
-    uint32_t rank[SORT_ITEMS];
+void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, int groups, hipStream_t stream)
+{
+    if (groups > 0) {
+        hipLaunchKernelGGL(group_prefix_kernel, dim3((num_tiles + 255) / 256), dim3(256), 0, stream, img, num_tiles,
+                           groups);
+        hipLaunchKernelGGL(tile_totals_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
+    } else {
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
+    }
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, int P, const int32_t* radii,
+                                                             GeomState g, ImageState img, uint64_t* entries,
+                                                             int64_t capacity)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    if ((int64_t)g.hdr->num_rendered > capacity) {  // binning buffer too small: render nothing, flag it
+        if (idx == 0) g.hdr->overflow = 1;
+        return;
+    }
+    if (idx >= P) return;
+    const int radius = radii[idx];
+    if (radius <= 0) return;
+    const float4 q2 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[2];
+    const float4 q3 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[3];
+    int x0, y0, x1, y1;
+    tile_rect(q2.y, q2.z, radius, cam.grid_x, cam.grid_y, x0, y0, x1, y1);
+    const uint64_t entry = ((uint64_t)__float_as_uint(q3.w) << 32) | (uint32_t)idx;
+    const int slice = blockIdx.x & (TILE_SLICES - 1);  // same slice the count came from (same launch geometry)
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const size_t b = (size_t)(y * cam.grid_x + x) * TILE_SLICES + slice;
+            const uint32_t pos = img.tile_base[b] + atomicAdd(&img.tile_count[b], 1u);
+            entries[pos] = entry;
+        }
+}
+
+// Grouped path: the same 1024-thread groups as the projection; each group owns, in every tile's
+// segment, the sub-range [ranges[t].x + prefix[group][t], +count[group][t]) and hands out its slots
+// with LDS atomics.
+__global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraParams cam, int P, int iters,
+                                                                       const int32_t* radii, GeomState g,
+                                                                       ImageState img, uint64_t* entries,
+                                                                       int64_t capacity)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cur[];
+    if ((int64_t)g.hdr->num_rendered > capacity) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) g.hdr->overflow = 1;
+        return;
+    }
+    const int num_tiles = cam.grid_x * cam.grid_y;
+    const uint32_t* row = img.group_counts + (size_t)blockIdx.x * num_tiles;
+    for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) s_cur[t] = img.ranges[2 * t] + row[t];
+    __syncthreads();
+    const int first = blockIdx.x * BIN_THREADS * iters;
+    for (int it = 0; it < iters; it++) {
+        const int idx = first + it * BIN_THREADS + threadIdx.x;
+        if (idx >= P) continue;
+        const int radius = radii[idx];
+        if (radius <= 0) continue;
+        const float4 q2 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[2];
+        const float4 q3 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[3];
+        int x0, y0, x1, y1;
+        tile_rect(q2.y, q2.z, radius, cam.grid_x, cam.grid_y, x0, y0, x1, y1);
+        const uint64_t entry = ((uint64_t)__float_as_uint(q3.w) << 32) | (uint32_t)idx;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) entries[atomicAdd(&s_cur[y * cam.grid_x + x], 1u)] = entry;
+    }
+}
+
+void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
+                      const BinState& b, int64_t capacity, bool grouped, hipStream_t stream)
+{
+    if (P <= 0) return;
+    if (grouped)
+        hipLaunchKernelGGL(emit_keys_grouped_kernel, dim3(bin_groups(P)), dim3(BIN_THREADS),
+                           (size_t)cam.grid_x * cam.grid_y * sizeof(uint32_t), stream, cam, P, bin_iters(P), radii, g,
+                           img, b.entries, capacity);
+    else
+        hipLaunchKernelGGL(emit_keys_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, cam, P, radii, g, img,
+                           b.entries, capacity);
+}
+
+// One workgroup (4 wave64) per tile.  Stable LSD radix sort of the tile's segment on the bytes of
+// (depth bits << 32 | id) listed by the caller's id_bytes (id bytes 0..id_bytes-1, then depth bytes).
+__global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ ranges, const uint32_t* num_ptr,
+                                                       int64_t capacity, uint64_t* entries, uint64_t* scratch,
+                                                       uint32_t* __restrict__ point_list, int id_bytes)
+{
+    __shared__ uint64_t s_buf[2][TILE_SORT_CAP];
+    __shared__ uint32_t s_cnt[4][256];  // per-wave digit counts, then per-wave destination cursors
+    __shared__ uint32_t s_scan[4];
+    if ((int64_t)*num_ptr > capacity) return;
+    const uint32_t start = ranges[2 * blockIdx.x];
+    const int n = (int)(ranges[2 * blockIdx.x + 1] - start);
+    if (n == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_lds = n <= TILE_SORT_CAP;
+    uint64_t* A;
+    uint64_t* B;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < n; i += 256) s_buf[0][i] = entries[start + i];
+        A = s_buf[0];
+        B = s_buf[1];
+    } else {
+        A = entries + start;
+        B = scratch + start;
+    }
+    // wave w owns the consecutive keys [w*chunk, min(n, (w+1)*chunk)), walked 64 at a time
+    const int chunk = ((n + 255) >> 8) << 6;
+    const int w_lo = wave * chunk;
+    const int w_hi = (w_lo + chunk < n) ? w_lo + chunk : n;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
-        const int64_t i = wbase + (int64_t)k * 64 + lane;
-        const bool valid = i < n;
-        key[k] = valid ? keys_in[i] : ~0ull;
-        val[k] = valid ? vals_in[i] : 0u;
-        const uint32_t d = digit_of(key[k], shift);
-        // lanes holding the same digit (invalid lanes form their own group via the extra ballot)
-        uint64_t peers = __ballot(valid);
-        if (!valid) peers = ~peers;
-#pragma unroll
-        for (int b = 0; b < RADIX_BITS; b++) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-        const uint32_t cnt = (uint32_t)__popcll(peers);
-        uint32_t old = 0;
-        if (valid) {
-            old = s_cnt[wave][d];
-            if (before == 0) s_cnt[wave][d] = old + cnt;  // group leader carries the count forward
-        }
-        rank[k] = old + before;
-    }
-    __syncthreads();
-    {
+
+    for (int pass = 0; pass < id_bytes + 4; pass++) {
+        const int shift = 8 * (pass < id_bytes ? pass : 4 + pass - id_bytes);
+        for (int i = threadIdx.x; i < 4 * 256; i += 256) (&s_cnt[0][0])[i] = 0;
+        __syncthreads();  // also orders the previous pass's scatter (or the initial load) before the reads
+        for (int i = w_lo + lane; i < w_hi; i += 64) atomicAdd(&s_cnt[wave][(uint32_t)(A[i] >> shift) & 255u], 1u);
+        __syncthreads();
         const int d = threadIdx.x;  // one digit per thread
-        uint32_t run = offsets[(size_t)d * nblocks + blockIdx.x];
+        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        if (__syncthreads_or(tot == (uint32_t)n)) continue;  // whole segment shares this digit: nothing to move
+        uint32_t total;
+        const uint32_t dbase = block_exclusive_scan(tot, s_scan, total);
+        s_cnt[0][d] = dbase;
+        s_cnt[1][d] = dbase + c0;
+        s_cnt[2][d] = dbase + c0 + c1;
+        s_cnt[3][d] = dbase + c0 + c1 + c2;
+        __syncthreads();
+        for (int base = w_lo; base < w_hi; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < w_hi;
+            const uint64_t key = valid ? A[i] : ~0ull;
+            const uint32_t dg = (uint32_t)(key >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+            if (!valid) peers = ~peers;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            s_base[w][d] = run;
-            run += s_cnt[w][d];
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long m = __ballot((dg >> b) & 1u);
+                peers &= ((dg >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+            if (valid) {
+                const uint32_t old = s_cnt[wave][dg];
+                if (before == 0) s_cnt[wave][dg] = old + (uint32_t)__popcll(peers);  // leader advances the cursor
+                B[old + before] = key;
+            }
         }
+        uint64_t* t = A;
+        A = B;
+        B = t;
+        __syncthreads();  // every wave is done with its cursors before the next pass clears them
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
-        const int64_t i = wbase + (int64_t)k * 64 + lane;
-        if (i < n) {
-            const uint32_t d = digit_of(key[k], shift);
-            const uint32_t pos = s_base[wave][d] + rank[k];
-            keys_out[pos] = key[k];
-            vals_out[pos] = val[k];
-        }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint64_t key = A[i];
+        point_list[start + i] = (uint32_t)key;
+        if (A != entries + start) entries[start + i] = key;
     }
 }
 
-int launch_radix_sort(const GeomState& g, const BinState& b, int64_t capacity, int passes, hipStream_t stream)
+void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
+                      int64_t capacity, hipStream_t stream)
 {
-    const int nb = b.sort_blocks;
-    int side = 0;
-    if (nb <= 0) return passes & 1;
-    for (int p = 0; p < passes; p++) {
-        const int shift = p * RADIX_BITS;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(SORT_BLOCK), 0, stream, &g.hdr->num_rendered, capacity,
-                           b.keys[side], b.counts, nb, shift);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, stream, b.counts, RADIX * nb);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(SORT_BLOCK), 0, stream, &g.hdr->num_rendered,
-                           capacity, b.keys[side], b.vals[side], b.keys[side ^ 1], b.vals[side ^ 1], b.counts, nb,
-                           shift);
-        side ^= 1;
-    }
-    return side;
-}
-
-// rasterizer_impl.cu:116-138 (ranges were zeroed by the scan kernel).
-__global__ void tile_ranges_kernel(const uint32_t* num_ptr, int64_t capacity, const uint64_t* keys, uint32_t* ranges)
-{
-    int64_t n = (int64_t)*num_ptr;
-    if (n > capacity) n = 0;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
-    if (idx == 0)
-        ranges[2 * cur] = 0;
-    else {
-        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
-        if (cur != prev) {
-            ranges[2 * prev + 1] = (uint32_t)idx;
-            ranges[2 * cur] = (uint32_t)idx;
-        }
-    }
-    if (idx == n - 1) ranges[2 * cur + 1] = (uint32_t)n;
-}
-
-void launch_tile_ranges(const GeomState& g, const uint64_t* sorted_keys, int64_t capacity, uint32_t* ranges,
-                        hipStream_t stream)
-{
-    if (capacity <= 0) return;
-    const int blocks = (int)((capacity + 255) / 256);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(256), 0, stream, &g.hdr->num_rendered, capacity,
-                       sorted_keys, ranges);
+    if (capacity <= 0 || num_tiles <= 0) return;
+    int id_bytes = 1;
+    while (id_bytes < 4 && ((uint64_t)(num_surfels > 0 ? num_surfels - 1 : 0) >> (8 * id_bytes))) id_bytes++;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(num_tiles), dim3(256), 0, stream, img.ranges, &g.hdr->num_rendered,
+                       capacity, b.entries, b.scratch, b.point_list, id_bytes);
 }
 
 }  // namespace surfel

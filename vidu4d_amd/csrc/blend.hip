@@ -89,6 +89,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
 __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y,
                                                        const uint32_t* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list,
+                                                       const uint32_t* __restrict__ num_ptr, int64_t capacity,
                                                        const float* __restrict__ rec, const float* __restrict__ bg,
                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                        float* __restrict__ out_color, float* __restrict__ out_others)
@@ -103,7 +104,9 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
     const bool inside = px < W && py < H;
     const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
     const uint32_t r0 = ranges[2 * tc.tile], r1 = ranges[2 * tc.tile + 1];
-    int todo = (int)(r1 - r0);
+    // binning buffer too small for this frame: nothing was emitted, render the background only (the
+    // caller re-runs with a larger buffer)
+    int todo = ((int64_t)*num_ptr > capacity) ? 0 : (int)(r1 - r0);
 
     FwdPixel s;
     bool done = !inside;
@@ -154,11 +157,12 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
 }
 
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const uint32_t* point_list,
-                      const float* background, float* out_color, float* out_others, hipStream_t stream)
+                      int64_t capacity, const float* background, float* out_color, float* out_others,
+                      hipStream_t stream)
 {
     hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(cam.grid_x, cam.grid_y)), dim3(256), 0, stream, cam.W, cam.H,
-                       cam.grid_x, cam.grid_y, img.ranges, point_list, g.rec, background, img.final_T, img.n_contrib,
-                       out_color, out_others);
+                       cam.grid_x, cam.grid_y, img.ranges, point_list, &g.hdr->num_rendered, capacity, g.rec,
+                       background, img.final_T, img.n_contrib, out_color, out_others);
 }
 
 // ---------------------------------------------------------------------------------------------

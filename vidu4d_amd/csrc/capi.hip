@@ -34,9 +34,9 @@ static int fail(int code, const char* fmt, ...)
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg).
 // Disabled by default: zero overhead (one branch) per stage.
-enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BWD_ZERO, ST_BLEND_BWD,
+enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_BLEND_FWD, ST_BWD_ZERO, ST_BLEND_BWD,
              ST_PREPROCESS_BWD, ST_COUNT };
-static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "emit_keys", "radix_sort", "tile_ranges",
+static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "tile_scan", "emit_keys", "tile_sort",
                                                    "blend_fwd", "bwd_zero", "blend_bwd", "preprocess_bwd"};
 struct StageSpan {
     hipEvent_t a, b;
@@ -177,16 +177,23 @@ extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void
     pa.colors_precomp = a->colors_precomp;
     pa.radii = a->radii;
     pa.geom = g;
+    pa.tile_count = img.tile_count;
+    pa.group_counts = img.group_counts;
+    pa.iters = bin_iters(a->P);
+    const int num_tiles = pa.cam.grid_x * pa.cam.grid_y;
+    const bool grouped = use_grouped_binning(num_tiles);
     {
         StageTimer t(ST_PREPROCESS, stream);
+        if (!grouped)
+            HIP_TRY(hipMemsetAsync(img.tile_count, 0, (size_t)num_tiles * TILE_SLICES * sizeof(uint32_t), stream));
         launch_preprocess_fwd(pa, stream);
     }
     STAGE_CHECK(a->debug, stream, "preprocess");
     {
         StageTimer t(ST_SCAN, stream);
-        launch_scan_blocks(g, a->P, img.ranges, pa.cam.grid_x * pa.cam.grid_y, stream);
+        launch_tile_scan(g, img, num_tiles, grouped ? bin_groups(a->P) : 0, stream);
     }
-    STAGE_CHECK(a->debug, stream, "scan");
+    STAGE_CHECK(a->debug, stream, "tile_scan");
     return VIDU4D_OK;
 }
 
@@ -226,26 +233,19 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     if (capacity > 0) {
         {
             StageTimer t(ST_EMIT, stream);
-            launch_emit_keys(cam, a->P, a->radii, g, b, capacity, stream);
+            launch_emit_keys(cam, a->P, a->radii, g, img, b, capacity, use_grouped_binning(cam.grid_x * cam.grid_y), stream);
         }
         STAGE_CHECK(a->debug, stream, "emit_keys");
-        const int passes = sort_passes(cam.grid_x, cam.grid_y);
-        int side;
         {
             StageTimer t(ST_SORT, stream);
-            side = launch_radix_sort(g, b, capacity, passes, stream);
+            launch_tile_sort(g, img, b, cam.grid_x * cam.grid_y, a->P, capacity, stream);
         }
-        STAGE_CHECK(a->debug, stream, "radix_sort");
-        {
-            StageTimer t(ST_RANGES, stream);
-            launch_tile_ranges(g, b.keys[side], capacity, img.ranges, stream);
-        }
-        STAGE_CHECK(a->debug, stream, "tile_ranges");
-        point_list = b.vals[side];
+        STAGE_CHECK(a->debug, stream, "tile_sort");
+        point_list = b.point_list;
     }
     {
         StageTimer t(ST_BLEND_FWD, stream);
-        launch_blend_fwd(cam, g, img, point_list, a->background, a->out_color, a->out_others, stream);
+        launch_blend_fwd(cam, g, img, point_list, capacity, a->background, a->out_color, a->out_others, stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
     return VIDU4D_OK;
@@ -274,8 +274,7 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     carve_geom((char*)a->geom_buffer, a->P, ba.geom);
     carve_image((char*)a->image_buffer, a->width, a->height, ba.img);
     carve_binning((char*)a->binning_buffer, a->binning_capacity, b);
-    const int side = sort_passes(ba.cam.grid_x, ba.cam.grid_y) & 1;
-    ba.point_list = a->binning_capacity > 0 ? b.vals[side] : nullptr;
+    ba.point_list = a->binning_capacity > 0 ? b.point_list : nullptr;
     ba.P = a->P;
     ba.background = a->background;
     ba.means3D = a->means3D;
@@ -339,7 +338,6 @@ extern "C" int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* a, const 
     carve_image((char*)a->image_buffer, a->width, a->height, img);
     carve_binning((char*)binning, capacity, b);
     const int gx = (a->width + TILE - 1) / TILE, gy = (a->height + TILE - 1) / TILE;
-    const int side = sort_passes(gx, gy) & 1;
     uint32_t R = 0;
     HIP_TRY(hipMemcpyAsync(&R, &g.hdr->num_rendered, sizeof(R), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -350,21 +348,26 @@ extern "C" int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* a, const 
         case VIDU4D_STATE_NUM_RENDERED: src = &g.hdr->num_rendered; n = 1; break;
         case VIDU4D_STATE_RECORDS: src = g.rec; n = (size_t)a->P * REC_FLOATS; break;
         case VIDU4D_STATE_TILES_TOUCHED: src = g.tiles_touched; n = (size_t)a->P; break;
-        case VIDU4D_STATE_POINT_LIST: src = b.vals[side]; n = R; break;
-        case VIDU4D_STATE_SORTED_KEYS: src = b.keys[side]; n = R; esz = 8; break;
+        case VIDU4D_STATE_POINT_LIST: src = b.point_list; n = R; break;
+        case VIDU4D_STATE_SORTED_KEYS: src = b.entries; n = R; esz = 8; break;
         case VIDU4D_STATE_RANGES: src = img.ranges; n = (size_t)gx * gy * 2; break;
         case VIDU4D_STATE_FINAL_T: src = img.final_T; n = 3 * hw; break;
         case VIDU4D_STATE_N_CONTRIB: src = img.n_contrib; n = 2 * hw; break;
-        case VIDU4D_STATE_UNSORTED_KEYS: src = b.keys[0]; n = R; esz = 8; break;
-        case VIDU4D_STATE_UNSORTED_VALUES: src = b.vals[0]; n = R; break;
         default: return fail(VIDU4D_E_INVALID, "unknown state array %d", what);
     }
-    if ((what == VIDU4D_STATE_POINT_LIST || what == VIDU4D_STATE_SORTED_KEYS || what >= VIDU4D_STATE_UNSORTED_KEYS) &&
-        (int64_t)R > capacity)
+    if ((what == VIDU4D_STATE_POINT_LIST || what == VIDU4D_STATE_SORTED_KEYS) && (int64_t)R > capacity)
         return fail(VIDU4D_E_BUFFER, "num_rendered %u exceeds capacity %lld", R, (long long)capacity);
     *count = (int64_t)n;
     if (n * esz > dst_bytes) return fail(VIDU4D_E_BUFFER, "dst too small: need %zu bytes", n * esz);
     if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * esz, hipMemcpyDefault, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (what == VIDU4D_STATE_SORTED_KEYS && n) {
+        // stored per tile as (depth bits << 32 | id); hand back the reference's (tile << 32 | depth bits)
+        std::vector<uint32_t> rng((size_t)gx * gy * 2);
+        HIP_TRY(hipMemcpy(rng.data(), img.ranges, rng.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t* k = (uint64_t*)dst;  // dst must be host memory for this array
+        for (size_t t = 0; t < (size_t)gx * gy; t++)
+            for (uint32_t i = rng[2 * t]; i < rng[2 * t + 1]; i++) k[i] = ((uint64_t)t << 32) | (k[i] >> 32);
+    }
     return VIDU4D_OK;
 }

@@ -2,183 +2,143 @@
 // per-surfel backward, frustum marking.  gfx950 only.
 //
 // Reference behaviour restated here (file:line in /root/reference/gs/submodules/
-// diff-surfel-rasterization/cuda_rasterizer/): preprocessCUDA forward.cu:166-260; InclusiveSum
-// rasterizer_impl.cu:278; duplicateWithKeys rasterizer_impl.cu:70-111; computeAABB +
+// diff-surfel-rasterization/cuda_rasterizer/): preprocessCUDA forward.cu:166-260; computeAABB +
 // preprocessCUDA backward backward.cu:599-649, :533-597; checkFrustum rasterizer_impl.cu:54-66.
 //
-// MI355X notes: one thread per surfel, 256-thread workgroups (4 wave64).  The tile-count prefix sum
-// is split so that it costs one tiny extra launch: the projection kernel reduces its workgroup's
-// counts (wave64 shuffle + LDS), one single-workgroup kernel scans the <= 4k workgroup sums, and the
-// emit kernel redoes the in-workgroup scan on the fly instead of reading back a materialised
-// offsets array.
+// MI355X notes: one thread per surfel, 256-thread workgroups (4 wave64).  The reference's
+// per-surfel prefix sum + global 64-bit sort is replaced by tile binning (binning.hip): this kernel
+// only counts, per tile, how many surfels touch it.
 #include "surfel_state.h"
+#include "wave_utils.h"
 
 namespace surfel {
 
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+// Projection of surfel idx; writes record / radius / tile count and returns the tile rect.
+__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const Camera& cam, int idx, Projected& o)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
+    const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
+    const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
+    const float scale[2] = {sc.x, sc.y};
+    const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+    uint32_t tiles = 0;
+    int radius = 0;
+    if (project_surfel(cam, p_world, quat, scale, o)) {
+        tiles = o.tiles;
+        radius = o.radius;
+        float rgb[3];
+        uint32_t clamp_mask = 0;
+        if (a.colors_precomp == nullptr) {
+            sh_forward(cam.sh_degree, p_world, cam.campos, a.shs + (size_t)idx * cam.sh_coeffs * 3, rgb, clamp_mask);
+        } else {
+            rgb[0] = a.colors_precomp[3 * idx];
+            rgb[1] = a.colors_precomp[3 * idx + 1];
+            rgb[2] = a.colors_precomp[3 * idx + 2];
+        }
+        float4* rec = reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
+        rec[0] = make_float4(o.T[0], o.T[1], o.T[2], o.T[3]);
+        rec[1] = make_float4(o.T[4], o.T[5], o.T[6], o.T[7]);
+        rec[2] = make_float4(o.T[8], o.center[0], o.center[1], a.opacities[idx]);
+        rec[3] = make_float4(o.normal[0], o.normal[1], o.normal[2], o.depth);
+        rec[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
+        float box[4];
+        contribution_box(o.T, o.center[0], o.center[1], a.opacities[idx], box);
+        rec[5] = make_float4(box[0], box[1], box[2], box[3]);
     }
-    return v;
+    a.radii[idx] = radius;
+    a.geom.tiles_touched[idx] = tiles;
+    return tiles;
 }
 
-// Exclusive scan over a 256-thread workgroup; returns this thread's exclusive prefix and the total.
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t& total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t inc = wave_inclusive_scan(v, lane);
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t t = s_wave[w];
-        if (w < wave) base += t;
-    }
-    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    return base + inc - v;
-}
-
+// Atomic path (more than BIN_MAX_TILES tiles): per-tile pair counts with global atomics.
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
 {
-    __shared__ uint32_t s_wave[4];
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const Camera cam = load_camera(a.cam);
-    uint32_t tiles = 0;
-    if (idx < a.P) {
-        const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-        const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
-        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
-        const float scale[2] = {sc.x, sc.y};
-        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-        Projected o;
-        int radius = 0;
-        if (project_surfel(cam, p_world, quat, scale, o)) {
-            tiles = o.tiles;
-            radius = o.radius;
-            float rgb[3];
-            uint32_t clamp_mask = 0;
-            if (a.colors_precomp == nullptr) {
-                sh_forward(cam.sh_degree, p_world, cam.campos, a.shs + (size_t)idx * cam.sh_coeffs * 3, rgb,
-                           clamp_mask);
-            } else {
-                rgb[0] = a.colors_precomp[3 * idx];
-                rgb[1] = a.colors_precomp[3 * idx + 1];
-                rgb[2] = a.colors_precomp[3 * idx + 2];
-            }
-            float4* rec = reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
-            rec[0] = make_float4(o.T[0], o.T[1], o.T[2], o.T[3]);
-            rec[1] = make_float4(o.T[4], o.T[5], o.T[6], o.T[7]);
-            rec[2] = make_float4(o.T[8], o.center[0], o.center[1], a.opacities[idx]);
-            rec[3] = make_float4(o.normal[0], o.normal[1], o.normal[2], o.depth);
-            rec[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
-            float box[4];
-            contribution_box(o.T, o.center[0], o.center[1], a.opacities[idx], box);
-            rec[5] = make_float4(box[0], box[1], box[2], box[3]);
-        }
-        a.radii[idx] = radius;
-        a.geom.tiles_touched[idx] = tiles;
+    if (idx >= a.P) return;
+    Projected o;
+    if (preprocess_one(a, cam, idx, o)) {
+        const int slice = blockIdx.x & (TILE_SLICES - 1);
+        for (int y = o.y0; y < o.y1; y++)
+            for (int x = o.x0; x < o.x1; x++)
+                atomicAdd(&a.tile_count[(y * cam.grid_x + x) * TILE_SLICES + slice], 1u);
     }
-    uint32_t total;
-    block_exclusive_scan(tiles, s_wave, total);
-    if (threadIdx.x == 0) a.geom.block_sums[blockIdx.x] = total;
+}
+
+// Grouped path: a 1024-thread workgroup (16 wave64) projects a.iters x 1024 consecutive surfels and
+// histograms their (surfel, tile) pairs in LDS; the row group_counts[group][*] is written once,
+// coalesced.  No global atomics.
+__global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(PreprocessArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+    const Camera cam = load_camera(a.cam);
+    const int num_tiles = cam.grid_x * cam.grid_y;
+    for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) s_hist[t] = 0;
+    __syncthreads();
+    const int first = blockIdx.x * BIN_THREADS * a.iters;
+    for (int it = 0; it < a.iters; it++) {
+        const int idx = first + it * BIN_THREADS + threadIdx.x;
+        if (idx < a.P) {
+            Projected o;
+            if (preprocess_one(a, cam, idx, o))
+                for (int y = o.y0; y < o.y1; y++)
+                    for (int x = o.x0; x < o.x1; x++) atomicAdd(&s_hist[y * cam.grid_x + x], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* row = a.group_counts + (size_t)blockIdx.x * num_tiles;
+    for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) row[t] = s_hist[t];
 }
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
-}
-
-// One workgroup: exclusive scan of the per-workgroup tile counts, total -> header, zero the tile
-// ranges (the reference's cudaMemset, rasterizer_impl.cu:311).
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(GeomState g, int nblocks, uint32_t* ranges, int num_tiles)
-{
-    __shared__ uint32_t s_part[16];
-    __shared__ uint32_t s_carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? g.block_sums[i] : 0;
-        const uint32_t inc = wave_inclusive_scan(v, lane);
-        if (lane == 63) s_part[wave] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (int w = 0; w < 16; w++) {
-            const uint32_t t = s_part[w];
-            if (w < wave) wbase += t;
-            tot += t;
-        }
-        const uint32_t carry = s_carry;
-        if (i < nblocks) g.block_offsets[i] = carry + wbase + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        g.hdr->num_rendered = s_carry;
-        g.hdr->overflow = 0;
-    }
-    for (int i = threadIdx.x; i < 2 * num_tiles; i += 1024) ranges[i] = 0;
-}
-
-void launch_scan_blocks(const GeomState& g, int P, uint32_t* ranges, int num_tiles, hipStream_t stream)
-{
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, g, pre_blocks(P), ranges, num_tiles);
-}
-
-// (tile | depth) key / surfel-id value pairs in the reference's emission order: surfel id ascending,
-// tiles row-major inside the rect (rasterizer_impl.cu:98-109).  The stable sort relies on it.
-__global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, int P, const int32_t* radii, GeomState g,
-                                                             uint64_t* keys, uint32_t* vals, int64_t capacity)
-{
-    __shared__ uint32_t s_wave[4];
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const uint32_t tiles = idx < P ? g.tiles_touched[idx] : 0;
-    uint32_t total;
-    uint32_t off = block_exclusive_scan(tiles, s_wave, total) + g.block_offsets[blockIdx.x];
-    if ((int64_t)g.hdr->num_rendered > capacity) {  // binning buffer too small: render nothing, flag it
-        if (idx == 0) g.hdr->overflow = 1;
-        return;
-    }
-    if (tiles == 0) return;
-    const float4 q2 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[2];
-    const float4 q3 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[3];
-    int x0, y0, x1, y1;
-    tile_rect(q2.y, q2.z, radii[idx], cam.grid_x, cam.grid_y, x0, y0, x1, y1);
-    const uint64_t dbits = (uint64_t)__float_as_uint(q3.w);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            const uint64_t key = ((uint64_t)(uint32_t)(y * cam.grid_x + x) << 32) | dbits;
-            keys[off] = key;
-            vals[off] = (uint32_t)idx;
-            off++;
-        }
-}
-
-void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const BinState& b,
-                      int64_t capacity, hipStream_t stream)
-{
-    if (P <= 0) return;
-    hipLaunchKernelGGL(emit_keys_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, cam, P, radii, g,
-                       b.keys[0], b.vals[0], capacity);
+    const int num_tiles = a.cam.grid_x * a.cam.grid_y;
+    if (use_grouped_binning(num_tiles))
+        hipLaunchKernelGGL(preprocess_fwd_grouped_kernel, dim3(bin_groups(a.P)), dim3(BIN_THREADS),
+                           (size_t)num_tiles * sizeof(uint32_t), stream, a);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
 }
 
 // Per-surfel backward.  Reads the accumulator filled by the backward blend and writes every output
 // gradient (zeros for culled surfels, which the reference gets from torch::zeros).
+//
+// SH_LDS (16 coefficients, 16-byte aligned tensors): the 192-byte SH rows of the workgroup's 256
+// surfels are one contiguous 48 KiB run in global memory, but a thread-per-surfel access walks it
+// with a 192-byte lane stride (every wave instruction touches 64 cache lines; measured 2.6x
+// over-fetch and 2.5x over-write).  Instead the run is copied with coalesced 16-byte loads into an
+// LDS tile with row stride 49 words (odd => the per-thread column walk is bank-conflict free), the
+// gradients are written back into the same tile and leave with coalesced 16-byte stores.
+constexpr int SH_ROW = 48, SH_STRIDE = 49;
+
+template <bool SH_LDS>
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];  // [256][49] when SH_LDS
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
     const Camera cam = load_camera(a.cam);
     const int M = cam.sh_coeffs;
-    float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
-    if (!(a.radii[idx] > 0)) {
+    const int block_first = blockIdx.x * PRE_BLOCK;
+    const int rows = (a.P - block_first) < PRE_BLOCK ? (a.P - block_first) : PRE_BLOCK;
+    if (SH_LDS) {
+        const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
+        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
+            const float4 v = g4[i];
+            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
+            float* d = s_sh + r * SH_STRIDE + c;
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+        __syncthreads();
+    }
+    const bool live = idx < a.P;
+    const bool visible = live && a.radii[idx] > 0;
+    float* sh_row = s_sh + threadIdx.x * SH_STRIDE;  // SH_LDS: this thread's private row (read, then overwritten)
+    float* dsh = (a.dL_dsh && live) ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+    if (live && !visible) {
         for (int k = 0; k < 3; k++) {
             a.dL_dmeans3D[3 * idx + k] = 0.f;
             a.dL_dmeans2D[3 * idx + k] = 0.f;
@@ -188,60 +148,89 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
         for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = 0.f;
         a.dL_dscales[2 * idx] = a.dL_dscales[2 * idx + 1] = 0.f;
         for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = 0.f;
-        if (dsh)
+        if (SH_LDS) {
+            for (int k = 0; k < SH_ROW; k++) sh_row[k] = 0.f;
+        } else if (dsh) {
             for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
-        return;
-    }
-    float acc[ACC_FLOATS];
-    {
-        const float4* p = reinterpret_cast<const float4*>(a.acc + (size_t)idx * ACC_FLOATS);
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const float4 v = p[k];
-            acc[4 * k] = v.x;
-            acc[4 * k + 1] = v.y;
-            acc[4 * k + 2] = v.z;
-            acc[4 * k + 3] = v.w;
         }
     }
-    float T[9];
-    uint32_t clamp_mask;
-    {
-        const float4* r = reinterpret_cast<const float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
-        const float4 q0 = r[0], q1 = r[1], q2 = r[2], q4 = r[4];
-        T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q0.w;
-        T[4] = q1.x; T[5] = q1.y; T[6] = q1.z; T[7] = q1.w;
-        T[8] = q2.x;
-        clamp_mask = __float_as_uint(q4.w);
-    }
-    const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
-    const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
-    const float scale[2] = {sc.x, sc.y};
-    const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-    SurfelGrads o;
-    surfel_backward(cam, p_world, quat, scale, T, acc, o);
+    if (visible) {
+        float acc[ACC_FLOATS];
+        {
+            const float4* p = reinterpret_cast<const float4*>(a.acc + (size_t)idx * ACC_FLOATS);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const float4 v = p[k];
+                acc[4 * k] = v.x;
+                acc[4 * k + 1] = v.y;
+                acc[4 * k + 2] = v.z;
+                acc[4 * k + 3] = v.w;
+            }
+        }
+        float T[9];
+        uint32_t clamp_mask;
+        {
+            const float4* r = reinterpret_cast<const float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2], q4 = r[4];
+            T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q0.w;
+            T[4] = q1.x; T[5] = q1.y; T[6] = q1.z; T[7] = q1.w;
+            T[8] = q2.x;
+            clamp_mask = __float_as_uint(q4.w);
+        }
+        const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+        const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
+        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const float scale[2] = {sc.x, sc.y};
+        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+        SurfelGrads o;
+        surfel_backward(cam, p_world, quat, scale, T, acc, o);
 
-    float dmean[3] = {o.dmean3D[0], o.dmean3D[1], o.dmean3D[2]};
-    const float dcol[3] = {acc[A_RGB], acc[A_RGB + 1], acc[A_RGB + 2]};
-    if (a.shs != nullptr)
-        sh_backward(cam.sh_degree, M, p_world, cam.campos, a.shs + (size_t)idx * M * 3, clamp_mask, dcol, dsh, dmean);
-    for (int k = 0; k < 3; k++) {
-        a.dL_dmeans3D[3 * idx + k] = dmean[k];
-        a.dL_dmeans2D[3 * idx + k] = o.dmean2D[k];
-        a.dL_dcolors[3 * idx + k] = dcol[k];
+        float dmean[3] = {o.dmean3D[0], o.dmean3D[1], o.dmean3D[2]};
+        const float dcol[3] = {acc[A_RGB], acc[A_RGB + 1], acc[A_RGB + 2]};
+        if (a.shs != nullptr) {
+            if (SH_LDS) {
+                // in place: coefficient k is read before gradient k is stored over it
+                sh_backward(cam.sh_degree, M, p_world, cam.campos, sh_row, clamp_mask, dcol, sh_row, dmean);
+            } else {
+                sh_backward(cam.sh_degree, M, p_world, cam.campos, a.shs + (size_t)idx * M * 3, clamp_mask, dcol, dsh,
+                            dmean);
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            a.dL_dmeans3D[3 * idx + k] = dmean[k];
+            a.dL_dmeans2D[3 * idx + k] = o.dmean2D[k];
+            a.dL_dcolors[3 * idx + k] = dcol[k];
+        }
+        a.dL_dopacity[idx] = acc[A_OPAC];
+        for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = o.dT[k];
+        a.dL_dscales[2 * idx] = o.dscale[0];
+        a.dL_dscales[2 * idx + 1] = o.dscale[1];
+        for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = o.drot[k];
     }
-    a.dL_dopacity[idx] = acc[A_OPAC];
-    for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = o.dT[k];
-    a.dL_dscales[2 * idx] = o.dscale[0];
-    a.dL_dscales[2 * idx + 1] = o.dscale[1];
-    for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = o.drot[k];
+    if (SH_LDS) {
+        if (visible && a.shs == nullptr)
+            for (int k = 0; k < SH_ROW; k++) sh_row[k] = 0.f;
+        __syncthreads();
+        float4* o4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)block_first * SH_ROW);
+        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
+            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
+            const float* d = s_sh + r * SH_STRIDE + c;
+            o4[i] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
 }
 
 void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
+    const bool sh_lds = a.shs != nullptr && a.dL_dsh != nullptr && a.cam.sh_coeffs == 16 &&
+                        (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0;
+    if (sh_lds)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK),
+                           (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
 }
 
 __global__ void mark_visible_kernel(int P, const float* means3D, const float* vm, uint8_t* present)

@@ -342,7 +342,8 @@ SURFEL_HD void sh_backward(int deg, int M, const float p_world[3], const float c
     for (int k = 0; k < 16; k++) {
         if (k < M) {
             if (k < n) {
-                const float dot = sh[3 * k] * dRGB[0] + sh[3 * k + 1] * dRGB[1] + sh[3 * k + 2] * dRGB[2];
+                const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];  // (dsh may alias sh)
+                const float dot = s0 * dRGB[0] + s1 * dRGB[1] + s2 * dRGB[2];
                 ddir[0] += bx[k] * dot;
                 ddir[1] += by[k] * dot;
                 ddir[2] += bz[k] * dot;

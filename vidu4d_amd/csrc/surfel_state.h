@@ -16,38 +16,42 @@
 
 namespace surfel {
 
-constexpr int PRE_BLOCK = 256;           // surfels per preprocess / emit workgroup
-constexpr int SORT_ITEMS = 16;           // keys per thread in one radix-sort workgroup
-constexpr int SORT_BLOCK = 256;
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // 4096 keys per workgroup
-constexpr int RADIX_BITS = 8;
-constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int PRE_BLOCK = 256;   // surfels per preprocess / emit workgroup
+constexpr int TILE_SLICES = 16;     // (atomic path) sub-counters per tile: spreads same-address serialisation
+// Grouped binning (the default): surfels are processed in <= BIN_MAX_GROUPS groups by 1024-thread
+// workgroups that count / place their pairs with LDS atomics only; the per-(group, tile) counts are
+// prefix-summed in between.  Needs one LDS word per tile.
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_MAX_GROUPS = 256;
+constexpr int BIN_MAX_TILES = 16384;  // 64 KiB of LDS counters
+constexpr int TILE_SORT_CAP = 3584;  // list entries a tile can sort entirely inside LDS (2 x 28 KiB ping-pong)
 
 struct Header {           // first 256 bytes of the geometry buffer
-    uint32_t num_rendered;  // R, written by the scan kernel
+    uint32_t num_rendered;  // R, written by the tile scan
     uint32_t overflow;      // set by emit when R > capacity
     uint32_t pad[62];
 };
 
 struct GeomState {
     Header* hdr;
-    float* rec;              // [P][20]   (surfel_math.h RecSlot)
+    float* rec;              // [P][24]   (surfel_math.h RecSlot)
     uint32_t* tiles_touched; // [P]
-    uint32_t* block_sums;    // [ceil(P/256)]
-    uint32_t* block_offsets; // [ceil(P/256)] exclusive scan of block_sums
 };
 
 struct ImageState {
-    float* final_T;       // [3][H*W]  T, dist1, dist2
-    uint32_t* n_contrib;  // [2][H*W]  last contributor, median contributor
-    uint32_t* ranges;     // [tiles][2]
+    float* final_T;        // [3][H*W]  T, dist1, dist2
+    uint32_t* n_contrib;   // [2][H*W]  last contributor, median contributor
+    uint32_t* ranges;      // [tiles][2]
+    uint32_t* tile_count;  // [tiles][TILE_SLICES] pair counts (preprocess), then emit cursors (atomic path);
+                           // [tiles] per-tile totals (grouped path)
+    uint32_t* tile_base;   // [tiles][TILE_SLICES] start of each (tile, slice) sub-segment (atomic path)
+    uint32_t* group_counts;  // [groups][tiles] pair counts per surfel group, then exclusive prefix over groups
 };
 
 struct BinState {
-    uint64_t* keys[2];    // ping-pong
-    uint32_t* vals[2];
-    uint32_t* counts;     // [RADIX][sort_blocks] per-pass digit histogram / offsets
-    int sort_blocks;
+    uint64_t* entries;     // [cap] (depth bits << 32 | surfel id), grouped by tile, sorted per tile
+    uint64_t* scratch;     // [cap] ping-pong space for tiles too long for LDS
+    uint32_t* point_list;  // [cap] sorted surfel ids == the reference's binningState.point_list
 };
 
 template <typename T>
@@ -59,6 +63,15 @@ inline void carve(char*& p, T*& out, size_t count)
 }
 
 inline int pre_blocks(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
+// grouped binning geometry: each 1024-thread workgroup walks bin_iters(P) x 1024 consecutive surfels
+inline int bin_iters(int P)
+{
+    const long long per = (long long)BIN_THREADS * BIN_MAX_GROUPS;
+    const int k = (int)((P + per - 1) / per);
+    return k > 1 ? k : 1;
+}
+inline int bin_groups(int P) { const int sb = BIN_THREADS * bin_iters(P); return (P + sb - 1) / sb; }
+inline bool use_grouped_binning(int num_tiles) { return num_tiles <= BIN_MAX_TILES; }
 
 inline size_t carve_geom(char* base, int P, GeomState& g)
 {
@@ -66,8 +79,6 @@ inline size_t carve_geom(char* base, int P, GeomState& g)
     carve(p, g.hdr, 1);
     carve(p, g.rec, (size_t)P * REC_FLOATS);
     carve(p, g.tiles_touched, (size_t)P);
-    carve(p, g.block_sums, (size_t)pre_blocks(P) + 1);
-    carve(p, g.block_offsets, (size_t)pre_blocks(P) + 1);
     return (size_t)(p - base) + 256;
 }
 
@@ -79,6 +90,9 @@ inline size_t carve_image(char* base, int W, int H, ImageState& s)
     carve(p, s.final_T, 3 * hw);
     carve(p, s.n_contrib, 2 * hw);
     carve(p, s.ranges, 2 * tiles);
+    carve(p, s.tile_count, tiles * TILE_SLICES);
+    carve(p, s.tile_base, tiles * TILE_SLICES);
+    carve(p, s.group_counts, tiles <= (size_t)BIN_MAX_TILES ? tiles * BIN_MAX_GROUPS : 0);
     return (size_t)(p - base) + 256;
 }
 
@@ -86,31 +100,10 @@ inline size_t carve_binning(char* base, int64_t capacity, BinState& b)
 {
     char* p = base;
     const size_t cap = (size_t)(capacity > 0 ? capacity : 0);
-    b.sort_blocks = (int)((cap + SORT_TILE - 1) / SORT_TILE);
-    carve(p, b.keys[0], cap);
-    carve(p, b.keys[1], cap);
-    carve(p, b.vals[0], cap);
-    carve(p, b.vals[1], cap);
-    carve(p, b.counts, (size_t)RADIX * (size_t)(b.sort_blocks > 0 ? b.sort_blocks : 1));
+    carve(p, b.entries, cap);
+    carve(p, b.scratch, cap);
+    carve(p, b.point_list, cap);
     return (size_t)(p - base) + 256;
-}
-
-// Number of 8-bit radix passes for keys of (32 + tile bits) significant bits
-// (rasterizer_impl.cu:301-309: SortPairs(..., 0, 32 + bit)).
-inline int higher_msb(uint32_t n)
-{
-    uint32_t msb = sizeof(n) * 4, step = msb;
-    while (step > 1) {
-        step /= 2;
-        if (n >> msb) msb += step; else msb -= step;
-    }
-    if (n >> msb) msb++;
-    return (int)msb;
-}
-inline int sort_passes(int grid_x, int grid_y)
-{
-    const int bits = 32 + higher_msb((uint32_t)(grid_x * grid_y));
-    return (bits + RADIX_BITS - 1) / RADIX_BITS;
 }
 
 // Camera as passed to kernels: scalars by value, view matrix and camera position stay in device
@@ -180,17 +173,22 @@ struct PreprocessArgs {
     const float* colors_precomp;
     int32_t* radii;
     GeomState geom;
+    uint32_t* tile_count;    // atomic path: [tiles][TILE_SLICES], zeroed before the launch
+    uint32_t* group_counts;  // grouped path: [groups][tiles]
+    int iters;               // grouped path: surfel batches per workgroup
 };
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
-void launch_scan_blocks(const GeomState& g, int P, uint32_t* ranges, int num_tiles, hipStream_t stream);
-void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const BinState& b,
+// counts -> ranges (exclusive scan over tiles), total -> header; atomic path: counts reset to 0 (they
+// become cursors); grouped path (groups > 0): per-(group, tile) counts become prefixes over the groups
+void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, int groups, hipStream_t stream);
+void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
+                      const BinState& b, int64_t capacity, bool grouped, hipStream_t stream);
+// per-tile stable radix sort of the (depth, id) entries; fills point_list
+void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
                       int64_t capacity, hipStream_t stream);
-// Sorts keys[0]/vals[0] (num_rendered read on the device); returns which ping-pong side holds the result.
-int launch_radix_sort(const GeomState& g, const BinState& b, int64_t capacity, int passes, hipStream_t stream);
-void launch_tile_ranges(const GeomState& g, const uint64_t* sorted_keys, int64_t capacity, uint32_t* ranges,
-                        hipStream_t stream);
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const uint32_t* point_list,
-                      const float* background, float* out_color, float* out_others, hipStream_t stream);
+                      int64_t capacity, const float* background, float* out_color, float* out_others,
+                      hipStream_t stream);
 
 struct BackwardArgs {
     CameraParams cam;
