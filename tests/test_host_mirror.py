@@ -1,0 +1,177 @@
+"""CPU tests of the host-side mirror of the reference interface: bob LBS warp, dual-quaternion
+algebra, KCamera, GaussianModel densify / prune / optimizer surgery, PLY round trip."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from vidu4d_amd.gs.cameras import KCamera
+from vidu4d_amd.gs.gaussian_model import GaussianModel, build_rotation
+from vidu4d_amd.lab4d import quat_transform as qt
+from vidu4d_amd.lab4d.bob_warp import SkinningWarp, apply_qt_to_gaussian, dual_quaternion_skinning_qt
+from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels, PointCloud, _Args
+from vidu4d_amd.lab4d.stage3 import Stage3Trainer
+
+
+def _rand_dq(M, B, g):
+    q = torch.nn.functional.normalize(torch.randn(M, B, 4, generator=g), dim=-1)
+    t = torch.randn(M, B, 3, generator=g) * 0.3
+    return qt.quaternion_translation_to_dual_quaternion(q, t)
+
+
+def test_dual_quaternion_algebra():
+    g = torch.Generator().manual_seed(0)
+    a, b = _rand_dq(3, 5, g), _rand_dq(3, 5, g)
+    p = torch.randn(3, 5, 3, generator=g)
+    # composition == sequential application; inverse undoes
+    ab = qt.dual_quaternion_mul(a, b)
+    assert torch.allclose(qt.dual_quaternion_apply(ab, p), qt.dual_quaternion_apply(a, qt.dual_quaternion_apply(b, p)),
+                          atol=1e-5)
+    assert torch.allclose(qt.dual_quaternion_apply(qt.dual_quaternion_inverse(a), qt.dual_quaternion_apply(a, p)), p,
+                          atol=1e-5)
+    # quaternion_apply == rotation matrix
+    q = torch.nn.functional.normalize(torch.randn(7, 4, generator=g), dim=-1)
+    v = torch.randn(7, 3, generator=g)
+    assert torch.allclose(qt.quaternion_apply(q, v), torch.einsum("nij,nj->ni", build_rotation(q), v), atol=1e-5)
+
+
+def test_dq_skinning_matches_materialised_reference_formulation():
+    """geom_utils.py:48-92 written the upstream way (explicit (M,N,B,4) copies + gather) vs ours."""
+    g = torch.Generator().manual_seed(1)
+    M, N, B = 2, 300, 25
+    se3 = _rand_dq(M, B, g)
+    skin = torch.softmax(torch.randn(M, N, B, generator=g) * 3, -1)
+    qr = se3[0][:, None].repeat(1, N, 1, 1)
+    qd = se3[1][:, None].repeat(1, N, 1, 1)
+    anchor = skin.argmax(-1).view(M, -1, 1, 1).repeat(1, 1, 1, 4)
+    sign = ((torch.gather(qr, 2, anchor) * qr).sum(-1) > 0)[..., None].float() * 2 - 1
+    qr_w = torch.einsum("bnk,bnkl->bnl", skin, sign * qr)
+    qd_w = torch.einsum("bnk,bnkl->bnl", skin, sign * qd)
+    inv = qr_w.norm(p=2, dim=-1, keepdim=True).reciprocal()
+    q_ref, t_ref = qt.dual_quaternion_to_quaternion_translation((qr_w * inv, qd_w * inv))
+    q, t = dual_quaternion_skinning_qt(se3, skin)
+    assert torch.allclose(q, q_ref, atol=1e-5) and torch.allclose(t, t_ref, atol=1e-5)
+
+
+def test_bob_warp_rigid_when_bones_move_together():
+    """If every bone undergoes the same rigid motion, every point undergoes exactly that motion."""
+    warp = SkinningWarp(num_frames=8, num_se3=25)
+    g = torch.Generator().manual_seed(2)
+    M, N = 2, 500
+    xyz = torch.randn(M, N, 1, 3, generator=g) * 0.1
+    rest = warp.articulation.rest("cpu")
+    rest = (rest[0][None].expand(M, -1, -1).contiguous(), rest[1][None].expand(M, -1, -1).contiguous())
+    q = torch.nn.functional.normalize(torch.randn(M, 1, 4, generator=g), dim=-1).expand(-1, 25, -1).contiguous()
+    t = (torch.randn(M, 1, 3, generator=g) * 0.2).expand(-1, 25, -1).contiguous()
+    rigid = qt.quaternion_translation_to_dual_quaternion(q, t)
+    t_art = qt.dual_quaternion_mul(rigid, rest)
+    (qq, tt), aux = warp(xyz, torch.arange(M), samples_dict={"rest_articulation": rest, "t_articulation": t_art},
+                         return_aux=True)
+    moved, _ = apply_qt_to_gaussian(xyz, None, qq, tt, M)
+    want = qt.quaternion_translation_apply(q[:, :1], t[:, :1], xyz.view(M, N, 3)).view(M, N, 1, 3)
+    assert torch.allclose(moved, want, atol=1e-5)
+    assert aux["skin_entropy"].shape == (M, N, 1) and aux["delta_skin"].shape == (M, N, 1)
+    # and gradients reach the canonical points through the skinning weights
+    xyz.requires_grad_(True)
+    (q2, t2) = warp(xyz, torch.arange(M))
+    (q2.sum() + t2.sum()).backward()
+    assert xyz.grad is not None and torch.isfinite(xyz.grad).all()
+
+
+def test_kcamera_matches_reference_conventions():
+    H, W = 96, 128
+    K = torch.tensor([[W / 1.0, 0, W / 2.0], [0, W / 1.0, H / 2.0], [0, 0, 1.0]])
+    Kinv = torch.inverse(K)
+    left, right = Kinv[0, 2], Kinv[0, 2] + Kinv[0, 0] * W
+    bottom, top = Kinv[1, 2], Kinv[1, 2] + Kinv[1, 1] * H
+    cam = KCamera(H=H, W=W, left=left, right=right, top=top, bottom=bottom, data_device="cpu")
+    assert torch.equal(cam.world_view_transform, torch.eye(4))
+    assert torch.equal(cam.camera_center, torch.zeros(3))
+    assert math.isclose(float(torch.tan(cam.FoVx * 0.5)), 0.5, rel_tol=1e-6)
+    assert math.isclose(float(torch.tan(cam.FoVy * 0.5)), 0.5 * H / W, rel_tol=1e-6)
+    assert cam.full_proj_transform.shape == (4, 4) and cam.original_image.shape == (1, H, W)
+    # a point on the optical axis projects to the NDC centre
+    p = torch.tensor([0.0, 0.0, 2.0, 1.0]) @ cam.full_proj_transform
+    assert abs(float(p[0] / p[3])) < 1e-6 and abs(float(p[1] / p[3])) < 1e-6
+
+
+def _model(n=400, seed=0):
+    rng = np.random.default_rng(seed)
+    opts = dict(fg_motion="gs-bob", sh_degree=3)
+    m = DeformableSurfels(opts, num_frames=8, device="cpu")
+    m.init_from_points(rng.normal(size=(n, 3)).astype(np.float32) * 0.1, rng.uniform(size=(n, 3)).astype(np.float32))
+    return m
+
+
+def test_gaussian_model_init_and_activations():
+    m = _model()
+    n = m._xyz.shape[0]
+    assert m._features_dc.shape == (n, 1, 3) and m._features_rest.shape == (n, 15, 3)
+    assert m._scaling.shape == (n, 2) and m._rotation.shape == (n, 4) and m._opacity.shape == (n, 1)
+    assert torch.allclose(m.get_opacity, torch.full((n, 1), 0.1), atol=1e-6)
+    assert torch.allclose(m.get_rotation.norm(dim=1), torch.ones(n), atol=1e-6)
+    assert m.get_features.shape == (n, 16, 3) and m.active_sh_degree == 0
+    for _ in range(5):
+        m.oneupSHdegree()
+    assert m.active_sh_degree == 3
+    # scales = sqrt(mean squared distance to the 3 nearest neighbours)
+    from scipy.spatial import cKDTree
+    pts = m._xyz.detach().numpy()
+    d, _ = cKDTree(pts).query(pts, k=4)
+    assert np.allclose(m.get_scaling[:, 0].detach().numpy(), np.sqrt((d[:, 1:] ** 2).mean(1)), rtol=1e-4)
+
+
+def test_densify_prune_keeps_optimizer_state_consistent():
+    m = _model(300)
+    tr = Stage3Trainer(m, dict(fg_motion="gs-bob"))
+    # one fake step so that Adam has state
+    for p in tr.surfel_params():
+        p.grad = torch.randn_like(p) * 1e-3
+    tr.gs_optimizer.step()
+    n0 = m._xyz.shape[0]
+    m.xyz_gradient_accum = torch.rand(n0, 1) * 1e-3
+    m.denom = torch.ones(n0, 1)
+    m._opacity.data[:10] = -10.0  # ~0 opacity: pruned
+    gen = torch.Generator().manual_seed(5)
+    m.densify_and_prune(2e-4, 0.005, extent=1.0, max_screen_size=None, generator=gen)
+    n1 = m._xyz.shape[0]
+    assert n1 != n0
+    for group in tr.gs_optimizer.param_groups:
+        if group["name"] == "bg_rgb":
+            continue
+        p = group["params"][0]
+        assert p.shape[0] == n1 and p.requires_grad
+        st = tr.gs_optimizer.state[p]
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+    assert m.xyz_gradient_accum.shape == (n1, 1) and m.denom.shape == (n1, 1) and m.max_radii2D.shape == (n1,)
+    assert m._regist_feat.shape[0] == n1
+    assert float(m.get_opacity.min()) >= 0.005 - 1e-6
+    # the optimizer still steps on the new tensors
+    for p in tr.surfel_params():
+        p.grad = torch.zeros_like(p)
+    tr.gs_optimizer.step()
+    m.reset_opacity()
+    assert float(m.get_opacity.max()) <= 0.01 + 1e-6
+
+
+def test_ply_round_trip(tmp_path):
+    m = _model(50)
+    path = str(tmp_path / "fg-gs.ply")
+    m.save_ply(path)
+    head = open(path, "rb").read(400).decode("ascii", "ignore")
+    assert "property float x" in head and "property float nx" in head and "property float f_dc_0" in head
+    m2 = GaussianModel(3, device="cpu")
+    m2.load_ply(path)
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(m, k).detach(), getattr(m2, k).detach()), k
+    names = m.construct_list_of_attributes()
+    assert names[:6] == ["x", "y", "z", "nx", "ny", "nz"] and names[-4:] == ["rot_0", "rot_1", "rot_2", "rot_3"]
+    assert len(names) == 6 + 3 + 45 + 1 + 2 + 4
+
+
+def test_stage3_defaults_match_reference_flags():
+    a = _Args({})
+    assert (a.position_lr_init, a.feature_lr, a.opacity_lr, a.scaling_lr, a.rotation_lr) == (5e-5, 2.5e-3, 0.05, 5e-3, 1e-3)
+    assert (a.densification_interval, a.densify_from_iter, a.densify_until_iter) == (100, 500, 15000)
+    assert (a.densify_grad_threshold, a.opacity_reset_interval, a.percent_dense) == (2e-4, 3000, 0.01)

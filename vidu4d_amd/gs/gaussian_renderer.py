@@ -1,0 +1,65 @@
+"""`render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None)`:
+the function Vidu4D's Stage-3 field calls once per frame
+(reference: gs/gaussian_renderer/__init__.py:21-164; caller lab4d/nnutils/deformable_gaussian.py:187).
+
+Same signature and the same keys in the returned dict: render, viewspace_points, visibility_filter,
+radii, acc, rend_normal, rend_dist, surf_depth, render_depth_median, render_depth_expected,
+surf_normal.  The rasterizer behind it is the MI355X-native `diff_surfel_rasterization`."""
+import torch
+
+from ..diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from .point_utils import depth_to_normal
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    xyz = pc.get_xyz
+    # dummy (N,3) tensor whose .grad receives the screen-space densification statistic (:29-33)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    fovx, fovy = viewpoint_camera.FoVx, viewpoint_camera.FoVy
+    tanfovx = torch.tan(fovx * 0.5) if isinstance(fovx, torch.Tensor) else torch.tan(torch.as_tensor(fovx * 0.5))
+    tanfovy = torch.tan(fovy * 0.5) if isinstance(fovy, torch.Tensor) else torch.tan(torch.as_tensor(fovy * 0.5))
+    settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=settings)
+
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    pipe.convert_SHs_python = False
+    # upstream passes BOTH shs and override_color (:83-84); the rasterizer accepts exactly one, and
+    # Vidu4D always passes override_color=None (deformable_gaussian.py:1183)
+    shs = pc.get_features if override_color is None else None
+    try:
+        xyz.retain_grad()
+    except Exception:
+        pass
+    rendered_image, radii, allmap = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
+                                               colors_precomp=override_color, opacities=pc.get_opacity,
+                                               scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii}
+
+    render_alpha = allmap[1:2]
+    render_normal = allmap[2:5]
+    render_normal = (render_normal.permute(1, 2, 0) @ viewpoint_camera.world_view_transform[:3, :3].T).permute(2, 0, 1)
+    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
+    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
+    render_dist = allmap[6:7]
+    ratio = getattr(pipe, "depth_ratio", 0.0)
+    surf_depth = render_depth_expected * (1 - ratio) + ratio * render_depth_median
+    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1) * render_alpha.detach()
+    rets.update({"acc": render_alpha, "rend_normal": render_normal, "rend_dist": render_dist,
+                 "surf_depth": torch.cat([surf_depth] * 3, 0),
+                 "render_depth_median": torch.cat([render_depth_median] * 3, 0),
+                 "render_depth_expected": torch.cat([render_depth_expected] * 3, 0), "surf_normal": surf_normal})
+    return rets

@@ -1,0 +1,166 @@
+"""DeformableSurfels: the Stage-3 4D surfel field (canonical surfels -> bob LBS warp -> camera space
+-> per-frame rasterization), i.e. the hot part of `DeformableGaussian`
+(reference: lab4d/nnutils/deformable_gaussian.py: __init__ :87-161, get_xyz/get_rotation overrides
+:163-176, render_view :178-202, get_gs_Kcamera :927-962, apply_qt_to_gaussian :1032-1046,
+query_field render loop :1175-1233, forward_warp :1395-1434).
+
+Out of scope here (auxiliary losses dropped by --rgb_loss_only, trainer.py:477-483): cycle loss,
+feature matching / reprojection, flow rendering, bone-density visualisation."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..gs.cameras import KCamera
+from ..gs.gaussian_model import GaussianModel
+from ..gs.gaussian_renderer import render
+from . import quat_transform as qt
+from .bob_warp import SkinningWarp, TimeEmbedding, apply_qt_to_gaussian
+
+
+class PipelineParams:
+    """2DGS PipelineParams defaults (gs/arguments/__init__.py:64-70)."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    depth_ratio = 0.0
+    debug = False
+
+
+class PointCloud:
+    def __init__(self, points, colors):
+        self.points, self.colors = points, colors
+
+
+class CameraMLP(nn.Module):
+    """time -> object-to-camera SE(3) as (quaternion, translation) (pose.py:29-150): a base pose plus
+    an MLP delta on the time code."""
+
+    def __init__(self, num_frames: int, base_trans=(0.0, 0.0, 3.0), W: int = 128):
+        super().__init__()
+        self.time_embedding = TimeEmbedding(num_frames)
+        self.base_quat = nn.Parameter(torch.tensor([1.0, 0.0, 0.0, 0.0]))
+        self.base_trans = nn.Parameter(torch.tensor(base_trans, dtype=torch.float32))
+        self.mlp = nn.Sequential(nn.Linear(self.time_embedding.out_channels, W), nn.ReLU(True), nn.Linear(W, 6))
+        nn.init.normal_(self.mlp[-1].weight, std=1e-2)
+        nn.init.zeros_(self.mlp[-1].bias)
+
+    def get_vals(self, frame_id):
+        d = self.mlp(self.time_embedding(frame_id))
+        q = qt.quaternion_mul(qt.axis_angle_to_quaternion(d[:, :3]), self.base_quat[None].expand(d.shape[0], -1))
+        return torch.nn.functional.normalize(q, dim=-1), self.base_trans[None] + d[:, 3:]
+
+
+def Kmatinv(Kmat):
+    """(…,3,3) intrinsics -> inverse (lab4d/utils/geom_utils.py Kmatinv)."""
+    return torch.inverse(Kmat)
+
+
+class DeformableSurfels(GaussianModel):
+    def __init__(self, opts: dict, num_frames: int, device="cuda"):
+        super().__init__(opts.get("sh_degree", 3), device=device)
+        self.opts = opts
+        self.num_frames = num_frames
+        motion = opts.get("fg_motion", "gs-bob")
+        assert motion.startswith("gs-"), motion
+        assert motion[3:] == "bob", "only the bag-of-bones warp is on the Stage-3 path"
+        self.warp = SkinningWarp(num_frames, num_se3=opts.get("num_se3", 25), delta_skin=opts.get("delta_skin", True))
+        self.camera_mlp = CameraMLP(num_frames)
+        self.pipeline = PipelineParams()
+        self.pipeline.debug = opts.get("debug_cuda", False)
+        self.register_buffer("background", torch.zeros(3))
+        self.learnable_bkgd = nn.Parameter(torch.zeros(3))
+        self.cameras_extent = opts.get("cameras_extent", 1.0)
+        self.to(self.device_)
+
+    # ---- initialisation from a point sample of the Stage-2 proxy mesh (init_proxy :354-409)
+    def init_from_points(self, points, colors, feat_channels: int = 16):
+        self.create_from_pcd(PointCloud(points, colors), spatial_lr_scale=1.0)
+        self._regist_feat = nn.Parameter(torch.zeros(self._xyz.shape[0], feat_channels, device=self._xyz.device))
+        self.training_setup(_Args(self.opts))
+
+    # ---- overrides used while rendering one warped frame (:163-176)
+    @property
+    def get_rotation(self):
+        if hasattr(self, "_override_rotation"):
+            return self.rotation_activation(self._override_rotation)
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._override_xyz if hasattr(self, "_override_xyz") else self._xyz
+
+    def render_view(self, view, override_xyz=None, override_rotation=None, override_color=None, override_bkgd=None):
+        if override_xyz is not None:
+            assert override_xyz.dim() == 2
+            self._override_xyz = override_xyz
+            self._override_rotation = override_rotation
+        try:
+            bkgd = self.background if override_bkgd is None else override_bkgd
+            rendered = render(view, self, self.pipeline, bkgd, override_color=override_color)
+        finally:
+            if override_xyz is not None:
+                del self._override_xyz
+                del self._override_rotation
+        if self.opts.get("gs_learnable_bg", True):
+            rendered["render"] = rendered["render"] + (1 - rendered["acc"]) * self.learnable_bkgd[:, None, None]
+        return rendered
+
+    def get_gs_Kcamera(self, Kinvs, Hs, Ws):
+        cams = []
+        for i in range(Kinvs.shape[0]):
+            Kinv, H, W = Kinvs[i], int(Hs[i]), int(Ws[i])
+            left, right = Kinv[0, 2], Kinv[0, 2] + Kinv[0, 0] * W
+            bottom, top = Kinv[1, 2], Kinv[1, 2] + Kinv[1, 1] * H
+            cams.append(KCamera(H=H, W=W, left=left, right=right, top=top, bottom=bottom, data_device=Kinv.device))
+        return cams
+
+    def forward_warp(self, xyz, rotation, frame_id, inst_id=None, samples_dict=None):
+        """Canonical -> time t (bob LBS) -> camera space.  xyz (M,N,1,3), rotation (M,N,4)."""
+        samples_dict = samples_dict or {}
+        M = frame_id.shape[0]
+        (q, t), aux = self.warp(xyz, frame_id, inst_id, samples_dict=samples_dict, return_qt=True, return_aux=True)
+        xyz_t, rot_t = apply_qt_to_gaussian(xyz, rotation, q, t, M)
+        cq, ct = samples_dict["field2cam"] if "field2cam" in samples_dict else self.camera_mlp.get_vals(frame_id)
+        N = xyz.shape[1]
+        cq = cq[:, None].expand(-1, N, -1)
+        ct = ct[:, None].expand(-1, N, -1)
+        xyz_cam, rot_cam = apply_qt_to_gaussian(xyz_t, rot_t, cq, ct, M)
+        self._aux_dict = aux
+        return xyz_cam, rot_cam, (q, t)
+
+    def render_frames(self, frame_id, Kinv, H, W, inst_id=None, samples_dict=None):
+        """The per-frame render loop of query_field (:1175-1233): returns a dict of (M,H,W,C) maps and
+        keeps the per-frame screen-space tensors the densification statistics need."""
+        M = frame_id.shape[0]
+        xyz = self._xyz[None, :, None].expand(M, -1, -1, -1)
+        rot = self._rotation[None].expand(M, -1, -1)
+        xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
+        cams = self.get_gs_Kcamera(Kinv, H, W)
+        stacked, per_frame = {}, {"viewspace_points": [], "visibility_filter": [], "radii": []}
+        for i in range(M):
+            r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i])
+            for k, v in r.items():
+                if k in per_frame:
+                    per_frame[k].append(v)
+                else:
+                    stacked.setdefault(k, []).append(v.permute(1, 2, 0))
+        out = {k: torch.stack(v, 0) for k, v in stacked.items()}
+        self._viewspace_points_batch = per_frame["viewspace_points"]
+        self._visibility_filter_batch = per_frame["visibility_filter"]
+        self._radii_batch = per_frame["radii"]
+        out["rendered"] = out["render"]
+        out["mask"] = out["acc"]
+        return out
+
+
+class _Args:
+    """dict -> attribute access with the Stage-3 defaults of lab4d/config.py:155-238."""
+    DEFAULTS = dict(percent_dense=0.01, position_lr_init=5e-5, position_lr_final=5e-7, position_lr_delay_mult=0.01,
+                    position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3,
+                    rotation_lr=1e-3, densification_interval=100, densify_from_iter=500, densify_until_iter=15000,
+                    densify_grad_threshold=2e-4, opacity_reset_interval=3000, lambda_normal=0.05, lambda_dist=0.0,
+                    lambda_dssim=0.0, sh_degree=3, gs_learnable_bg=True, rgb_wt=0.1, mask_wt=0.1, learning_rate=5e-4)
+
+    def __init__(self, opts):
+        self.__dict__.update(self.DEFAULTS)
+        self.__dict__.update({k: v for k, v in opts.items() if k in self.DEFAULTS})
