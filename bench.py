@@ -93,6 +93,28 @@ def cpu_baseline(scene, n_images: int):
             "fwd_only_images_per_s": n_images / t_fwd}
 
 
+def torch_cpu_baseline(scene, n_images: int):
+    """The pure-PyTorch CPU render BASELINE.json's north_star asks to be timed beside the GPU number
+    (oracle/torch_render.py: vectorised forward, autograd backward), all host cores."""
+    from oracle import torch_render as tr
+    from vidu4d_amd.synthetic import make_upstream_grads
+    torch.set_num_threads(os.cpu_count() or 1)
+    dc, do = make_upstream_grads(scene.width, scene.height)
+    t_all = 0.0
+    for f in range(n_images):
+        ins = [x.clone().requires_grad_(True) for x in (scene.means3D, scene.opacities, scene.scales,
+                                                         scene.rotations, scene.shs)]
+        t0 = time.perf_counter()
+        color, radii, others, state = tr.rasterize(ins[0], ins[1], ins[2], ins[3], scene.viewmatrix, scene.campos,
+                                                   scene.bg, scene.width, scene.height, scene.tanfovx, scene.tanfovy,
+                                                   scene.sh_degree, shs=ins[4])
+        ((color * dc).sum() + (others * do).sum()).backward()
+        t_all += time.perf_counter() - t0
+    return {"value": n_images / t_all, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_images} frame(s) fwd+bwd, pure-PyTorch vectorised render + autograd, "
+                      f"{scene.num_surfels} surfels {scene.width}x{scene.height}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +124,8 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--frames", type=int, default=120)
     ap.add_argument("--cpu-images", type=int, default=6, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--torch-cpu-images", type=int, default=1,
+                    help="frames timed on the pure-PyTorch CPU render (0 = skip; ~10-20 s each at 200k/512^2)")
     ap.add_argument("--no-stage-timers", action="store_true")
     args = ap.parse_args()
 
@@ -237,6 +261,8 @@ def main():
                                "algorithmic_bytes_per_launch": stage_bytes(dom, N, R, W * H, T, K)}
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
+        if world == 1 and args.torch_cpu_images > 0:
+            out["cpu_baseline_pytorch"] = torch_cpu_baseline(scene_cpu, args.torch_cpu_images)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

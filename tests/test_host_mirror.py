@@ -175,3 +175,25 @@ def test_stage3_defaults_match_reference_flags():
     assert (a.position_lr_init, a.feature_lr, a.opacity_lr, a.scaling_lr, a.rotation_lr) == (5e-5, 2.5e-3, 0.05, 5e-3, 1e-3)
     assert (a.densification_interval, a.densify_from_iter, a.densify_until_iter) == (100, 500, 15000)
     assert (a.densify_grad_threshold, a.opacity_reset_interval, a.percent_dense) == (2e-4, 3000, 0.01)
+
+
+def test_train_entry_flag_parsing(tmp_path):
+    """The reference's Stage-3 command line (README.md:44) parses; foreign flags are tolerated."""
+    from vidu4d_amd.lab4d.train import load_obj_points, parse_flags
+    argv = ("--seqname cat-pikachu-0 --logname gs --fg_motion gs-bob --num_rounds 61 --load_path a/ckpt_0020.pth "
+            "--gs_init_mesh a/021-fg-geo.obj --imgs_per_gpu 1 --pixels_per_image -1 --eval_res 256 --rgb_timefree "
+            "--rgb_dirfree --rgb_loss_only --gs_optim_warp=False --data_prefix full --force_center_cam "
+            "--nogs_learnable_bg --feature_lr=0.001").split()
+    opts, ignored = parse_flags(argv)
+    assert opts["fg_motion"] == "gs-bob" and opts["num_rounds"] == 61 and opts["pixels_per_image"] == -1
+    assert opts["rgb_loss_only"] is True and opts["gs_optim_warp"] is False and opts["force_center_cam"] is True
+    assert opts["gs_learnable_bg"] is False and opts["feature_lr"] == 0.001
+    assert ignored == ["--rgb_timefree", "--rgb_dirfree"]
+    ff = tmp_path / "opts.log"
+    ff.write_text("--densification_interval=50\n--sh_degree=2\n")
+    opts, _ = parse_flags([f"--flagfile={ff}", "--seqname", "x"])
+    assert opts["densification_interval"] == 50 and opts["sh_degree"] == 2 and opts["seqname"] == "x"
+    obj = tmp_path / "m.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\nf 1/1 2/1 4/1\n")
+    pts = load_obj_points(str(obj), 500, np.random.default_rng(0))
+    assert pts.shape == (500, 3) and (pts >= -1e-6).all() and (pts.sum(1) <= 1 + 1e-5).all()

@@ -72,6 +72,14 @@ class Stage3Trainer:
         self.gs_optimizer = torch.optim.Adam(groups, lr=c.learning_rate, eps=1e-15)
         m.optimizer = self.gs_optimizer
         self._flat = None
+        # --gs_optim_warp=False (the README's Stage-3 command): warp and camera networks come from the
+        # Stage-2 checkpoint and are never stepped (trainer.py:592-598).  Upstream still back-propagates
+        # into them; freezing them is results-equivalent for the surfels and skips the weight-gradient
+        # GEMMs and the (M,N,B,.) broadcast reductions of the warp backward.
+        self.optim_warp = bool((opts or model.opts).get("gs_optim_warp", False))
+        for mod in (m.warp, m.camera_mlp):
+            for prm in mod.parameters():
+                prm.requires_grad_(self.optim_warp)
 
     # ---- the path's only exchange
     def surfel_params(self):

@@ -1,0 +1,158 @@
+"""Stage-3 entry point with the reference's command line:
+
+    python lab4d/train.py --seqname cat-pikachu-0 --logname gs --fg_motion gs-bob --num_rounds 61 \\
+        --load_path logdir/…/ckpt_0020.pth --gs_init_mesh logdir/…/021-fg-geo.obj --imgs_per_gpu 1 \\
+        --pixels_per_image -1 --eval_res 256 --rgb_timefree --rgb_dirfree --rgb_loss_only \\
+        --gs_optim_warp=False --data_prefix full --force_center_cam            (README.md:44)
+
+(reference: lab4d/train.py:20-51, lab4d/config.py:8-251 absl flags, lab4d/engine/trainer.py:288-333
+rounds of `iters_per_round` steps with a `%03d-fg-gs.ply` export per round, multifields.py:292-293).
+
+What runs here is the Stage-3 hot path only: surfels initialised from `--gs_init_mesh` (or a
+synthetic proxy when the file is absent), the bob warp, the MI355X rasterizer, the surfel optimizer
+and densify cadence, frame-parallel over the ranks torchrun starts.  Dataset loading, Stage-2
+checkpoints and evaluation are outside this build: without them the targets are
+synthetic frames and the run says so.  Flags of the reference that do not concern this path are
+accepted and listed as ignored, so the reference's command lines keep working."""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+STAGE3_FLAGS = dict(
+    seqname="synthetic", logname="tmp", logroot="logdir", fg_motion="gs-bob", num_rounds=1, iters_per_round=200,
+    load_path="", gs_init_mesh="", imgs_per_gpu=1, pixels_per_image=-1, eval_res=256, train_res=256,
+    rgb_loss_only=False, gs_optim_warp=False, data_prefix="full", force_center_cam=False, sh_degree=3,
+    position_lr_init=5e-5, position_lr_final=5e-7, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+    feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3, rotation_lr=1e-3, percent_dense=0.01,
+    densification_interval=100, densify_from_iter=500, densify_until_iter=15000, densify_grad_threshold=2e-4,
+    opacity_reset_interval=3000, outlier_filtering_interval=2000, lambda_normal=0.05, lambda_dist=0.0,
+    lambda_dssim=0.0, gs_learnable_bg=True, debug_cuda=False, learning_rate=5e-4, num_frames=120,
+    num_surfels=200000, seed=0)
+
+
+def parse_flags(argv):
+    """absl-style parsing: --name=value, --name value, --name / --noname for booleans, --flagfile=path."""
+    opts, ignored = dict(STAGE3_FLAGS), []
+    args = list(argv)
+    i = 0
+    while i < len(args):
+        a = args[i]
+        i += 1
+        if not a.startswith("--"):
+            ignored.append(a)
+            continue
+        name, eq, val = a[2:].partition("=")
+        if name == "flagfile":
+            path = val if eq else args[i]
+            i += 0 if eq else 1
+            with open(path) as f:
+                args[i:i] = [ln.strip() for ln in f if ln.strip() and not ln.startswith("#")]
+            continue
+        if name.startswith("no") and name[2:] in opts and isinstance(opts[name[2:]], bool) and not eq:
+            opts[name[2:]] = False
+            continue
+        if name not in opts:
+            ignored.append(a)
+            if not eq and i < len(args) and not args[i].startswith("--"):
+                i += 1  # swallow its value
+            continue
+        cur = opts[name]
+        if isinstance(cur, bool):
+            opts[name] = True if not eq else val.lower() in ("1", "true", "yes")
+            continue
+        if not eq:
+            val = args[i]
+            i += 1
+        opts[name] = type(cur)(val) if not isinstance(cur, str) else val
+    return opts, ignored
+
+
+def load_obj_points(path: str, n: int, rng) -> np.ndarray:
+    """Area-weighted surface samples of a triangle mesh (load_mesh_as_pcd_trimesh,
+    deformable_gaussian.py:1797-1829, without trimesh)."""
+    verts, faces = [], []
+    with open(path) as f:
+        for ln in f:
+            if ln.startswith("v "):
+                verts.append([float(x) for x in ln.split()[1:4]])
+            elif ln.startswith("f "):
+                idx = [int(t.split("/")[0]) - 1 for t in ln.split()[1:]]
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    v, f = np.asarray(verts, np.float32), np.asarray(faces, np.int64)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    pick = rng.choice(len(f), size=n, p=area / area.sum())
+    u, w = rng.random(n), rng.random(n)
+    flip = u + w > 1
+    u[flip], w[flip] = 1 - u[flip], 1 - w[flip]
+    return (a[pick] + u[:, None] * (b[pick] - a[pick]) + w[:, None] * (c[pick] - a[pick])).astype(np.float32)
+
+
+def main(argv=None):
+    opts, ignored = parse_flags(sys.argv[1:] if argv is None else argv)
+    if not opts["fg_motion"].startswith("gs-"):
+        raise SystemExit("this build implements Stage-3 only: --fg_motion must be gs-bob (Stage-2 neural SDF is "
+                         "out of scope, DESIGN.md §9)")
+    import torch.distributed as dist
+    from .deformable_surfels import DeformableSurfels
+    from .stage3 import Stage3Trainer, synthetic_batch
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("Stage-3 needs a GPU: the rasterizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    say = print if rank == 0 else (lambda *a, **k: None)
+    if ignored:
+        say("flags accepted but not used by the Stage-3 hot path:", " ".join(ignored))
+
+    rng = np.random.default_rng(opts["seed"])  # identical canonical surfels on every rank
+    torch.manual_seed(opts["seed"])
+    n = opts["num_surfels"]
+    if opts["gs_init_mesh"] and os.path.exists(opts["gs_init_mesh"]):
+        pts = load_obj_points(opts["gs_init_mesh"], n, rng)
+        say(f"initialised {n} surfels from {opts['gs_init_mesh']}")
+    else:
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        pts = 0.25 * d / np.linalg.norm(d, axis=1, keepdims=True)
+        say(f"--gs_init_mesh not found: initialising {n} surfels on a synthetic proxy sphere")
+    model = DeformableSurfels(opts, num_frames=opts["num_frames"], device=dev)
+    model.init_from_points(pts, rng.uniform(size=(n, 3)).astype(np.float32))
+    trainer = Stage3Trainer(model, opts)
+    res = opts["train_res"] if opts["pixels_per_image"] == -1 else opts["eval_res"]
+    say(f"no dataset reader in this build: fitting synthetic {res}x{res} frames "
+        f"({opts['num_frames']} frames, {2 * opts['imgs_per_gpu']} per GPU per step, {world} GPU(s))")
+    logdir = os.path.join(opts["logroot"], f"{opts['seqname']}-{opts['logname']}")
+    if rank == 0:
+        os.makedirs(logdir, exist_ok=True)
+    per_step = 2 * opts["imgs_per_gpu"]
+    step = 0
+    for rnd in range(opts["num_rounds"]):
+        t0 = time.perf_counter()
+        for _ in range(opts["iters_per_round"]):
+            first = (step * per_step * world + rank * per_step) % opts["num_frames"]
+            ids = [(first + k) % opts["num_frames"] for k in range(per_step)]
+            losses = trainer.train_step(synthetic_batch(model, ids, res, res, seed=step))
+            step += 1
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        say(f"round {rnd}: {opts['iters_per_round']} steps, {opts['iters_per_round'] * per_step * world / dt:.1f} "
+            f"images/s, surfels {model._xyz.shape[0]}, loss " +
+            " ".join(f"{k}={float(v):.4g}" for k, v in losses.items()))
+        if rank == 0:
+            model.save_ply(os.path.join(logdir, "%03d-fg-gs.ply" % rnd))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
