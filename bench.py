@@ -73,7 +73,7 @@ def cpu_baseline(scene, n_images: int):
     """The CPU oracle (oracle/surfel_oracle.c, OpenMP over tiles/surfels) on the same workload."""
     from oracle import surfel_oracle as so
     from vidu4d_amd.synthetic import frame_motion, make_upstream_grads
-    cores = so.set_threads(os.cpu_count() or 1)
+    cores = so.set_threads(min(64, os.cpu_count() or 1))  # the tile loop stops scaling beyond ~64 threads
     dc, do = make_upstream_grads(scene.width, scene.height)
     t_fwd = t_all = 0.0
     for f in range(n_images + 1):
@@ -93,12 +93,12 @@ def cpu_baseline(scene, n_images: int):
             "fwd_only_images_per_s": n_images / t_fwd}
 
 
-def torch_cpu_baseline(scene, n_images: int):
+def torch_cpu_baseline(scene, n_images: int, threads: int):
     """The pure-PyTorch CPU render BASELINE.json's north_star asks to be timed beside the GPU number
-    (oracle/torch_render.py: vectorised forward, autograd backward), all host cores."""
+    (oracle/torch_render.py: vectorised forward, autograd backward)."""
     from oracle import torch_render as tr
     from vidu4d_amd.synthetic import make_upstream_grads
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     dc, do = make_upstream_grads(scene.width, scene.height)
     t_all = 0.0
     for f in range(n_images):
@@ -110,9 +110,26 @@ def torch_cpu_baseline(scene, n_images: int):
                                                    scene.sh_degree, shs=ins[4])
         ((color * dc).sum() + (others * do).sum()).backward()
         t_all += time.perf_counter() - t0
-    return {"value": n_images / t_all, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": n_images / t_all, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"{n_images} frame(s) fwd+bwd, pure-PyTorch vectorised render + autograd, "
                       f"{scene.num_surfels} surfels {scene.width}x{scene.height}"}
+
+
+def torch_cpu_baseline_bounded(args, limit_s: float = 150.0):
+    """Runs the PyTorch CPU baseline in a child process so that a slow host cannot hold up the bench:
+    past `limit_s` the child is killed and the field reports the bound instead of a rate."""
+    import subprocess
+    threads = min(32, os.cpu_count() or 1)  # beyond ~32 threads the many small tensor ops only contend
+    cmd = [sys.executable, os.path.abspath(__file__), "--_torch_cpu_child", str(args.torch_cpu_images), "--surfels",
+           str(args.surfels), "--res", str(args.res), "--_threads", str(threads)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if line else {"value": None, "error": (r.stderr or "no output")[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": f"did not finish {args.torch_cpu_images} frame(s) within {limit_s:.0f} s (< "
+                          f"{args.torch_cpu_images / limit_s:.4f} images/s)"}
 
 
 def main():
@@ -127,7 +144,14 @@ def main():
     ap.add_argument("--torch-cpu-images", type=int, default=1,
                     help="frames timed on the pure-PyTorch CPU render (0 = skip; ~10-20 s each at 200k/512^2)")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--_torch_cpu_child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--_threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args._torch_cpu_child:
+        from vidu4d_amd.synthetic import make_scene
+        print(json.dumps(torch_cpu_baseline(make_scene(args.surfels, args.res, seed=1234), args._torch_cpu_child,
+                                            args._threads)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -262,7 +286,7 @@ def main():
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
         if world == 1 and args.torch_cpu_images > 0:
-            out["cpu_baseline_pytorch"] = torch_cpu_baseline(scene_cpu, args.torch_cpu_images)
+            out["cpu_baseline_pytorch"] = torch_cpu_baseline_bounded(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
