@@ -163,9 +163,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # VIDU4D_BENCH_FORCE_DIST=1 exercises the collective path with a 1-rank RCCL group (CI on one GPU)
+    use_dist = world > 1 or os.environ.get("VIDU4D_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import diff_surfel_rasterization as dsr
@@ -188,7 +191,7 @@ def main():
     opac = scene.opacities.clone().requires_grad_(True)
     scales = scene.scales.clone().requires_grad_(True)
     shs = scene.shs.clone().requires_grad_(True)
-    flat = torch.empty(N * GRAD_FLOATS_PER_SURFEL, device=dev) if world > 1 else None
+    flat = torch.empty(N * GRAD_FLOATS_PER_SURFEL, device=dev) if use_dist else None
     counter = {"slot": 0, "R": 0.0, "n": 0}
 
     def step():
@@ -205,13 +208,13 @@ def main():
             torch.autograd.backward([color, allmap], [dc, do])
             g_means = m.grad if g_means is None else g_means + m.grad
             g_rot = r.grad if g_rot is None else g_rot + r.grad
-        if world > 1:  # the path's only exchange: canonical-surfel gradients, once per optimizer step
+        if use_dist:  # the path's only exchange: canonical-surfel gradients, once per optimizer step
             torch.cat([g_means.reshape(-1), opac.grad.reshape(-1), scales.grad.reshape(-1), g_rot.reshape(-1),
                        shs.grad.reshape(-1)], out=flat)
             dist.all_reduce(flat)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -227,7 +230,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     _lib.profile_enable(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -287,10 +290,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
         if world == 1 and args.torch_cpu_images > 0:
             out["cpu_baseline_pytorch"] = torch_cpu_baseline_bounded(args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it so that the JSON is the LAST line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
