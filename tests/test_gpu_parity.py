@@ -237,3 +237,29 @@ def test_partial_tiles_1080p_slice(gpu_device):
     d, shs, cols, out = _native_forward(sc, gpu_device)
     _check_forward(sc, st, out)
     _check_backward(sc, st, d, shs, cols, out, gpu_device)
+
+
+def test_concentrated_scene_long_tile_lists(gpu_device):
+    """Object-centric scene (the realistic Stage-3 case): 30k surfels inside ~3x3 tiles, i.e. tile
+    lists far longer than the LDS-resident sort capacity (3584) -> the global-memory ping-pong path
+    of the in-tile radix sort, many staging rounds and early saturation in the blend."""
+    sc = make_scene(30_000, 160, 128, seed=91, sigma_px=1.0)
+    g = torch.Generator().manual_seed(91)
+    sc.means3D[:, 0] = (torch.rand(30_000, generator=g) - 0.5) * 0.25 * sc.means3D[:, 2]
+    sc.means3D[:, 1] = (torch.rand(30_000, generator=g) - 0.5) * 0.25 * sc.means3D[:, 2]
+    sc.opacities[:] = 0.1  # Stage-3 initialisation: hundreds of contributors per pixel
+    st = oracle_forward(sc)
+    assert int((st["ranges"][:, 1] - st["ranges"][:, 0]).max()) > 3584
+    d, shs, cols, out = _native_forward(sc, gpu_device)
+    _check_forward(sc, st, out)
+    _check_backward(sc, st, d, shs, cols, out, gpu_device)
+
+
+def test_more_tiles_than_lds_counters(gpu_device):
+    """> 16384 tiles: the binning falls back from LDS histograms to sliced global atomics."""
+    sc = make_scene(6000, 2304, 2048, seed=93, sigma_px=3.0)
+    assert ((2304 + 15) // 16) * ((2048 + 15) // 16) > 16384
+    st = oracle_forward(sc)
+    d, shs, cols, out = _native_forward(sc, gpu_device)
+    _check_forward(sc, st, out)
+    _check_backward(sc, st, d, shs, cols, out, gpu_device)
