@@ -121,7 +121,7 @@ def torch_cpu_baseline_bounded(args, limit_s: float = 150.0):
     import subprocess
     threads = min(32, os.cpu_count() or 1)  # beyond ~32 threads the many small tensor ops only contend
     cmd = [sys.executable, os.path.abspath(__file__), "--_torch_cpu_child", str(args.torch_cpu_images), "--surfels",
-           str(args.surfels), "--res", str(args.res), "--_threads", str(threads)]
+           str(args.surfels), "--res", str(args.res), "--height", str(args.height), "--_threads", str(threads)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -138,7 +138,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--surfels", type=int, default=200_000)
-    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--res", type=int, default=512, help="image width (and height unless --height is given)")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--frames", type=int, default=120)
     ap.add_argument("--cpu-images", type=int, default=6, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--torch-cpu-images", type=int, default=1,
@@ -149,7 +150,8 @@ def main():
     args = ap.parse_args()
     if args._torch_cpu_child:
         from vidu4d_amd.synthetic import make_scene
-        print(json.dumps(torch_cpu_baseline(make_scene(args.surfels, args.res, seed=1234), args._torch_cpu_child,
+        print(json.dumps(torch_cpu_baseline(make_scene(args.surfels, args.res, args.height or None, seed=1234),
+                                            args._torch_cpu_child,
                                             args._threads)), flush=True)
         return
 
@@ -176,7 +178,7 @@ def main():
     from vidu4d_amd.synthetic import frame_motion, make_scene, make_upstream_grads
 
     N, W = args.surfels, args.res
-    scene_cpu = make_scene(N, W, seed=1234)
+    scene_cpu = make_scene(N, W, args.height or None, seed=1234)
     scene = scene_cpu.to(dev)
     H = scene.height
     dc, do = (t.to(dev) for t in make_upstream_grads(W, H))

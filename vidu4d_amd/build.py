@@ -23,6 +23,10 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fgpu-rdc" if False else "",
          "-Wall", "-Wno-unused-function", "-I", INCLUDE]
 FLAGS = [f for f in FLAGS if f]
+# Per-file extras.  blend.hip: clang's SLP vectoriser turns pairs of scalar fp32 ops into v_pk_* but
+# pays for it with v_mov_b32 to assemble the register pairs -- 266 vs 248 VALU instructions in the
+# backward inner loop (and 125 vs 110 VGPRs); the kernels are VALU-issue bound, so it is switched off.
+EXTRA_FLAGS = {"blend.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -48,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [spath, os.path.abspath(__file__)] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", spath, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", spath, "-o", obj])
 
     def run(cmd):
         if verbose:

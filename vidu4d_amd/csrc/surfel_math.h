@@ -560,15 +560,18 @@ SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal
     return true;
 }
 
-// Backward per-pixel state (backward.cu:192-244).
+// Backward per-pixel state (backward.cu:192-244).  The reference carries last_alpha / last_color /
+// last_depth / last_normal and folds the previous sample into the accum_*_rec running values at the
+// START of the next processed sample (backward.cu:337, :371, :375, :380).  Here the same update
+// (same operands, same operations, hence the same bits) is applied at the END of the sample that
+// produced them, which removes eight carried registers and their copies from the inner loop.
 struct BwdPixel {
     float T, T_final;
     float dL_dpixel[3];
     float dL_ddepth, dL_daccum, dL_dreg, dL_dnormal2D[3], dL_dmedian_depth, dL_dmax_dweight;
     float final_D, final_D2, final_A;
     float bg_dot_dpixel;
-    float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0};
-    float last_alpha = 0, last_depth = 0, last_normal[3] = {0, 0, 0};
+    float accum_rec[3] = {0, 0, 0};
     float accum_depth_rec = 0, accum_alpha_rec = 0, accum_normal_rec[3] = {0, 0, 0};
     float last_dL_dT = 0;
     uint32_t last_contributor, median_contributor;
@@ -580,13 +583,12 @@ SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float
                         const float rgb[3], float pixx, float pixy, bool is_median, float g[ACC_FLOATS])
 {
     const float alpha = e.alpha, G = e.G, c_d = e.depth;
-    const float inv_1ma = fast_rcp(1.f - alpha);
+    const float one_m_alpha = 1.f - alpha;
+    const float inv_1ma = fast_rcp(one_m_alpha);
     s.T = s.T * inv_1ma;
     const float w = alpha * s.T;
     float dL_dalpha = 0.0f;
     for (int ch = 0; ch < 3; ch++) {
-        s.accum_rec[ch] = s.last_alpha * s.last_color[ch] + (1.f - s.last_alpha) * s.accum_rec[ch];
-        s.last_color[ch] = rgb[ch];
         dL_dalpha += (rgb[ch] - s.accum_rec[ch]) * s.dL_dpixel[ch];
         g[A_RGB + ch] = w * s.dL_dpixel[ch];
     }
@@ -599,24 +601,26 @@ SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float
     }
     dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2.0f * m_d * s.final_D) * s.dL_dreg;
     dL_dalpha += dL_dweight - s.last_dL_dT;
-    s.last_dL_dT = dL_dweight * alpha + (1.0f - alpha) * s.last_dL_dT;
+    s.last_dL_dT = dL_dweight * alpha + one_m_alpha * s.last_dL_dT;
     const float dL_dmd = 2.0f * w * (m_d * s.final_A - s.final_D) * s.dL_dreg;
     dL_dz += dL_dmd * dmd_dd;
 
-    s.accum_depth_rec = s.last_alpha * s.last_depth + (1.f - s.last_alpha) * s.accum_depth_rec;
-    s.last_depth = c_d;
     dL_dalpha += (c_d - s.accum_depth_rec) * s.dL_ddepth;
-    s.accum_alpha_rec = s.last_alpha + (1.f - s.last_alpha) * s.accum_alpha_rec;
     dL_dalpha += (1.0f - s.accum_alpha_rec) * s.dL_daccum;
     for (int ch = 0; ch < 3; ch++) {
-        s.accum_normal_rec[ch] = s.last_alpha * s.last_normal[ch] + (1.f - s.last_alpha) * s.accum_normal_rec[ch];
-        s.last_normal[ch] = normal[ch];
         dL_dalpha += (normal[ch] - s.accum_normal_rec[ch]) * s.dL_dnormal2D[ch];
         g[A_NRM + ch] = w * s.dL_dnormal2D[ch];
     }
     dL_dalpha *= s.T;
-    s.last_alpha = alpha;
     dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot_dpixel;
+
+    // fold this sample into the running "what lies behind" values (see the struct comment)
+    for (int ch = 0; ch < 3; ch++) {
+        s.accum_rec[ch] = alpha * rgb[ch] + one_m_alpha * s.accum_rec[ch];
+        s.accum_normal_rec[ch] = alpha * normal[ch] + one_m_alpha * s.accum_normal_rec[ch];
+    }
+    s.accum_depth_rec = alpha * c_d + one_m_alpha * s.accum_depth_rec;
+    s.accum_alpha_rec = alpha + one_m_alpha * s.accum_alpha_rec;
 
     const float dL_dG = opacity * dL_dalpha;  // straight-through the 0.99 clamp (backward.cu:400)
     dL_dz += w * s.dL_ddepth;
