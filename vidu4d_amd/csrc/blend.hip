@@ -121,18 +121,38 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
             unsigned long long m = uniform_u64(s_mask[wave][k]);
+            // two list entries per trip: their evaluations are independent, so the scheduler interleaves
+            // the two dependency chains (LDS read -> cross product -> rcp -> exp); the accumulation stays
+            // in list order.  This is what hides latency when a SIMD has only one or two resident waves
+            // (small images, object-centric scenes).
             while (m) {
-                const int j = k * 64 + __builtin_ctzll(m);
+                const int ja = k * 64 + __builtin_ctzll(m);
                 m &= m - 1;
-                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-                const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
-                PairEval e;
-                const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && !done;
-                if (!__any(ok)) continue;
-                if (ok) {
-                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-                    const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                    if (!fwd_accumulate(s, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
+                const bool two = m != 0;
+                const int jb = two ? k * 64 + __builtin_ctzll(m) : ja;
+                if (two) m &= m - 1;
+                const float4 a0 = s_rec[ja * 5 + 0], a1 = s_rec[ja * 5 + 1], a2 = s_rec[ja * 5 + 2];
+                const float4 b0 = s_rec[jb * 5 + 0], b1 = s_rec[jb * 5 + 1], b2 = s_rec[jb * 5 + 2];
+                const float TuA[3] = {a0.x, a0.y, a0.z}, TvA[3] = {a0.w, a1.x, a1.y}, TwA[3] = {a1.z, a1.w, a2.x};
+                const float TuB[3] = {b0.x, b0.y, b0.z}, TvB[3] = {b0.w, b1.x, b1.y}, TwB[3] = {b1.z, b1.w, b2.x};
+                PairEval ea, eb;
+                bool okA = eval_pair_flat(TuA, TvA, TwA, a2.y, a2.z, a2.w, pixx, pixy, ea);
+                bool okB = eval_pair_flat(TuB, TvB, TwB, b2.y, b2.z, b2.w, pixx, pixy, eb) && two;
+                okA = okA && !done;
+                if (__any(okA)) {
+                    if (okA) {
+                        const float4 q3 = s_rec[ja * 5 + 3], q4 = s_rec[ja * 5 + 4];
+                        const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                        if (!fwd_accumulate(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = true;
+                    }
+                }
+                okB = okB && !done;
+                if (__any(okB)) {
+                    if (okB) {
+                        const float4 q3 = s_rec[jb * 5 + 3], q4 = s_rec[jb * 5 + 4];
+                        const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                        if (!fwd_accumulate(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = true;
+                    }
                 }
             }
         }
