@@ -181,6 +181,22 @@ int vidu4d_quaternion_mul_backward_backward(int64_t B, const float* gg_a, const 
                                             float* g_a, float* g_b, void* stream);
 int vidu4d_quaternion_conjugate(int64_t B, const float* q, float* out, void* stream);
 
+/* ---- fused bob linear-blend-skinning apply (forward warp of Stage-3): replaces the chain
+ *      dual_quaternion_skinning(return_qt=True) (lab4d/utils/geom_utils.py:48-92) ->
+ *      apply_qt_to_gaussian (lab4d/nnutils/deformable_gaussian.py:1032-1046) -> field2cam apply
+ *      (:1425-1430).  wT (B,N): softmax skinning weights, transposed; se3_qr/se3_qd (M,B,4): per-frame
+ *      bone transforms as dual quaternions; xyz (N,3), rot (N,4): canonical surfels; cam_q (M,4),
+ *      cam_t (M,3): object-to-camera.  Outputs out_xyz (M,N,3), out_rot (M,N,4).  The backward
+ *      writes per-frame gradients g_wT (M,B,N), g_xyz (M,N,3), g_rot (M,N,4); bone and camera
+ *      parameters are treated as constants. ---- */
+int vidu4d_lbs_forward(int M, int N, int B, const float* wT, const float* se3_qr, const float* se3_qd,
+                       const float* xyz, const float* rot, const float* cam_q, const float* cam_t, float* out_xyz,
+                       float* out_rot, void* stream);
+int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_qr, const float* se3_qd,
+                        const float* xyz, const float* rot, const float* cam_q, const float* cam_t,
+                        const float* g_out_xyz, const float* g_out_rot, float* g_wT, float* g_xyz, float* g_rot,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,90 @@
+"""GPU parity of the fused bob-LBS apply (csrc/lbs.hip) against the torch composite it replaces
+(bob_warp.dual_quaternion_skinning_qt -> apply_qt_to_gaussian x2; reference geom_utils.py:48-92,
+deformable_gaussian.py:1032-1046, :1425-1430).  Floating point: 1e-5 relative to the output scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(dev, M, N, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    from vidu4d_amd.lab4d import quat_transform as qt
+    qr = torch.nn.functional.normalize(torch.randn(M, B, 4, generator=g), dim=-1)
+    tr = 0.3 * torch.randn(M, B, 3, generator=g)
+    se3 = qt.quaternion_translation_to_dual_quaternion(qr, tr)
+    logits = 3.0 * torch.randn(N, B, generator=g)
+    xyz = 0.5 * torch.randn(N, 3, generator=g)
+    rot = torch.randn(N, 4, generator=g)
+    cq = torch.nn.functional.normalize(torch.randn(M, 4, generator=g), dim=-1)
+    ct = torch.randn(M, 3, generator=g)
+    return [t.to(dev) for t in (se3[0], se3[1], logits, xyz, rot, cq, ct)]
+
+
+def _composite(se3, logits, xyz, rot, cq, ct):
+    from vidu4d_amd.lab4d.bob_warp import apply_qt_to_gaussian, dual_quaternion_skinning_qt
+    M, N = se3[0].shape[0], xyz.shape[0]
+    prob = logits.softmax(-1)[None].expand(M, -1, -1)
+    q, t = dual_quaternion_skinning_qt(se3, prob)
+    x = xyz[None, :, None].expand(M, -1, -1, -1)
+    r = rot[None].expand(M, -1, -1)
+    x1, r1 = apply_qt_to_gaussian(x, r, q, t, M)
+    x2, r2 = apply_qt_to_gaussian(x1, r1, cq[:, None].expand(-1, N, -1), ct[:, None].expand(-1, N, -1), M)
+    return x2[:, :, 0], r2
+
+
+@pytest.mark.parametrize("M,N,B", [(2, 5000, 25), (1, 257, 25), (3, 1000, 7), (1, 1, 64)])
+def test_lbs_forward_backward_matches_composite(gpu_device, M, N, B):
+    from vidu4d_amd.lab4d.lbs_fused import lbs_apply
+    dev = gpu_device
+    qr, qd, logits, xyz, rot, cq, ct = _inputs(dev, M, N, B, seed=M * 1000 + N)
+    g = torch.Generator().manual_seed(7)
+    gx, gr = torch.randn(M, N, 3, generator=g).to(dev), torch.randn(M, N, 4, generator=g).to(dev)
+    res = {}
+    for name in ("fused", "torch"):
+        l, x, r = (t.clone().requires_grad_(True) for t in (logits, xyz, rot))
+        if name == "fused":
+            ox, orot = lbs_apply(l.softmax(-1), (qr, qd), x, r, cq, ct)
+        else:
+            ox, orot = _composite((qr, qd), l, x, r, cq, ct)
+        ((ox * gx).sum() + (orot * gr).sum()).backward()
+        res[name] = [t.detach().cpu().numpy() for t in (ox, orot, l.grad, x.grad, r.grad)]
+    for a, b, what in zip(res["fused"], res["torch"], ("xyz", "rot", "g_logits", "g_xyz", "g_rot")):
+        scale = max(1.0, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-5 * scale, (what, np.abs(a - b).max(), scale)
+
+
+def test_lbs_rejects_trainable_bones_and_bad_sizes(gpu_device):
+    from vidu4d_amd.lab4d.lbs_fused import lbs_apply
+    dev = gpu_device
+    qr, qd, logits, xyz, rot, cq, ct = _inputs(dev, 1, 16, 25, seed=0)
+    with pytest.raises(RuntimeError, match="requires grad"):
+        lbs_apply(logits.softmax(-1), (qr.requires_grad_(True), qd), xyz, rot, cq, ct)
+    qr2, qd2, logits2, *_ = _inputs(dev, 1, 16, 65, seed=0)
+    with pytest.raises(RuntimeError):
+        lbs_apply(logits2.softmax(-1), (qr2, qd2), xyz, rot, cq, ct)
+    ox, orot = lbs_apply(logits[:0].softmax(-1), (qr.detach(), qd), xyz[:0], rot[:0], cq, ct)
+    assert ox.shape == (1, 0, 3) and orot.shape == (1, 0, 4)
+
+
+def test_render_frames_fused_equals_unfused(gpu_device):
+    from tests.test_gpu_stage3 import _model
+    from vidu4d_amd.lab4d.stage3 import make_intrinsics_inv
+    dev = gpu_device
+    H = W = 96
+    out = {}
+    for fused in (True, False):
+        m = _model(dev, seed=3, fused_warp=fused)
+        for mod in (m.warp, m.camera_mlp):
+            for p in mod.parameters():
+                p.requires_grad_(False)
+        assert m.fused_warp_ok() == fused
+        fid = torch.tensor([1, 5], device=dev)
+        r = m.render_frames(fid, make_intrinsics_inv(2, H, W, device=dev), [H, H], [W, W])
+        (r["rendered"].mean() + r["rend_normal"].mean() + r["mask"].mean()).backward()
+        out[fused] = (r["rendered"].detach(), r["surf_depth"].detach(), m._xyz.grad.clone(), m._rotation.grad.clone(),
+                      m._aux_dict["skin_entropy"].detach())
+    for a, b in zip(out[True], out[False]):
+        scale = max(1e-3, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-3 * scale, (float((a - b).abs().max()), scale)

@@ -1,0 +1,219 @@
+// lbs.hip -- fused "bob" linear-blend-skinning apply for gfx950: per canonical surfel and frame,
+// hemisphere-aligned dual-quaternion blend of the bone transforms, normalisation, conversion to
+// (rotation, translation), application to the surfel centre and orientation, and the object-to-
+// camera transform -- forward and backward in one kernel each.
+//
+// Replaces, for the Stage-3 forward warp, the chain dual_quaternion_skinning(return_qt=True)
+// (/root/reference/lab4d/utils/geom_utils.py:48-92) -> apply_qt_to_gaussian
+// (lab4d/nnutils/deformable_gaussian.py:1032-1046) -> field2cam apply (:1425-1430), which upstream
+// runs as ~40 elementwise torch kernels per frame over (M,N,B,4) materialised copies of the bone
+// dual quaternions.  The skinning weights (softmax of the Gaussian-bone logits + delta MLP) are an
+// input: in the forward warp they do not depend on the frame (warping.py:415-425 uses the rest
+// articulation and the mean time code), so the caller computes them once per step.
+//
+// One thread per (frame, surfel).  Bone dual quaternions and the BxB hemisphere-sign table of the
+// frame live in LDS (wave-uniform broadcast reads); weights are read transposed (B,N) so that the
+// 25 loads of a wave are coalesced.  Gradients are produced w.r.t. the weights, the canonical centre
+// and the canonical orientation (per frame; the caller sums over frames); bone and camera
+// parameters are treated as constants (--gs_optim_warp=False, the README's Stage-3 setting).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vidu4d_surfel.h"
+
+namespace {
+
+constexpr int MAX_BONES = 64;
+
+struct Q {
+    float w, x, y, z;
+};
+__device__ __forceinline__ Q qmul(Q a, Q b)
+{
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q qconj(Q a) { return {a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ Q qadd(Q a, Q b) { return {a.w + b.w, a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ Q qscale(Q a, float s) { return {a.w * s, a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float qdot(Q a, Q b) { return a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ Q qvec(float x, float y, float z) { return {0.f, x, y, z}; }
+
+// y = q (0,p) q*  and its adjoint w.r.t. q (as 4 free components, like autograd of the reference's
+// quaternion_apply, quat_transform.py:259-276) and p.
+__device__ __forceinline__ void rotate(Q q, Q p, Q& p1, Q& out)
+{
+    p1 = qmul(q, p);
+    out = qmul(p1, qconj(q));
+}
+__device__ __forceinline__ void rotate_bwd(Q q, Q p, Q p1, Q g_out_vec, Q& g_q, Q& g_p)
+{
+    // out = p1 * conj(q); only the vector part of out is used downstream (g_out_vec.w == 0)
+    const Q g_p1 = qmul(g_out_vec, q);               // g * conj(conj(q))
+    const Q g_qc = qmul(qconj(p1), g_out_vec);        // gradient w.r.t. conj(q)
+    g_q = qadd(qconj(g_qc), qmul(g_p1, qconj(p)));    // + through p1 = q * p
+    g_p = qmul(qconj(q), g_p1);
+}
+
+struct Frame {
+    Q qr[MAX_BONES];
+    Q qd[MAX_BONES];
+};
+
+// Stages bone dual quaternions of frame m into LDS and builds the hemisphere-sign bit table.
+__device__ __forceinline__ void stage_frame(const float* se3_qr, const float* se3_qd, int m, int B, float* s_q,
+                                            unsigned long long* s_sign)
+{
+    for (int i = threadIdx.x; i < B * 4; i += blockDim.x) {
+        s_q[i] = se3_qr[(size_t)m * B * 4 + i];
+        s_q[MAX_BONES * 4 + i] = se3_qd[(size_t)m * B * 4 + i];
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < B; a += blockDim.x) {
+        unsigned long long bits = 0;
+        for (int b = 0; b < B; b++) {
+            float d = 0.f;
+            for (int k = 0; k < 4; k++) d += s_q[a * 4 + k] * s_q[b * 4 + k];
+            if (d > 0.f) bits |= 1ull << b;
+        }
+        s_sign[a] = bits;  // bit b set: bone b is in bone a's hemisphere (geom_utils.py:70-72)
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ Q ldq(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void lbs_kernel(int N, int B, const float* __restrict__ wT /*(B,N)*/,
+                                                  const float* __restrict__ se3_qr, const float* __restrict__ se3_qd,
+                                                  const float* __restrict__ xyz, const float* __restrict__ rot,
+                                                  const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+                                                  float* __restrict__ out_xyz, float* __restrict__ out_rot,
+                                                  const float* __restrict__ g_out_xyz,
+                                                  const float* __restrict__ g_out_rot, float* __restrict__ g_wT,
+                                                  float* __restrict__ g_xyz, float* __restrict__ g_rot)
+{
+    __shared__ float s_q[2 * MAX_BONES * 4];
+    __shared__ unsigned long long s_sign[MAX_BONES];
+    const int m = blockIdx.y;
+    stage_frame(se3_qr, se3_qd, m, B, s_q, s_sign);
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+
+    // skinning weights of this surfel, arg-max bone
+    float w[MAX_BONES];
+    int anchor = 0;
+    float best = -1e30f;
+#pragma unroll 5
+    for (int b = 0; b < B; b++) {
+        w[b] = wT[(size_t)b * N + n];
+        if (w[b] > best) {  // first maximum, like torch.argmax
+            best = w[b];
+            anchor = b;
+        }
+    }
+    const unsigned long long hemi = s_sign[anchor];
+    Q Qr = {0, 0, 0, 0}, Qd = {0, 0, 0, 0};
+    for (int b = 0; b < B; b++) {
+        const float ws = ((hemi >> b) & 1ull) ? w[b] : -w[b];
+        Qr = qadd(Qr, qscale(ldq(s_q + b * 4), ws));
+        Qd = qadd(Qd, qscale(ldq(s_q + MAX_BONES * 4 + b * 4), ws));
+    }
+    const float inv = 1.0f / sqrtf(qdot(Qr, Qr));
+    const Q q = qscale(Qr, inv), d = qscale(Qd, inv);
+    const Q tq = qscale(qmul(d, qconj(q)), 2.0f);  // translation = vector part (quat_transform.py:346-352)
+    const Q p = qvec(xyz[3 * n], xyz[3 * n + 1], xyz[3 * n + 2]);
+    const Q r = ldq(rot + 4 * n);
+    Q p1, px;
+    rotate(q, p, p1, px);
+    const Q xt = qvec(px.x + tq.x, px.y + tq.y, px.z + tq.z);
+    const Q rt = qmul(q, r);
+    const Q cq = ldq(cam_q + 4 * m);
+    const float* ct = cam_t + 3 * m;
+    Q c1, cx;
+    rotate(cq, xt, c1, cx);
+    if (!BACKWARD) {
+        const size_t o = (size_t)m * N + n;
+        out_xyz[3 * o] = cx.x + ct[0];
+        out_xyz[3 * o + 1] = cx.y + ct[1];
+        out_xyz[3 * o + 2] = cx.z + ct[2];
+        const Q rc = qmul(cq, rt);
+        out_rot[4 * o] = rc.w;
+        out_rot[4 * o + 1] = rc.x;
+        out_rot[4 * o + 2] = rc.y;
+        out_rot[4 * o + 3] = rc.z;
+        return;
+    }
+    // ---------------- backward
+    const size_t o = (size_t)m * N + n;
+    const Q g_xc = qvec(g_out_xyz[3 * o], g_out_xyz[3 * o + 1], g_out_xyz[3 * o + 2]);
+    const Q g_rc = ldq(g_out_rot + 4 * o);
+    // camera transform: xc = cq xt cq* + ct ; rc = cq * rt   (cq, ct constant)
+    Q g_cq_unused, g_xt;
+    rotate_bwd(cq, xt, c1, g_xc, g_cq_unused, g_xt);
+    g_xt.w = 0.f;
+    const Q g_rt = qmul(qconj(cq), g_rc);
+    // xt = q p q* + t ; rt = q * r
+    Q g_q, g_p;
+    rotate_bwd(q, p, p1, g_xt, g_q, g_p);
+    g_q = qadd(g_q, qmul(g_rt, qconj(r)));
+    const Q g_r = qmul(qconj(q), g_rt);
+    // t = 2 vec(d * conj(q))
+    const Q g_tq = qscale(g_xt, 2.0f);                 // gradient w.r.t. the quaternion d*conj(q) (vector part)
+    const Q g_d = qmul(g_tq, q);                       // g * conj(conj(q))
+    g_q = qadd(g_q, qconj(qmul(qconj(d), g_tq)));      // through conj(q)
+    // q = Qr / |Qr| ; d = Qd / |Qr|
+    const float gq_q = qdot(g_q, q), gd_d = qdot(g_d, d);
+    const Q g_Qr = qscale(qadd(g_q, qscale(q, -(gq_q + gd_d))), inv);
+    const Q g_Qd = qscale(g_d, inv);
+    // weights: Qr = sum_b s_b w_b qr_b (signs constant)
+    for (int b = 0; b < B; b++) {
+        const float s = ((hemi >> b) & 1ull) ? 1.0f : -1.0f;
+        const float gw = s * (qdot(g_Qr, ldq(s_q + b * 4)) + qdot(g_Qd, ldq(s_q + MAX_BONES * 4 + b * 4)));
+        g_wT[((size_t)m * B + b) * N + n] = gw;
+    }
+    g_xyz[3 * o] = g_p.x;
+    g_xyz[3 * o + 1] = g_p.y;
+    g_xyz[3 * o + 2] = g_p.z;
+    g_rot[4 * o] = g_r.w;
+    g_rot[4 * o + 1] = g_r.x;
+    g_rot[4 * o + 2] = g_r.y;
+    g_rot[4 * o + 3] = g_r.z;
+}
+
+int check(int M, int N, int B)
+{
+    if (M < 0 || N < 0 || B <= 0 || B > MAX_BONES) return VIDU4D_E_INVALID;
+    return VIDU4D_OK;
+}
+
+}  // namespace
+
+extern "C" int vidu4d_lbs_forward(int M, int N, int B, const float* wT, const float* se3_qr, const float* se3_qd,
+                                  const float* xyz, const float* rot, const float* cam_q, const float* cam_t,
+                                  float* out_xyz, float* out_rot, void* stream)
+{
+    if (check(M, N, B)) return VIDU4D_E_INVALID;
+    if (M == 0 || N == 0) return VIDU4D_OK;
+    if (!wT || !se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !out_xyz || !out_rot) return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(lbs_kernel<false>, dim3((N + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, N, B, wT, se3_qr,
+                       se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}
+
+extern "C" int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_qr, const float* se3_qd,
+                                   const float* xyz, const float* rot, const float* cam_q, const float* cam_t,
+                                   const float* g_out_xyz, const float* g_out_rot, float* g_wT /*(M,B,N)*/,
+                                   float* g_xyz /*(M,N,3)*/, float* g_rot /*(M,N,4)*/, void* stream)
+{
+    if (check(M, N, B)) return VIDU4D_E_INVALID;
+    if (M == 0 || N == 0) return VIDU4D_OK;
+    if (!wT || !se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !g_out_xyz || !g_out_rot || !g_wT || !g_xyz ||
+        !g_rot)
+        return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(lbs_kernel<true>, dim3((N + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, N, B, wT, se3_qr,
+                       se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot, g_wT, g_xyz, g_rot);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}

@@ -15,7 +15,8 @@ from ..gs.cameras import KCamera
 from ..gs.gaussian_model import GaussianModel
 from ..gs.gaussian_renderer import render
 from . import quat_transform as qt
-from .bob_warp import SkinningWarp, TimeEmbedding, apply_qt_to_gaussian
+from .bob_warp import SkinningWarp, TimeEmbedding, apply_qt_to_gaussian, cross_entropy_skin_loss
+from .lbs_fused import lbs_apply
 
 
 class PipelineParams:
@@ -128,13 +129,49 @@ class DeformableSurfels(GaussianModel):
         self._aux_dict = aux
         return xyz_cam, rot_cam, (q, t)
 
+    def fused_warp_ok(self, inst_id=None) -> bool:
+        """The fused HIP warp applies when bone and camera networks are frozen (--gs_optim_warp=False)
+        and all frames of the batch share one instance code."""
+        if not self._xyz.is_cuda or not self.opts.get("fused_warp", True):
+            return False
+        if any(p.requires_grad for mod in (self.warp, self.camera_mlp) for p in mod.parameters()):
+            return False
+        return inst_id is None or bool((inst_id == inst_id[0]).all())
+
+    def forward_warp_fused(self, frame_id, inst_id=None, samples_dict=None):
+        """forward_warp for frozen bones: the skinning weights of the forward warp depend on neither the
+        frame nor the time code (warping.py:415-425: rest articulation, mean time embedding), so they are
+        evaluated once for the step; blend + apply + camera transform run in one HIP kernel per
+        direction (csrc/lbs.hip).  -> xyz_cam (M,N,3), rot_cam (M,N,4)."""
+        samples_dict = samples_dict or {}
+        w = self.warp
+        if "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
+            rest_art, t_art = samples_dict["rest_articulation"], samples_dict["t_articulation"]
+        else:
+            t_art, rest_art = w.articulation.get_vals_and_mean(frame_id)
+        se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
+        rest1 = (rest_art[0][:1], rest_art[1][:1])
+        skin, delta = w.skinning_model(self._xyz[None], rest1, None, None if inst_id is None else inst_id[:1])
+        cq, ct = samples_dict["field2cam"] if "field2cam" in samples_dict else self.camera_mlp.get_vals(frame_id)
+        xyz_cam, rot_cam = lbs_apply(skin[0].softmax(-1), se3, self._xyz, self._rotation, cq, ct)
+        M = frame_id.shape[0]
+        aux = {"skin_entropy": cross_entropy_skin_loss(skin)[..., None].expand(M, -1, -1)}
+        if delta is not None:
+            aux["delta_skin"] = delta.pow(2).mean(-1, keepdim=True).expand(M, -1, -1)
+        self._aux_dict = aux
+        return xyz_cam, rot_cam
+
     def render_frames(self, frame_id, Kinv, H, W, inst_id=None, samples_dict=None):
         """The per-frame render loop of query_field (:1175-1233): returns a dict of (M,H,W,C) maps and
         keeps the per-frame screen-space tensors the densification statistics need."""
         M = frame_id.shape[0]
-        xyz = self._xyz[None, :, None].expand(M, -1, -1, -1)
-        rot = self._rotation[None].expand(M, -1, -1)
-        xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
+        if self.fused_warp_ok(inst_id):
+            xyz_cam, rot_cam = self.forward_warp_fused(frame_id, inst_id, samples_dict)
+            xyz_cam = xyz_cam[:, :, None]
+        else:
+            xyz = self._xyz[None, :, None].expand(M, -1, -1, -1)
+            rot = self._rotation[None].expand(M, -1, -1)
+            xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
         cams = self.get_gs_Kcamera(Kinv, H, W)
         stacked, per_frame = {}, {"viewspace_points": [], "visibility_filter": [], "radii": []}
         for i in range(M):
