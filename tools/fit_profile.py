@@ -4,9 +4,10 @@ from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
 from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
 dev = torch.device("cuda:0")
 N, H, W, frames = 200_000, 512, 512, 120
+RADIUS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0  # object radius; camera at distance 3, tan(fov/2)=0.5
 rng = np.random.default_rng(0)
 m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=frames, device=dev)
-pts = rng.normal(size=(N, 3)).astype(np.float32); pts = 0.3 * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
+pts = rng.normal(size=(N, 3)).astype(np.float32); pts = RADIUS * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32), )
 with torch.no_grad(): m._scaling.add_(0.0)
 tr = Stage3Trainer(m)
@@ -17,8 +18,9 @@ from torch.profiler import profile, ProfilerActivity
 t0 = time.perf_counter(); K = 10
 for i in range(K): tr.train_step(batches[i % 4])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-print(f"FIT_STEP 200k/512^2, 2 frames/step: {dt*1e3:.2f} ms/step = {2/dt:.1f} images/s")
+print(f"FIT_STEP 200k/512^2 radius {RADIUS}, 2 frames/step: {dt*1e3:.2f} ms/step = {2/dt:.1f} images/s")
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for i in range(3): tr.train_step(batches[i % 4])
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=14, max_name_column_width=60))

@@ -1,0 +1,48 @@
+"""Tile-list statistics of the object-centric Stage-3 scene (diagnostic)."""
+import sys, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from vidu4d_amd import _C, _lib
+from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch, make_intrinsics_inv
+import vidu4d_amd.diff_surfel_rasterization as dsr
+dev = torch.device("cuda:0")
+N, H, W, frames = 200_000, 512, 512, 120
+rng = np.random.default_rng(0)
+m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=frames, device=dev)
+pts = rng.normal(size=(N, 3)).astype(np.float32); pts = 0.3 * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
+m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32))
+tr = Stage3Trainer(m)
+captured = {}
+orig = _C.rasterize_gaussians
+def spy(*a, **k):
+    out = orig(*a, **k)
+    captured["out"] = out
+    return out
+_C.rasterize_gaussians = spy
+dsr._C.rasterize_gaussians = spy
+b = synthetic_batch(m, [0, 1], H, W)
+with torch.no_grad():
+    r = m.render_frames(b["frameid"], b["Kinv"], b["H"], b["W"])
+R, color, others, radii, geom, binning, img = captured["out"]
+print("num_rendered", R, "visible", int((radii > 0).sum()), "radius mean/max", float(radii[radii > 0].float().mean()), int(radii.max()))
+tiles = ((W + 15) // 16) * ((H + 15) // 16)
+rg = _C.read_state("ranges", None, geom, binning, img, N, W, H, torch.int32, 2 * tiles).numpy().reshape(-1, 2)
+ln = rg[:, 1] - rg[:, 0]
+print("tiles nonempty", int((ln > 0).sum()), "of", tiles, "len mean(nonempty)", ln[ln > 0].mean(), "max", ln.max(), "p90", np.percentile(ln[ln > 0], 90))
+nc = _C.read_state("n_contrib", None, geom, binning, img, N, W, H, torch.int32, 2 * W * H).numpy()
+last = nc[: W * H].reshape(H, W)
+print("last contributor: mean over covered px", last[last > 0].mean(), "max", last.max())
+lt = last.reshape(H // 16, 16, W // 16, 16).max(axis=(1, 3)).reshape(-1)
+print("per-tile max last-contributor: mean", lt[ln > 0].mean(), "max", lt.max(), " sum(len)", ln.sum(), " sum(tile max last)", lt.sum())
+print("alpha mean", float(others[1].mean()), "alpha max", float(others[1].max()))
+_lib.profile_enable(True)
+orig_fw = orig
+_C.rasterize_gaussians = orig; dsr._C.rasterize_gaussians = orig
+for i in range(3):
+    tr.train_step(b)
+torch.cuda.synchronize()
+_lib.profile_read()
+for i in range(5):
+    tr.train_step(b)
+torch.cuda.synchronize()
+print({k: round(v[0] / max(v[1], 1), 4) for k, v in _lib.profile_read().items()})

@@ -146,6 +146,44 @@ __global__ __launch_bounds__(1024) void tile_totals_scan_kernel(GeomState g, Ima
     }
 }
 
+// Longest-list-first schedule for the blend kernels.  Workgroups are dispatched in index order, so
+// giving index b the tile with the b-th longest list lets the short tiles fill in behind the long
+// ones instead of a long tile starting last and running alone (the lists of an object-centric frame
+// differ by 10x and more).  One workgroup: bucket sort of the tile ids on 1024 length classes.
+__global__ __launch_bounds__(1024) void tile_order_kernel(ImageState img, int num_tiles)
+{
+    __shared__ uint32_t s_bin[1024];
+    __shared__ uint32_t s_scan[16];
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    s_bin[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int t = threadIdx.x; t < num_tiles; t += 1024) mx = max(mx, img.ranges[2 * t + 1] - img.ranges[2 * t]);
+    for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint64_t denom = (uint64_t)s_max + 1;
+    auto bucket = [&](int t) {
+        const uint32_t len = img.ranges[2 * t + 1] - img.ranges[2 * t];
+        return 1023u - (uint32_t)(((uint64_t)len << 10) / denom);
+    };
+    for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&s_bin[bucket(t)], 1u);
+    __syncthreads();
+    const uint32_t c = s_bin[threadIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(c, lane);
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++)
+        if (w < wave) wbase += s_scan[w];
+    s_bin[threadIdx.x] = wbase + inc - c;  // exclusive start of this length class
+    __syncthreads();
+    for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tile_order[atomicAdd(&s_bin[bucket(t)], 1u)] = (uint32_t)t;
+}
+
 void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, int groups, hipStream_t stream)
 {
     if (groups > 0) {
@@ -155,6 +193,7 @@ void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, 
     } else {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
     }
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, img, num_tiles);
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, int P, const int32_t* radii,
@@ -231,7 +270,8 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
 
 // One workgroup (4 wave64) per tile.  Stable LSD radix sort of the tile's segment on the bytes of
 // (depth bits << 32 | id) listed by the caller's id_bytes (id bytes 0..id_bytes-1, then depth bytes).
-__global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ ranges, const uint32_t* num_ptr,
+__global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
+                                                       const uint32_t* __restrict__ ranges, const uint32_t* num_ptr,
                                                        int64_t capacity, uint64_t* entries, uint64_t* scratch,
                                                        uint32_t* __restrict__ point_list, int id_bytes)
 {
@@ -239,8 +279,9 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     __shared__ uint32_t s_cnt[4][256];  // per-wave digit counts, then per-wave destination cursors
     __shared__ uint32_t s_scan[4];
     if ((int64_t)*num_ptr > capacity) return;
-    const uint32_t start = ranges[2 * blockIdx.x];
-    const int n = (int)(ranges[2 * blockIdx.x + 1] - start);
+    const uint32_t tile = tile_order[blockIdx.x];  // longest list first
+    const uint32_t start = ranges[2 * tile];
+    const int n = (int)(ranges[2 * tile + 1] - start);
     if (n == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_lds = n <= TILE_SORT_CAP;
@@ -314,7 +355,8 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
     if (capacity <= 0 || num_tiles <= 0) return;
     int id_bytes = 1;
     while (id_bytes < 4 && ((uint64_t)(num_surfels > 0 ? num_surfels - 1 : 0) >> (8 * id_bytes))) id_bytes++;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(num_tiles), dim3(256), 0, stream, img.ranges, &g.hdr->num_rendered,
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(num_tiles), dim3(256), 0, stream, img.tile_order, img.ranges,
+                       &g.hdr->num_rendered,
                        capacity, b.entries, b.scratch, b.point_list, id_bytes);
 }
 

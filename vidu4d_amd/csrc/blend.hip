@@ -35,18 +35,17 @@ struct TileCoord {
     bool valid;
 };
 
-__device__ __forceinline__ TileCoord xcd_tile(int grid_x, int grid_y)
+// Workgroup b renders tile_order[b]: longest list first (binning.hip, tile_order_kernel).  Consecutive
+// workgroup ids go to consecutive XCDs, so the long tiles are also spread over the 8 XCDs.
+__device__ __forceinline__ TileCoord scheduled_tile(const uint32_t* tile_order, int grid_x, int grid_y)
 {
-    const int ntiles = grid_x * grid_y;
-    const int per = (ntiles + 7) >> 3;
     TileCoord t;
-    t.tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    t.valid = t.tile < ntiles;
+    t.tile = (int)tile_order[blockIdx.x];
+    t.valid = true;
     t.tx = t.tile % grid_x;
     t.ty = t.tile / grid_x;
     return t;
 }
-inline int xcd_grid(int grid_x, int grid_y) { return ((grid_x * grid_y + 7) >> 3) * 8; }
 
 // Stages one surfel record (q0..q4) into LDS slot `slot` and returns q5, the contribution box.
 __device__ __forceinline__ float4 stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
@@ -86,7 +85,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y,
+__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, const uint32_t* __restrict__ tile_order,
                                                        const uint32_t* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list,
                                                        const uint32_t* __restrict__ num_ptr, int64_t capacity,
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
 {
     __shared__ float4 s_rec[FWD_BATCH * 5];
     __shared__ unsigned long long s_mask[4][4];
-    const TileCoord tc = xcd_tile(grid_x, grid_y);
+    const TileCoord tc = scheduled_tile(tile_order, grid_x, grid_y);
     if (!tc.valid) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -180,8 +179,8 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
                       int64_t capacity, const float* background, float* out_color, float* out_others,
                       hipStream_t stream)
 {
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(xcd_grid(cam.grid_x, cam.grid_y)), dim3(256), 0, stream, cam.W, cam.H,
-                       cam.grid_x, cam.grid_y, img.ranges, point_list, &g.hdr->num_rendered, capacity, g.rec,
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(cam.grid_x * cam.grid_y), dim3(256), 0, stream, cam.W, cam.H,
+                       cam.grid_x, cam.grid_y, img.tile_order, img.ranges, point_list, &g.hdr->num_rendered, capacity, g.rec,
                        background, img.final_T, img.n_contrib, out_color, out_others);
 }
 
@@ -233,7 +232,7 @@ __device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
     return v;
 }
 
-__global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y,
+__global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const uint32_t* __restrict__ tile_order,
                                                        const uint32_t* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list,
                                                        const float* __restrict__ rec, const float* __restrict__ bg,
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     __shared__ uint32_t s_id[BWD_BATCH];
     __shared__ unsigned long long s_mask[4][4];
     __shared__ uint32_t s_max;
-    const TileCoord tc = xcd_tile(grid_x, grid_y);
+    const TileCoord tc = scheduled_tile(tile_order, grid_x, grid_y);
     if (!tc.valid) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -371,8 +370,8 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
 
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(xcd_grid(a.cam.grid_x, a.cam.grid_y)), dim3(256), 0, stream, a.cam.W,
-                       a.cam.H, a.cam.grid_x, a.cam.grid_y, a.img.ranges, a.point_list, a.geom.rec, a.background,
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.cam.grid_x * a.cam.grid_y), dim3(256), 0, stream, a.cam.W,
+                       a.cam.H, a.cam.grid_x, a.cam.grid_y, a.img.tile_order, a.img.ranges, a.point_list, a.geom.rec, a.background,
                        a.img.final_T, a.img.n_contrib, a.dL_dcolor, a.dL_dothers, a.acc);
 }
 

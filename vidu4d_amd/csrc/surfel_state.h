@@ -46,6 +46,7 @@ struct ImageState {
                            // [tiles] per-tile totals (grouped path)
     uint32_t* tile_base;   // [tiles][TILE_SLICES] start of each (tile, slice) sub-segment (atomic path)
     uint32_t* group_counts;  // [groups][tiles] pair counts per surfel group, then exclusive prefix over groups
+    uint32_t* tile_order;  // [tiles] tile ids, longest list first: workgroup b of the blend kernels takes tile_order[b]
 };
 
 struct BinState {
@@ -93,6 +94,7 @@ inline size_t carve_image(char* base, int W, int H, ImageState& s)
     carve(p, s.tile_count, tiles * TILE_SLICES);
     carve(p, s.tile_base, tiles * TILE_SLICES);
     carve(p, s.group_counts, tiles <= (size_t)BIN_MAX_TILES ? tiles * BIN_MAX_GROUPS : 0);
+    carve(p, s.tile_order, tiles);
     return (size_t)(p - base) + 256;
 }
 

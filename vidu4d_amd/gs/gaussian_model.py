@@ -261,8 +261,9 @@ class GaussianModel(nn.Module):
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         g = viewspace_point_tensor.grad if viewspace_point_tensor.grad is not None else viewspace_point_tensor
-        self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        f = update_filter[:, None].to(self.denom.dtype)  # masked adds without nonzero() (no host sync)
+        self.xyz_gradient_accum += torch.norm(g, dim=-1, keepdim=True) * f
+        self.denom += f
 
     # ---- PLY I/O: binary little-endian, attribute order x,y,z,nx,ny,nz,f_dc_*,f_rest_*,opacity,scale_*,rot_*
     # with channel-major f_dc / f_rest (reference :189-268)

@@ -5,6 +5,8 @@ the function Vidu4D's Stage-3 field calls once per frame
 Same signature and the same keys in the returned dict: render, viewspace_points, visibility_filter,
 radii, acc, rend_normal, rend_dist, surf_depth, render_depth_median, render_depth_expected,
 surf_normal.  The rasterizer behind it is the MI355X-native `diff_surfel_rasterization`."""
+import math
+
 import torch
 
 from ..diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
@@ -21,8 +23,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         pass
 
     fovx, fovy = viewpoint_camera.FoVx, viewpoint_camera.FoVy
-    tanfovx = torch.tan(fovx * 0.5) if isinstance(fovx, torch.Tensor) else torch.tan(torch.as_tensor(fovx * 0.5))
-    tanfovy = torch.tan(fovy * 0.5) if isinstance(fovy, torch.Tensor) else torch.tan(torch.as_tensor(fovy * 0.5))
+    tanfovx, tanfovy = math.tan(float(fovx) * 0.5), math.tan(float(fovy) * 0.5)
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,

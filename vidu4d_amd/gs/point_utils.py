@@ -5,6 +5,9 @@ import torch
 
 
 def depths_to_points(view, depthmap):
+    if hasattr(view, "pixel_rays"):  # KCamera: pixel-ray grid cached per camera
+        rays_d, rays_o = view.pixel_rays()
+        return depthmap.reshape(-1, 1) * rays_d + rays_o
     dev = depthmap.device
     c2w = (view.world_view_transform.T).inverse()
     W, H = view.image_width, view.image_height

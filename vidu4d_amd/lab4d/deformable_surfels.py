@@ -107,12 +107,23 @@ class DeformableSurfels(GaussianModel):
         return rendered
 
     def get_gs_Kcamera(self, Kinvs, Hs, Ws):
+        """One camera per frame from the inverse intrinsics (:927-962).  The intrinsics come to the host
+        in one copy; cameras are cached on their six defining numbers (with --force_center_cam every
+        frame of a video shares them)."""
         cams = []
-        for i in range(Kinvs.shape[0]):
-            Kinv, H, W = Kinvs[i], int(Hs[i]), int(Ws[i])
+        Kh = Kinvs.detach().float().cpu()
+        cache = self.__dict__.setdefault("_camera_cache", {})
+        for i in range(Kh.shape[0]):
+            Kinv, H, W = Kh[i], int(Hs[i]), int(Ws[i])
             left, right = Kinv[0, 2], Kinv[0, 2] + Kinv[0, 0] * W
             bottom, top = Kinv[1, 2], Kinv[1, 2] + Kinv[1, 1] * H
-            cams.append(KCamera(H=H, W=W, left=left, right=right, top=top, bottom=bottom, data_device=Kinv.device))
+            key = (H, W, float(left), float(right), float(top), float(bottom), str(Kinvs.device))
+            if key not in cache:
+                if len(cache) > 64:
+                    cache.clear()
+                cache[key] = KCamera(H=H, W=W, left=left, right=right, top=top, bottom=bottom,
+                                     data_device=Kinvs.device)
+            cams.append(cache[key])
         return cams
 
     def forward_warp(self, xyz, rotation, frame_id, inst_id=None, samples_dict=None):
@@ -136,7 +147,7 @@ class DeformableSurfels(GaussianModel):
             return False
         if any(p.requires_grad for mod in (self.warp, self.camera_mlp) for p in mod.parameters()):
             return False
-        return inst_id is None or bool((inst_id == inst_id[0]).all())
+        return inst_id is None or len(set(inst_id.tolist())) == 1
 
     def forward_warp_fused(self, frame_id, inst_id=None, samples_dict=None):
         """forward_warp for frozen bones: the skinning weights of the forward warp depend on neither the

@@ -30,14 +30,16 @@ def compute_losses(rendered: dict, batch: dict, step: int, cfg) -> dict:
     vis2d = batch["vis2d"].float()
     maskfg = batch["mask"].float()
     sel = vis2d.expand(-1, -1, -1, 3) > 0
-    l1 = torch.zeros_like(rendered["rendered"])
-    l1[sel] = torch.abs(rendered["rendered"][sel] - batch["rgb"][sel])
-    loss = {"rgb": (1.0 - cfg.lambda_dssim) * l1.mean() * torch.ones(()).to(l1)}
+    l1 = torch.where(sel, torch.abs(rendered["rendered"] - batch["rgb"]), torch.zeros((), device=vis2d.device))
+    loss = {"rgb": (1.0 - cfg.lambda_dssim) * l1.mean()}
     loss["mask"] = (rendered["mask"] - maskfg).pow(2) * vis2d
 
-    def reduce(v):  # mean over the positive entries (model.py:996-999)
+    def reduce(v):
+        """Mean over the positive entries, or over everything when none is positive (model.py:996-999),
+        without boolean-mask indexing (which would block the host on a nonzero()): every term here is
+        non-negative, so the fallback mean is 0 = sum / 1."""
         pos = v > 0
-        return v[pos].mean() if bool(pos.any()) else v.mean()
+        return (v * pos).sum() / pos.sum().clamp_min(1)
 
     out = {"rgb": reduce(loss["rgb"]) * cfg.rgb_wt, "mask": reduce(loss["mask"]) * cfg.mask_wt}
     lam_n = cfg.lambda_normal if step > 8000 else 0.0
@@ -69,7 +71,8 @@ class Stage3Trainer:
         ]
         if c.gs_learnable_bg:
             groups.append({"params": [m.learnable_bkgd], "lr": c.feature_lr, "name": "bg_rgb"})
-        self.gs_optimizer = torch.optim.Adam(groups, lr=c.learning_rate, eps=1e-15)
+        # one multi-tensor kernel per step on the GPU (same update rule as the reference's Adam)
+        self.gs_optimizer = torch.optim.Adam(groups, lr=c.learning_rate, eps=1e-15, fused=m._xyz.is_cuda)
         m.optimizer = self.gs_optimizer
         self._flat = None
         # --gs_optim_warp=False (the README's Stage-3 command): warp and camera networks come from the
@@ -134,7 +137,7 @@ class Stage3Trainer:
             if step < c.densify_until_iter:
                 for i in range(len(m._radii_batch)):
                     vis, radii = m._visibility_filter_batch[i], m._radii_batch[i]
-                    m.max_radii2D[vis] = torch.max(m.max_radii2D[vis], radii[vis].float())
+                    m.max_radii2D = torch.where(vis, torch.maximum(m.max_radii2D, radii.float()), m.max_radii2D)
                     m.add_densification_stats(m._viewspace_points_batch[i], vis)
                 gen = None
                 if step > c.densify_from_iter and step % c.densification_interval == 0:
