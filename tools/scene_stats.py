@@ -9,7 +9,8 @@ dev = torch.device("cuda:0")
 N, H, W, frames = 200_000, 512, 512, 120
 rng = np.random.default_rng(0)
 m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=frames, device=dev)
-pts = rng.normal(size=(N, 3)).astype(np.float32); pts = 0.3 * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
+RADIUS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+pts = rng.normal(size=(N, 3)).astype(np.float32); pts = RADIUS * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32))
 tr = Stage3Trainer(m)
 captured = {}

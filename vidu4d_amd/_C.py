@@ -50,7 +50,8 @@ def _check_cuda(*ts):
 
 
 def _pinned_slot(device):
-    key = str(device)
+    # one slot per (device, stream): frames rendered concurrently on different streams must not share it
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _pinned:
         _pinned[key] = torch.zeros(2, dtype=torch.int32).pin_memory()
     return _pinned[key]

@@ -172,6 +172,14 @@ class DeformableSurfels(GaussianModel):
         self._aux_dict = aux
         return xyz_cam, rot_cam
 
+    def _frame_streams(self, M):
+        if M < 2:
+            return None
+        pool = self.__dict__.setdefault("_stream_pool", [])
+        while len(pool) < M:
+            pool.append(torch.cuda.Stream(device=self._xyz.device))
+        return pool
+
     def render_frames(self, frame_id, Kinv, H, W, inst_id=None, samples_dict=None):
         """The per-frame render loop of query_field (:1175-1233): returns a dict of (M,H,W,C) maps and
         keeps the per-frame screen-space tensors the densification statistics need."""
@@ -185,13 +193,32 @@ class DeformableSurfels(GaussianModel):
             xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
         cams = self.get_gs_Kcamera(Kinv, H, W)
         stacked, per_frame = {}, {"viewspace_points": [], "visibility_filter": [], "radii": []}
+        # Frames of a step are independent until the loss: each one is queued on its own HIP stream so
+        # that the tile workgroups of all frames are resident together (an object-centric frame fills
+        # only a fraction of the 256 CUs, and its blend kernels are bound by the longest tile's serial
+        # chain, not by throughput).  autograd replays each frame's backward on the stream of its
+        # forward, so the backward kernels overlap the same way.  Per-frame results are unchanged.
+        streams = self._frame_streams(M) if xyz_cam.is_cuda and self.opts.get("frame_streams", True) else None
+        if streams:
+            main = torch.cuda.current_stream(xyz_cam.device)
+            ready = main.record_event()
         for i in range(M):
-            r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i])
+            if streams:
+                streams[i].wait_event(ready)
+                with torch.cuda.stream(streams[i]):
+                    r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i])
+                    for v in r.values():
+                        v.record_stream(main)
+            else:
+                r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i])
             for k, v in r.items():
                 if k in per_frame:
                     per_frame[k].append(v)
                 else:
                     stacked.setdefault(k, []).append(v.permute(1, 2, 0))
+        if streams:
+            for st in streams[:M]:
+                main.wait_stream(st)
         out = {k: torch.stack(v, 0) for k, v in stacked.items()}
         self._viewspace_points_batch = per_frame["viewspace_points"]
         self._visibility_filter_batch = per_frame["visibility_filter"]
