@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 1
+#define VIDU4D_SURFEL_ABI 2
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -93,6 +93,10 @@ typedef struct Vidu4dSurfelForwardArgs {
     size_t geom_bytes;
     void* image_buffer;              /* >= vidu4d_surfel_image_bytes(W,H) */
     size_t image_bytes;
+    int segment_split;               /* !=0: tiles whose list exceeds 1024 entries are blended segment-parallel
+                                        (512-entry segments on separate workgroups; three launches instead of
+                                        one).  Pays off when few tiles hold most pairs (object-centric frames);
+                                        results agree with the unsplit blend to fp32 re-association. */
 } Vidu4dSurfelForwardArgs;
 
 int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* args, void* stream);

@@ -22,7 +22,13 @@ import torch
 from . import _lib
 
 _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
+# Segment-parallel blending of long tile lists (csrc/blend.hip): "auto" switches it on for a frame
+# when the previous frame of the same shape had a tile list longer than SPLIT_AUTO_LEN entries (the
+# longest tile's serial chain then bounds the blend kernels); "1" / "0" force it on / off.
+_SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
+SPLIT_AUTO_LEN = 2048
 _capacity_hint: dict = {}
+_max_tile_len: dict = {}
 _pinned: dict = {}
 
 
@@ -53,7 +59,7 @@ def _pinned_slot(device):
     # one slot per (device, stream): frames rendered concurrently on different streams must not share it
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _pinned:
-        _pinned[key] = torch.zeros(2, dtype=torch.int32).pin_memory()
+        _pinned[key] = torch.zeros(4, dtype=torch.int32).pin_memory()  # Header: R, overflow, max_tile_len, segments
     return _pinned[key]
 
 
@@ -106,6 +112,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.geom_buffer, a.geom_bytes = geom.data_ptr(), geom.numel()
     a.image_buffer, a.image_bytes = img.data_ptr(), img.numel()
     stream = _stream(dev)
+    key = (P, W, H, str(dev))
+    if _SPLIT == "auto":
+        a.segment_split = int(_max_tile_len.get(key, 0) > SPLIT_AUTO_LEN)
+    else:
+        a.segment_split = int(_SPLIT == "1")
 
     if P == 0:  # rasterize_points.cu:105: nothing is launched, outputs are zeros
         out_color.zero_()
@@ -114,7 +125,6 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         return 0, out_color, out_others, radii, geom, binning, img
 
     _lib.check(lib.vidu4d_surfel_forward_plan(C.byref(a), stream), "surfel forward (plan)")
-    key = (P, W, H, str(dev))
     hint = _capacity_hint.get(key)
     R = C.c_int64(0)
     if _EXACT or hint is None or debug:
@@ -128,13 +138,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         cap = hint
         binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
         slot = _pinned_slot(dev)
-        slot.copy_(geom[:8].view(torch.int32), non_blocking=True)
+        slot.copy_(geom[:16].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
                    "surfel forward (run)")
         ev.synchronize()  # waits for preprocess + scan only; sort and blend keep running
         num_rendered = int(slot[0])
+        _max_tile_len[key] = int(slot[2])
         if num_rendered > cap:  # guess too small: queue the tail again with an exact buffer
             cap = num_rendered
             binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)

@@ -150,20 +150,26 @@ __global__ __launch_bounds__(1024) void tile_totals_scan_kernel(GeomState g, Ima
 // giving index b the tile with the b-th longest list lets the short tiles fill in behind the long
 // ones instead of a long tile starting last and running alone (the lists of an object-centric frame
 // differ by 10x and more).  One workgroup: bucket sort of the tile ids on 1024 length classes.
-__global__ __launch_bounds__(1024) void tile_order_kernel(ImageState img, int num_tiles)
+__global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageState img, int num_tiles)
 {
     __shared__ uint32_t s_bin[1024];
     __shared__ uint32_t s_scan[16];
     __shared__ uint32_t s_max;
+    __shared__ uint32_t s_any;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_max = 0;
     s_bin[threadIdx.x] = 0;
     __syncthreads();
     uint32_t mx = 0;
-    for (int t = threadIdx.x; t < num_tiles; t += 1024) mx = max(mx, img.ranges[2 * t + 1] - img.ranges[2 * t]);
+    for (int t = threadIdx.x; t < num_tiles; t += 1024) {
+        mx = max(mx, img.ranges[2 * t + 1] - img.ranges[2 * t]);
+        img.seg_first[t] = SEG_NONE;
+    }
     for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+    if (lane == 0) atomicMax(&s_max, mx);
     __syncthreads();
-    const uint64_t denom = (uint64_t)s_max + 1;
+    const uint32_t max_len = s_max;
+    const uint64_t denom = (uint64_t)max_len + 1;
     auto bucket = [&](int t) {
         const uint32_t len = img.ranges[2 * t + 1] - img.ranges[2 * t];
         return 1023u - (uint32_t)(((uint64_t)len << 10) / denom);
@@ -171,7 +177,6 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(ImageState img, int nu
     for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&s_bin[bucket(t)], 1u);
     __syncthreads();
     const uint32_t c = s_bin[threadIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t inc = wave_inclusive_scan(c, lane);
     if (lane == 63) s_scan[wave] = inc;
     __syncthreads();
@@ -182,6 +187,52 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(ImageState img, int nu
     s_bin[threadIdx.x] = wbase + inc - c;  // exclusive start of this length class
     __syncthreads();
     for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tile_order[atomicAdd(&s_bin[bucket(t)], 1u)] = (uint32_t)t;
+    __syncthreads();  // tile_order is read back below (same workgroup: the barrier orders the global accesses)
+
+    // Segment table for the tiles longer than SPLIT_MIN (blend.hip): exclusive prefix of their segment
+    // counts by schedule position.  The long tiles sit at the front of the schedule, so the walk stops
+    // at the first chunk of 1024 positions that holds none (a length class may straddle SPLIT_MIN,
+    // hence "none in a whole chunk" and not "the first short tile").
+    uint32_t carry = 0, split_pos = 0;
+    for (int base = 0; base < num_tiles; base += 1024) {
+        const int pos = base + threadIdx.x;
+        uint32_t nseg = 0, tile = 0;
+        if (pos < num_tiles) {
+            tile = img.tile_order[pos];
+            const uint32_t len = img.ranges[2 * tile + 1] - img.ranges[2 * tile];
+            if (len > (uint32_t)SPLIT_MIN) nseg = (len + SEG_LEN - 1) / SEG_LEN;
+        }
+        if (threadIdx.x == 0) s_any = 0;
+        __syncthreads();
+        const uint32_t sc = wave_inclusive_scan(nseg, lane);
+        if (lane == 63) s_scan[wave] = sc;
+        if (nseg) atomicMax(&s_any, (uint32_t)pos + 1);
+        __syncthreads();
+        uint32_t wb = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t v = s_scan[w];
+            if (w < wave) wb += v;
+            tot += v;
+        }
+        const uint32_t any = s_any;
+        if (pos < num_tiles) {
+            const uint32_t first = carry + wb + sc - nseg;
+            img.seg_prefix[pos] = first;
+            if (nseg) img.seg_first[tile] = first;
+        }
+        carry += tot;
+        if (any) split_pos = any;
+        __syncthreads();
+        if (!any) break;
+    }
+    if (threadIdx.x == 0) {
+        img.seg_prefix[split_pos] = carry;  // closes the last split tile's interval
+        g.hdr->max_tile_len = max_len;
+        g.hdr->num_segments = carry;
+        g.hdr->num_split_pos = split_pos;
+        g.hdr->split_used = 0;
+    }
 }
 
 void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, int groups, hipStream_t stream)
@@ -193,7 +244,7 @@ void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, 
     } else {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
     }
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, img, num_tiles);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, int P, const int32_t* radii,

@@ -23,6 +23,8 @@
 //     row_half_mirror, quad_perm: 15 DPP adds for 16 values instead of 96), then combined across the
 //     4 waves with LDS float atomics, and only one global atomic per (entry, component) is issued
 //     per 256-entry batch.  The reference issues up to 16 global atomics per (pixel, entry).
+#include <algorithm>
+
 #include "surfel_state.h"
 
 namespace surfel {
@@ -85,31 +87,165 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, const uint32_t* __restrict__ tile_order,
-                                                       const uint32_t* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list,
-                                                       const uint32_t* __restrict__ num_ptr, int64_t capacity,
-                                                       const float* __restrict__ rec, const float* __restrict__ bg,
-                                                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+// Where a workgroup of the blend kernels works.  Unsplit launch: workgroup b blends all of tile
+// tile_order[b].  Split launch: workgroups [0, num_segments) take one segment each of the tiles
+// longer than SPLIT_MIN (found by bisection of the segment prefix over the schedule positions, which
+// hold those tiles at the front), the following `tiles` workgroups take the remaining whole tiles.
+struct WorkItem {
+    TileCoord tc;
+    int seg;       // -1: the whole tile
+    uint32_t slot; // segment slot in seg_data
+    bool valid;
+};
+
+template <bool SPLIT>
+__device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageState& img, int grid_x, int grid_y,
+                                              bool overflow)
+{
+    WorkItem w;
+    w.seg = -1;
+    w.slot = 0;
+    w.valid = true;
+    int tile;
+    if (SPLIT) {
+        const uint32_t nseg = hdr->num_segments;
+        if (blockIdx.x < nseg) {
+            if (overflow) {  // binning buffer too small (seg_data too): the whole-tile workgroups render the background
+                w.valid = false;
+                return w;
+            }
+            int lo = 0, hi = (int)hdr->num_split_pos - 1;
+            while (lo < hi) {  // largest position whose prefix is <= blockIdx.x
+                const int mid = (lo + hi + 1) >> 1;
+                if (img.seg_prefix[mid] <= blockIdx.x) lo = mid;
+                else hi = mid - 1;
+            }
+            tile = (int)img.tile_order[lo];
+            w.seg = (int)(blockIdx.x - img.seg_prefix[lo]);
+            w.slot = blockIdx.x;
+        } else {
+            const uint32_t pos = blockIdx.x - nseg;
+            if (pos >= (uint32_t)(grid_x * grid_y)) {
+                w.valid = false;
+                return w;
+            }
+            tile = (int)img.tile_order[pos];
+            if (!overflow && img.seg_first[tile] != SEG_NONE) w.valid = false;  // blended by its segments
+        }
+    } else {
+        tile = (int)img.tile_order[blockIdx.x];
+    }
+    w.tc.tile = tile;
+    w.tc.valid = true;
+    w.tc.tx = tile % grid_x;
+    w.tc.ty = tile / grid_x;
+    return w;
+}
+
+__device__ __forceinline__ void write_pixel(const FwdPixel& s, size_t HW, size_t pid, const float* bg, float* final_T,
+                                            uint32_t* n_contrib, float* out_color, float* out_others)
+{
+    final_T[pid] = s.T;
+    final_T[pid + HW] = s.dist1;
+    final_T[pid + 2 * HW] = s.dist2;
+    n_contrib[pid] = s.last_contributor;
+    n_contrib[pid + HW] = s.median_contributor;
+    for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pid] = s.C[ch] + s.T * bg[ch];
+    out_others[pid] = s.D;
+    out_others[pid + HW] = 1.0f - s.T;
+    out_others[pid + 2 * HW] = s.N[0];
+    out_others[pid + 3 * HW] = s.N[1];
+    out_others[pid + 4 * HW] = s.N[2];
+    out_others[pid + 5 * HW] = s.median_depth;
+    out_others[pid + 6 * HW] = s.distortion;
+    out_others[pid + 7 * HW] = s.median_weight;
+}
+
+// Pass 1 of the segment-parallel forward: the product of (1 - alpha) over one segment, per pixel
+// (the same acceptance test and the same multiplication as the blend itself, minus everything else).
+__global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
+                                                         ImageState img, const uint32_t* __restrict__ point_list,
+                                                         int64_t capacity, const float* __restrict__ rec,
+                                                         float* __restrict__ seg_data)
+{
+    __shared__ float4 s_rec[FWD_BATCH * 5];
+    __shared__ unsigned long long s_mask[4][4];
+    const bool overflow = (int64_t)hdr->num_rendered > capacity;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->split_used = !overflow && hdr->num_segments > 0;  // for backward
+    if (overflow || blockIdx.x >= hdr->num_segments) return;
+    const WorkItem wk = find_work<true>(hdr, img, grid_x, grid_y, false);
+    const TileCoord tc = wk.tc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
+    const uint32_t r0 = img.ranges[2 * tc.tile], r1 = img.ranges[2 * tc.tile + 1];
+    const int begin = wk.seg * SEG_LEN;
+    int todo = min((int)(r1 - r0) - begin, SEG_LEN);
+    float T = 1.0f;
+    for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
+        __syncthreads();
+        const bool have = (int)threadIdx.x < todo;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) box = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            unsigned long long m = uniform_u64(s_mask[wave][k]);
+            while (m) {
+                const int j = k * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
+                const float Tu[3] = {a0.x, a0.y, a0.z}, Tv[3] = {a0.w, a1.x, a1.y}, Tw[3] = {a1.z, a1.w, a2.x};
+                PairEval e;
+                if (eval_pair_flat(Tu, Tv, Tw, a2.y, a2.z, a2.w, pixx, pixy, e)) T = T * (1.0f - e.alpha);
+            }
+        }
+    }
+    seg_data[((size_t)wk.slot * SEG_FLOATS + SG_TSEG) * 256 + threadIdx.x] = T;
+}
+
+// The blend (pass 2 of the segment-parallel forward when SPLIT).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
+                                                       ImageState img, const uint32_t* __restrict__ point_list,
+                                                       int64_t capacity, const float* __restrict__ rec,
+                                                       const float* __restrict__ bg, float* __restrict__ seg_data,
                                                        float* __restrict__ out_color, float* __restrict__ out_others)
 {
     __shared__ float4 s_rec[FWD_BATCH * 5];
     __shared__ unsigned long long s_mask[4][4];
-    const TileCoord tc = scheduled_tile(tile_order, grid_x, grid_y);
-    if (!tc.valid) return;
+    const bool overflow = (int64_t)hdr->num_rendered > capacity;
+    const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
+    if (!wk.valid) return;
+    const TileCoord tc = wk.tc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
     const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
-    const uint32_t r0 = ranges[2 * tc.tile], r1 = ranges[2 * tc.tile + 1];
+    const uint32_t r0 = img.ranges[2 * tc.tile], r1 = img.ranges[2 * tc.tile + 1];
     // binning buffer too small for this frame: nothing was emitted, render the background only (the
     // caller re-runs with a larger buffer)
-    int todo = ((int64_t)*num_ptr > capacity) ? 0 : (int)(r1 - r0);
+    int todo = overflow ? 0 : (int)(r1 - r0);
+    int begin = 0;
 
     FwdPixel s;
     bool done = !inside;
-    for (int base = 0; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
+    bool dead = false;
+    if (SPLIT && wk.seg >= 0) {
+        begin = wk.seg * SEG_LEN;
+        todo = min(todo - begin, SEG_LEN);
+        // transmittance left by the earlier segments of this tile; below T_EPS the pixel saturated
+        // inside one of them (the running product only decreases), and this segment adds nothing
+        const uint32_t first = wk.slot - (uint32_t)wk.seg;
+        for (int q = 0; q < wk.seg; q++)
+            s.T = s.T * seg_data[((size_t)(first + q) * SEG_FLOATS + SG_TSEG) * 256 + threadIdx.x];
+        dead = wk.seg > 0 && s.T < T_EPS;
+        done = done || dead;
+    }
+    for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const bool have = (int)threadIdx.x < todo;
         float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -156,32 +292,101 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
             }
         }
     }
-    if (inside) {
-        const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
-        final_T[pid] = s.T;
-        final_T[pid + HW] = s.dist1;
-        final_T[pid + 2 * HW] = s.dist2;
-        n_contrib[pid] = s.last_contributor;
-        n_contrib[pid + HW] = s.median_contributor;
-        for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pid] = s.C[ch] + s.T * bg[ch];
-        out_others[pid] = s.D;
-        out_others[pid + HW] = 1.0f - s.T;
-        out_others[pid + 2 * HW] = s.N[0];
-        out_others[pid + 3 * HW] = s.N[1];
-        out_others[pid + 4 * HW] = s.N[2];
-        out_others[pid + 5 * HW] = s.median_depth;
-        out_others[pid + 6 * HW] = s.distortion;
-        out_others[pid + 7 * HW] = s.median_weight;
+    if (SPLIT && wk.seg >= 0) {
+        // partial results of this segment; blend_combine_kernel adds the segments up in list order
+        float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
+        for (int ch = 0; ch < 3; ch++) {
+            d[(SG_C + ch) * 256] = s.C[ch];
+            d[(SG_N + ch) * 256] = s.N[ch];
+        }
+        d[SG_D * 256] = s.D;
+        d[SG_TEND * 256] = dead ? -1.0f : s.T;
+        d[SG_M1 * 256] = s.dist1;
+        d[SG_M2 * 256] = s.dist2;
+        d[SG_DIST * 256] = s.distortion;
+        d[SG_MED_D * 256] = s.median_depth;
+        d[SG_MED_W * 256] = s.median_weight;
+        d[SG_MED_C * 256] = __uint_as_float(s.median_contributor);
+        d[SG_LAST * 256] = __uint_as_float(s.last_contributor);
+        return;
     }
+    if (inside)
+        write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
 }
 
-void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const uint32_t* point_list,
-                      int64_t capacity, const float* background, float* out_color, float* out_others,
+// Pass 3: adds the segments of a split tile up in list order.  The colour / depth / normal / moment
+// partials were accumulated with the exact transmittance, so they simply add; the distortion needs
+// the cross terms between a segment and the moments of everything in front of it:
+//   sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i),  A_i = A_p + a_i, M1_i = M1_p + m1_i, M2_i = M2_p + m2_i
+// where _p is the state at the segment start and a_i, m1_i, m2_i run inside the segment.  Pass 2 used
+// the global accumulated alpha (1 - T) and segment-local moments, which leaves
+//   M2_p * (sum w_i) - 2 M1_p * (sum w_i m_i)      with sum w_i = T_start - T_end.
+__global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
+                                                           ImageState img, int64_t capacity,
+                                                           const float* __restrict__ bg,
+                                                           float* __restrict__ seg_data,
+                                                           float* __restrict__ out_color,
+                                                           float* __restrict__ out_others)
+{
+    if ((int64_t)hdr->num_rendered > capacity || blockIdx.x >= hdr->num_split_pos) return;
+    const int tile = (int)img.tile_order[blockIdx.x];
+    const uint32_t first = img.seg_first[tile];
+    if (first == SEG_NONE) return;
+    const int nseg = (int)((img.ranges[2 * tile + 1] - img.ranges[2 * tile] + SEG_LEN - 1) / SEG_LEN);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = (tile % grid_x) * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = (tile / grid_x) * TILE + (wave >> 1) * 8 + (lane >> 3);
+    FwdPixel s;
+    float T_raw = 1.0f;
+    for (int q = 0; q < nseg; q++) {
+        const float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
+        const float T_start = T_raw;
+        const float T_end = d[SG_TEND * 256];
+        T_raw = T_raw * d[SG_TSEG * 256];
+        if (T_end < 0.f) continue;  // saturated before this segment
+        const float m1 = d[SG_M1 * 256], m2 = d[SG_M2 * 256];
+        s.distortion += d[SG_DIST * 256] + (s.dist2 * (T_start - T_end) - 2.0f * s.dist1 * m1);
+        for (int ch = 0; ch < 3; ch++) {
+            s.C[ch] += d[(SG_C + ch) * 256];
+            s.N[ch] += d[(SG_N + ch) * 256];
+        }
+        s.D += d[SG_D * 256];
+        s.dist1 += m1;
+        s.dist2 += m2;
+        s.T = T_end;
+        const uint32_t last = __float_as_uint(d[SG_LAST * 256]), med = __float_as_uint(d[SG_MED_C * 256]);
+        if (last) s.last_contributor = last;
+        if (med) {
+            s.median_contributor = med;
+            s.median_depth = d[SG_MED_D * 256];
+            s.median_weight = d[SG_MED_W * 256];
+        }
+    }
+    if (px < W && py < H)
+        write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
+}
+
+void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
+                      int64_t capacity, bool split, const float* background, float* out_color, float* out_others,
                       hipStream_t stream)
 {
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(cam.grid_x * cam.grid_y), dim3(256), 0, stream, cam.W, cam.H,
-                       cam.grid_x, cam.grid_y, img.tile_order, img.ranges, point_list, &g.hdr->num_rendered, capacity, g.rec,
-                       background, img.final_T, img.n_contrib, out_color, out_others);
+    const int tiles = cam.grid_x * cam.grid_y;
+    const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
+    if (!split || capacity <= 0) {
+        hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
+                           cam.grid_y, g.hdr, img, point_list, capacity, g.rec, background, b.seg_data, out_color,
+                           out_others);
+        return;
+    }
+    const int segs = (int)seg_capacity(capacity);                       // upper bounds: the device knows the
+    const int split_tiles = (int)std::min<int64_t>(tiles, capacity / SPLIT_MIN + 1);  // exact counts
+    hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, cam.grid_y,
+                       g.hdr, img, point_list, capacity, g.rec, b.seg_data);
+    hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
+                       cam.grid_y, g.hdr, img, point_list, capacity, g.rec, background, b.seg_data, out_color,
+                       out_others);
+    hipLaunchKernelGGL(blend_combine_kernel, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
+                       cam.grid_y, g.hdr, img, capacity, background, b.seg_data, out_color, out_others);
 }
 
 // ---------------------------------------------------------------------------------------------

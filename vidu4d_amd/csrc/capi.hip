@@ -229,7 +229,6 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     carve_binning((char*)binning, capacity, b);
     const CameraParams cam =
         make_camera_params(a->viewmatrix, a->campos, a->width, a->height, a->tan_fovx, a->tan_fovy, a->D, a->M);
-    const uint32_t* point_list = nullptr;
     if (capacity > 0) {
         {
             StageTimer t(ST_EMIT, stream);
@@ -241,11 +240,11 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
             launch_tile_sort(g, img, b, cam.grid_x * cam.grid_y, a->P, capacity, stream);
         }
         STAGE_CHECK(a->debug, stream, "tile_sort");
-        point_list = b.point_list;
     }
     {
         StageTimer t(ST_BLEND_FWD, stream);
-        launch_blend_fwd(cam, g, img, point_list, capacity, a->background, a->out_color, a->out_others, stream);
+        launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, a->background, a->out_color, a->out_others,
+                         stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
     return VIDU4D_OK;

@@ -26,10 +26,37 @@ constexpr int BIN_MAX_GROUPS = 256;
 constexpr int BIN_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int TILE_SORT_CAP = 3584;  // list entries a tile can sort entirely inside LDS (2 x 28 KiB ping-pong)
 
+// Segment-parallel blending of long tile lists.  A tile whose list is longer than SPLIT_MIN entries
+// is cut into segments of SEG_LEN entries, each blended by its own workgroup: front-to-back
+// compositing is associative, so a segment needs from its predecessors only the transmittance they
+// leave behind (one float per pixel).  See blend.hip for the three passes.
+constexpr int SEG_LEN = 512;
+constexpr int SPLIT_MIN = 1024;
+constexpr int SEG_FLOATS = 16;  // per (segment, pixel) values, slot-major: seg_data[(slot * 16 + k) * 256 + pixel]
+enum SegSlot {
+    SG_TSEG = 0,   // product of (1 - alpha) over the segment (pass 1)
+    SG_C = 1,      // colour partial sum (3)          -- pass 2; after the combine: sum over LATER segments
+    SG_D = 4,      // depth partial
+    SG_N = 5,      // normal partial (3)
+    SG_TEND = 8,   // transmittance at the end of the segment, -1 when the pixel was saturated before it
+    SG_M1 = 9,     // sum w m  (distortion first moment)
+    SG_M2 = 10,    // sum w m^2
+    SG_DIST = 11,  // distortion partial (segment-local moments, global accumulated alpha)
+    SG_MED_D = 12, SG_MED_W = 13, SG_MED_C = 14,  // median depth / weight / contributor seen in this segment
+    SG_LAST = 15   // last contributor seen in this segment
+};
+constexpr uint32_t SEG_NONE = 0xFFFFFFFFu;
+// segments of all split tiles: sum ceil(len / SEG_LEN) <= R / SEG_LEN + (#tiles longer than SPLIT_MIN)
+inline int64_t seg_capacity(int64_t capacity) { return capacity / SEG_LEN + capacity / SPLIT_MIN + 2; }
+
 struct Header {           // first 256 bytes of the geometry buffer
     uint32_t num_rendered;  // R, written by the tile scan
     uint32_t overflow;      // set by emit when R > capacity
-    uint32_t pad[62];
+    uint32_t max_tile_len;  // longest tile list (tile_order_kernel)
+    uint32_t num_segments;  // segments over all tiles longer than SPLIT_MIN
+    uint32_t num_split_pos; // schedule positions [0, num_split_pos) hold every split tile
+    uint32_t split_used;    // the forward blended long tiles segment-parallel (seg_data is valid)
+    uint32_t pad[58];
 };
 
 struct GeomState {
@@ -47,12 +74,15 @@ struct ImageState {
     uint32_t* tile_base;   // [tiles][TILE_SLICES] start of each (tile, slice) sub-segment (atomic path)
     uint32_t* group_counts;  // [groups][tiles] pair counts per surfel group, then exclusive prefix over groups
     uint32_t* tile_order;  // [tiles] tile ids, longest list first: workgroup b of the blend kernels takes tile_order[b]
+    uint32_t* seg_first;   // [tiles] first segment slot of a split tile, SEG_NONE otherwise
+    uint32_t* seg_prefix;  // [tiles + 1] by schedule position: exclusive prefix of the segment counts
 };
 
 struct BinState {
     uint64_t* entries;     // [cap] (depth bits << 32 | surfel id), grouped by tile, sorted per tile
     uint64_t* scratch;     // [cap] ping-pong space for tiles too long for LDS
     uint32_t* point_list;  // [cap] sorted surfel ids == the reference's binningState.point_list
+    float* seg_data;       // [seg_capacity(cap)][SEG_FLOATS][256] per-segment, per-pixel partial results
 };
 
 template <typename T>
@@ -95,6 +125,8 @@ inline size_t carve_image(char* base, int W, int H, ImageState& s)
     carve(p, s.tile_base, tiles * TILE_SLICES);
     carve(p, s.group_counts, tiles <= (size_t)BIN_MAX_TILES ? tiles * BIN_MAX_GROUPS : 0);
     carve(p, s.tile_order, tiles);
+    carve(p, s.seg_first, tiles);
+    carve(p, s.seg_prefix, tiles + 1);
     return (size_t)(p - base) + 256;
 }
 
@@ -105,6 +137,7 @@ inline size_t carve_binning(char* base, int64_t capacity, BinState& b)
     carve(p, b.entries, cap);
     carve(p, b.scratch, cap);
     carve(p, b.point_list, cap);
+    carve(p, b.seg_data, cap ? (size_t)seg_capacity(capacity) * SEG_FLOATS * 256 : 0);
     return (size_t)(p - base) + 256;
 }
 
@@ -188,8 +221,9 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
 // per-tile stable radix sort of the (depth, id) entries; fills point_list
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
                       int64_t capacity, hipStream_t stream);
-void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const uint32_t* point_list,
-                      int64_t capacity, const float* background, float* out_color, float* out_others,
+// split: blend tiles longer than SPLIT_MIN segment-parallel (three launches instead of one)
+void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
+                      int64_t capacity, bool split, const float* background, float* out_color, float* out_others,
                       hipStream_t stream);
 
 struct BackwardArgs {
