@@ -141,6 +141,8 @@ typedef struct Vidu4dSurfelBackwardArgs {
     float* dL_dsh;                   /* (P,M,3) or NULL when M == 0 */
     float* dL_dscales;               /* (P,2) */
     float* dL_drotations;            /* (P,4) */
+    int segment_split;               /* !=0: walk long tile lists segment-parallel; takes effect only when the
+                                        forward that filled the buffers ran with segment_split != 0 */
 } Vidu4dSurfelBackwardArgs;
 
 int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* args, void* stream);

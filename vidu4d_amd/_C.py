@@ -154,13 +154,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     _capacity_hint[key] = max(int(num_rendered * 1.25) + 4096, 4096)
     # the capacity the buffers were carved with travels to backward inside the buffer tensor
     binning._vidu4d_capacity = cap
+    binning._vidu4d_split = int(a.segment_split)
     return num_rendered, out_color, out_others, radii, geom, binning, img
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 binning_capacity=None):
+                                 binning_capacity=None, segment_split=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations)"""
     lib = _lib.load()
     _check_cuda(background, means3D, radii, colors, scales, rotations, viewmatrix, projmatrix, sh, campos, geomBuffer,
@@ -210,6 +211,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     b.dL_dout_color, b.dL_dout_others = dL_dout_color.data_ptr(), dL_dout_others.data_ptr()
     b.geom_buffer, b.binning_buffer, b.image_buffer = geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr()
     b.binning_capacity = int(binning_capacity)
+    if segment_split is None:
+        segment_split = getattr(binningBuffer, "_vidu4d_split", 0)
+    b.segment_split = int(segment_split)
     b.workspace, b.workspace_bytes = ws.data_ptr(), ws.numel()
     b.dL_dmeans2D, b.dL_dcolors, b.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dcolors.data_ptr(), dL_dopacity.data_ptr()
     b.dL_dmeans3D, b.dL_dtransMat, b.dL_dsh = dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh)

@@ -42,7 +42,7 @@ class BackwardArgs(C.Structure):
         ("image_buffer", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dL_dmeans2D", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dopacity", C.c_void_p),
         ("dL_dmeans3D", C.c_void_p), ("dL_dtransMat", C.c_void_p), ("dL_dsh", C.c_void_p),
-        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
+        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("segment_split", C.c_int),
     ]
 
 

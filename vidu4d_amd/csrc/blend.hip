@@ -37,18 +37,6 @@ struct TileCoord {
     bool valid;
 };
 
-// Workgroup b renders tile_order[b]: longest list first (binning.hip, tile_order_kernel).  Consecutive
-// workgroup ids go to consecutive XCDs, so the long tiles are also spread over the 8 XCDs.
-__device__ __forceinline__ TileCoord scheduled_tile(const uint32_t* tile_order, int grid_x, int grid_y)
-{
-    TileCoord t;
-    t.tile = (int)tile_order[blockIdx.x];
-    t.valid = true;
-    t.tx = t.tile % grid_x;
-    t.ty = t.tile / grid_x;
-    return t;
-}
-
 // Stages one surfel record (q0..q4) into LDS slot `slot` and returns q5, the contribution box.
 __device__ __forceinline__ float4 stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
 {
@@ -88,7 +76,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
 }
 
 // Where a workgroup of the blend kernels works.  Unsplit launch: workgroup b blends all of tile
-// tile_order[b].  Split launch: workgroups [0, num_segments) take one segment each of the tiles
+// tile_order[b] -- longest list first (binning.hip, tile_order_kernel); consecutive workgroup ids go
+// to consecutive XCDs, so the long tiles are also spread over the 8 XCDs.  Split launch: workgroups [0, num_segments) take one segment each of the tiles
 // longer than SPLIT_MIN (found by bisection of the segment prefix over the schedule positions, which
 // hold those tiles at the front), the following `tiles` workgroups take the remaining whole tiles.
 struct WorkItem {
@@ -364,6 +353,35 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     }
     if (px < W && py < H)
         write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
+
+    // For the segment-parallel backward: replace each segment's partials by the sums over the segments
+    // BEHIND it (what the back-to-front recurrences of the backward have accumulated when they reach
+    // the segment's last entry), and the median weight if the median sample lies behind it.
+    float sufC[3] = {0, 0, 0}, sufN[3] = {0, 0, 0}, sufD = 0, sufM1 = 0, sufM2 = 0, med_w = 0;
+    for (int q = nseg - 1; q >= 0; q--) {
+        float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
+        if (d[SG_TEND * 256] < 0.f) continue;
+        const float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
+        const float n0 = d[(SG_N + 0) * 256], n1 = d[(SG_N + 1) * 256], n2 = d[(SG_N + 2) * 256];
+        const float dd = d[SG_D * 256], m1 = d[SG_M1 * 256], m2 = d[SG_M2 * 256];
+        const bool has_med = __float_as_uint(d[SG_MED_C * 256]) != 0 &&
+                             __float_as_uint(d[SG_MED_C * 256]) == s.median_contributor;
+        const float mw = d[SG_MED_W * 256];
+        d[(SG_C + 0) * 256] = sufC[0];
+        d[(SG_C + 1) * 256] = sufC[1];
+        d[(SG_C + 2) * 256] = sufC[2];
+        d[(SG_N + 0) * 256] = sufN[0];
+        d[(SG_N + 1) * 256] = sufN[1];
+        d[(SG_N + 2) * 256] = sufN[2];
+        d[SG_D * 256] = sufD;
+        d[SG_M1 * 256] = sufM1;
+        d[SG_M2 * 256] = sufM2;
+        d[SG_MED_W * 256] = med_w;
+        sufC[0] += c0, sufC[1] += c1, sufC[2] += c2;
+        sufN[0] += n0, sufN[1] += n1, sufN[2] += n2;
+        sufD += dd, sufM1 += m1, sufM2 += m2;
+        if (has_med) med_w = mw;
+    }
 }
 
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
@@ -437,22 +455,29 @@ __device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
     return v;
 }
 
-__global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const uint32_t* __restrict__ tile_order,
-                                                       const uint32_t* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list,
+// SPLIT: the tiles the forward blended segment-parallel are walked segment-parallel here too.  The
+// back-to-front recurrences of a segment start from what the segments behind it add up to (stored by
+// blend_combine_kernel); everything else is the single-workgroup loop restricted to the segment.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
+                                                       ImageState img, const uint32_t* __restrict__ point_list,
                                                        const float* __restrict__ rec, const float* __restrict__ bg,
-                                                       const float* __restrict__ final_T,
-                                                       const uint32_t* __restrict__ n_contrib,
+                                                       const float* __restrict__ seg_data,
                                                        const float* __restrict__ dL_dcolor,
                                                        const float* __restrict__ dL_dothers, float* __restrict__ acc)
 {
+    const uint32_t* __restrict__ ranges = img.ranges;
+    const float* __restrict__ final_T = img.final_T;
+    const uint32_t* __restrict__ n_contrib = img.n_contrib;
     __shared__ float4 s_rec[BWD_BATCH * 5];
     __shared__ float s_acc[BWD_BATCH * ACC_FLOATS];
     __shared__ uint32_t s_id[BWD_BATCH];
     __shared__ unsigned long long s_mask[4][4];
     __shared__ uint32_t s_max;
-    const TileCoord tc = scheduled_tile(tile_order, grid_x, grid_y);
-    if (!tc.valid) return;
+    // (a forward that ran unsplit left no segment state: every tile is then walked whole)
+    const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, SPLIT && !hdr->split_used);
+    if (!wk.valid) return;
+    const TileCoord tc = wk.tc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
     const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
@@ -460,6 +485,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
     const uint32_t r0 = ranges[2 * tc.tile];
     const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
+    const int seg_begin = (SPLIT && wk.seg >= 0) ? wk.seg * SEG_LEN : 0;
 
     BwdPixel s;
     s.last_contributor = 0;
@@ -485,6 +511,29 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     s.T = s.T_final;
     s.final_A = 1.0f - s.T_final;
     s.bg_dot_dpixel = bg[0] * s.dL_dpixel[0] + bg[1] * s.dL_dpixel[1] + bg[2] * s.dL_dpixel[2];
+    if (SPLIT && wk.seg >= 0) {
+        const float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
+        const float T_end = d[SG_TEND * 256];
+        // the entries of this segment lie in [seg_begin, seg_begin + SEG_LEN): clip the pixel's range
+        const uint32_t seg_end = (uint32_t)(seg_begin + SEG_LEN);
+        if (s.last_contributor > seg_end) {
+            // the walk enters from the segments behind: start from what they add up to
+            const float inv = 1.0f / T_end;
+            const float behind = T_end - s.T_final;  // sum of their blend weights
+            for (int ch = 0; ch < 3; ch++) {
+                s.accum_rec[ch] = d[(SG_C + ch) * 256] * inv;
+                s.accum_normal_rec[ch] = d[(SG_N + ch) * 256] * inv;
+            }
+            s.accum_depth_rec = d[SG_D * 256] * inv;
+            s.accum_alpha_rec = behind * inv;
+            s.last_dL_dT = inv * (s.dL_dmax_dweight * d[SG_MED_W * 256] +
+                                  s.dL_dreg * (s.final_D2 * behind + s.final_A * d[SG_M2 * 256] -
+                                               2.0f * s.final_D * d[SG_M1 * 256]));
+            s.T = T_end;
+            s.last_contributor = seg_end;
+        }
+        if (s.last_contributor <= (uint32_t)seg_begin) s.last_contributor = 0;  // nothing of this pixel in here
+    }
 
     // entries at or beyond every pixel's last contributor never matter: skip them wholesale
     // (per wave for the inner loop, per workgroup for the staging)
@@ -506,8 +555,8 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     const int slot16 = c16 < 9 ? c16 : (c16 == 9 ? A_OPAC : (c16 < 13 ? c16 + 2 : c16 + 3));
     const int slot2 = A_M2D + ((lane >> 3) & 1);
 
-    for (int hi = n_used; hi > 0; hi -= BWD_BATCH) {
-        const int cnt = hi < BWD_BATCH ? hi : BWD_BATCH;
+    for (int hi = n_used; hi > seg_begin; hi -= BWD_BATCH) {
+        const int cnt = hi - seg_begin < BWD_BATCH ? hi - seg_begin : BWD_BATCH;
         __syncthreads();
         {
             // threads 0..127 stage (back to front: slot t <-> list entry hi-1-t), all zero the accumulators
@@ -575,9 +624,15 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
 
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.cam.grid_x * a.cam.grid_y), dim3(256), 0, stream, a.cam.W,
-                       a.cam.H, a.cam.grid_x, a.cam.grid_y, a.img.tile_order, a.img.ranges, a.point_list, a.geom.rec, a.background,
-                       a.img.final_T, a.img.n_contrib, a.dL_dcolor, a.dL_dothers, a.acc);
+    const int tiles = a.cam.grid_x * a.cam.grid_y;
+    if (a.split && a.seg_data)
+        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), 0, stream,
+                           a.cam.W, a.cam.H, a.cam.grid_x, a.cam.grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec,
+                           a.background, a.seg_data, a.dL_dcolor, a.dL_dothers, a.acc);
+    else
+        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x,
+                           a.cam.grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data,
+                           a.dL_dcolor, a.dL_dothers, a.acc);
 }
 
 }  // namespace surfel

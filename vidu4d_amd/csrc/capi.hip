@@ -274,6 +274,9 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     carve_image((char*)a->image_buffer, a->width, a->height, ba.img);
     carve_binning((char*)a->binning_buffer, a->binning_capacity, b);
     ba.point_list = a->binning_capacity > 0 ? b.point_list : nullptr;
+    ba.seg_data = a->binning_capacity > 0 ? b.seg_data : nullptr;
+    ba.capacity = a->binning_capacity;
+    ba.split = a->segment_split != 0 && a->binning_capacity > 0;
     ba.P = a->P;
     ba.background = a->background;
     ba.means3D = a->means3D;

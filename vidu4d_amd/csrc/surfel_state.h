@@ -241,6 +241,9 @@ struct BackwardArgs {
     GeomState geom;
     ImageState img;
     const uint32_t* point_list;
+    const float* seg_data;  // per-segment state of the segment-parallel forward (or NULL)
+    int64_t capacity;
+    bool split;             // walk the split tiles segment-parallel (needs the forward to have run split)
     float* acc;  // [P][20] workspace
     float* dL_dmeans2D;
     float* dL_dcolors;

@@ -69,6 +69,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.binning_capacity = getattr(binning_buf, "_vidu4d_capacity", max(num_rendered, 1))
+        ctx.segment_split = getattr(binning_buf, "_vidu4d_split", 0)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf,
                               binning_buf, img_buf)
         ctx.mark_non_differentiable(radii)
@@ -85,13 +86,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         if rs.debug:
             saved = _snapshot(native_args)
             try:
-                grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity)
+                grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity,
+                                                        segment_split=ctx.segment_split)
             except Exception:
                 torch.save(saved, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         else:
-            grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity)
+            grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity,
+                                                        segment_split=ctx.segment_split)
         (g_means2D, g_colors_precomp, g_opacities, g_means3D, g_cov3Ds_precomp, g_sh, g_scales,
          g_rotations) = grads
         return (g_means3D, g_means2D, g_sh, g_colors_precomp, g_opacities, g_scales, g_rotations, g_cov3Ds_precomp,
