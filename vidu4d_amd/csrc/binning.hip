@@ -28,6 +28,8 @@
 // Ordering by (depth, id) equals the reference's stable sort because a surfel is emitted at most
 // once per tile, in id order.  No pass ever moves a pair across tiles, so pairs cross HBM three
 // times (emit, sort in, sort out) instead of thirteen.
+#include <algorithm>
+
 #include "surfel_state.h"
 #include "wave_utils.h"
 
@@ -319,55 +321,68 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
                            b.entries, capacity);
 }
 
-// One workgroup (4 wave64) per tile.  Stable LSD radix sort of the tile's segment on the bytes of
+// One workgroup per tile.  Stable LSD radix sort of the tile's segment on the bytes of
 // (depth bits << 32 | id) listed by the caller's id_bytes (id bytes 0..id_bytes-1, then depth bytes).
-__global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
-                                                       const uint32_t* __restrict__ ranges, const uint32_t* num_ptr,
-                                                       int64_t capacity, uint64_t* entries, uint64_t* scratch,
-                                                       uint32_t* __restrict__ point_list, int id_bytes)
+// <4, true>: 4 wave64, lists up to TILE_SORT_CAP are sorted inside LDS, longer ones ping-pong through
+// global memory (unless `skip_long`: then the <16, false> launch takes them -- 16 wave64 per tile,
+// global ping-pong only; the long tiles are the first positions of the longest-first schedule).
+template <int WAVES, bool IN_LDS>
+__global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
+                                                              const uint32_t* __restrict__ ranges,
+                                                              const uint32_t* num_ptr, int64_t capacity,
+                                                              uint64_t* entries, uint64_t* scratch,
+                                                              uint32_t* __restrict__ point_list, int id_bytes,
+                                                              int skip_long)
 {
-    __shared__ uint64_t s_buf[2][TILE_SORT_CAP];
-    __shared__ uint32_t s_cnt[4][256];  // per-wave digit counts, then per-wave destination cursors
-    __shared__ uint32_t s_scan[4];
+    constexpr int THREADS = WAVES * 64;
+    __shared__ uint64_t s_buf[IN_LDS ? 2 : 1][IN_LDS ? TILE_SORT_CAP : 1];
+    __shared__ uint32_t s_cnt[WAVES][256];  // per-wave digit counts, then per-wave destination cursors
+    __shared__ uint32_t s_scan[16];
     if ((int64_t)*num_ptr > capacity) return;
     const uint32_t tile = tile_order[blockIdx.x];  // longest list first
     const uint32_t start = ranges[2 * tile];
     const int n = (int)(ranges[2 * tile + 1] - start);
     if (n == 0) return;
+    if (IN_LDS ? (skip_long && n > TILE_SORT_CAP) : n <= TILE_SORT_CAP) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool in_lds = n <= TILE_SORT_CAP;
+    const bool in_lds = IN_LDS && n <= TILE_SORT_CAP;
     uint64_t* A;
     uint64_t* B;
     if (in_lds) {
-        for (int i = threadIdx.x; i < n; i += 256) s_buf[0][i] = entries[start + i];
+        for (int i = threadIdx.x; i < n; i += THREADS) s_buf[0][i] = entries[start + i];
         A = s_buf[0];
-        B = s_buf[1];
+        B = s_buf[IN_LDS ? 1 : 0];
     } else {
         A = entries + start;
         B = scratch + start;
     }
     // wave w owns the consecutive keys [w*chunk, min(n, (w+1)*chunk)), walked 64 at a time
-    const int chunk = ((n + 255) >> 8) << 6;
-    const int w_lo = wave * chunk;
+    const int chunk = ((n + THREADS - 1) / THREADS) << 6;
+    const int w_lo = min(wave * chunk, n);
     const int w_hi = (w_lo + chunk < n) ? w_lo + chunk : n;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     for (int pass = 0; pass < id_bytes + 4; pass++) {
         const int shift = 8 * (pass < id_bytes ? pass : 4 + pass - id_bytes);
-        for (int i = threadIdx.x; i < 4 * 256; i += 256) (&s_cnt[0][0])[i] = 0;
+        for (int i = threadIdx.x; i < WAVES * 256; i += THREADS) (&s_cnt[0][0])[i] = 0;
         __syncthreads();  // also orders the previous pass's scatter (or the initial load) before the reads
         for (int i = w_lo + lane; i < w_hi; i += 64) atomicAdd(&s_cnt[wave][(uint32_t)(A[i] >> shift) & 255u], 1u);
         __syncthreads();
-        const int d = threadIdx.x;  // one digit per thread
-        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
-        const uint32_t tot = c0 + c1 + c2 + c3;
+        const int d = threadIdx.x & 255;  // one digit per thread (threads 0..255)
+        uint32_t tot = 0;
+        if (threadIdx.x < 256)
+            for (int w = 0; w < WAVES; w++) tot += s_cnt[w][d];
         if (__syncthreads_or(tot == (uint32_t)n)) continue;  // whole segment shares this digit: nothing to move
         uint32_t total;
-        const uint32_t dbase = block_exclusive_scan(tot, s_scan, total);
-        s_cnt[0][d] = dbase;
-        s_cnt[1][d] = dbase + c0;
-        s_cnt[2][d] = dbase + c0 + c1;
-        s_cnt[3][d] = dbase + c0 + c1 + c2;
+        const uint32_t dbase = block_exclusive_scan(tot, s_scan, total);  // (waves >= 4 contribute zeros)
+        if (threadIdx.x < 256) {
+            uint32_t run = dbase;
+            for (int w = 0; w < WAVES; w++) {
+                const uint32_t c = s_cnt[w][d];
+                s_cnt[w][d] = run;
+                run += c;
+            }
+        }
         __syncthreads();
         for (int base = w_lo; base < w_hi; base += 64) {
             const int i = base + lane;
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
         B = t;
         __syncthreads();  // every wave is done with its cursors before the next pass clears them
     }
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t key = A[i];
         point_list[start + i] = (uint32_t)key;
         if (A != entries + start) entries[start + i] = key;
@@ -401,14 +416,18 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
 }
 
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
-                      int64_t capacity, hipStream_t stream)
+                      int64_t capacity, bool long_pass, hipStream_t stream)
 {
     if (capacity <= 0 || num_tiles <= 0) return;
     int id_bytes = 1;
     while (id_bytes < 4 && ((uint64_t)(num_surfels > 0 ? num_surfels - 1 : 0) >> (8 * id_bytes))) id_bytes++;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(num_tiles), dim3(256), 0, stream, img.tile_order, img.ranges,
-                       &g.hdr->num_rendered,
-                       capacity, b.entries, b.scratch, b.point_list, id_bytes);
+    if (long_pass) {  // at most capacity / TILE_SORT_CAP tiles can be that long; they lead the schedule
+        const int longs = (int)std::min<int64_t>(num_tiles, capacity / TILE_SORT_CAP + 1);
+        hipLaunchKernelGGL((tile_sort_kernel<16, false>), dim3(longs), dim3(1024), 0, stream, img.tile_order,
+                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0);
+    }
+    hipLaunchKernelGGL((tile_sort_kernel<4, true>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order, img.ranges,
+                       &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, long_pass ? 1 : 0);
 }
 
 }  // namespace surfel

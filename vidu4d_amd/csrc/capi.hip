@@ -237,7 +237,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
         STAGE_CHECK(a->debug, stream, "emit_keys");
         {
             StageTimer t(ST_SORT, stream);
-            launch_tile_sort(g, img, b, cam.grid_x * cam.grid_y, a->P, capacity, stream);
+            launch_tile_sort(g, img, b, cam.grid_x * cam.grid_y, a->P, capacity, a->segment_split != 0, stream);
         }
         STAGE_CHECK(a->debug, stream, "tile_sort");
     }

@@ -219,8 +219,9 @@ void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, 
 void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
                       const BinState& b, int64_t capacity, bool grouped, hipStream_t stream);
 // per-tile stable radix sort of the (depth, id) entries; fills point_list
+// long_pass: lists longer than TILE_SORT_CAP get a 16-wave workgroup of their own launch
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
-                      int64_t capacity, hipStream_t stream);
+                      int64_t capacity, bool long_pass, hipStream_t stream);
 // split: blend tiles longer than SPLIT_MIN segment-parallel (three launches instead of one)
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, const float* background, float* out_color, float* out_others,
