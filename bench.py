@@ -141,6 +141,10 @@ def main():
     ap.add_argument("--res", type=int, default=512, help="image width (and height unless --height is given)")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--frames", type=int, default=120)
+    ap.add_argument("--scene", choices=["uniform", "object"], default="uniform",
+                    help="uniform: BASELINE.md scene (surfels spread over the frustum); object: the same surfels "
+                         "inside a ball covering about a third of the image (uneven tile lists)")
+    ap.add_argument("--object-radius", type=float, default=1.0)
     ap.add_argument("--cpu-images", type=int, default=6, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--torch-cpu-images", type=int, default=1,
                     help="frames timed on the pure-PyTorch CPU render (0 = skip; ~10-20 s each at 200k/512^2)")
@@ -175,10 +179,13 @@ def main():
 
     import diff_surfel_rasterization as dsr
     from vidu4d_amd import _lib
-    from vidu4d_amd.synthetic import frame_motion, make_scene, make_upstream_grads
+    from vidu4d_amd.synthetic import frame_motion, make_object_scene, make_scene, make_upstream_grads
 
     N, W = args.surfels, args.res
-    scene_cpu = make_scene(N, W, args.height or None, seed=1234)
+    if args.scene == "object":
+        scene_cpu = make_object_scene(N, W, args.height or None, radius=args.object_radius, seed=1234)
+    else:
+        scene_cpu = make_scene(N, W, args.height or None, seed=1234)
     scene = scene_cpu.to(dev)
     H = scene.height
     dc, do = (t.to(dev) for t in make_upstream_grads(W, H))
@@ -240,15 +247,16 @@ def main():
     images = world * args.steps * FRAMES_PER_STEP
     value = images / elapsed
     out = {
-        "metric": "train images/sec (fwd+bwd raster) @200k surfels, 512^2" if (N, W) == (200_000, 512)
-        else f"train images/sec (fwd+bwd raster) @{N} surfels, {W}x{H}",
+        "metric": ("train images/sec (fwd+bwd raster) @200k surfels, 512^2" if (N, W) == (200_000, 512)
+                   else f"train images/sec (fwd+bwd raster) @{N} surfels, {W}x{H}") +
+                  (f" [object-centric scene, radius {args.object_radius}]" if args.scene == "object" else ""),
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[2] op-level: Stage-3 gs-bob rasterizer fwd+bwd, {N} surfels, "
                                f"{W}x{H}, SH degree 3, {args.frames} frames sharded one-frame-per-GPU, "
                                f"{FRAMES_PER_STEP} frames per step per GPU",
-                   "surfels": N, "width": W, "height": H, "frames": args.frames, "frames_per_step": FRAMES_PER_STEP,
+                   "scene": args.scene, "surfels": N, "width": W, "height": H, "frames": args.frames, "frames_per_step": FRAMES_PER_STEP,
                    "parallelism": f"frame-parallel x{world}" + (" + RCCL all-reduce of surfel grads" if world > 1 else "")},
     }
 

@@ -97,6 +97,9 @@ typedef struct Vidu4dSurfelForwardArgs {
                                         (512-entry segments on separate workgroups; three launches instead of
                                         one).  Pays off when few tiles hold most pairs (object-centric frames);
                                         results agree with the unsplit blend to fp32 re-association. */
+    uint32_t* depth_used;            /* optional device counter (or NULL): atomic max of the deepest list position
+                                        any pixel of the frame blended, i.e. the serial chain length of the
+                                        unsplit blend.  Callers use it to decide segment_split for later frames. */
 } Vidu4dSurfelForwardArgs;
 
 int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* args, void* stream);

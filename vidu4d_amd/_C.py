@@ -23,12 +23,14 @@ from . import _lib
 
 _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 # Segment-parallel blending of long tile lists (csrc/blend.hip): "auto" switches it on for a frame
-# when the previous frame of the same shape had a tile list longer than SPLIT_AUTO_LEN entries (the
-# longest tile's serial chain then bounds the blend kernels); "1" / "0" force it on / off.
+# when, in an earlier frame of the same shape, some pixel blended deeper than SPLIT_AUTO_LEN list
+# entries (the serial chain of that tile then bounds the blend kernels; long lists that saturate
+# early do not count -- splitting them only adds work); "1" / "0" force it on / off.
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = 2048
 _capacity_hint: dict = {}
-_max_tile_len: dict = {}
+_depth_stat: dict = {}   # key -> (device counter, pinned copy)
+_depth_hint: dict = {}
 _pinned: dict = {}
 
 
@@ -113,8 +115,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.image_buffer, a.image_bytes = img.data_ptr(), img.numel()
     stream = _stream(dev)
     key = (P, W, H, str(dev))
+    stat = None
     if _SPLIT == "auto":
-        a.segment_split = int(_max_tile_len.get(key, 0) > SPLIT_AUTO_LEN)
+        a.segment_split = int(_depth_hint.get(key, 0) > SPLIT_AUTO_LEN)
+        stat = _depth_stat.get((key, stream))
+        if stat is None:
+            stat = _depth_stat[(key, stream)] = (torch.zeros(1, dtype=torch.int32, device=dev),
+                                                 torch.zeros(1, dtype=torch.int32).pin_memory())
+        a.depth_used = stat[0].data_ptr()
     else:
         a.segment_split = int(_SPLIT == "1")
 
@@ -139,13 +147,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
         slot = _pinned_slot(dev)
         slot.copy_(geom[:16].view(torch.int32), non_blocking=True)
+        if stat is not None:  # depth reached by the previous frame on this stream; then reset for this one
+            stat[1].copy_(stat[0], non_blocking=True)
+            stat[0].zero_()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
                    "surfel forward (run)")
         ev.synchronize()  # waits for preprocess + scan only; sort and blend keep running
         num_rendered = int(slot[0])
-        _max_tile_len[key] = int(slot[2])
+        if stat is not None:
+            _depth_hint[key] = int(stat[1][0])
         if num_rendered > cap:  # guess too small: queue the tail again with an exact buffer
             cap = num_rendered
             binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)

@@ -25,7 +25,7 @@ class ForwardArgs(C.Structure):
         ("transMat_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("campos", C.c_void_p), ("out_color", C.c_void_p), ("out_others", C.c_void_p), ("radii", C.c_void_p),
         ("geom_buffer", C.c_void_p), ("geom_bytes", C.c_size_t), ("image_buffer", C.c_void_p),
-        ("image_bytes", C.c_size_t), ("segment_split", C.c_int),
+        ("image_bytes", C.c_size_t), ("segment_split", C.c_int), ("depth_used", C.c_void_p),
     ]
 
 

@@ -131,6 +131,20 @@ __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageStat
     return w;
 }
 
+// Deepest list position blended by any pixel of this workgroup -> frame-wide maximum (a hint for the
+// caller's split decision; the longest tiles run first, so most workgroups only read).
+__device__ __forceinline__ void report_depth(uint32_t* depth_used, uint32_t last_contributor)
+{
+    if (!depth_used) return;
+    uint32_t v = last_contributor;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v > *depth_used) atomicMax(depth_used, v);
+}
+
 __device__ __forceinline__ void write_pixel(const FwdPixel& s, size_t HW, size_t pid, const float* bg, float* final_T,
                                             uint32_t* n_contrib, float* out_color, float* out_others)
 {
@@ -201,7 +215,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        int64_t capacity, const float* __restrict__ rec,
                                                        const float* __restrict__ bg, float* __restrict__ seg_data,
-                                                       float* __restrict__ out_color, float* __restrict__ out_others)
+                                                       float* __restrict__ out_color, float* __restrict__ out_others,
+                                                       uint32_t* depth_used)
 {
     __shared__ float4 s_rec[FWD_BATCH * 5];
     __shared__ unsigned long long s_mask[4][4];
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
     }
     if (inside)
         write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
+    report_depth(depth_used, s.last_contributor);
 }
 
 // Pass 3: adds the segments of a split tile up in list order.  The colour / depth / normal / moment
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
                                                            const float* __restrict__ bg,
                                                            float* __restrict__ seg_data,
                                                            float* __restrict__ out_color,
-                                                           float* __restrict__ out_others)
+                                                           float* __restrict__ out_others, uint32_t* depth_used)
 {
     if ((int64_t)hdr->num_rendered > capacity || blockIdx.x >= hdr->num_split_pos) return;
     const int tile = (int)img.tile_order[blockIdx.x];
@@ -354,6 +370,8 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     if (px < W && py < H)
         write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
 
+    report_depth(depth_used, s.last_contributor);
+
     // For the segment-parallel backward: replace each segment's partials by the sums over the segments
     // BEHIND it (what the back-to-front recurrences of the backward have accumulated when they reach
     // the segment's last entry), and the median weight if the median sample lies behind it.
@@ -386,14 +404,14 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
 
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, const float* background, float* out_color, float* out_others,
-                      hipStream_t stream)
+                      uint32_t* depth_used, hipStream_t stream)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
         hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
                            cam.grid_y, g.hdr, img, point_list, capacity, g.rec, background, b.seg_data, out_color,
-                           out_others);
+                           out_others, depth_used);
         return;
     }
     const int segs = (int)seg_capacity(capacity);                       // upper bounds: the device knows the
@@ -402,9 +420,9 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
                        g.hdr, img, point_list, capacity, g.rec, b.seg_data);
     hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
                        cam.grid_y, g.hdr, img, point_list, capacity, g.rec, background, b.seg_data, out_color,
-                       out_others);
+                       out_others, depth_used);
     hipLaunchKernelGGL(blend_combine_kernel, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                       cam.grid_y, g.hdr, img, capacity, background, b.seg_data, out_color, out_others);
+                       cam.grid_y, g.hdr, img, capacity, background, b.seg_data, out_color, out_others, depth_used);
 }
 
 // ---------------------------------------------------------------------------------------------

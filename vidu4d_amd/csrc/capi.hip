@@ -244,7 +244,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     {
         StageTimer t(ST_BLEND_FWD, stream);
         launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, a->background, a->out_color, a->out_others,
-                         stream);
+                         a->depth_used, stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
     return VIDU4D_OK;

@@ -225,7 +225,7 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
 // split: blend tiles longer than SPLIT_MIN segment-parallel (three launches instead of one)
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, const float* background, float* out_color, float* out_others,
-                      hipStream_t stream);
+                      uint32_t* depth_used, hipStream_t stream);
 
 struct BackwardArgs {
     CameraParams cam;

@@ -99,6 +99,21 @@ def make_scene(n: int, width: int, height: int | None = None, seed: int = 1234, 
     return scene.to(device)
 
 
+def make_object_scene(n: int, width: int, height: int | None = None, radius: float = 1.0, seed: int = 1234,
+                      **kw) -> SurfelScene:
+    """Object-centric variant of `make_scene` (what a Stage-3 frame looks like after lab4d's crop around
+    the object): same surfel attributes, but the centres fill a ball of `radius` at depth 3 (camera at the
+    origin, tan(fov/2) = 0.5, so radius 1 covers about a third of the image).  Tile lists are then very
+    uneven -- a few hundred tiles hold all pairs -- which is the regime the longest-first schedule and
+    the segment-parallel blend exist for."""
+    sc = make_scene(n, width, height, seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed + 7)
+    d = torch.randn(n, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True) * torch.rand(n, 1, generator=g).pow(1.0 / 3.0)
+    sc.means3D = (radius * d + torch.tensor([0.0, 0.0, 3.0])).float().contiguous()
+    return sc
+
+
 def make_upstream_grads(width: int, height: int, seed: int = 4321, device="cpu"):
     """Upstream gradients for op-level runs: N(0,1)/(H*W) on the colour image and on
     all 8 auxiliary planes (worst case: every backward branch live)."""
