@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's roofline refers to (run on the GPU box through gpurun):
+#   1. --kernel-trace --stats of the default bench command      -> gpurun_out/prof/trace
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes -> gpurun_out/prof/{fetch,write}
+# then tools/parse_profiles.py condenses them into profiles/<tag>_*.csv and profiles/pmc_traffic.json.
+# Usage: tools/profile_round.sh <tag> [extra bench.py args]
+set -u
+TAG=${1:-r01}; shift || true
+R=$(pwd); export TMPDIR=/tmp
+OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- \
+  python $R/bench.py --steps 30 --warmup 5 --cpu-images 0 --torch-cpu-images 0 "$@" > $OUT/trace_bench.log 2>&1
+tail -1 $OUT/trace_bench.log
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/$c -o pmc --output-format csv -- \
+    python $R/bench.py --steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --no-stage-timers "$@" > $OUT/$c.log 2>&1
+done
+cd $R
+python tools/parse_profiles.py $OUT $TAG
