@@ -197,3 +197,42 @@ def test_train_entry_flag_parsing(tmp_path):
     obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\nf 1/1 2/1 4/1\n")
     pts = load_obj_points(str(obj), 500, np.random.default_rng(0))
     assert pts.shape == (500, 3) and (pts >= -1e-6).all() and (pts.sum(1) <= 1 + 1e-5).all()
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    """ckpt_%04d.pth in the reference layout (trainer.py:335-422): key prefix, DDP prefix stripping,
+    surfel tensors resized to the checkpoint's point count, optimizer rebuilt, PLY next to it."""
+    import numpy as np
+    import torch
+    from vidu4d_amd.lab4d import checkpoint as ck
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer
+
+    def make(n, seed):
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(seed)
+        m = DeformableSurfels(dict(fg_motion="gs-bob"), num_frames=4, device="cpu")
+        m.init_from_points(rng.normal(size=(n, 3)).astype(np.float32) * 0.2, rng.uniform(size=(n, 3)).astype(np.float32))
+        return m
+
+    a = make(300, 0)
+    ta = Stage3Trainer(a)
+    ta.current_steps = 1234
+    path = ck.save_checkpoint(ta, str(tmp_path), round_count=3)
+    assert path.endswith("ckpt_0003.pth") and (tmp_path / "ckpt_latest.pth").exists() and (tmp_path / "003-fg-gs.ply").exists()
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) >= {"current_steps", "current_round", "model", "optimizer"} and raw["current_round"] == 3
+    for k in ck.SURFEL_KEYS:
+        assert ck.FG_PREFIX + k in raw["model"]
+    # a DDP-style checkpoint into a model with a different point count
+    raw["model"] = {"module." + k: v for k, v in raw["model"].items()}
+    torch.save(raw, tmp_path / "ddp.pth")
+    b = make(120, 1)
+    tb = Stage3Trainer(b)
+    info = ck.load_checkpoint(str(tmp_path / "ddp.pth"), b, tb)
+    assert b._xyz.shape[0] == 300 and b.max_radii2D.shape[0] == 300 and tb.current_steps == 1234
+    for k in ck.SURFEL_KEYS:
+        assert torch.equal(getattr(a, k).detach(), getattr(b, k).detach())
+    assert torch.equal(a.warp.skinning_model.log_gauss.detach(), b.warp.skinning_model.log_gauss.detach())
+    assert not info["unexpected_keys"]
+    assert tb.gs_optimizer.param_groups[0]["params"][0] is b._xyz

@@ -1,0 +1,75 @@
+"""Stage-3 checkpoints in the reference's on-disk layout.
+
+Reference: Trainer.save_checkpoint / load_checkpoint (lab4d/engine/trainer.py:335-422): a
+`torch.save`d dict {"current_steps", "current_round", "model": state_dict, "optimizer": state_dict}
+written to `<save_dir>/ckpt_%04d.pth` and copied to `ckpt_latest.pth`; the foreground surfel field
+lives under the key prefix `fields.field_params.fg.` (`_xyz`, `_features_dc`, `_features_rest`,
+`_opacity`, `_scaling`, `_rotation`, `_regist_feat`, then the warp / camera sub-modules).  On load the
+`module.` prefix of DDP checkpoints is stripped, the surfel parameters are re-created with the
+checkpoint's point count, the state dict is applied with strict=False, and the optimizer state is NOT
+restored (upstream comments that part out, :416-421) -- the surfel optimizer is rebuilt instead.
+Per-round `%03d-fg-gs.ply` files use GaussianModel.save_ply (attribute order of gaussian_model.py:189-220).
+
+Sub-module keys (warp, camera MLP) are carried under the same prefix; they load into this
+repository's modules where name and shape agree and are reported otherwise (the reference's warp
+modules are not re-implemented layer for layer)."""
+from __future__ import annotations
+
+import os
+import shutil
+
+import torch
+import torch.nn as nn
+
+FG_PREFIX = "fields.field_params.fg."
+SURFEL_KEYS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_regist_feat")
+
+
+def remove_ddp_prefix(state: dict) -> dict:
+    """`module.` prefix of DistributedDataParallel checkpoints (lab4d/utils/torch_utils.py)."""
+    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+
+
+def model_state(model) -> dict:
+    return {FG_PREFIX + k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def save_checkpoint(trainer, save_dir: str, round_count: int, save_freq: int = 1, rank: int = 0):
+    """-> path written, or None when this rank / round does not save."""
+    if rank != 0 or round_count % max(1, save_freq) != 0:
+        return None
+    os.makedirs(save_dir, exist_ok=True)
+    path = os.path.join(save_dir, "ckpt_%04d.pth" % round_count)
+    ckpt = {"current_steps": trainer.current_steps, "current_round": round_count,
+            "model": model_state(trainer.model), "optimizer": trainer.gs_optimizer.state_dict()}
+    torch.save(ckpt, path)
+    shutil.copyfile(path, os.path.join(save_dir, "ckpt_latest.pth"))
+    trainer.model.save_ply(os.path.join(save_dir, "%03d-fg-gs.ply" % round_count))
+    return path
+
+
+def load_checkpoint(load_path: str, model, trainer=None, map_location=None) -> dict:
+    """Updates `model` in place; returns the checkpoint dict plus "missing_keys" / "unexpected_keys"."""
+    ckpt = torch.load(load_path, map_location=map_location or model._xyz.device, weights_only=False)
+    states = remove_ddp_prefix(ckpt["model"])
+    fg = {k[len(FG_PREFIX):]: v for k, v in states.items() if k.startswith(FG_PREFIX)}
+    if not fg:  # a bare surfel-field state dict
+        fg = dict(states)
+    if "_xyz" in fg:
+        n = fg["_xyz"].shape[0]
+        dev = model._xyz.device
+        for k in SURFEL_KEYS:
+            if k in fg:  # surfel tensors take the checkpoint's point count (trainer.py:386-399)
+                setattr(model, k, nn.Parameter(torch.empty_like(fg[k], device=dev)))
+        model.max_radii2D = torch.zeros(n, device=dev)
+        model.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
+        model.denom = torch.zeros(n, 1, device=dev)
+    own = model.state_dict()
+    usable = {k: v for k, v in fg.items() if k in own and own[k].shape == v.shape}
+    res = model.load_state_dict(usable, strict=False)
+    ckpt["missing_keys"] = list(res.missing_keys)
+    ckpt["unexpected_keys"] = sorted(set(fg) - set(usable))
+    if trainer is not None:  # fresh optimizer over the re-created parameters, step counter from the file
+        trainer.__init__(model, trainer.cfg.__dict__ | {"gs_optim_warp": trainer.optim_warp})
+        trainer.current_steps = int(ckpt.get("current_steps", 0))
+    return ckpt

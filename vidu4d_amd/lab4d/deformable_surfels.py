@@ -149,6 +149,22 @@ class DeformableSurfels(GaussianModel):
             return False
         return inst_id is None or len(set(inst_id.tolist())) == 1
 
+    def _frozen_warp_table(self):
+        params = [p for mod in (self.warp.articulation, self.camera_mlp) for p in mod.parameters()]
+        version = sum(p._version for p in params)
+        tab = self.__dict__.get("_warp_table")
+        if tab is None or tab["version"] != version:
+            with torch.no_grad():
+                ids = torch.arange(self.num_frames, device=self._xyz.device)
+                t_art, rest_art = self.warp.articulation.get_vals_and_mean(ids)
+                se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
+                cq, ct = self.camera_mlp.get_vals(ids)
+                tab = {"version": version, "se3_qr": se3[0].contiguous(), "se3_qd": se3[1].contiguous(),
+                       "rest1": (rest_art[0][:1].contiguous(), rest_art[1][:1].contiguous()),
+                       "cam_q": cq.contiguous(), "cam_t": ct.contiguous()}
+            self.__dict__["_warp_table"] = tab
+        return tab
+
     def forward_warp_fused(self, frame_id, inst_id=None, samples_dict=None):
         """forward_warp for frozen bones: the skinning weights of the forward warp depend on neither the
         frame nor the time code (warping.py:415-425: rest articulation, mean time embedding), so they are
@@ -156,14 +172,23 @@ class DeformableSurfels(GaussianModel):
         direction (csrc/lbs.hip).  -> xyz_cam (M,N,3), rot_cam (M,N,4)."""
         samples_dict = samples_dict or {}
         w = self.warp
-        if "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
-            rest_art, t_art = samples_dict["rest_articulation"], samples_dict["t_articulation"]
+        overrides = any(k in samples_dict for k in ("rest_articulation", "t_articulation", "field2cam"))
+        if overrides:
+            if "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
+                rest_art, t_art = samples_dict["rest_articulation"], samples_dict["t_articulation"]
+            else:
+                t_art, rest_art = w.articulation.get_vals_and_mean(frame_id)
+            se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
+            rest1 = (rest_art[0][:1], rest_art[1][:1])
+            cq, ct = samples_dict["field2cam"] if "field2cam" in samples_dict else self.camera_mlp.get_vals(frame_id)
         else:
-            t_art, rest_art = w.articulation.get_vals_and_mean(frame_id)
-        se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
-        rest1 = (rest_art[0][:1], rest_art[1][:1])
+            # frozen networks: bone transforms and cameras of ALL frames are constants of the run; they are
+            # evaluated once (and again whenever a parameter is written) and indexed per step
+            tab = self._frozen_warp_table()
+            se3 = (tab["se3_qr"][frame_id], tab["se3_qd"][frame_id])
+            rest1 = tab["rest1"]
+            cq, ct = tab["cam_q"][frame_id], tab["cam_t"][frame_id]
         skin, delta = w.skinning_model(self._xyz[None], rest1, None, None if inst_id is None else inst_id[:1])
-        cq, ct = samples_dict["field2cam"] if "field2cam" in samples_dict else self.camera_mlp.get_vals(frame_id)
         xyz_cam, rot_cam = lbs_apply(skin[0].softmax(-1), se3, self._xyz, self._rotation, cq, ct)
         M = frame_id.shape[0]
         aux = {"skin_entropy": cross_entropy_skin_loss(skin)[..., None].expand(M, -1, -1)}
