@@ -206,6 +206,12 @@ int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_q
                         const float* g_out_xyz, const float* g_out_rot, float* g_wT, float* g_xyz, float* g_rot,
                         void* stream);
 
+/* ---- mean squared distance of every point to its 3 nearest other points (exact): replaces
+ *      simple-knn's distCUDA2 (gs/submodules/simple-knn/spatial.cu:15-25, simple_knn.cu:185-221), used
+ *      once by GaussianModel.create_from_pcd (gs/scene/gaussian_model.py:134-136).  points (P,3),
+ *      mean_dist2 (P).  Fewer than 4 points leave FLT_MAX terms in the mean, as upstream. ---- */
+int vidu4d_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,8 +5,8 @@ densify_and_prune :434-448, add_densification_stats :450-452, PLY I/O :189-268).
 
 Same attribute and method names and the same semantics, with two practical differences: tensors
 live on the device given at construction instead of a hard-coded "cuda", and the one-off scale
-initialisation (mean squared distance to the 3 nearest neighbours, simple-knn's distCUDA2) is a
-scipy cKDTree query unless a callable is supplied (init-time only)."""
+initialisation (mean squared distance to the 3 nearest neighbours, simple-knn's distCUDA2) runs the
+HIP kernel csrc/knn.hip on a GPU and a scipy cKDTree query for host-only construction."""
 from __future__ import annotations
 
 import os
@@ -117,7 +117,13 @@ class GaussianModel(nn.Module):
         n, m = xyz.shape[0], (self.max_sh_degree + 1) ** 2
         features = torch.zeros(n, 3, m, device=dev)
         features[:, :3, 0] = color
-        d2 = dist2_fn(pts) if dist2_fn is not None else mean_knn_dist2(pts)
+        if dist2_fn is not None:
+            d2 = dist2_fn(pts)
+        elif xyz.is_cuda:  # the HIP 3-NN kernel (csrc/knn.hip), as upstream's distCUDA2
+            from ..simple_knn import distCUDA2
+            d2 = distCUDA2(xyz)
+        else:              # host-only construction (CPU tests): same quantity from a k-d tree
+            d2 = mean_knn_dist2(pts)
         dist2 = torch.clamp_min(torch.as_tensor(d2, dtype=torch.float32, device=dev), 1e-7)
         scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 2)
         rots = torch.rand(n, 4, device=dev)  # upstream initialises with uniform random quaternions (:141)
