@@ -78,3 +78,33 @@ def test_stage3_fit_reduces_loss_and_densifies(gpu_device):
     assert np.mean(hist[-8:]) < 0.8 * np.mean(hist[:8]), hist
     assert student._xyz.shape[0] != n0, "densify/prune never changed the surfel count"
     assert student.max_radii2D.shape[0] == student._xyz.shape[0]
+
+
+def test_deferred_capacity_check_detects_overflow_and_replays(gpu_device):
+    """Stage3Trainer runs the rasterizer without its per-frame host wait; a frame that outgrows the
+    binning buffer guessed from the previous one must be detected by the per-step check and the step
+    replayed, giving the same parameters as a run with exact buffers."""
+    from vidu4d_amd import _C
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    dev = gpu_device
+    H = W = 96
+    res = {}
+    for mode in ("deferred", "exact"):
+        m = _model(dev, n=4000, seed=5, densify_until_iter=0)
+        tr = Stage3Trainer(m)
+        batches = [synthetic_batch(m, [0, 1], H, W, seed=0), synthetic_batch(m, [2, 3], H, W, seed=1)]
+        if mode == "exact":
+            _C._EXACT, old = True, _C._EXACT
+        try:
+            tr.train_step(batches[0])
+            if mode == "deferred":  # pretend the previous frames were almost empty: the guess is far too small
+                for k in list(_C._capacity_hint):
+                    _C._capacity_hint[k] = 64
+            tr.train_step(batches[1])
+        finally:
+            if mode == "exact":
+                _C._EXACT = old
+        res[mode] = m._xyz.detach().clone(), m._features_dc.detach().clone()
+        assert not _C._pending
+    for a, b in zip(res["deferred"], res["exact"]):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))

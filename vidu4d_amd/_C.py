@@ -29,6 +29,13 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = 2048
 _capacity_hint: dict = {}
+# Deferred capacity check (opt-in, for callers that can replay a step -- Stage3Trainer): the forward
+# does not wait for the pair count at all; it leaves (event, pinned slot, capacity) in `_pending`, and
+# `check_deferred()` -- called once per step after everything is queued -- reports whether some frame
+# overflowed its binning buffer (it then rendered only the background) so that the caller can discard
+# the step and run it again.  The host can then run a whole step ahead of the GPU.
+_deferred = False
+_pending: list = []
 _depth_stat: dict = {}   # key -> (device counter, pinned copy)
 _depth_hint: dict = {}
 _pinned: dict = {}
@@ -55,6 +62,36 @@ def _check_cuda(*ts):
         if t is not None and t.numel() and not t.is_cuda:
             raise RuntimeError("diff_surfel_rasterization: all tensors must be CUDA/HIP tensors "
                                "(there is no CPU path in the MI355X build)")
+
+
+class deferred_capacity_check:
+    """Context manager: rasterize_gaussians calls inside do not block on the pair count."""
+
+    def __enter__(self):
+        global _deferred
+        self._old, _deferred = _deferred, True
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred
+        _deferred = self._old
+        return False
+
+
+def check_deferred() -> bool:
+    """Waits for the pair counts of the deferred forwards queued since the last call (their events were
+    recorded right after the tile scan, long passed by the time a step is fully queued), refreshes the
+    capacity / split hints, and returns False if any of them overflowed its binning buffer."""
+    ok = True
+    for ev, slot, stat, cap, key in _pending:
+        ev.synchronize()
+        n = int(slot[0])
+        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
+        if stat is not None:
+            _depth_hint[key] = int(stat[1][0])
+        ok = ok and n <= cap
+    _pending.clear()
+    return ok
 
 
 def _pinned_slot(device):
@@ -146,6 +183,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         cap = hint
         binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
         slot = _pinned_slot(dev)
+        if _deferred and any(p[1] is slot for p in _pending):
+            # a deferred forward keeps its read-back slot until check_deferred() has looked at it
+            slot = torch.empty(4, dtype=torch.int32).pin_memory()
         slot.copy_(geom[:16].view(torch.int32), non_blocking=True)
         if stat is not None:  # depth reached by the previous frame on this stream; then reset for this one
             stat[1].copy_(stat[0], non_blocking=True)
@@ -154,6 +194,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         ev.record(torch.cuda.current_stream(dev))
         _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
                    "surfel forward (run)")
+        if _deferred and not debug:
+            _pending.append((ev, slot, stat, cap, key))
+            binning._vidu4d_capacity = cap
+            binning._vidu4d_split = int(a.segment_split)
+            return cap, out_color, out_others, radii, geom, binning, img
         ev.synchronize()  # waits for preprocess + scan only; sort and blend keep running
         num_rendered = int(slot[0])
         if stat is not None:

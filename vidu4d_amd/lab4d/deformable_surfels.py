@@ -110,6 +110,12 @@ class DeformableSurfels(GaussianModel):
         """One camera per frame from the inverse intrinsics (:927-962).  The intrinsics come to the host
         in one copy; cameras are cached on their six defining numbers (with --force_center_cam every
         frame of a video shares them)."""
+        # the same intrinsics tensor as last time (same storage, not written since): same cameras, and no
+        # device-to-host copy -- that copy would make the host wait for all queued GPU work every step
+        tkey = (Kinvs.data_ptr(), Kinvs._version, tuple(Kinvs.shape), tuple(int(h) for h in Hs), tuple(int(w) for w in Ws))
+        last = self.__dict__.get("_camera_last")
+        if last is not None and last[0] == tkey:
+            return last[1]
         cams = []
         Kh = Kinvs.detach().float().cpu()
         cache = self.__dict__.setdefault("_camera_cache", {})
@@ -124,6 +130,7 @@ class DeformableSurfels(GaussianModel):
                 cache[key] = KCamera(H=H, W=W, left=left, right=right, top=top, bottom=bottom,
                                      data_device=Kinvs.device)
             cams.append(cache[key])
+        self.__dict__["_camera_last"] = (tkey, cams, Kinvs)  # (keeps the tensor alive: its address is the key)
         return cams
 
     def forward_warp(self, xyz, rotation, frame_id, inst_id=None, samples_dict=None):

@@ -121,15 +121,31 @@ class Stage3Trainer:
         dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX)
 
     # ---- one optimizer step on this rank's frames
+    def _forward_backward(self, batch: dict, step: int) -> dict:
+        m = self.model
+        rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"])
+        losses = compute_losses(rendered, batch, step, self.cfg)
+        total = sum(losses.values())
+        total.backward()
+        return losses
+
     def train_step(self, batch: dict) -> dict:
         m, c = self.model, self.cfg
         step = self.current_steps
         if step > 0 and step % 1000 == 0:
             m.oneupSHdegree()  # trainer.py:464-466
-        rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"])
-        losses = compute_losses(rendered, batch, step, c)
-        total = sum(losses.values())
-        total.backward()
+        if m._xyz.is_cuda:
+            # The rasterizer's only host wait (the pair count that sizes the binning buffer) is deferred to
+            # one check per step: if a frame outgrew its buffer -- it then rendered only the background --
+            # the gradients of this step are dropped and the step is replayed with exact buffers.
+            from .. import _C
+            with _C.deferred_capacity_check():
+                losses = self._forward_backward(batch, step)
+            if not _C.check_deferred():
+                self.gs_optimizer.zero_grad(set_to_none=True)
+                losses = self._forward_backward(batch, step)
+        else:
+            losses = self._forward_backward(batch, step)
         self.allreduce_gradients()
         torch.nn.utils.clip_grad_norm_(self.surfel_params(), 5.0)
 
