@@ -13,8 +13,18 @@ from vidu4d_amd.synthetic import make_scene, make_upstream_grads
 pytestmark = pytest.mark.gpu
 
 
+def _poison_allocator(dev, mbytes=768):
+    """Fills the caching allocator's free blocks with NaNs so that the `torch.empty` buffers the native
+    calls allocate start out poisoned: an output element or a piece of scratch state that a kernel reads
+    or returns without writing it first then shows up as NaN instead of hiding behind zeroed memory."""
+    blocks = [torch.full((mbytes * 1024 * 1024 // 4 // 6,), float("nan"), device=dev) for _ in range(6)]
+    blocks += [torch.full((n,), float("nan"), device=dev) for n in (3 * 512 * 512, 8 * 512 * 512, 200_000 * 20, 200_000 * 48)]
+    del blocks
+
+
 def _native_forward(sc, dev, colors_precomp=None, debug=False):
     from vidu4d_amd import _C
+    _poison_allocator(dev)
     d = sc.to(dev)
     empty = torch.empty(0, device=dev)
     shs = empty if colors_precomp is not None else d.shs
@@ -66,6 +76,7 @@ def _check_backward(sc, st, d, shs, cols, out, dev):
     R, color, others, radii, geom, binning, img = out
     dc, do = make_upstream_grads(sc.width, sc.height)
     g = so.backward(st, dc, do)
+    _poison_allocator(dev)
     empty = torch.empty(0, device=dev)
     got = _C.rasterize_gaussians_backward(d.bg, d.means3D, radii, cols, d.scales, d.rotations, 1.0, empty,
                                           d.viewmatrix, d.projmatrix, sc.tanfovx, sc.tanfovy, dc.to(dev), do.to(dev),

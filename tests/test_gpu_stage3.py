@@ -108,3 +108,4 @@ def test_deferred_capacity_check_detects_overflow_and_replays(gpu_device):
         assert not _C._pending
     for a, b in zip(res["deferred"], res["exact"]):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+

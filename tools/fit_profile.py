@@ -3,16 +3,18 @@ sys.path.insert(0, "/root/repo")
 from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
 from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
 dev = torch.device("cuda:0")
-N, H, W, frames = 200_000, 512, 512, 120
+N, H, W, frames = int(__import__("os").environ.get("FIT_N", "200000")), 512, 512, 120
 RADIUS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0  # object radius; camera at distance 3, tan(fov/2)=0.5
 rng = np.random.default_rng(0)
-m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=frames, device=dev)
+import os
+m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0, frame_streams=os.environ.get("FIT_STREAMS", "1") == "1"), num_frames=frames, device=dev)
 pts = rng.normal(size=(N, 3)).astype(np.float32); pts = RADIUS * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32), )
 with torch.no_grad(): m._scaling.add_(0.0)
 tr = Stage3Trainer(m)
 batches = [synthetic_batch(m, [(2*i) % frames, (2*i+1) % frames], H, W, seed=i) for i in range(4)]
-for i in range(3): tr.train_step(batches[i % 4])
+for b in batches: b["Kinv"] = batches[0]["Kinv"]  # one intrinsics tensor for the run (--force_center_cam)
+for i in range(6): tr.train_step(batches[i % 4])
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 t0 = time.perf_counter(); K = 10

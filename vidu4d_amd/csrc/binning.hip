@@ -421,9 +421,10 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
     if (capacity <= 0 || num_tiles <= 0) return;
     int id_bytes = 1;
     while (id_bytes < 4 && ((uint64_t)(num_surfels > 0 ? num_surfels - 1 : 0) >> (8 * id_bytes))) id_bytes++;
-    if (long_pass) {  // at most capacity / TILE_SORT_CAP tiles can be that long; they lead the schedule
-        const int longs = (int)std::min<int64_t>(num_tiles, capacity / TILE_SORT_CAP + 1);
-        hipLaunchKernelGGL((tile_sort_kernel<16, false>), dim3(longs), dim3(1024), 0, stream, img.tile_order,
+    if (long_pass) {
+        // the long tiles lead the schedule, but it is sorted by length CLASS only (a long tile may sit behind
+        // shorter ones of its class), so every position gets a workgroup; the short ones exit at once
+        hipLaunchKernelGGL((tile_sort_kernel<16, false>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order,
                            img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0);
     }
     hipLaunchKernelGGL((tile_sort_kernel<4, true>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order, img.ranges,

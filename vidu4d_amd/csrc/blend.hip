@@ -414,8 +414,11 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
                            out_others, depth_used);
         return;
     }
-    const int segs = (int)seg_capacity(capacity);                       // upper bounds: the device knows the
-    const int split_tiles = (int)std::min<int64_t>(tiles, capacity / SPLIT_MIN + 1);  // exact counts
+    // upper bounds; the device knows the exact counts.  The combine runs over ALL schedule positions: the
+    // schedule is sorted by length CLASS, so a split tile may sit behind unsplit ones of its class and the
+    // number of positions that hold split tiles is not bounded by capacity / SPLIT_MIN.
+    const int segs = (int)seg_capacity(capacity);
+    const int split_tiles = tiles;
     hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, cam.grid_y,
                        g.hdr, img, point_list, capacity, g.rec, b.seg_data);
     hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
