@@ -328,3 +328,44 @@ def test_segment_parallel_blend_equals_single_workgroup_blend(gpu_device, monkey
     for a, b in zip(res["0"][:2], res["1"][:2]):
         scale = np.abs(a).max()
         assert np.abs(a - b).max() <= 2e-5 * scale
+
+
+def test_interleaved_frames_keep_their_own_state(gpu_device, monkeypatch):
+    """forward(A), forward(B), backward(B), backward(A) -- how autograd runs a multi-frame step -- must
+    give each frame the gradients it gets alone, with the segment-parallel path on and recycled
+    (poisoned) allocator blocks: per-frame scratch state may not leak between the frames."""
+    from vidu4d_amd import _C
+    from vidu4d_amd.synthetic import make_object_scene
+    monkeypatch.setattr(_C, "_SPLIT", "1")
+    dev = gpu_device
+    W = H = 256
+    scenes = [make_object_scene(60_000, W, H, radius=0.5, seed=300 + f, opacity_mode="init").to(dev) for f in range(2)]
+    dc, do = (t.to(dev) for t in make_upstream_grads(W, H))
+    empty = torch.empty(0, device=dev)
+
+    def fwd(sc):
+        _poison_allocator(dev, 256)
+        return _C.rasterize_gaussians(sc.bg, sc.means3D, empty, sc.opacities, sc.scales, sc.rotations, 1.0, empty,
+                                      sc.viewmatrix, sc.projmatrix, sc.tanfovx, sc.tanfovy, H, W, sc.shs, 3, sc.campos,
+                                      False, False)
+
+    def bwd(sc, out):
+        _poison_allocator(dev, 256)
+        R, color, others, radii, geom, binning, img = out
+        return _C.rasterize_gaussians_backward(sc.bg, sc.means3D, radii, empty, sc.scales, sc.rotations, 1.0, empty,
+                                               sc.viewmatrix, sc.projmatrix, sc.tanfovx, sc.tanfovy, dc, do, sc.shs, 3,
+                                               sc.campos, geom, R, binning, img, False)
+
+    alone = []
+    for sc in scenes:
+        out = fwd(sc)
+        alone.append((out[1].clone(), [t.clone() for t in bwd(sc, out)]))
+    outs = [fwd(sc) for sc in scenes]
+    grads = {1: bwd(scenes[1], outs[1]), 0: bwd(scenes[0], outs[0])}
+    for f in range(2):
+        assert torch.equal(outs[f][1], alone[f][0])
+        for a, b in zip(grads[f], alone[f][1]):
+            if b.numel():
+                assert torch.isfinite(a).all()
+                scale = max(float(b.abs().max()), 1e-20)
+                assert float((a - b).abs().max()) <= 1e-4 * scale  # (float atomics: order varies run to run)
