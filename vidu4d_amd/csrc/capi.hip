@@ -59,16 +59,16 @@ struct StageTimer {
             sp = g_span_pool.back();
             g_span_pool.pop_back();
         } else {
-            hipEventCreate(&sp.a);
-            hipEventCreate(&sp.b);
+            (void)hipEventCreate(&sp.a);
+            (void)hipEventCreate(&sp.b);
         }
         sp.stage = stage;
-        hipEventRecord(sp.a, stream);
+        (void)hipEventRecord(sp.a, stream);
     }
     ~StageTimer()
     {
         if (!on) return;
-        hipEventRecord(sp.b, stream);
+        (void)hipEventRecord(sp.b, stream);
         g_spans.push_back(sp);
     }
 };
