@@ -58,4 +58,36 @@ with open(os.path.join(summ, f"{tag}_pmc_fetch_write.csv"), "w") as f:
                       "hbm_bytes_per_launch": (fe * corr + wr) * 1024.0}
         f.write(f"surfel::{k},{fe:.1f},{wr:.1f},{len(d['FETCH_SIZE'])}\n")
 json.dump(traffic, open(os.path.join(summ, "pmc_traffic.json"), "w"), indent=1)
+
+# 3. SQ counters: per-kernel mean per launch
+sq = find("SQ", "*counter_collection.csv")
+if sq:
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(sq)):
+        name = r.get("Kernel_Name", "")
+        if "surfel::" not in name:
+            continue
+        key = next((v for k, v in SHORT.items() if k in name), None)
+        if key:
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS",
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
+    # average duration per kernel from the un-instrumented trace pass
+    dur = defaultdict(list)
+    if stats:
+        for r in csv.DictReader(open(stats)):
+            key = next((v for k, v in SHORT.items() if k in r["Name"]), None)
+            if key and "surfel::" in r["Name"]:
+                dur[key].append((float(r["AverageNs"]), int(r["Calls"])))
+    SIMDS, CLK_GHZ = 1024, 2.4  # 256 CU x 4 SIMD; peak engine clock: a wave64 VALU instruction occupies its SIMD for 4 cycles
+    with open(os.path.join(summ, f"{tag}_pmc_sq.csv"), "w") as f:
+        f.write("# valu_issue_util = SQ_INSTS_VALU * 4 cycles / (1024 SIMDs * avg duration * 2.4 GHz): share of the VALU issue slots used\n")
+        f.write("kernel,launches," + ",".join(c + "_per_launch" for c in cols) + ",avg_duration_us,valu_issue_util\n")
+        for k, d in acc.items():
+            m = {c: (sum(d[c]) / len(d[c]) if d[c] else float("nan")) for c in cols}
+            n = len(next(iter(d.values())))
+            # (tile_scan aggregates three kernels: no single duration)
+            ns = max(dur[k], key=lambda t: t[1])[0] if dur.get(k) and k != "tile_scan" else float("nan")
+            util = m["SQ_INSTS_VALU"] * 4.0 / (SIMDS * ns * CLK_GHZ) if ns == ns else float("nan")
+            f.write(f"surfel::{k},{n}," + ",".join(f"{m[c]:.4g}" for c in cols) + f",{ns / 1e3:.1f},{util:.3f}\n")
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in traffic.items()}))
