@@ -465,6 +465,39 @@ __device__ __forceinline__ float row_reduce_scatter16(float (&v)[16], int lane)
     return v[0];
 }
 
+// Wave-wide reduce-scatter of 16 values with the gfx950 lane-swap instructions.  v_permlane32_swap
+// exchanges the upper 32 lanes of one register with the lower 32 lanes of another, v_permlane16_swap
+// the odd 16-lane rows of one with the even rows of the other: after "swap, add" on register pairs
+// (k, k+8) and then (k, k+4) the 16 inputs have become 4 registers in which row r holds, per column,
+// the sum over the four rows of value k + 4r -- the two steps that cross the rows need no select at
+// all (8+8 and 4+4 instructions).  Two select-and-add DPP steps and two plain quad adds finish the
+// columns: every lane of quad q in row r then holds the wave total of value q + 4r.
+// 35 VALU instructions instead of the 45 selects/adds (+ register shuffling) of four row-local
+// halvings, and the LDS accumulation that follows has 16 distinct addresses instead of 4 lanes each.
+__device__ __forceinline__ void swap_add32(float& a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_add16(float& a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wave_reduce_scatter16(float (&v)[16], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) swap_add32(v[k], v[k + 8]);  // lanes 0-31: value k, lanes 32-63: value k + 8
+#pragma unroll
+    for (int k = 0; k < 4; k++) swap_add16(v[k], v[k + 4]);  // row r: value k + 4r
+    halve<DPP_ROW_MIRROR, 4>(v, (lane & 8) != 0);            // columns 0-7: k = 0,1   columns 8-15: k = 2,3
+    halve<DPP_ROW_HALF_MIRROR, 2>(v, (lane & 4) != 0);       // quad q: k = q
+    float t = v[0];
+    t += dpp_xchg<DPP_QUAD_XOR2>(t);
+    t += dpp_xchg<DPP_QUAD_XOR1>(t);
+    return t;
+}
+
 // Same for 2 values: lane L holds the row total of component ((L >> 3) & 1).
 __device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
 {
@@ -572,8 +605,10 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     const int n_used = (int)s_max;
 
     // accumulator slot handled by this lane after the row reduce-scatter
-    const int c16 = lane & 15;
+    // (after wave_reduce_scatter16 every lane of quad q in row r holds value q + 4r; lane 0 of the quad adds it)
+    const int c16 = ((lane & 15) >> 2) + 4 * (lane >> 4);
     const int slot16 = c16 < 9 ? c16 : (c16 == 9 ? A_OPAC : (c16 < 13 ? c16 + 2 : c16 + 3));
+    const bool adds16 = (lane & 3) == 0;
     const int slot2 = A_M2D + ((lane >> 3) & 1);
 
     for (int hi = n_used; hi > seg_begin; hi -= BWD_BATCH) {
@@ -618,8 +653,8 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
                 }
                 float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
                                g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
-                const float r16 = row_reduce_scatter16(v, lane);
-                if (r16 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot16], r16);
+                const float r16 = wave_reduce_scatter16(v, lane);
+                if (adds16 && r16 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot16], r16);
                 if (__any(g[A_M2D] != 0.f || g[A_M2D + 1] != 0.f)) {
                     const float r2 = row_reduce_scatter2(g[A_M2D], g[A_M2D + 1], lane);
                     if ((lane & 7) == 0 && r2 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot2], r2);
