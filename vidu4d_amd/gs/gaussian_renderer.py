@@ -13,7 +13,14 @@ from ..diff_surfel_rasterization import GaussianRasterizationSettings, GaussianR
 from .point_utils import depth_to_normal
 
 
-def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+GEOMETRY_KEYS = ("rend_normal", "surf_depth", "render_depth_median", "render_depth_expected", "surf_normal")
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           outputs=None):
+    """`outputs` (extension; default None = everything, as upstream): an iterable of dict keys the caller
+    will read.  When it names none of GEOMETRY_KEYS the depth / normal post-processing (about 25
+    elementwise launches per frame, twice that in the backward) is skipped and those keys are absent."""
     xyz = pc.get_xyz
     # dummy (N,3) tensor whose .grad receives the screen-space densification statistic (:29-33)
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
@@ -51,6 +58,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             "radii": radii}
 
     render_alpha = allmap[1:2]
+    if outputs is not None and not any(k in GEOMETRY_KEYS for k in outputs):
+        rets.update({"acc": render_alpha, "rend_dist": allmap[6:7]})
+        return rets
     render_normal = allmap[2:5]
     render_normal = (render_normal.permute(1, 2, 0) @ viewpoint_camera.world_view_transform[:3, :3].T).permute(2, 0, 1)
     render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)

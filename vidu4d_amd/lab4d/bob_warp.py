@@ -119,16 +119,21 @@ class SkinningField(nn.Module):
     def get_gauss(self):
         return self.log_gauss.exp()
 
-    def bone_coords(self, xyz, bone2obj):
-        """xyz (M,N,3), bone2obj ((M,B,4),(M,B,4)) -> (M,N,B,3) Gaussian-bone coordinates."""
+    def bone_frames(self, bone2obj):
+        """Object -> bone rotation (M,B,3,3) and translation (M,B,3) of the bone frames; a constant of the
+        run while the articulation is frozen (the caller may cache it)."""
         q, t = qt.dual_quaternion_to_quaternion_translation(qt.dual_quaternion_inverse(bone2obj))
-        R = quaternion_to_matrix(q)  # (M,B,3,3) object -> bone
+        return quaternion_to_matrix(q), t
+
+    def bone_coords(self, xyz, bone2obj, bone_frames=None):
+        """xyz (M,N,3), bone2obj ((M,B,4),(M,B,4)) -> (M,N,B,3) Gaussian-bone coordinates."""
+        R, t = bone_frames if bone_frames is not None else self.bone_frames(bone2obj)
         xb = torch.einsum("mbij,mnj->mnbi", R, xyz) + t[:, None]
         return xb / self.get_gauss()[None, None]
 
-    def forward(self, xyz, bone2obj, frame_id, inst_id):
+    def forward(self, xyz, bone2obj, frame_id, inst_id, bone_frames=None):
         """-> (skin logits (M,N,B), delta (M,N,B) or None)"""
-        xb = self.bone_coords(xyz, bone2obj)
+        xb = self.bone_coords(xyz, bone2obj, bone_frames)
         dist2 = xb.pow(2).sum(-1)
         if not self.delta_skin:
             return -dist2, None

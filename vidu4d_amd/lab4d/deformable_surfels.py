@@ -90,14 +90,15 @@ class DeformableSurfels(GaussianModel):
     def get_xyz(self):
         return self._override_xyz if hasattr(self, "_override_xyz") else self._xyz
 
-    def render_view(self, view, override_xyz=None, override_rotation=None, override_color=None, override_bkgd=None):
+    def render_view(self, view, override_xyz=None, override_rotation=None, override_color=None, override_bkgd=None,
+                    outputs=None):
         if override_xyz is not None:
             assert override_xyz.dim() == 2
             self._override_xyz = override_xyz
             self._override_rotation = override_rotation
         try:
             bkgd = self.background if override_bkgd is None else override_bkgd
-            rendered = render(view, self, self.pipeline, bkgd, override_color=override_color)
+            rendered = render(view, self, self.pipeline, bkgd, override_color=override_color, outputs=outputs)
         finally:
             if override_xyz is not None:
                 del self._override_xyz
@@ -166,8 +167,9 @@ class DeformableSurfels(GaussianModel):
                 t_art, rest_art = self.warp.articulation.get_vals_and_mean(ids)
                 se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
                 cq, ct = self.camera_mlp.get_vals(ids)
+                rest1 = (rest_art[0][:1].contiguous(), rest_art[1][:1].contiguous())
                 tab = {"version": version, "se3_qr": se3[0].contiguous(), "se3_qd": se3[1].contiguous(),
-                       "rest1": (rest_art[0][:1].contiguous(), rest_art[1][:1].contiguous()),
+                       "rest1": rest1, "bone_frames": self.warp.skinning_model.bone_frames(rest1),
                        "cam_q": cq.contiguous(), "cam_t": ct.contiguous()}
             self.__dict__["_warp_table"] = tab
         return tab
@@ -195,7 +197,9 @@ class DeformableSurfels(GaussianModel):
             se3 = (tab["se3_qr"][frame_id], tab["se3_qd"][frame_id])
             rest1 = tab["rest1"]
             cq, ct = tab["cam_q"][frame_id], tab["cam_t"][frame_id]
-        skin, delta = w.skinning_model(self._xyz[None], rest1, None, None if inst_id is None else inst_id[:1])
+        frames = None if overrides else tab["bone_frames"]
+        skin, delta = w.skinning_model(self._xyz[None], rest1, None, None if inst_id is None else inst_id[:1],
+                                       bone_frames=frames)
         xyz_cam, rot_cam = lbs_apply(skin[0].softmax(-1), se3, self._xyz, self._rotation, cq, ct)
         M = frame_id.shape[0]
         aux = {"skin_entropy": cross_entropy_skin_loss(skin)[..., None].expand(M, -1, -1)}
@@ -212,7 +216,7 @@ class DeformableSurfels(GaussianModel):
             pool.append(torch.cuda.Stream(device=self._xyz.device))
         return pool
 
-    def render_frames(self, frame_id, Kinv, H, W, inst_id=None, samples_dict=None):
+    def render_frames(self, frame_id, Kinv, H, W, inst_id=None, samples_dict=None, outputs=None):
         """The per-frame render loop of query_field (:1175-1233): returns a dict of (M,H,W,C) maps and
         keeps the per-frame screen-space tensors the densification statistics need."""
         M = frame_id.shape[0]
@@ -238,11 +242,13 @@ class DeformableSurfels(GaussianModel):
             if streams:
                 streams[i].wait_event(ready)
                 with torch.cuda.stream(streams[i]):
-                    r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i])
+                    r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i],
+                                         outputs=outputs)
                     for v in r.values():
                         v.record_stream(main)
             else:
-                r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i])
+                r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i],
+                                     outputs=outputs)
             for k, v in r.items():
                 if k in per_frame:
                     per_frame[k].append(v)

@@ -130,7 +130,10 @@ class Stage3Trainer:
     # ---- one optimizer step on this rank's frames
     def _forward_backward(self, batch: dict, step: int) -> dict:
         m = self.model
-        rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"])
+        # the depth / normal maps are only read by the regularisers, whose weights are 0 until step 8000
+        need_geometry = step > 8000 and (self.cfg.lambda_normal != 0.0)
+        outputs = None if need_geometry else ("render", "acc", "rend_dist")
+        rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=outputs)
         losses = compute_losses(rendered, batch, step, self.cfg)
         total = sum(losses.values())
         total.backward()
