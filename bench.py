@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--torch-cpu-images", type=int, default=1,
                     help="frames timed on the pure-PyTorch CPU render (0 = skip; ~10-20 s each at 200k/512^2)")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--frame-streams", type=int, default=1, help="queue the frames of a step on separate HIP streams")
     ap.add_argument("--_torch_cpu_child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--_threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -201,23 +202,56 @@ def main():
     scales = scene.scales.clone().requires_grad_(True)
     shs = scene.shs.clone().requires_grad_(True)
     flat = torch.empty(N * GRAD_FLOATS_PER_SURFEL, device=dev) if use_dist else None
+    use_distributed_exchange = use_dist
+    opac_f, scales_f, shs_f = opac, scales, shs
     counter = {"slot": 0, "R": 0.0, "n": 0}
 
+    # The frames of a step are independent until their gradients are summed: like Stage3Trainer, each one
+    # is queued on its own HIP stream, so the tail of one frame's blend kernels overlaps the next frame's
+    # projection / binning instead of leaving CUs idle (--frame-streams 0: one stream).
+    use_streams = bool(args.frame_streams)
+    side = [torch.cuda.Stream(device=dev) for _ in range(FRAMES_PER_STEP)] if use_streams else None
+
+    def one_frame(i):
+        m = means[i].detach().requires_grad_(True)
+        r = rots[i].detach().requires_grad_(True)
+        m2d = torch.zeros_like(m, requires_grad=True)
+        color, radii, allmap = rast(means3D=m, means2D=m2d, opacities=opac_f, shs=shs_f, scales=scales_f, rotations=r)
+        torch.autograd.backward([color, allmap], [dc, do])
+        return m.grad, r.grad
+
+    from vidu4d_amd import _C as native
+
     def step():
+        # (like Stage3Trainer) the rasterizer's host wait for the pair count is deferred to one check per
+        # step; a frame that outgrew its binning buffer would have rendered only its background, so the
+        # step is then repeated -- it never happens after the warm-up, and it is inside the timed region
+        with native.deferred_capacity_check():
+            step_once()
+        if not native.check_deferred():
+            step_once()
+
+    def step_once():
         for t in (opac, scales, shs):
             t.grad = None
-        g_means = g_rot = None
-        for _ in range(FRAMES_PER_STEP):
+        main = torch.cuda.current_stream(dev)
+        ready = main.record_event() if use_streams else None
+        per_frame = []
+        for k in range(FRAMES_PER_STEP):
             i = counter["slot"] % len(frames)
             counter["slot"] += 1
-            m = means[i].detach().requires_grad_(True)
-            r = rots[i].detach().requires_grad_(True)
-            m2d = torch.zeros_like(m, requires_grad=True)
-            color, radii, allmap = rast(means3D=m, means2D=m2d, opacities=opac, shs=shs, scales=scales, rotations=r)
-            torch.autograd.backward([color, allmap], [dc, do])
-            g_means = m.grad if g_means is None else g_means + m.grad
-            g_rot = r.grad if g_rot is None else g_rot + r.grad
-        if use_dist:  # the path's only exchange: canonical-surfel gradients, once per optimizer step
+            if use_streams:
+                side[k].wait_event(ready)
+                with torch.cuda.stream(side[k]):
+                    per_frame.append(one_frame(i))
+            else:
+                per_frame.append(one_frame(i))
+        if use_streams:
+            for st in side:
+                main.wait_stream(st)
+        g_means = sum(g[0] for g in per_frame)
+        g_rot = sum(g[1] for g in per_frame)
+        if use_distributed_exchange:  # the path's only exchange: canonical-surfel gradients, once per optimizer step
             torch.cat([g_means.reshape(-1), opac.grad.reshape(-1), scales.grad.reshape(-1), g_rot.reshape(-1),
                        shs.grad.reshape(-1)], out=flat)
             dist.all_reduce(flat)
