@@ -14,10 +14,14 @@ the colour image and all 8 auxiliary planes.  Frames are sharded one-frame-per-G
 ranks (rank r renders frames r, r+N, ...: frame-parallel, weak scaling); with N > 1 every step ends
 with ONE RCCL all-reduce of the flat canonical-surfel gradient buffer (58 floats per surfel), the
 only exchange the path has.  value = N * K * FRAMES_PER_STEP / max-over-ranks time.
+As in Stage3Trainer, the frames of a step are queued on separate HIP streams and the rasterizer's
+host wait for the pair count is deferred to one check per step (--frame-streams 0: one stream).
 
 Extra objects on the JSON line: "roofline" (dominant kernel: algorithmic bytes per launch /
-its average launch duration, measured with HIP events on the launch stream inside the timed
-region) and "cpu_baseline" (the CPU oracle timed on this box's host cores, rank 0, N = 1 only).
+its average launch duration, measured with HIP events on the launch stream over extra steps of
+the same workload right after the timed region, frames serialised -- under the timed region's
+two-stream overlap an event pair does not measure a launch duration) and "cpu_baseline" (the CPU
+oracle timed on this box's host cores, rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -209,8 +213,8 @@ def main():
     # The frames of a step are independent until their gradients are summed: like Stage3Trainer, each one
     # is queued on its own HIP stream, so the tail of one frame's blend kernels overlaps the next frame's
     # projection / binning instead of leaving CUs idle (--frame-streams 0: one stream).
-    use_streams = bool(args.frame_streams)
-    side = [torch.cuda.Stream(device=dev) for _ in range(FRAMES_PER_STEP)] if use_streams else None
+    mode = {"streams": bool(args.frame_streams)}
+    side = [torch.cuda.Stream(device=dev) for _ in range(FRAMES_PER_STEP)]
 
     def one_frame(i):
         m = means[i].detach().requires_grad_(True)
@@ -234,6 +238,7 @@ def main():
     def step_once():
         for t in (opac, scales, shs):
             t.grad = None
+        use_streams = mode["streams"]
         main = torch.cuda.current_stream(dev)
         ready = main.record_event() if use_streams else None
         per_frame = []
@@ -264,15 +269,25 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if not args.no_stage_timers:
-        _lib.profile_read(reset=True)
-        _lib.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    _lib.profile_enable(False)
+    # Per-kernel launch durations for the roofline: HIP events on the launch stream around every stage
+    # (vidu4d_surfel_profile_*), over further steps of the same workload with the frames of a step queued
+    # one after the other.  In the timed region above two frames overlap on two streams, and an event
+    # pair around a kernel then measures that kernel sharing the GPU with another frame's kernels -- not
+    # a launch duration (rocprofv3's kernel trace, which serialises, would not agree with it either).
+    if not args.no_stage_timers:
+        mode["streams"] = False
+        _lib.profile_read(reset=True)
+        _lib.profile_enable(True)
+        for _ in range(min(args.steps, 20)):
+            step()
+        sync()
+        _lib.profile_enable(False)
+        mode["streams"] = bool(args.frame_streams)
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -295,7 +310,7 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (live HIP-event stage timers of the timed region)
+        # ---- roofline of the dominant kernel (live HIP-event stage timers, see above)
         from vidu4d_amd import _C
         # num_rendered of this rank's frames (read once, outside the timed region)
         Rs = []
@@ -329,6 +344,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                                "avg_launch_ms": stages[dom]["ms_avg"],
+                               "timing": "HIP events on the launch stream, %d extra steps after the timed region with "
+                                         "the frames of a step serialised on one stream" % min(args.steps, 20),
                                "algorithmic_bytes_per_launch": stage_bytes(dom, N, R, W * H, T, K)}
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
