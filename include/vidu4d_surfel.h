@@ -212,6 +212,21 @@ int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_q
  *      mean_dist2 (P).  Fewer than 4 points leave FLT_MAX terms in the mean, as upstream. ---- */
 int vidu4d_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* stream);
 
+/* ---- fused post-processing of the auxiliary planes: what gs.gaussian_renderer.render computes after the
+ *      blend (gs/gaussian_renderer/__init__.py:118-151, gs/utils/point_utils.py:9-37).  allmap (8,H,W);
+ *      rays_d (H*W,3), rays_o (3): pixel rays of the camera; view3x3 (3,3) row-major = the block the
+ *      rendered normals are multiplied by from the right; outputs rend_normal (3,H,W), depth_median /
+ *      depth_expected / surf_depth (H,W), surf_normal (3,H,W).  The backward writes g_allmap (8,H,W)
+ *      completely (planes 1 [through the division only], 6, 7 get what flows through these outputs: the
+ *      caller adds the gradients of its own reads of alpha / distortion); any g_* input may be NULL. ---- */
+int vidu4d_post_forward(int W, int H, const float* allmap, const float* rays_d, const float* rays_o,
+                        const float* view3x3, float depth_ratio, float* rend_normal, float* depth_median,
+                        float* depth_expected, float* surf_depth, float* surf_normal, void* stream);
+int vidu4d_post_backward(int W, int H, const float* allmap, const float* surf_depth, const float* rays_d,
+                         const float* rays_o, const float* view3x3, float depth_ratio, const float* g_rend_normal,
+                         const float* g_depth_median, const float* g_depth_expected, const float* g_surf_depth,
+                         const float* g_surf_normal, float* g_allmap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@ pts = rng.normal(size=(N, 3)).astype(np.float32); pts = RADIUS * pts / np.linalg
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32), )
 with torch.no_grad(): m._scaling.add_(0.0)
 tr = Stage3Trainer(m)
+tr.current_steps = int(os.environ.get("FIT_STEP0", "0"))  # > 8000: normal-consistency regulariser on
+m.pipeline.fused_post = os.environ.get("FIT_FUSED_POST", "1") == "1"
 batches = [synthetic_batch(m, [(2*i) % frames, (2*i+1) % frames], H, W, seed=i) for i in range(4)]
 for b in batches: b["Kinv"] = batches[0]["Kinv"]  # one intrinsics tensor for the run (--force_center_cam)
 for i in range(6): tr.train_step(batches[i % 4])

@@ -74,6 +74,8 @@ SYMBOLS = {
     "vidu4d_lbs_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 10),
     "vidu4d_lbs_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 13),
     "vidu4d_knn_mean_dist2": (C.c_int, [C.c_int, _P, _P, _P]),
+    "vidu4d_post_forward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
+    "vidu4d_post_backward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 STATE = dict(num_rendered=0, records=1, tiles_touched=2, point_list=3, sorted_keys=4, ranges=5, final_T=6,

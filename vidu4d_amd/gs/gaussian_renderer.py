@@ -61,12 +61,22 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if outputs is not None and not any(k in GEOMETRY_KEYS for k in outputs):
         rets.update({"acc": render_alpha, "rend_dist": allmap[6:7]})
         return rets
+    ratio = getattr(pipe, "depth_ratio", 0.0)
+    if allmap.is_cuda and getattr(pipe, "fused_post", True) and hasattr(viewpoint_camera, "pixel_rays"):
+        # one HIP kernel per direction for everything below (csrc/post.hip); the x3 copies become views
+        from .post_fused import surfel_post
+        rays_d, rays_o = viewpoint_camera.pixel_rays()
+        rn, med, expd, sd, sn = surfel_post(allmap, rays_d, rays_o,
+                                            viewpoint_camera.world_view_transform[:3, :3].T, ratio)
+        rets.update({"acc": render_alpha, "rend_normal": rn, "rend_dist": allmap[6:7],
+                     "surf_depth": sd.expand(3, -1, -1), "render_depth_median": med.expand(3, -1, -1),
+                     "render_depth_expected": expd.expand(3, -1, -1), "surf_normal": sn})
+        return rets
     render_normal = allmap[2:5]
     render_normal = (render_normal.permute(1, 2, 0) @ viewpoint_camera.world_view_transform[:3, :3].T).permute(2, 0, 1)
     render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
     render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
     render_dist = allmap[6:7]
-    ratio = getattr(pipe, "depth_ratio", 0.0)
     surf_depth = render_depth_expected * (1 - ratio) + ratio * render_depth_median
     surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1) * render_alpha.detach()
     rets.update({"acc": render_alpha, "rend_normal": render_normal, "rend_dist": render_dist,
