@@ -35,6 +35,7 @@ _capacity_hint: dict = {}
 # overflowed its binning buffer (it then rendered only the background) so that the caller can discard
 # the step and run it again.  The host can then run a whole step ahead of the GPU.
 _deferred = False
+_graph_mode = False   # deferred + nothing that cannot be captured into a hipGraph (no events)
 _pending: list = []
 _depth_stat: dict = {}   # key -> (device counter, pinned copy)
 _depth_hint: dict = {}
@@ -78,13 +79,47 @@ class deferred_capacity_check:
         return False
 
 
+class graph_capture_mode:
+    """Context manager for hipGraph capture of a step: like deferred_capacity_check, without events; the
+    pair-count read-backs go to the per-(stream, index) slots that an eager deferred run on the capture
+    stream created before.  `.frames` holds (slot, stat, capacity, key) of the captured forwards; after a
+    replay and a stream synchronise pass them to `check_slots`."""
+
+    def __enter__(self):
+        global _deferred, _graph_mode
+        self._old = (_deferred, _graph_mode)
+        _deferred = _graph_mode = True
+        self._n0 = len(_pending)
+        self.frames = []
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred, _graph_mode
+        _deferred, _graph_mode = self._old
+        self.frames = [(p[1], p[2], p[3], p[4]) for p in _pending[self._n0:]]
+        del _pending[self._n0:]
+        return False
+
+
+def check_slots(frames) -> bool:
+    ok = True
+    for slot, stat, cap, key in frames:
+        n = int(slot[0])
+        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
+        if stat is not None:
+            _depth_hint[key] = int(stat[1][0])
+        ok = ok and n <= cap
+    return ok
+
+
 def check_deferred() -> bool:
     """Waits for the pair counts of the deferred forwards queued since the last call (their events were
     recorded right after the tile scan, long passed by the time a step is fully queued), refreshes the
     capacity / split hints, and returns False if any of them overflowed its binning buffer."""
     ok = True
-    for ev, slot, stat, cap, key in _pending:
-        ev.synchronize()
+    for ev, slot, stat, cap, key, _sid in _pending:
+        if ev is not None:
+            ev.synchronize()
         n = int(slot[0])
         _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
         if stat is not None:
@@ -95,8 +130,12 @@ def check_deferred() -> bool:
 
 
 def _pinned_slot(device):
-    # one slot per (device, stream): frames rendered concurrently on different streams must not share it
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    # one slot per (device, stream): frames rendered concurrently on different streams must not share it;
+    # deferred forwards keep theirs until they have been checked, so the k-th pending forward of a stream
+    # gets the k-th slot of that stream (the same ones every step)
+    sid = torch.cuda.current_stream(device).cuda_stream
+    k = sum(1 for p in _pending if p[4][3] == str(device) and p[5] == sid) if _deferred else 0
+    key = (str(device), sid, k)
     if key not in _pinned:
         _pinned[key] = torch.zeros(4, dtype=torch.int32).pin_memory()  # Header: R, overflow, max_tile_len, segments
     return _pinned[key]
@@ -183,19 +222,18 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         cap = hint
         binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
         slot = _pinned_slot(dev)
-        if _deferred and any(p[1] is slot for p in _pending):
-            # a deferred forward keeps its read-back slot until check_deferred() has looked at it
-            slot = torch.empty(4, dtype=torch.int32).pin_memory()
         slot.copy_(geom[:16].view(torch.int32), non_blocking=True)
         if stat is not None:  # depth reached by the previous frame on this stream; then reset for this one
             stat[1].copy_(stat[0], non_blocking=True)
             stat[0].zero_()
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
+        ev = None
+        if not _graph_mode:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
         _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
                    "surfel forward (run)")
         if _deferred and not debug:
-            _pending.append((ev, slot, stat, cap, key))
+            _pending.append((ev, slot, stat, cap, key, stream))
             binning._vidu4d_capacity = cap
             binning._vidu4d_split = int(a.segment_split)
             return cap, out_color, out_others, radii, geom, binning, img

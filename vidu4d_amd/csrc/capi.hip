@@ -156,6 +156,21 @@ static int check_forward(const Vidu4dSurfelForwardArgs* a)
     return VIDU4D_OK;
 }
 
+// Zero fill as a kernel rather than hipMemsetAsync: a memset node captured into a hipGraph is not
+// ordered with the neighbouring kernel nodes on replay in this ROCm build (the backward's accumulator
+// came back partly unzeroed; tools/hipgraph_replay_check.py) -- and a kernel costs the same.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* p, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static void zero_fill(void* p, size_t bytes, hipStream_t stream)  // p 16-byte aligned, bytes a multiple of 16
+{
+    const size_t n16 = bytes / 16;
+    if (n16)
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, (uint4*)p, n16);
+}
+
 extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -185,7 +200,7 @@ extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void
     {
         StageTimer t(ST_PREPROCESS, stream);
         if (!grouped)
-            HIP_TRY(hipMemsetAsync(img.tile_count, 0, (size_t)num_tiles * TILE_SLICES * sizeof(uint32_t), stream));
+            zero_fill(img.tile_count, (size_t)num_tiles * TILE_SLICES * sizeof(uint32_t), stream);
         launch_preprocess_fwd(pa, stream);
     }
     STAGE_CHECK(a->debug, stream, "preprocess");
@@ -300,7 +315,7 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
 
     {
         StageTimer t(ST_BWD_ZERO, stream);
-        HIP_TRY(hipMemsetAsync(ba.acc, 0, (size_t)a->P * ACC_FLOATS * sizeof(float), stream));
+        zero_fill(ba.acc, (size_t)a->P * ACC_FLOATS * sizeof(float), stream);
     }
     {
         StageTimer t(ST_BLEND_BWD, stream);
