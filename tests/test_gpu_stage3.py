@@ -144,3 +144,4 @@ def test_fused_post_processing_matches_torch_composite(gpu_device):
         for a, b in zip(res[True][1], res[False][1]):
             assert torch.isfinite(a).all()
             assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-12), ratio
+

@@ -38,6 +38,8 @@ def compute_losses(rendered: dict, batch: dict, step: int, cfg) -> dict:
         """Mean over the positive entries, or over everything when none is positive (model.py:996-999),
         without boolean-mask indexing (which would block the host on a nonzero()): every term here is
         non-negative, so the fallback mean is 0 = sum / 1."""
+        if v.dim() == 0:
+            return v  # (a scalar is its own mean over the positive entries, or over everything)
         pos = v > 0
         return (v * pos).sum() / pos.sum().clamp_min(1)
 
@@ -163,7 +165,7 @@ class Stage3Trainer:
             if step < c.densify_until_iter:
                 for i in range(len(m._radii_batch)):
                     vis, radii = m._visibility_filter_batch[i], m._radii_batch[i]
-                    m.max_radii2D = torch.where(vis, torch.maximum(m.max_radii2D, radii.float()), m.max_radii2D)
+                    m.max_radii2D.copy_(torch.where(vis, torch.maximum(m.max_radii2D, radii.float()), m.max_radii2D))
                     m.add_densification_stats(m._viewspace_points_batch[i], vis)
                 gen = None
                 if step > c.densify_from_iter and step % c.densification_interval == 0:
