@@ -231,9 +231,16 @@ def main():
         # step; a frame that outgrew its binning buffer would have rendered only its background, so the
         # step is then repeated -- it never happens after the warm-up, and it is inside the timed region
         with native.deferred_capacity_check():
-            step_once()
+            grads = step_once()
         if not native.check_deferred():
-            step_once()
+            grads = step_once()
+        # the path's only exchange: canonical-surfel gradients, once per optimizer step.  (After the capacity
+        # check, so that a repeated step on one rank cannot add a collective the other ranks do not make.)
+        if use_distributed_exchange:
+            g_means, g_rot = grads
+            torch.cat([g_means.reshape(-1), opac.grad.reshape(-1), scales.grad.reshape(-1), g_rot.reshape(-1),
+                       shs.grad.reshape(-1)], out=flat)
+            dist.all_reduce(flat)
 
     def step_once():
         for t in (opac, scales, shs):
@@ -254,12 +261,7 @@ def main():
         if use_streams:
             for st in side:
                 main.wait_stream(st)
-        g_means = sum(g[0] for g in per_frame)
-        g_rot = sum(g[1] for g in per_frame)
-        if use_distributed_exchange:  # the path's only exchange: canonical-surfel gradients, once per optimizer step
-            torch.cat([g_means.reshape(-1), opac.grad.reshape(-1), scales.grad.reshape(-1), g_rot.reshape(-1),
-                       shs.grad.reshape(-1)], out=flat)
-            dist.all_reduce(flat)
+        return sum(g[0] for g in per_frame), sum(g[1] for g in per_frame)
 
     def sync():
         if use_dist:
