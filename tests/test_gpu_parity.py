@@ -300,9 +300,7 @@ def test_segment_parallel_blend_matches_oracle(gpu_device, monkeypatch, which):
     elif which == "mixed":
         sc = make_scene(60_000, 256, 192, seed=95, sigma_px=6.0)  # some tiles above, most below the split length
     else:
-        sc = _concentrated(20_000, seed=96)
-        sc.width, sc.height = 150, 121  # partial tiles on both borders
-        sc = make_scene(20_000, 150, 121, seed=96, sigma_px=1.0)
+        sc = make_scene(20_000, 150, 121, seed=96, sigma_px=1.0)  # partial tiles on both borders
         g = torch.Generator().manual_seed(96)
         sc.means3D[:, 0] = (torch.rand(20_000, generator=g) - 0.2) * 0.5 * sc.means3D[:, 2]
         sc.means3D[:, 1] = (torch.rand(20_000, generator=g) - 0.2) * 0.5 * sc.means3D[:, 2]
