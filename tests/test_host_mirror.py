@@ -236,3 +236,37 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     assert torch.equal(a.warp.skinning_model.log_gauss.detach(), b.warp.skinning_model.log_gauss.detach())
     assert not info["unexpected_keys"]
     assert tb.gs_optimizer.param_groups[0]["params"][0] is b._xyz
+
+
+def test_vidloader_reads_reference_layout(tmp_path):
+    """database/processed/... .npy layout (vidloader.py:81-166) -> a Stage-3 frame batch; Kinv as
+    model.py:417-427 builds it from the raw intrinsics and the crop transform."""
+    import numpy as np
+    import torch
+    from vidu4d_amd.lab4d.vidloader import K2inv, K2mat, SequenceData
+    rng = np.random.default_rng(0)
+    F, H, W = 5, 12, 16
+    seq, prefix = "cat-0000", "full-256"
+    for sub in ("JPEGImages", "Annotations"):
+        (tmp_path / sub / "Full-Resolution" / seq).mkdir(parents=True)
+    rgb = rng.uniform(size=(F, H, W, 3)).astype(np.float16)
+    ann = (rng.uniform(size=(F, H, W, 2)) > 0.4)
+    crop2raw = np.stack([np.array([2.0, 2.0, 10.0 + i, 20.0]) for i in range(F)]).astype(np.float32)
+    np.save(tmp_path / "JPEGImages" / "Full-Resolution" / seq / f"{prefix}.npy", rgb)
+    np.save(tmp_path / "Annotations" / "Full-Resolution" / seq / f"{prefix}.npy", ann)
+    np.save(tmp_path / "Annotations" / "Full-Resolution" / seq / f"{prefix}-crop2raw.npy", crop2raw)
+    np.save(tmp_path / "Annotations" / "Full-Resolution" / seq / f"{prefix}-is_detected.npy", np.array([1, 1, 0, 1, 1]))
+    ds = SequenceData(str(tmp_path), seq, prefix)
+    assert len(ds) == F and ds.img_size == (H, W)
+    K = np.array([500.0, 510.0, 320.0, 240.0], dtype=np.float32)
+    b = ds.frame_batch([3, 1], K, frame_offset=100)
+    assert b["frameid"].tolist() == [103, 101] and b["H"] == [H, H] and b["W"] == [W, W]
+    assert b["rgb"].shape == (2, H, W, 3) and b["rgb"].dtype == torch.float32
+    assert np.allclose(b["rgb"].numpy(), rgb[[3, 1]].astype(np.float32))
+    assert np.array_equal(b["mask"].numpy()[..., 0] > 0, ann[[3, 1], ..., 0])
+    assert np.array_equal(b["vis2d"].numpy()[..., 0] > 0, ann[[3, 1], ..., 1]) and b["is_detected"].tolist() == [True, True]
+    # a crop pixel (u, v) maps to the raw pixel (2u + cx_c, 2v + cy_c), then to the ray through it
+    u, v = 5.0, 7.0
+    ray = b["Kinv"][0] @ torch.tensor([u, v, 1.0])
+    assert np.allclose(ray.numpy(), [((2 * u + 13.0) - 320.0) / 500.0, ((2 * v + 20.0) - 240.0) / 510.0, 1.0], atol=1e-6)
+    assert torch.allclose(K2inv(torch.tensor(K)) @ K2mat(torch.tensor(K)), torch.eye(3), atol=1e-6)
