@@ -96,7 +96,12 @@ typedef struct Vidu4dSurfelForwardArgs {
     int segment_split;               /* !=0: tiles whose list exceeds 1024 entries are blended segment-parallel
                                         (512-entry segments on separate workgroups; three launches instead of
                                         one).  Pays off when few tiles hold most pairs (object-centric frames);
-                                        results agree with the unsplit blend to fp32 re-association. */
+                                        results agree with the unsplit blend to fp32 re-association.
+                                        k > 1: additionally, only the first k segments of a tile are blended (a
+                                        caller that knows how deep earlier frames went saves the rest of the
+                                        transmittance pass); if some pixel was still unsaturated after them the
+                                        frame is incomplete and word 6 of the geometry buffer (`truncated`) is
+                                        set: blend it again with segment_split = 1. */
     uint32_t* depth_used;            /* optional device counter (or NULL): atomic max of the deepest list position
                                         any pixel of the frame blended, i.e. the serial chain length of the
                                         unsplit blend.  Callers use it to decide segment_split for later frames. */

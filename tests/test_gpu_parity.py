@@ -423,3 +423,36 @@ def test_two_frames_on_two_streams_equal_serial_execution(gpu_device):
             assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())  # (float atomics: order varies)
     for x, y in zip(g_ser, g_par):
         assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
+
+
+def test_segment_limit_reports_truncation_and_replay_is_exact(gpu_device, monkeypatch):
+    """Deferred calls limit the split to the segments earlier frames needed (+25 %).  A frame that fits
+    must come out like the unlimited blend; a frame that needs more must be flagged by the per-step
+    check, and blending it again must give the unlimited result."""
+    from vidu4d_amd import _C
+    dev = gpu_device
+    sc = _concentrated(30_000, seed=98)
+    sc.opacities[:] = 0.05
+    key = (30_000, sc.width, sc.height, str(dev))
+    monkeypatch.setattr(_C, "_SPLIT", "1")
+    _native_forward(sc, dev)
+    ref = _native_forward(sc, dev)[3]          # split on, unlimited
+    depth = int(_state("n_contrib", ref, sc, torch.int32, 2 * sc.width * sc.height)[: sc.width * sc.height].max())
+    assert depth > 4 * 512                     # deepest list position any pixel blended
+    monkeypatch.setattr(_C, "_SPLIT", "auto")
+    monkeypatch.setitem(_C._depth_hint, key, depth)
+    for hint, want_ok in ((depth, True), (depth // 3, False)):
+        _C._unlimited.pop(key, None)
+        _C._depth_hint[key] = hint
+        with _C.deferred_capacity_check():
+            out = _native_forward(sc, dev)[3]
+        assert 1 < out[5]._vidu4d_split < (depth * 2) // 512
+        assert _C.check_deferred() == want_ok
+        if not want_ok:
+            assert _C._unlimited[key] > 0
+            _C._depth_hint[key] = hint          # (even with the stale hint the next calls must not be limited)
+            with _C.deferred_capacity_check():
+                out = _native_forward(sc, dev)[3]
+            assert out[5]._vidu4d_split == 1 and _C.check_deferred()
+        for a, b in ((out[1], ref[1]), (out[2], ref[2])):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())

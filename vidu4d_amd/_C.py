@@ -39,6 +39,10 @@ _graph_mode = False   # deferred + nothing that cannot be captured into a hipGra
 _pending: list = []
 _depth_stat: dict = {}   # key -> (device counter, pinned copy)
 _depth_hint: dict = {}
+# Deferred calls also limit the split to the segments the previous frames needed (+25 %, +1): the
+# transmittance pass then skips the tail of long lists that saturate early.  A frame that needed more
+# sets Header::truncated, check_deferred() reports it like an overflow, and the next calls run unlimited.
+_unlimited: dict = {}
 _pinned: dict = {}
 
 
@@ -107,7 +111,10 @@ def check_slots(frames) -> bool:
         n = int(slot[0])
         _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
         if stat is not None:
-            _depth_hint[key] = int(stat[1][0])
+            _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
+        if int(slot[6]):
+            _unlimited[key] = 4
+            ok = False
         ok = ok and n <= cap
     return ok
 
@@ -123,7 +130,10 @@ def check_deferred() -> bool:
         n = int(slot[0])
         _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
         if stat is not None:
-            _depth_hint[key] = int(stat[1][0])
+            _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
+        if int(slot[6]):  # the segment limit cut a tile short: this frame is incomplete, the next ones run unlimited
+            _unlimited[key] = 4
+            ok = False
         ok = ok and n <= cap
     _pending.clear()
     return ok
@@ -137,7 +147,7 @@ def _pinned_slot(device):
     k = sum(1 for p in _pending if p[4][3] == str(device) and p[5] == sid) if _deferred else 0
     key = (str(device), sid, k)
     if key not in _pinned:
-        _pinned[key] = torch.zeros(4, dtype=torch.int32).pin_memory()  # Header: R, overflow, max_tile_len, segments
+        _pinned[key] = torch.zeros(8, dtype=torch.int32).pin_memory()  # Header words 0..7 (surfel_state.h)
     return _pinned[key]
 
 
@@ -193,7 +203,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     key = (P, W, H, str(dev))
     stat = None
     if _SPLIT == "auto":
-        a.segment_split = int(_depth_hint.get(key, 0) > SPLIT_AUTO_LEN)
+        depth = _depth_hint.get(key, 0)
+        a.segment_split = int(depth > SPLIT_AUTO_LEN)
+        if a.segment_split and _deferred and not debug:
+            if _unlimited.get(key, 0) > 0:
+                _unlimited[key] -= 1
+            else:
+                a.segment_split = max(2, (int(depth * 1.25) + 511) // 512 + 1)
         stat = _depth_stat.get((key, stream))
         if stat is None:
             stat = _depth_stat[(key, stream)] = (torch.zeros(1, dtype=torch.int32, device=dev),
@@ -222,25 +238,32 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         cap = hint
         binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
         slot = _pinned_slot(dev)
-        slot.copy_(geom[:16].view(torch.int32), non_blocking=True)
         if stat is not None:  # depth reached by the previous frame on this stream; then reset for this one
             stat[1].copy_(stat[0], non_blocking=True)
             stat[0].zero_()
-        ev = None
-        if not _graph_mode:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-        _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
-                   "surfel forward (run)")
         if _deferred and not debug:
+            # nobody waits for the header before the step is fully queued: read it back after the blend, so
+            # that it also carries the `truncated` flag of a segment-limited split
+            _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
+                       "surfel forward (run)")
+            slot.copy_(geom[:32].view(torch.int32), non_blocking=True)
+            ev = None
+            if not _graph_mode:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
             _pending.append((ev, slot, stat, cap, key, stream))
             binning._vidu4d_capacity = cap
             binning._vidu4d_split = int(a.segment_split)
             return cap, out_color, out_others, radii, geom, binning, img
+        slot.copy_(geom[:32].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
+                   "surfel forward (run)")
         ev.synchronize()  # waits for preprocess + scan only; sort and blend keep running
         num_rendered = int(slot[0])
         if stat is not None:
-            _depth_hint[key] = int(stat[1][0])
+            _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
         if num_rendered > cap:  # guess too small: queue the tail again with an exact buffer
             cap = num_rendered
             binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)

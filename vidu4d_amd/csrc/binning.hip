@@ -234,6 +234,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageStat
         g.hdr->num_segments = carry;
         g.hdr->num_split_pos = split_pos;
         g.hdr->split_used = 0;
+        g.hdr->truncated = 0;
     }
 }
 

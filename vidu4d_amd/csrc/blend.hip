@@ -168,7 +168,7 @@ __device__ __forceinline__ void write_pixel(const FwdPixel& s, size_t HW, size_t
 // (the same acceptance test and the same multiplication as the blend itself, minus everything else).
 __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                          ImageState img, const uint32_t* __restrict__ point_list,
-                                                         int64_t capacity, const float* __restrict__ rec,
+                                                         int64_t capacity, int max_seg, const float* __restrict__ rec,
                                                          float* __restrict__ seg_data)
 {
     __shared__ float4 s_rec[FWD_BATCH * 5];
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
     if (blockIdx.x == 0 && threadIdx.x == 0) hdr->split_used = !overflow && hdr->num_segments > 0;  // for backward
     if (overflow || blockIdx.x >= hdr->num_segments) return;
     const WorkItem wk = find_work<true>(hdr, img, grid_x, grid_y, false);
+    if (wk.seg >= max_seg) return;
     const TileCoord tc = wk.tc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
-                                                       int64_t capacity, const float* __restrict__ rec,
+                                                       int64_t capacity, int max_seg, const float* __restrict__ rec,
                                                        const float* __restrict__ bg, float* __restrict__ seg_data,
                                                        float* __restrict__ out_color, float* __restrict__ out_others,
                                                        uint32_t* depth_used)
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
     __shared__ unsigned long long s_mask[4][4];
     const bool overflow = (int64_t)hdr->num_rendered > capacity;
     const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
-    if (!wk.valid) return;
+    if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     const TileCoord tc = wk.tc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
 // where _p is the state at the segment start and a_i, m1_i, m2_i run inside the segment.  Pass 2 used
 // the global accumulated alpha (1 - T) and segment-local moments, which leaves
 //   M2_p * (sum w_i) - 2 M1_p * (sum w_i m_i)      with sum w_i = T_start - T_end.
-__global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
-                                                           ImageState img, int64_t capacity,
+__global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
+                                                           ImageState img, int64_t capacity, int max_seg,
                                                            const float* __restrict__ bg,
                                                            float* __restrict__ seg_data,
                                                            float* __restrict__ out_color,
@@ -337,7 +338,8 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     const int tile = (int)img.tile_order[blockIdx.x];
     const uint32_t first = img.seg_first[tile];
     if (first == SEG_NONE) return;
-    const int nseg = (int)((img.ranges[2 * tile + 1] - img.ranges[2 * tile] + SEG_LEN - 1) / SEG_LEN);
+    const int nseg_all = (int)((img.ranges[2 * tile + 1] - img.ranges[2 * tile] + SEG_LEN - 1) / SEG_LEN);
+    const int nseg = nseg_all < max_seg ? nseg_all : max_seg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = (tile % grid_x) * TILE + (wave & 1) * 8 + (lane & 7);
     const int py = (tile / grid_x) * TILE + (wave >> 1) * 8 + (lane >> 3);
@@ -371,6 +373,9 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
         write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
 
     report_depth(depth_used, s.last_contributor);
+    // the caller's segment limit cut this tile short and this pixel had not saturated yet: its values are
+    // incomplete -- tell the caller (who blends the frame again without the limit)
+    if (nseg < nseg_all && px < W && py < H && T_raw >= T_EPS) hdr->truncated = 1;
 
     // For the segment-parallel backward: replace each segment's partials by the sums over the segments
     // BEHIND it (what the back-to-front recurrences of the backward have accumulated when they reach
@@ -403,14 +408,14 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
 }
 
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
-                      int64_t capacity, bool split, const float* background, float* out_color, float* out_others,
-                      uint32_t* depth_used, hipStream_t stream)
+                      int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
+                      float* out_others, uint32_t* depth_used, hipStream_t stream)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
         hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                           cam.grid_y, g.hdr, img, point_list, capacity, g.rec, background, b.seg_data, out_color,
+                           cam.grid_y, g.hdr, img, point_list, capacity, 0, g.rec, background, b.seg_data, out_color,
                            out_others, depth_used);
         return;
     }
@@ -420,12 +425,12 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     const int segs = (int)seg_capacity(capacity);
     const int split_tiles = tiles;
     hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, cam.grid_y,
-                       g.hdr, img, point_list, capacity, g.rec, b.seg_data);
+                       g.hdr, img, point_list, capacity, max_seg, g.rec, b.seg_data);
     hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                       cam.grid_y, g.hdr, img, point_list, capacity, g.rec, background, b.seg_data, out_color,
+                       cam.grid_y, g.hdr, img, point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color,
                        out_others, depth_used);
     hipLaunchKernelGGL(blend_combine_kernel, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                       cam.grid_y, g.hdr, img, capacity, background, b.seg_data, out_color, out_others, depth_used);
+                       cam.grid_y, g.hdr, img, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -516,7 +521,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        const float* __restrict__ rec, const float* __restrict__ bg,
-                                                       const float* __restrict__ seg_data,
+                                                       const float* __restrict__ seg_data, int max_seg,
                                                        const float* __restrict__ dL_dcolor,
                                                        const float* __restrict__ dL_dothers, float* __restrict__ acc)
 {
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     __shared__ uint32_t s_max;
     // (a forward that ran unsplit left no segment state: every tile is then walked whole)
     const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, SPLIT && !hdr->split_used);
-    if (!wk.valid) return;
+    if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     const TileCoord tc = wk.tc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -684,10 +689,10 @@ void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
     if (a.split && a.seg_data)
         hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), 0, stream,
                            a.cam.W, a.cam.H, a.cam.grid_x, a.cam.grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec,
-                           a.background, a.seg_data, a.dL_dcolor, a.dL_dothers, a.acc);
+                           a.background, a.seg_data, a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc);
     else
         hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x,
-                           a.cam.grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data,
+                           a.cam.grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0,
                            a.dL_dcolor, a.dL_dothers, a.acc);
 }
 

@@ -258,7 +258,9 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     }
     {
         StageTimer t(ST_BLEND_FWD, stream);
-        launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, a->background, a->out_color, a->out_others,
+        // segment_split: 0 off, 1 on, k > 1: on, at most k segments per tile (Header::truncated reports a miss)
+        const int max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
+        launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, max_seg, a->background, a->out_color, a->out_others,
                          a->depth_used, stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
@@ -292,6 +294,7 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     ba.seg_data = a->binning_capacity > 0 ? b.seg_data : nullptr;
     ba.capacity = a->binning_capacity;
     ba.split = a->segment_split != 0 && a->binning_capacity > 0;
+    ba.max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
     ba.P = a->P;
     ba.background = a->background;
     ba.means3D = a->means3D;

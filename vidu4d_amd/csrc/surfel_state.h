@@ -56,7 +56,8 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t num_segments;  // segments over all tiles longer than SPLIT_MIN
     uint32_t num_split_pos; // schedule positions [0, num_split_pos) hold every split tile
     uint32_t split_used;    // the forward blended long tiles segment-parallel (seg_data is valid)
-    uint32_t pad[58];
+    uint32_t truncated;     // a pixel was still unsaturated after the last segment the caller allowed (max_seg)
+    uint32_t pad[57];
 };
 
 struct GeomState {
@@ -223,9 +224,11 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
                       int64_t capacity, bool long_pass, hipStream_t stream);
 // split: blend tiles longer than SPLIT_MIN segment-parallel (three launches instead of one)
+// max_seg: only the first max_seg segments of a split tile are blended (a caller that knows how deep the
+// previous frames went saves the rest of pass 1); Header::truncated is set if that was not enough
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
-                      int64_t capacity, bool split, const float* background, float* out_color, float* out_others,
-                      uint32_t* depth_used, hipStream_t stream);
+                      int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
+                      float* out_others, uint32_t* depth_used, hipStream_t stream);
 
 struct BackwardArgs {
     CameraParams cam;
@@ -245,6 +248,7 @@ struct BackwardArgs {
     const float* seg_data;  // per-segment state of the segment-parallel forward (or NULL)
     int64_t capacity;
     bool split;             // walk the split tiles segment-parallel (needs the forward to have run split)
+    int max_seg;            // the forward's segment limit
     float* acc;  // [P][20] workspace
     float* dL_dmeans2D;
     float* dL_dcolors;
