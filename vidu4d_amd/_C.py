@@ -27,7 +27,7 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 # entries (the serial chain of that tile then bounds the blend kernels; long lists that saturate
 # early do not count -- splitting them only adds work); "1" / "0" force it on / off.
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
-SPLIT_AUTO_LEN = 2048
+SPLIT_AUTO_LEN = int(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_LEN", "2048"))
 _capacity_hint: dict = {}
 # Deferred capacity check (opt-in, for callers that can replay a step -- Stage3Trainer): the forward
 # does not wait for the pair count at all; it leaves (event, pinned slot, capacity) in `_pending`, and
