@@ -26,7 +26,7 @@ def run(sc, dc, do, mode):
     rg = _C.read_state("ranges", None, geom, binning, img, sc.num_surfels, sc.width, sc.height, torch.int32, 2 * ((sc.width + 15) // 16) * ((sc.height + 15) // 16)).view(-1, 2)
     return R, color, others, ncon, [t for t in g if t.numel()], int((rg[:, 1] - rg[:, 0]).max())
 
-t0 = time.time(); n = 0; bad = 0
+t0 = time.time(); n = 0; bad = 0; nlim = 0; nfit = 0
 while time.time() - t0 < budget:
     N = int(rng.choice([3000, 20000, 60000, 150000]))
     W = int(rng.choice([96, 130, 256, 400, 512])); H = int(rng.choice([80, 128, 256, 333, 512]))
@@ -42,6 +42,28 @@ while time.time() - t0 < budget:
     a = run(sc, dc, do, "0"); b = run(sc, dc, do, "1")
     n += 1
     msgs = []
+    # segment-limited deferred call with the hint set to a fraction of the true depth: either it is flagged
+    # as truncated, or it must equal the unlimited result
+    depth = int(b[3][: W * H].max())
+    if b[5] > 1024 and depth > 2048:
+        key = (sc.num_surfels, W, H, str(dev))
+        _C._unlimited.pop(key, None)
+        _C._depth_hint[key] = max(2049, int(depth * float(rng.choice([0.3, 0.6, 0.81, 1.0]))))
+        _C._SPLIT = "auto"
+        with _C.deferred_capacity_check():
+            poison()
+            o = _C.rasterize_gaussians(sc.bg, sc.means3D, empty, sc.opacities, sc.scales, sc.rotations, 1.0, empty, sc.viewmatrix,
+                                       sc.projmatrix, sc.tanfovx, sc.tanfovy, H, W, sc.shs, 3, sc.campos, False, False)
+            poison()
+            go = _C.rasterize_gaussians_backward(sc.bg, sc.means3D, o[3], empty, sc.scales, sc.rotations, 1.0, empty, sc.viewmatrix,
+                                                 sc.projmatrix, sc.tanfovx, sc.tanfovy, dc, do, sc.shs, 3, sc.campos, o[4], o[0], o[5], o[6], False)
+        ok = _C.check_deferred()
+        nlim += 1
+        if ok:
+            nfit += 1
+            if float((o[1] - b[1]).abs().max()) > 3e-5 * max(float(b[1].abs().max()), 1e-20): msgs.append("LIMITED color differs")
+            for i, (x, y) in enumerate(zip([t for t in go if t.numel()], b[4])):
+                if float((x - y).abs().max()) > 2e-3 * max(float(y.abs().max()), 1e-20): msgs.append(f"LIMITED grad{i} differs")
     if a[0] != b[0]: msgs.append("R")
     for name, x, y in (("color", a[1], b[1]), ("others", a[2], b[2])):
         if not torch.isfinite(y).all(): msgs.append(name + " nonfinite")
@@ -65,4 +87,4 @@ while time.time() - t0 < budget:
     if msgs:
         bad += 1
         print("MISMATCH", "n_contrib_flips", nflip, dict(N=N, W=W, H=H, radius=radius, kind=str(kind), om=om, sp=sp, maxlen=a[5]), msgs, flush=True)
-print(f"fuzz: {n} scenes, {bad} with mismatches, {time.time() - t0:.0f} s")
+print(f"fuzz: {n} scenes, {bad} with mismatches, {nlim} segment-limited calls of which {nfit} fit their limit, {time.time() - t0:.0f} s")
