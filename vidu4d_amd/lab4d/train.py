@@ -10,9 +10,11 @@ rounds of `iters_per_round` steps with a `%03d-fg-gs.ply` export per round, mult
 
 What runs here is the Stage-3 hot path only: surfels initialised from `--gs_init_mesh` (or a
 synthetic proxy when the file is absent), the bob warp, the MI355X rasterizer, the surfel optimizer
-and densify cadence, frame-parallel over the ranks torchrun starts.  Dataset loading, Stage-2
-checkpoints and evaluation are outside this build: without them the targets are
-synthetic frames and the run says so.  Flags of the reference that do not concern this path are
+and densify cadence, frame-parallel over the ranks torchrun starts, `ckpt_%04d.pth` / `ckpt_latest.pth`
+every `--save_freq` rounds and `--load_path` in the reference's layout (checkpoint.py).  Frames come
+from `<data_root>/processed/...` (vidloader.py) when `--intrinsics fx,fy,cx,cy` is given and the
+sequence is there; otherwise the targets are synthetic frames and the run says so.  Stage-2 and
+evaluation are outside this build.  Flags of the reference that do not concern this path are
 accepted and listed as ignored, so the reference's command lines keep working."""
 from __future__ import annotations
 
@@ -32,7 +34,7 @@ STAGE3_FLAGS = dict(
     densification_interval=100, densify_from_iter=500, densify_until_iter=15000, densify_grad_threshold=2e-4,
     opacity_reset_interval=3000, outlier_filtering_interval=2000, lambda_normal=0.05, lambda_dist=0.0,
     lambda_dssim=0.0, gs_learnable_bg=True, debug_cuda=False, learning_rate=5e-4, num_frames=120,
-    num_surfels=200000, seed=0)
+    num_surfels=200000, seed=0, save_freq=10, data_root="database", intrinsics="")
 
 
 def parse_flags(argv):
@@ -128,9 +130,29 @@ def main(argv=None):
     model = DeformableSurfels(opts, num_frames=opts["num_frames"], device=dev)
     model.init_from_points(pts, rng.uniform(size=(n, 3)).astype(np.float32))
     trainer = Stage3Trainer(model, opts)
+    from . import checkpoint
+    if opts["load_path"] and os.path.exists(opts["load_path"]):
+        info = checkpoint.load_checkpoint(opts["load_path"], model, trainer)
+        say(f"loaded {opts['load_path']}: {model._xyz.shape[0]} surfels, step {trainer.current_steps}; "
+            f"{len(info['unexpected_keys'])} checkpoint keys without a counterpart here")
+    elif opts["load_path"]:
+        say(f"--load_path {opts['load_path']} not found: starting from the initialisation")
+    data = None
+    droot = os.path.join(opts["data_root"], "processed")
+    if opts["intrinsics"] and os.path.isdir(droot):
+        from .vidloader import SequenceData
+        try:
+            data = SequenceData(droot, opts["seqname"] if "-" in opts["seqname"][-5:] else opts["seqname"] + "-0000",
+                                f"{opts['data_prefix']}-{opts['train_res']}")
+            K = [float(x) for x in opts["intrinsics"].split(",")]
+            say(f"reading {len(data)} frames of {data.seq} ({data.prefix}) from {droot}")
+        except (FileNotFoundError, ValueError) as e:
+            say(f"dataset not usable ({e}): falling back to synthetic frames")
+            data = None
     res = opts["train_res"] if opts["pixels_per_image"] == -1 else opts["eval_res"]
-    say(f"no dataset reader in this build: fitting synthetic {res}x{res} frames "
-        f"({opts['num_frames']} frames, {2 * opts['imgs_per_gpu']} per GPU per step, {world} GPU(s))")
+    if data is None:
+        say(f"no --intrinsics / processed data for this sequence: fitting synthetic {res}x{res} frames "
+            f"({opts['num_frames']} frames, {2 * opts['imgs_per_gpu']} per GPU per step, {world} GPU(s))")
     logdir = os.path.join(opts["logroot"], f"{opts['seqname']}-{opts['logname']}")
     if rank == 0:
         os.makedirs(logdir, exist_ok=True)
@@ -141,14 +163,19 @@ def main(argv=None):
         for _ in range(opts["iters_per_round"]):
             first = (step * per_step * world + rank * per_step) % opts["num_frames"]
             ids = [(first + k) % opts["num_frames"] for k in range(per_step)]
-            losses = trainer.train_step(synthetic_batch(model, ids, res, res, seed=step))
+            if data is not None:
+                batch = data.frame_batch([i % len(data) for i in ids], K, device=dev)
+            else:
+                batch = synthetic_batch(model, ids, res, res, seed=step)
+            losses = trainer.train_step(batch)
             step += 1
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         say(f"round {rnd}: {opts['iters_per_round']} steps, {opts['iters_per_round'] * per_step * world / dt:.1f} "
             f"images/s, surfels {model._xyz.shape[0]}, loss " +
             " ".join(f"{k}={float(v):.4g}" for k, v in losses.items()))
-        if rank == 0:
+        checkpoint.save_checkpoint(trainer, logdir, rnd, save_freq=opts["save_freq"], rank=rank)
+        if rank == 0 and rnd % max(1, opts["save_freq"]) != 0:
             model.save_ply(os.path.join(logdir, "%03d-fg-gs.ply" % rnd))
     if world > 1:
         dist.destroy_process_group()
