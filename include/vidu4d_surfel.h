@@ -216,6 +216,10 @@ int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_q
  *      once by GaussianModel.create_from_pcd (gs/scene/gaussian_model.py:134-136).  points (P,3),
  *      mean_dist2 (P).  Fewer than 4 points leave FLT_MAX terms in the mean, as upstream. ---- */
 int vidu4d_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* stream);
+/* number of points (the query included) strictly closer than `radius` to each point: the neighbour count of
+ * open3d's remove_radius_outlier, which the reference's Stage-3 loop runs on the CPU every 2000 steps
+ * (lab4d/engine/trainer.py:573-588).  points (P,3), counts (P) int32. */
+int vidu4d_radius_count(int P, const float* points, float radius, int32_t* counts, void* stream);
 
 /* ---- fused post-processing of the auxiliary planes: what gs.gaussian_renderer.render computes after the
  *      blend (gs/gaussian_renderer/__init__.py:118-151, gs/utils/point_utils.py:9-37).  allmap (8,H,W);

@@ -69,7 +69,51 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mean_dist2_kernel(int P, const 
     if (live) out[idx] = (b0 + b1 + b2) / 3.0f;
 }
 
+// Number of points (the query included) closer than `radius` to each point: what open3d's
+// remove_radius_outlier counts (the Stage-3 loop's periodic outlier pass, lab4d/engine/trainer.py:573-588,
+// which upstream runs on the CPU).  Same all-pairs LDS-tiled scan as above.
+__global__ __launch_bounds__(KNN_BLOCK) void radius_count_kernel(int P, const float* __restrict__ points, float r2,
+                                                                int32_t* __restrict__ out)
+{
+    __shared__ float4 s_pts[KNN_BLOCK];
+    const int idx = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    const bool live = idx < P;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) {
+        qx = points[3 * idx];
+        qy = points[3 * idx + 1];
+        qz = points[3 * idx + 2];
+    }
+    int count = 0;
+    const int tiles = (P + KNN_BLOCK - 1) / KNN_BLOCK;
+    for (int t = 0; t < tiles; t++) {
+        const int src = t * KNN_BLOCK + threadIdx.x;
+        __syncthreads();
+        s_pts[threadIdx.x] = src < P ? make_float4(points[3 * src], points[3 * src + 1], points[3 * src + 2], 0.f)
+                                     : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);  // never within any radius
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < KNN_BLOCK; j++) {
+            const float4 p = s_pts[j];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            count += (dx * dx + dy * dy + dz * dz < r2) ? 1 : 0;
+        }
+    }
+    if (live) out[idx] = count;
+}
+
 }  // namespace
+
+extern "C" int vidu4d_radius_count(int P, const float* points, float radius, int32_t* counts, void* stream)
+{
+    if (P < 0 || !(radius >= 0.f)) return VIDU4D_E_INVALID;
+    if (P == 0) return VIDU4D_OK;
+    if (!points || !counts) return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(radius_count_kernel, dim3((P + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), 0,
+                       (hipStream_t)stream, P, points, radius * radius, counts);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}
 
 extern "C" int vidu4d_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* stream)
 {

@@ -272,7 +272,8 @@ class _Args:
                     position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3,
                     rotation_lr=1e-3, densification_interval=100, densify_from_iter=500, densify_until_iter=15000,
                     densify_grad_threshold=2e-4, opacity_reset_interval=3000, lambda_normal=0.05, lambda_dist=0.0,
-                    lambda_dssim=0.0, sh_degree=3, gs_learnable_bg=True, rgb_wt=0.1, mask_wt=0.1, learning_rate=5e-4)
+                    lambda_dssim=0.0, sh_degree=3, gs_learnable_bg=True, rgb_wt=0.1, mask_wt=0.1, learning_rate=5e-4,
+                    outlier_filtering_interval=2000, outlier_stop_iter=29000)
 
     def __init__(self, opts):
         self.__dict__.update(self.DEFAULTS)

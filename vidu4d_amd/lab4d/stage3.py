@@ -178,6 +178,13 @@ class Stage3Trainer:
                                             size_threshold, generator=gen)
                 if step > 0 and step % c.opacity_reset_interval == 0:
                     m.reset_opacity()
+                if (m._xyz.is_cuda and c.densify_from_iter < step < c.outlier_stop_iter
+                        and step % c.outlier_filtering_interval == 0):
+                    # trainer.py:573-588: open3d remove_radius_outlier(nb_points=20, radius=0.004) on the CPU
+                    # upstream; here the neighbour count is a HIP kernel and nothing leaves the GPU.  Every rank
+                    # holds the same surfels, so every rank prunes the same ones.
+                    from ..simple_knn import radius_neighbor_count
+                    m.prune_points(radius_neighbor_count(m.get_xyz, 0.004) <= 20)
         self.gs_optimizer.step()
         self.gs_optimizer.zero_grad(set_to_none=True)
         self.current_steps += 1

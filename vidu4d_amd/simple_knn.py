@@ -19,3 +19,17 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     _lib.check(lib.vidu4d_knn_mean_dist2(pts.shape[0], pts.data_ptr(), out.data_ptr(),
                                          torch.cuda.current_stream(pts.device).cuda_stream), "knn_mean_dist2")
     return out
+
+
+def radius_neighbor_count(points: torch.Tensor, radius: float) -> torch.Tensor:
+    """Points (the query included) strictly within `radius` of each point, int32 (P,): the count that
+    open3d's `remove_radius_outlier(nb_points, radius)` compares with nb_points (a point is kept when
+    count > nb_points; reference use: lab4d/engine/trainer.py:573-588)."""
+    if not points.is_cuda:
+        raise RuntimeError("radius_neighbor_count: a CUDA/HIP tensor is required (no CPU path)")
+    pts = points.detach().float().contiguous()
+    out = torch.empty(pts.shape[0], dtype=torch.int32, device=pts.device)
+    lib = _lib.load()
+    _lib.check(lib.vidu4d_radius_count(pts.shape[0], pts.data_ptr(), float(radius), out.data_ptr(),
+                                       torch.cuda.current_stream(pts.device).cuda_stream), "radius_count")
+    return out
