@@ -229,8 +229,10 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     torch.save(raw, tmp_path / "ddp.pth")
     b = make(120, 1)
     tb = Stage3Trainer(b)
-    info = ck.load_checkpoint(str(tmp_path / "ddp.pth"), b, tb)
+    info = ck.load_checkpoint(str(tmp_path / "ddp.pth"), b, tb, reset_steps=False)
     assert b._xyz.shape[0] == 300 and b.max_radii2D.shape[0] == 300 and tb.current_steps == 1234
+    ck.load_checkpoint(str(tmp_path / "ddp.pth"), b, tb)  # the reference's default: --reset_steps
+    assert tb.current_steps == 0
     for k in ck.SURFEL_KEYS:
         assert torch.equal(getattr(a, k).detach(), getattr(b, k).detach())
     assert torch.equal(a.warp.skinning_model.log_gauss.detach(), b.warp.skinning_model.log_gauss.detach())

@@ -48,8 +48,10 @@ def save_checkpoint(trainer, save_dir: str, round_count: int, save_freq: int = 1
     return path
 
 
-def load_checkpoint(load_path: str, model, trainer=None, map_location=None) -> dict:
-    """Updates `model` in place; returns the checkpoint dict plus "missing_keys" / "unexpected_keys"."""
+def load_checkpoint(load_path: str, model, trainer=None, map_location=None, reset_steps: bool = True) -> dict:
+    """Updates `model` in place; returns the checkpoint dict plus "missing_keys" / "unexpected_keys".
+    reset_steps (the reference's flag, default True, config.py:139-143): the step counter restarts at 0
+    -- Stage-3 on top of a Stage-2 checkpoint -- instead of resuming the checkpoint's schedule."""
     ckpt = torch.load(load_path, map_location=map_location or model._xyz.device, weights_only=False)
     states = remove_ddp_prefix(ckpt["model"])
     fg = {k[len(FG_PREFIX):]: v for k, v in states.items() if k.startswith(FG_PREFIX)}
@@ -71,5 +73,5 @@ def load_checkpoint(load_path: str, model, trainer=None, map_location=None) -> d
     ckpt["unexpected_keys"] = sorted(set(fg) - set(usable))
     if trainer is not None:  # fresh optimizer over the re-created parameters, step counter from the file
         trainer.__init__(model, trainer.cfg.__dict__ | {"gs_optim_warp": trainer.optim_warp})
-        trainer.current_steps = int(ckpt.get("current_steps", 0))
+        trainer.current_steps = 0 if reset_steps else int(ckpt.get("current_steps", 0))
     return ckpt

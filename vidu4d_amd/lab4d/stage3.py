@@ -144,8 +144,9 @@ class Stage3Trainer:
     def train_step(self, batch: dict) -> dict:
         m, c = self.model, self.cfg
         step = self.current_steps
-        if step > 0 and step % 1000 == 0:
-            m.oneupSHdegree()  # trainer.py:464-466
+        if step % 1000 == 0:
+            m.oneupSHdegree()  # trainer.py:465-466 (also at step 0, as upstream); update_learning_rate (:464) is a
+            #                    no-op upstream -- its `"._xyz" in param_group["params"]` test never holds
         if m._xyz.is_cuda:
             # The rasterizer's only host wait (the pair count that sizes the binning buffer) is deferred to
             # one check per step: if a frame outgrew its buffer -- it then rendered only the background --
@@ -176,7 +177,7 @@ class Stage3Trainer:
                     if step % (10 * c.densification_interval) == 0:
                         m.densify_and_prune(c.densify_grad_threshold * 0.1, 0.002, m.cameras_extent * 100,
                                             size_threshold, generator=gen)
-                if step > 0 and step % c.opacity_reset_interval == 0:
+                if step % c.opacity_reset_interval == 0:  # (step 0 included, as upstream: trainer.py:570)
                     m.reset_opacity()
                 if (m._xyz.is_cuda and c.densify_from_iter < step < c.outlier_stop_iter
                         and step % c.outlier_filtering_interval == 0):

@@ -34,7 +34,7 @@ STAGE3_FLAGS = dict(
     densification_interval=100, densify_from_iter=500, densify_until_iter=15000, densify_grad_threshold=2e-4,
     opacity_reset_interval=3000, outlier_filtering_interval=2000, lambda_normal=0.05, lambda_dist=0.0,
     lambda_dssim=0.0, gs_learnable_bg=True, debug_cuda=False, learning_rate=5e-4, num_frames=120,
-    num_surfels=200000, seed=0, save_freq=10, data_root="database", intrinsics="")
+    num_surfels=200000, seed=0, save_freq=10, data_root="database", intrinsics="", reset_steps=True)
 
 
 def parse_flags(argv):
@@ -132,7 +132,7 @@ def main(argv=None):
     trainer = Stage3Trainer(model, opts)
     from . import checkpoint
     if opts["load_path"] and os.path.exists(opts["load_path"]):
-        info = checkpoint.load_checkpoint(opts["load_path"], model, trainer)
+        info = checkpoint.load_checkpoint(opts["load_path"], model, trainer, reset_steps=opts["reset_steps"])
         say(f"loaded {opts['load_path']}: {model._xyz.shape[0]} surfels, step {trainer.current_steps}; "
             f"{len(info['unexpected_keys'])} checkpoint keys without a counterpart here")
     elif opts["load_path"]:
