@@ -272,3 +272,28 @@ def test_vidloader_reads_reference_layout(tmp_path):
     ray = b["Kinv"][0] @ torch.tensor([u, v, 1.0])
     assert np.allclose(ray.numpy(), [((2 * u + 13.0) - 320.0) / 500.0, ((2 * v + 20.0) - 240.0) / 510.0, 1.0], atol=1e-6)
     assert torch.allclose(K2inv(torch.tensor(K)) @ K2mat(torch.tensor(K)), torch.eye(3), atol=1e-6)
+
+
+def test_train_cli_flag_parsing_and_mesh_sampling(tmp_path):
+    """lab4d/train.py: absl-style flags of the reference's Stage-3 command line (README.md:44), unknown
+    flags collected as ignored, --flagfile expansion; area-weighted sampling of an OBJ proxy mesh."""
+    import numpy as np
+    from vidu4d_amd.lab4d.train import load_obj_points, parse_flags
+    ff = tmp_path / "opts.log"
+    ff.write_text("--num_rounds=3\n# comment\n--iters_per_round 50\n")
+    opts, ignored = parse_flags(["--seqname", "cat-pikachu-0", "--logname=gs", "--fg_motion", "gs-bob", "--imgs_per_gpu", "1",
+                                 "--pixels_per_image", "-1", "--rgb_timefree", "--rgb_dirfree", "--rgb_loss_only",
+                                 "--gs_optim_warp=False", "--data_prefix", "full", "--force_center_cam", "--nogs_learnable_bg",
+                                 "--eval_res", "256", f"--flagfile={ff}", "--feature_lr", "0.005"])
+    assert opts["seqname"] == "cat-pikachu-0" and opts["logname"] == "gs" and opts["fg_motion"] == "gs-bob"
+    assert opts["rgb_loss_only"] is True and opts["gs_optim_warp"] is False and opts["force_center_cam"] is True
+    assert opts["gs_learnable_bg"] is False and opts["pixels_per_image"] == -1 and opts["eval_res"] == 256
+    assert opts["num_rounds"] == 3 and opts["iters_per_round"] == 50 and opts["feature_lr"] == 0.005
+    assert "--rgb_timefree" in ignored and "--rgb_dirfree" in ignored
+    obj = tmp_path / "proxy.obj"  # a unit square of two triangles plus a far, tiny triangle
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 5 5 5\nv 5.001 5 5\nv 5 5.001 5\nf 1 2 3 4\nf 5/1 6/1 7/1\n")
+    pts = load_obj_points(str(obj), 4000, np.random.default_rng(0))
+    assert pts.shape == (4000, 3) and pts.dtype == np.float32
+    on_square = (np.abs(pts[:, 2]) < 1e-6) & (pts[:, 0] >= 0) & (pts[:, 0] <= 1) & (pts[:, 1] >= 0) & (pts[:, 1] <= 1)
+    assert on_square.mean() > 0.99                      # area-weighted: the tiny triangle gets ~1e-6 of the samples
+    assert abs((pts[on_square, 0] > pts[on_square, 1]).mean() - 0.5) < 0.05   # both halves of the quad

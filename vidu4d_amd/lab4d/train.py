@@ -53,7 +53,7 @@ def parse_flags(argv):
             path = val if eq else args[i]
             i += 0 if eq else 1
             with open(path) as f:
-                args[i:i] = [ln.strip() for ln in f if ln.strip() and not ln.startswith("#")]
+                args[i:i] = [tok for ln in f if ln.strip() and not ln.lstrip().startswith("#") for tok in ln.split()]
             continue
         if name.startswith("no") and name[2:] in opts and isinstance(opts[name[2:]], bool) and not eq:
             opts[name[2:]] = False
