@@ -79,12 +79,20 @@ def test_oracle_matches_real_reference(case, gpu_device):
     _compare(case, st, g, rf, rg, sc)
 
 
-def test_product_matches_real_reference_headline(gpu_device):
-    """Product vs reference directly, at the headline size (no oracle in between)."""
+@pytest.mark.parametrize("scene", ["headline", "object_split"])
+def test_product_matches_real_reference_headline(gpu_device, scene, monkeypatch):
+    """Product vs reference directly (no oracle in between): at the headline size, and on an
+    object-centric frame with Stage-3 initialisation opacities blended segment-parallel (lists of several
+    thousand entries that never saturate -- the regime the reference walks with one thread block per tile)."""
     _need_ref()
     import diff_surfel_rasterization as dsr
-    from vidu4d_amd.synthetic import make_scene
-    sc = make_scene(200_000, 512)
+    from vidu4d_amd import _C
+    from vidu4d_amd.synthetic import make_object_scene, make_scene
+    if scene == "headline":
+        sc = make_scene(200_000, 512)
+    else:
+        monkeypatch.setattr(_C, "_SPLIT", "1")
+        sc = make_object_scene(120_000, 512, radius=0.4, opacity_mode="init")
     d = sc.to(gpu_device)
     dc, do = (t.to(gpu_device) for t in make_upstream_grads(512, 512))
     rf = ref.forward(d)
@@ -96,6 +104,8 @@ def test_product_matches_real_reference_headline(gpu_device):
     color, radii, allmap = dsr.GaussianRasterizer(rs)(means3D=leaves[0], means2D=m2d, opacities=leaves[1],
                                                       shs=leaves[4], scales=leaves[2], rotations=leaves[3])
     torch.autograd.backward([color, allmap], [dc, do])
+    if scene == "object_split":
+        assert int(rf["num_rendered"]) > 200_000  # (long lists: the split is really exercised)
     # At 512x512 the reference's AABB extent (h = sqrt(c^2 - ...), forward.cu:152-159) cancels ~4 digits
     # (c ~ 256 px, h ~ 3 px), so the FMA contraction hipcc applies to the reference moves ceil(3h) by
     # one for a few surfels per thousand; the product follows the oracle's fixed operation order.
