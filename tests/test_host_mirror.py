@@ -36,45 +36,29 @@ def test_dual_quaternion_algebra():
     assert torch.allclose(qt.quaternion_apply(q, v), torch.einsum("nij,nj->ni", build_rotation(q), v), atol=1e-5)
 
 
-def test_dq_skinning_matches_materialised_reference_formulation():
-    """geom_utils.py:48-92 written the upstream way (explicit (M,N,B,4) copies + gather) vs ours."""
-    g = torch.Generator().manual_seed(1)
-    M, N, B = 2, 300, 25
-    se3 = _rand_dq(M, B, g)
-    skin = torch.softmax(torch.randn(M, N, B, generator=g) * 3, -1)
-    qr = se3[0][:, None].repeat(1, N, 1, 1)
-    qd = se3[1][:, None].repeat(1, N, 1, 1)
-    anchor = skin.argmax(-1).view(M, -1, 1, 1).repeat(1, 1, 1, 4)
-    sign = ((torch.gather(qr, 2, anchor) * qr).sum(-1) > 0)[..., None].float() * 2 - 1
-    qr_w = torch.einsum("bnk,bnkl->bnl", skin, sign * qr)
-    qd_w = torch.einsum("bnk,bnkl->bnl", skin, sign * qd)
-    inv = qr_w.norm(p=2, dim=-1, keepdim=True).reciprocal()
-    q_ref, t_ref = qt.dual_quaternion_to_quaternion_translation((qr_w * inv, qd_w * inv))
-    q, t = dual_quaternion_skinning_qt(se3, skin)
-    assert torch.allclose(q, q_ref, atol=1e-5) and torch.allclose(t, t_ref, atol=1e-5)
-
-
 def test_bob_warp_rigid_when_bones_move_together():
     """If every bone undergoes the same rigid motion, every point undergoes exactly that motion."""
-    warp = SkinningWarp(num_frames=8, num_se3=25)
+    from vidu4d_amd.lab4d.nets import make_frame_info
+    torch.manual_seed(3)
+    warp = SkinningWarp(make_frame_info([0, 8]), num_se3=25)
     g = torch.Generator().manual_seed(2)
     M, N = 2, 500
     xyz = torch.randn(M, N, 1, 3, generator=g) * 0.1
-    rest = warp.articulation.rest("cpu")
-    rest = (rest[0][None].expand(M, -1, -1).contiguous(), rest[1][None].expand(M, -1, -1).contiguous())
+    _, rest = warp.articulation.get_vals_and_mean(torch.arange(M))
+    rest = (rest[0].detach(), rest[1].detach())
     q = torch.nn.functional.normalize(torch.randn(M, 1, 4, generator=g), dim=-1).expand(-1, 25, -1).contiguous()
     t = (torch.randn(M, 1, 3, generator=g) * 0.2).expand(-1, 25, -1).contiguous()
     rigid = qt.quaternion_translation_to_dual_quaternion(q, t)
     t_art = qt.dual_quaternion_mul(rigid, rest)
     (qq, tt), aux = warp(xyz, torch.arange(M), samples_dict={"rest_articulation": rest, "t_articulation": t_art},
-                         return_aux=True)
+                         return_aux=True, return_qt=True)
     moved, _ = apply_qt_to_gaussian(xyz, None, qq, tt, M)
     want = qt.quaternion_translation_apply(q[:, :1], t[:, :1], xyz.view(M, N, 3)).view(M, N, 1, 3)
     assert torch.allclose(moved, want, atol=1e-5)
-    assert aux["skin_entropy"].shape == (M, N, 1) and aux["delta_skin"].shape == (M, N, 1)
+    assert aux["skin_entropy"].shape == (M, N, 1, 1) and aux["delta_skin"].shape == (M, N, 1, 1)
     # and gradients reach the canonical points through the skinning weights
     xyz.requires_grad_(True)
-    (q2, t2) = warp(xyz, torch.arange(M))
+    (q2, t2) = warp(xyz, torch.arange(M), return_qt=True)
     (q2.sum() + t2.sum()).backward()
     assert xyz.grad is not None and torch.isfinite(xyz.grad).all()
 

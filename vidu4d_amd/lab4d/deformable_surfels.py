@@ -15,8 +15,9 @@ from ..gs.cameras import KCamera
 from ..gs.gaussian_model import GaussianModel
 from ..gs.gaussian_renderer import render
 from . import quat_transform as qt
-from .bob_warp import SkinningWarp, TimeEmbedding, apply_qt_to_gaussian, cross_entropy_skin_loss
+from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss
 from .lbs_fused import lbs_apply
+from .nets import CameraMLP, make_frame_info
 
 
 class PipelineParams:
@@ -32,50 +33,60 @@ class PointCloud:
         self.points, self.colors = points, colors
 
 
-class CameraMLP(nn.Module):
-    """time -> object-to-camera SE(3) as (quaternion, translation) (pose.py:29-150): a base pose plus
-    an MLP delta on the time code."""
-
-    def __init__(self, num_frames: int, base_trans=(0.0, 0.0, 3.0), W: int = 128):
-        super().__init__()
-        self.time_embedding = TimeEmbedding(num_frames)
-        self.base_quat = nn.Parameter(torch.tensor([1.0, 0.0, 0.0, 0.0]))
-        self.base_trans = nn.Parameter(torch.tensor(base_trans, dtype=torch.float32))
-        self.mlp = nn.Sequential(nn.Linear(self.time_embedding.out_channels, W), nn.ReLU(True), nn.Linear(W, 6))
-        nn.init.normal_(self.mlp[-1].weight, std=1e-2)
-        nn.init.zeros_(self.mlp[-1].bias)
-
-    def get_vals(self, frame_id):
-        d = self.mlp(self.time_embedding(frame_id))
-        q = qt.quaternion_mul(qt.axis_angle_to_quaternion(d[:, :3]), self.base_quat[None].expand(d.shape[0], -1))
-        return torch.nn.functional.normalize(q, dim=-1), self.base_trans[None] + d[:, 3:]
-
-
 def Kmatinv(Kmat):
     """(…,3,3) intrinsics -> inverse (lab4d/utils/geom_utils.py Kmatinv)."""
     return torch.inverse(Kmat)
 
 
 class DeformableSurfels(GaussianModel):
-    def __init__(self, opts: dict, num_frames: int, device="cuda"):
+    """State-dict keys under `fields.field_params.fg.` as upstream: `_xyz`, `_features_dc`, `_features_rest`,
+    `_scaling`, `_rotation`, `_opacity`, `_regist_feat`, `logsigma`, `logibeta`, `aabb`, `learnable_bkgd`,
+    `warp.*` (bob_warp.SkinningWarp), `camera_mlp.*` (nets.CameraMLP)."""
+
+    def __init__(self, opts: dict, num_frames: int, device="cuda", data_info: dict | None = None):
         super().__init__(opts.get("sh_degree", 3), device=device)
         self.opts = opts
-        self.num_frames = num_frames
+        data_info = dict(data_info or {})
+        if "frame_info" not in data_info:
+            data_info["frame_info"] = make_frame_info([0, num_frames])
+        frame_info = data_info["frame_info"]
+        self.frame_offset = frame_info["frame_offset"]
+        self.frame_offset_raw = frame_info["frame_offset_raw"]
+        self.num_frames = int(self.frame_offset[-1])
+        self.num_inst = 1
         motion = opts.get("fg_motion", "gs-bob")
         assert motion.startswith("gs-"), motion
-        assert motion[3:] == "bob", "only the bag-of-bones warp is on the Stage-3 path"
-        self.warp = SkinningWarp(num_frames, num_se3=opts.get("num_se3", 25), delta_skin=opts.get("delta_skin", True))
-        self.camera_mlp = CameraMLP(num_frames)
+        self.fg_motion = motion[3:]
+        self.warp = create_warp(self.fg_motion, data_info)
+        self.logsigma = nn.Parameter(torch.tensor([1.0]).log())
+        self.logibeta = nn.Parameter(-torch.tensor([0.1]).log())
+        rtmat = data_info.get("rtmat")
+        synthetic_cam = rtmat is None
+        if synthetic_cam:  # no camera prior: every frame looks at the object from 3 units away
+            rtmat = torch.eye(4).repeat(int(self.frame_offset_raw[-1]), 1, 1)
+            rtmat[:, 2, 3] = 3.0
+        self.camera_mlp = CameraMLP(rtmat, frame_info=frame_info)
+        if synthetic_cam:
+            self.camera_mlp.base_init()
+            with torch.no_grad():  # an untrained translation head near the prior, so that synthetic runs see the object
+                self.camera_mlp.trans[2].weight.mul_(0.1)
+                self.camera_mlp.trans[2].bias.copy_(torch.tensor([0.0, 0.0, 3.0]))
+        self.register_buffer("aabb", torch.zeros(2, 3))
         self.pipeline = PipelineParams()
         self.pipeline.debug = opts.get("debug_cuda", False)
-        self.register_buffer("background", torch.zeros(3))
-        self.learnable_bkgd = nn.Parameter(torch.zeros(3))
+        self.background_feat = torch.zeros(3, device=self.device_)  # what render_view is handed upstream (:147, :1190)
+        if opts.get("gs_learnable_bg", True):
+            self.learnable_bkgd = nn.Parameter(torch.tensor([0.5, 0.5, 0.5]))
         self.cameras_extent = opts.get("cameras_extent", 1.0)
         self.to(self.device_)
 
     # ---- initialisation from a point sample of the Stage-2 proxy mesh (init_proxy :354-409)
     def init_from_points(self, points, colors, feat_channels: int = 16):
-        self.create_from_pcd(PointCloud(points, colors), spatial_lr_scale=1.0)
+        import numpy as np
+        pts = np.asarray(points)
+        # scene radius as upstream (:402-407); it scales the densify / prune size thresholds
+        self.cameras_extent = float(np.linalg.norm(pts - pts.mean(axis=0, keepdims=True), axis=-1).max() * 1.1)
+        self.create_from_pcd(PointCloud(points, colors), spatial_lr_scale=self.cameras_extent)
         self._regist_feat = nn.Parameter(torch.zeros(self._xyz.shape[0], feat_channels, device=self._xyz.device))
         self.training_setup(_Args(self.opts))
 
@@ -97,13 +108,13 @@ class DeformableSurfels(GaussianModel):
             self._override_xyz = override_xyz
             self._override_rotation = override_rotation
         try:
-            bkgd = self.background if override_bkgd is None else override_bkgd
+            bkgd = self.background_feat if override_bkgd is None else override_bkgd
             rendered = render(view, self, self.pipeline, bkgd, override_color=override_color, outputs=outputs)
         finally:
             if override_xyz is not None:
                 del self._override_xyz
                 del self._override_rotation
-        if self.opts.get("gs_learnable_bg", True):
+        if hasattr(self, "learnable_bkgd"):
             rendered["render"] = rendered["render"] + (1 - rendered["acc"]) * self.learnable_bkgd[:, None, None]
         return rendered
 

@@ -81,3 +81,46 @@ def axis_angle_to_quaternion(axis_angle: torch.Tensor) -> torch.Tensor:
     small = angle.abs() < 1e-6
     k = torch.where(small, 0.5 - angle * angle / 48, torch.sin(half) / torch.where(small, torch.ones_like(angle), angle))
     return torch.cat([torch.cos(half), axis_angle * k], -1)
+
+
+def quaternion_translation_inverse(q, t):
+    q_inv = quaternion_conjugate(q)
+    return q_inv, quaternion_apply(q_inv, -t)
+
+
+def quaternion_translation_mul(qt1, qt2):
+    (q1, t1), (q2, t2) = qt1, qt2
+    return quaternion_mul(q1, q2), quaternion_apply(q1, t2) + t1
+
+
+def quaternion_to_matrix(q: torch.Tensor) -> torch.Tensor:
+    """(..., 4) w-first, any norm -> (..., 3, 3) rotation (quat_transform.py:221-255: the 2/|q|^2 form)."""
+    w, x, y, z = q.unbind(-1)
+    s = 2.0 / (q * q).sum(-1)
+    rows = (1 - s * (y * y + z * z), s * (x * y - z * w), s * (x * z + y * w),
+            s * (x * y + z * w), 1 - s * (x * x + z * z), s * (y * z - x * w),
+            s * (x * z - y * w), s * (y * z + x * w), 1 - s * (x * x + y * y))
+    return torch.stack(rows, -1).view(q.shape[:-1] + (3, 3))
+
+
+def matrix_to_quaternion(m: torch.Tensor) -> torch.Tensor:
+    """(..., 3, 3) -> (..., 4): of the four algebraically equal candidates (one per largest component)
+    the best conditioned one (quat_transform.py:484-535)."""
+    lead = m.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.reshape(lead + (9,)).unbind(-1)
+    diag = torch.stack((1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22), -1)
+    q_abs = torch.sqrt(diag.clamp_min(0))
+    cand = torch.stack((torch.stack((q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01), -1),
+                        torch.stack((m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20), -1),
+                        torch.stack((m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21), -1),
+                        torch.stack((m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2), -1)), -2)
+    cand = cand / (2.0 * q_abs[..., None].clamp_min(0.1))
+    best = q_abs.argmax(-1)
+    return torch.gather(cand, -2, best[..., None, None].expand(lead + (1, 4))).squeeze(-2)
+
+
+def quaternion_translation_to_se3(q, t):
+    rt = torch.cat((quaternion_to_matrix(q), t[..., None]), -1)
+    bottom = torch.zeros_like(rt[..., :1, :])
+    bottom[..., 0, 3] = 1
+    return torch.cat((rt, bottom), -2)

@@ -70,7 +70,8 @@ class Stage3Trainer:
         c = self.cfg
         m = model
         groups = [
-            {"params": [m._xyz], "lr": c.position_lr_init * m.spatial_lr_scale, "name": "xyz"},
+            # (the trainer's own spatial_lr_scale is 1, trainer.py:236 -- not the model's scene radius)
+            {"params": [m._xyz], "lr": c.position_lr_init * 1.0, "name": "xyz"},
             {"params": [m._features_dc], "lr": c.feature_lr, "name": "f_dc"},
             {"params": [m._features_rest], "lr": c.feature_lr / 20.0, "name": "f_rest"},
             {"params": [m._opacity], "lr": c.opacity_lr, "name": "opacity"},
