@@ -18,9 +18,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/gs/submodules/diff-surfel-rasterization"
 OUT_DIR = os.path.join(os.path.dirname(HERE), "_ref")
 OUT = os.path.join(OUT_DIR, "libref_surfel.so")
+# Second variant, "strict": the same sources compiled with floating-point contraction OFF and rsqrtf spelled
+# 1/sqrtf -- i.e. every fp32 operation is the IEEE operation the source names, in source order.  How a
+# compiler contracts a*b+c into FMAs (nvcc and hipcc both do, each its own way) is unspecified, so the
+# default build is ONE possible rounding of the reference; the strict build is the reference's arithmetic
+# itself, and it is what the CPU oracle (which fixes source order too) must match bit for bit on every
+# integer output.  tests/test_gpu_reference.py compares oracle / product with both.
+OUT_STRICT = os.path.join(OUT_DIR, "libref_surfel_strict.so")
+VARIANTS = {"default": (OUT, []), "strict": (OUT_STRICT, ["-ffp-contract=off", "-DREF_STRICT_RSQRT"])}
 
 
 def build(force=False):
+    outs = [_build_variant(out, extra, force) for out, extra in VARIANTS.values()]
+    return outs[0]
+
+
+def _build_variant(OUT, extra_flags, force=False):
     if not os.path.isdir(REF):
         print("reference sources not present: skipping oracle/_ref build")
         return None
@@ -32,10 +45,11 @@ def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-munsafe-fp-atomics",
              "-I", os.path.join(HERE, "shim"), "-I", os.path.join(REF, "cuda_rasterizer"),
-             "-I", os.path.join(REF, "third_party", "glm")]
+             "-I", os.path.join(REF, "third_party", "glm")] + list(extra_flags)
+    tag = os.path.basename(OUT).rsplit(".", 1)[0]
     objs = []
     for src in srcs:
-        obj = os.path.join(OUT_DIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(OUT_DIR, tag + "_" + os.path.basename(src).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         text = open(src).read()
         # nvcc accepts the kernel-launch chevrons written with inner spaces ("<< <grid, block >> >");

@@ -8,21 +8,32 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(os.path.dirname(_HERE), "_ref", "libref_surfel.so")
-_lib = None
+LIBS = {"default": os.path.join(os.path.dirname(_HERE), "_ref", "libref_surfel.so"),
+        # fp contraction off, rsqrtf = 1/sqrtf: the reference's arithmetic in source order (build_ref.py)
+        "strict": os.path.join(os.path.dirname(_HERE), "_ref", "libref_surfel_strict.so")}
+LIB = LIBS["default"]
+_libs = {}
+_variant = "default"
 
 
-def available() -> bool:
-    return os.path.exists(LIB)
+def available(variant: str = "default") -> bool:
+    return os.path.exists(LIBS[variant])
+
+
+def use(variant: str):
+    """Selects the build the following forward / backward / state calls run ("default" or "strict")."""
+    global _variant
+    assert variant in LIBS, variant
+    _variant = variant
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(LIB)
-        _lib.ref_forward.restype = C.c_int
-        _lib.ref_state.restype = C.c_long
-    return _lib
+    if _variant not in _libs:
+        L = C.CDLL(LIBS[_variant])
+        L.ref_forward.restype = C.c_int
+        L.ref_state.restype = C.c_long
+        _libs[_variant] = L
+    return _libs[_variant]
 
 
 def _p(t):

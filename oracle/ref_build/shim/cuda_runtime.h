@@ -16,3 +16,8 @@
 #ifndef __trap
 #define __trap() __builtin_trap()
 #endif
+#ifdef REF_STRICT_RSQRT
+/* "strict" variant (build_ref.py): the approximate v_rsq_f32 behind rsqrtf is replaced by the correctly
+ * rounded 1/sqrt, so that the build evaluates exactly the fp32 operations the source names. */
+#define rsqrtf(x) (1.0f / sqrtf(x))
+#endif

@@ -529,7 +529,7 @@ def gen_densify(out_dir):
     gm.create_from_pcd(pcd, 1.0)
     out["pcd_points"], out["pcd_colors"] = pts, cols
     for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
-        out["init" + k] = getattr(gm, k)
+        out["init" + k] = getattr(gm, k).detach().clone()
     args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=5e-5, position_lr_final=5e-7,
                                  position_lr_delay_mult=0.01, position_lr_max_steps=30000)
     gm.training_setup(args)
@@ -596,7 +596,7 @@ def gen_densify(out_dir):
         st = gm.optimizer.state[p]
         out[f"post_m_{n}"], out[f"post_v_{n}"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
     out["post_accum"], out["post_denom"], out["post_max_radii2D"] = gm.xyz_gradient_accum, gm.denom, gm.max_radii2D
-    out["post_step_xyz"] = gm.optimizer.state[params()["xyz"]]["step"]
+    out["post_step_xyz"] = gm.optimizer.state[params()["xyz"]]["step"].clone()
 
     gm.reset_opacity()
     out["reset_opacity"] = params()["opacity"].detach().clone()

@@ -169,13 +169,11 @@ class GaussianModel(nn.Module):
         for group in self.optimizer.param_groups:
             if group["name"] != name:
                 continue
-            old = group["params"][0]
-            state = self.optimizer.state.pop(old, None)
+            # Upstream (:270-290) zeroes the moments but files them back under the OLD parameter object before
+            # swapping the parameter in, so the replacement starts WITHOUT Adam state: its next update runs
+            # with a fresh step count (bias correction restarts).  Reproduced: the old state is dropped.
+            self.optimizer.state.pop(group["params"][0], None)
             new = nn.Parameter(tensor.requires_grad_(True))
-            if state is not None:
-                state["exp_avg"] = torch.zeros_like(tensor)
-                state["exp_avg_sq"] = torch.zeros_like(tensor)
-                self.optimizer.state[new] = state
             group["params"][0] = new
             out[name] = new
             return out
@@ -230,14 +228,16 @@ class GaussianModel(nn.Module):
         r = self._regist_feat[mask]
         return r if reps is None else r.repeat(reps, 1)
 
-    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None, samples=None):
+        """`samples` (extension, tests): the (N * selected, 3) normal draws to use instead of sampling."""
         n0, dev = self.get_xyz.shape[0], self.get_xyz.device
         padded = torch.zeros(n0, device=dev)
         padded[:grads.shape[0]] = grads.squeeze()
         sel = (padded >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
         stds = self.get_scaling[sel].repeat(N, 1)
         stds = torch.cat([stds, torch.zeros_like(stds[:, :1])], dim=-1)  # surfels: no extent along the normal
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        if samples is None:
+            samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
         rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
         new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[sel].repeat(N, 1)
         new_scaling = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
@@ -253,11 +253,11 @@ class GaussianModel(nn.Module):
         self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel],
                                    self._opacity[sel], self._scaling[sel], self._rotation[sel], self._regist(sel))
 
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None, samples=None):
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
         self.densify_and_clone(grads, max_grad, extent)
-        self.densify_and_split(grads, max_grad, extent, generator=generator)
+        self.densify_and_split(grads, max_grad, extent, generator=generator, samples=samples)
         prune_mask = (self.get_opacity < min_opacity).squeeze(-1)
         if max_screen_size:
             big_vs = self.max_radii2D > max_screen_size

@@ -29,8 +29,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     except Exception:
         pass
 
-    fovx, fovy = viewpoint_camera.FoVx, viewpoint_camera.FoVy
-    tanfovx, tanfovy = math.tan(float(fovx) * 0.5), math.tan(float(fovy) * 0.5)
+    # fp32 tan of the fp32 field of view, as upstream's torch.tan(FoV * 0.5) (:36-37); the focal length and
+    # with it every radius / tile rect downstream is derived from this number
+    tanfovx, tanfovy = (float(torch.tan(torch.as_tensor(f, dtype=torch.float32).cpu() * 0.5))
+                        for f in (viewpoint_camera.FoVx, viewpoint_camera.FoVy))
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,

@@ -213,9 +213,9 @@ class DeformableSurfels(GaussianModel):
                                        bone_frames=frames)
         xyz_cam, rot_cam = lbs_apply(skin[0].softmax(-1), se3, self._xyz, self._rotation, cq, ct)
         M = frame_id.shape[0]
-        aux = {"skin_entropy": cross_entropy_skin_loss(skin)[..., None].expand(M, -1, -1)}
+        aux = {"skin_entropy": cross_entropy_skin_loss(skin)[..., None, None].expand(M, -1, -1, -1)}  # (M,N,1,1)
         if delta is not None:
-            aux["delta_skin"] = delta.pow(2).mean(-1, keepdim=True).expand(M, -1, -1)
+            aux["delta_skin"] = delta.pow(2).mean(-1, keepdim=True)[..., None, :].expand(M, -1, -1, -1)
         self._aux_dict = aux
         return xyz_cam, rot_cam
 

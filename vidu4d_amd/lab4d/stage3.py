@@ -23,37 +23,55 @@ from .deformable_surfels import DeformableSurfels, _Args
 SURFEL_GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "regist_feat")
 
 
+def mask_balance_weight(maskfg, vis2d, is_detected):
+    """get_mask_balance_wt (model.py:586-611): foreground and background pixels of the visible, detected
+    frames contribute equally to the silhouette loss.  Sync-free (sums and torch.where, no indexing)."""
+    vis = vis2d * is_detected
+    seen = (vis > 0).to(maskfg.dtype)
+    total = vis.sum()
+    pos_wt = total / (maskfg * seen).sum()
+    neg_wt = total / ((1 - maskfg) * seen).sum()
+    both = (maskfg.sum() > 0) & ((1 - maskfg).sum() > 0)
+    return torch.where(both, 0.5 * pos_wt * maskfg + 0.5 * neg_wt * (1 - maskfg), torch.ones_like(maskfg))
+
+
+def mean_of_positive(v):
+    """apply_loss_weights (model.py:996-999): mean over the entries > 0, over everything when there is none;
+    without boolean-mask indexing (a nonzero() would block the host)."""
+    if v.dim() == 0:
+        return v
+    pos = v > 0
+    n = pos.sum()
+    return torch.where(n > 0, (v * pos).sum() / n.clamp_min(1), v.mean())
+
+
 def compute_losses(rendered: dict, batch: dict, step: int, cfg) -> dict:
-    """rendered: maps (M,H,W,C) from DeformableSurfels.render_frames; batch: rgb (M,H,W,3),
-    mask (M,H,W,1), vis2d (M,H,W,1).  Returns the weighted scalar terms the reference keeps under
-    --rgb_loss_only: rgb, mask, normal_loss, dist_loss (trainer.py:477-483)."""
+    """rendered: maps (M,H,W,C) from DeformableSurfels.render_frames; batch: rgb (M,H,W,3), mask (M,H,W,1),
+    vis2d (M,H,W,1), is_detected (M,) (optional: all detected).  Returns the weighted scalar terms the reference
+    keeps under --rgb_loss_only (trainer.py:477-483): rgb, mask, normal_loss, dist_loss -- the values of
+    dvr_model.compute_recon_loss / mask_losses / compute_reg_loss / apply_loss_weights for field_type "fg"
+    (model.py:613-693, :895-978, :803-842, :980-1012), pinned in tests/test_refpy_host.py::test_stage3_losses.
+    Upstream quirks kept on purpose: the colour term is ONE scalar L1 (then spread over the fg-and-visible
+    pixels and averaged back, i.e. it vanishes when no such pixel exists), and the normal-consistency dot
+    product is summed over the FRAME axis of the (M,H,W,3) maps (:831: `.sum(dim=0)`)."""
     vis2d = batch["vis2d"].float()
     maskfg = batch["mask"].float()
+    M = vis2d.shape[0]
+    det = batch["is_detected"].float() if "is_detected" in batch else torch.ones(M, device=vis2d.device)
+    det = det.view(M, 1, 1, 1)
+    zero = torch.zeros((), device=vis2d.device)
     sel = vis2d.expand(-1, -1, -1, 3) > 0
-    l1 = torch.where(sel, torch.abs(rendered["rendered"] - batch["rgb"]), torch.zeros((), device=vis2d.device))
-    loss = {"rgb": (1.0 - cfg.lambda_dssim) * l1.mean()}
-    loss["mask"] = (rendered["mask"] - maskfg).pow(2) * vis2d
-
-    def reduce(v):
-        """Mean over the positive entries, or over everything when none is positive (model.py:996-999),
-        without boolean-mask indexing (which would block the host on a nonzero()): every term here is
-        non-negative, so the fallback mean is 0 = sum / 1."""
-        if v.dim() == 0:
-            return v  # (a scalar is its own mean over the positive entries, or over everything)
-        pos = v > 0
-        return (v * pos).sum() / pos.sum().clamp_min(1)
-
-    out = {"rgb": reduce(loss["rgb"]) * cfg.rgb_wt, "mask": reduce(loss["mask"]) * cfg.mask_wt}
+    l1 = torch.where(sel, torch.abs(rendered["rendered"] - batch["rgb"]), zero).mean() * (1.0 - cfg.lambda_dssim)
+    rgb = l1 * (maskfg * vis2d)                                   # mask_losses: type-specific key, fg field
+    mask = (rendered["mask"] - maskfg).pow(2) * mask_balance_weight(maskfg, vis2d, det) * vis2d * det
+    out = {"rgb": mean_of_positive(rgb) * cfg.rgb_wt, "mask": mean_of_positive(mask) * cfg.mask_wt}
     lam_n = cfg.lambda_normal if step > 8000 else 0.0
     lam_d = cfg.lambda_dist if step > 8000 else 0.0
     # A regulariser with weight 0 (both, for the first 8000 steps, model.py:817-842) contributes a
     # gradient of exactly 0: it is not put on the autograd tape at all, which spares the backward of the
     # whole depth-to-normal chain (~100 launches per step).
-    zero = torch.zeros((), device=vis2d.device)
     if lam_n != 0.0:
-        rn = rendered["rend_normal"].permute(3, 0, 1, 2)  # (3,M,H,W)
-        sn = rendered["surf_normal"].permute(3, 0, 1, 2)
-        out["normal_loss"] = lam_n * (1 - (rn * sn).sum(dim=0)).mean()
+        out["normal_loss"] = lam_n * (1 - (rendered["rend_normal"] * rendered["surf_normal"]).sum(dim=0)).mean()
     else:
         out["normal_loss"] = zero
     out["dist_loss"] = lam_d * rendered["rend_dist"].mean() if lam_d != 0.0 else zero
