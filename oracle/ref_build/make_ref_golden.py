@@ -14,6 +14,11 @@ sys.path.insert(0, ROOT)
 from oracle.ref_build import ref  # noqa: E402
 from vidu4d_amd.synthetic import make_scene, make_upstream_grads  # noqa: E402
 
+# name -> (reference build variant, scene).  "strict" = fp contraction off + exact rsqrt (build_ref.py): the
+# reference's arithmetic in source order, which the oracle reproduces bit for bit on every binning integer.
+STRICT_CASES = {
+    "strict_mid": dict(n=6000, width=128, height=128, seed=31),
+}
 CASES = {
     "tiny": dict(n=64, width=32, height=32, seed=5),
     "ragged": dict(n=600, width=70, height=50, seed=7, bg=(0.2, 0.5, 0.7)),
@@ -25,7 +30,12 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0")
     out_dir = os.path.join(ROOT, "gpurun_out", "ref_golden")
     os.makedirs(out_dir, exist_ok=True)
-    for name, kw in CASES.items():
+    jobs = [(n, kw, "default") for n, kw in CASES.items()] + [(n, kw, "strict") for n, kw in STRICT_CASES.items()]
+    for name, kw, variant in jobs:
+        if not ref.available(variant):
+            print("skipping", name, "(library variant not built)")
+            continue
+        ref.use(variant)
         sc = make_scene(**kw)
         d = sc.to(dev)
         dc, do = make_upstream_grads(sc.width, sc.height)
@@ -40,12 +50,15 @@ if __name__ == "__main__":
                    dL_dothers=do.numpy(), radii=rf["radii"].cpu().numpy(), color=rf["color"].cpu().numpy(),
                    others=rf["others"].cpu().numpy(), point_list=ref.state("point_list", R),
                    ranges=ref.state("ranges", gx * gy * 2).reshape(-1, 2),
-                   n_contrib=ref.state("n_contrib", 2 * sc.width * sc.height).reshape(2, sc.height, sc.width))
+                   n_contrib=ref.state("n_contrib", 2 * sc.width * sc.height).reshape(2, sc.height, sc.width),
+                   tiles_touched=ref.state("tiles_touched", sc.num_surfels), sorted_keys=ref.state("sorted_keys", R),
+                   variant=variant)
         for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh"):
             out[k] = rg[k].cpu().numpy()
         path = os.path.join(out_dir, f"ref_{name}.npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path))
+    ref.use("default")
     # reference timing on this GPU (fwd+bwd, 200k / 512^2), for DESIGN.md / BASELINE.md
     sc = make_scene(200_000, 512).to(dev)
     dc, do = (t.to(dev) for t in make_upstream_grads(512, 512))
