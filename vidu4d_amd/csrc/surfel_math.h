@@ -366,7 +366,7 @@ SURFEL_HD void sh_backward(int deg, int M, const float p_world[3], const float c
 // Per-(pixel, surfel) evaluation shared by the forward and backward blend (forward.cu:358-399,
 // backward.cu:282-323).
 struct PairEval {
-    float sx, sy, pz;
+    float sx, sy, pz, ipz;
     float kx, ky, kz, lx, ly, lz;
     float dx, dy;
     float rho3d, rho2d;
@@ -415,6 +415,7 @@ SURFEL_HD bool eval_pair(const float Tu[3], const float Tv[3], const float Tw[3]
     if (pz == 0.0f) return false;
     e.pz = pz;
     const float ipz = fast_rcp(pz);
+    e.ipz = ipz;
     e.sx = px * ipz;
     e.sy = py * ipz;
     e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
@@ -449,6 +450,7 @@ SURFEL_HD bool eval_pair_flat(const float Tu[3], const float Tv[3], const float 
     const float pz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
     e.pz = pz;
     const float ipz = fast_rcp(pz);
+    e.ipz = ipz;
     e.sx = px * ipz;
     e.sy = py * ipz;
     e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
@@ -577,24 +579,28 @@ struct BwdPixel {
     uint32_t last_contributor, median_contributor;
 };
 
-// Gradient contributions of one (pixel, surfel) pair, in AccSlot order (backward.cu:325-446).
-// `is_median` == (contributor == median_contributor - 1).
-SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float opacity, const float normal[3],
-                        const float rgb[3], float pixx, float pixy, bool is_median, float g[ACC_FLOATS])
+// The part of one (pixel, surfel) pair's backward that runs through the pixel's back-to-front recurrences
+// (backward.cu:325-400): advances the pixel state and returns the blend weight w = alpha * T, dL/dalpha
+// (final), dL/dz so far (median + distortion + depth terms).  `is_median` == (contributor == median_contributor - 1).
+struct PairGrad {
+    float w, dL_dalpha, dL_dz;
+};
+
+SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float normal[3], const float rgb[3],
+                                 bool is_median)
 {
-    const float alpha = e.alpha, G = e.G, c_d = e.depth;
+    const float alpha = e.alpha, c_d = e.depth;
     const float one_m_alpha = 1.f - alpha;
     const float inv_1ma = fast_rcp(one_m_alpha);
     s.T = s.T * inv_1ma;
     const float w = alpha * s.T;
     float dL_dalpha = 0.0f;
-    for (int ch = 0; ch < 3; ch++) {
-        dL_dalpha += (rgb[ch] - s.accum_rec[ch]) * s.dL_dpixel[ch];
-        g[A_RGB + ch] = w * s.dL_dpixel[ch];
-    }
+    for (int ch = 0; ch < 3; ch++) dL_dalpha += (rgb[ch] - s.accum_rec[ch]) * s.dL_dpixel[ch];
     float dL_dz = 0.0f, dL_dweight = 0.0f;
-    const float m_d = map_depth(c_d);
-    const float dmd_dd = (FAR_PLANE * NEAR_PLANE) * fast_rcp((FAR_PLANE - NEAR_PLANE) * c_d * c_d);
+    // m_d = far (d - near) / ((far - near) d) and its derivative far near / ((far - near) d^2) from ONE reciprocal
+    const float inv_d = fast_rcp((FAR_PLANE - NEAR_PLANE) * c_d);
+    const float m_d = (FAR_PLANE * c_d - FAR_PLANE * NEAR_PLANE) * inv_d;
+    const float dmd_dd = (FAR_PLANE * NEAR_PLANE * (FAR_PLANE - NEAR_PLANE)) * inv_d * inv_d;
     if (is_median) {
         dL_dz += s.dL_dmedian_depth;
         dL_dweight += s.dL_dmax_dweight;
@@ -607,10 +613,7 @@ SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float
 
     dL_dalpha += (c_d - s.accum_depth_rec) * s.dL_ddepth;
     dL_dalpha += (1.0f - s.accum_alpha_rec) * s.dL_daccum;
-    for (int ch = 0; ch < 3; ch++) {
-        dL_dalpha += (normal[ch] - s.accum_normal_rec[ch]) * s.dL_dnormal2D[ch];
-        g[A_NRM + ch] = w * s.dL_dnormal2D[ch];
-    }
+    for (int ch = 0; ch < 3; ch++) dL_dalpha += (normal[ch] - s.accum_normal_rec[ch]) * s.dL_dnormal2D[ch];
     dL_dalpha *= s.T;
     dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot_dpixel;
 
@@ -621,17 +624,33 @@ SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float
     }
     s.accum_depth_rec = alpha * c_d + one_m_alpha * s.accum_depth_rec;
     s.accum_alpha_rec = alpha + one_m_alpha * s.accum_alpha_rec;
-
-    const float dL_dG = opacity * dL_dalpha;  // straight-through the 0.99 clamp (backward.cu:400)
     dL_dz += w * s.dL_ddepth;
-    g[A_OPAC] = G * dL_dalpha;
+    PairGrad r;
+    r.w = w;
+    r.dL_dalpha = dL_dalpha;
+    r.dL_dz = dL_dz;
+    return r;
+}
+
+// Gradient contributions of one (pixel, surfel) pair, in AccSlot order (backward.cu:325-446).
+SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float opacity, const float normal[3],
+                        const float rgb[3], float pixx, float pixy, bool is_median, float g[ACC_FLOATS])
+{
+    const float dLdpix[3] = {s.dL_dpixel[0], s.dL_dpixel[1], s.dL_dpixel[2]};
+    const PairGrad pg = bwd_pair_core(s, e, normal, rgb, is_median);
+    const float G = e.G, dL_dz = pg.dL_dz;
+    for (int ch = 0; ch < 3; ch++) {
+        g[A_RGB + ch] = pg.w * dLdpix[ch];
+        g[A_NRM + ch] = pg.w * s.dL_dnormal2D[ch];
+    }
+    const float dL_dG = opacity * pg.dL_dalpha;  // straight-through the 0.99 clamp (backward.cu:400)
+    g[A_OPAC] = G * pg.dL_dalpha;
     g[15] = 0.f;
     g[19] = 0.f;
     if (e.rho3d <= e.rho2d) {
         const float dL_dsx = dL_dG * -G * e.sx + dL_dz * Tw[0];
         const float dL_dsy = dL_dG * -G * e.sy + dL_dz * Tw[1];
-        const float ipz = fast_rcp(e.pz);
-        const float dsx_pz = dL_dsx * ipz, dsy_pz = dL_dsy * ipz;
+        const float dsx_pz = dL_dsx * e.ipz, dsy_pz = dL_dsy * e.ipz;
         const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * e.sx + dsy_pz * e.sy);
         // dL_dk = l x dL_dp ; dL_dl = dL_dp x k
         const float dkx = e.ly * dpz - e.lz * dpy, dky = e.lz * dpx - e.lx * dpz, dkz = e.lx * dpy - e.ly * dpx;
