@@ -89,36 +89,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(GeomState g, ImageState
     }
 }
 
-// Grouped path, step 1: one thread per tile turns its column group_counts[*][t] into an exclusive
-// prefix over the groups (in place) and leaves the tile's total in tile_count[t].
-__global__ __launch_bounds__(256) void group_prefix_kernel(ImageState img, int num_tiles, int groups)
+// Grouped path, step 2: exclusive scan of the tile totals -> ranges, total -> num_rendered
+// (one 1024-thread workgroup).
+__device__ __forceinline__ void tile_totals_scan(GeomState g, ImageState img, int num_tiles, uint32_t* s_part)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= num_tiles) return;
-    uint32_t run = 0;
-    int g = 0;
-    for (; g + 8 <= groups; g += 8) {
-        uint32_t c[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = img.group_counts[(size_t)(g + k) * num_tiles + t];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            img.group_counts[(size_t)(g + k) * num_tiles + t] = run;
-            run += c[k];
-        }
-    }
-    for (; g < groups; g++) {
-        const uint32_t c = img.group_counts[(size_t)g * num_tiles + t];
-        img.group_counts[(size_t)g * num_tiles + t] = run;
-        run += c;
-    }
-    img.tile_count[t] = run;
-}
-
-// Grouped path, step 2: exclusive scan of the tile totals -> ranges, total -> num_rendered.
-__global__ __launch_bounds__(1024) void tile_totals_scan_kernel(GeomState g, ImageState img, int num_tiles)
-{
-    __shared__ uint32_t s_part[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (int base = 0; base < num_tiles; base += 1024) {
@@ -152,12 +126,19 @@ __global__ __launch_bounds__(1024) void tile_totals_scan_kernel(GeomState g, Ima
 // giving index b the tile with the b-th longest list lets the short tiles fill in behind the long
 // ones instead of a long tile starting last and running alone (the lists of an object-centric frame
 // differ by 10x and more).  One workgroup: bucket sort of the tile ids on 1024 length classes.
-__global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageState img, int num_tiles)
+struct TileOrderShared {
+    uint32_t bin[1024];
+    uint32_t scan[16];
+    uint32_t max;
+    uint32_t any;
+};
+
+__device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_tiles, TileOrderShared& sh)
 {
-    __shared__ uint32_t s_bin[1024];
-    __shared__ uint32_t s_scan[16];
-    __shared__ uint32_t s_max;
-    __shared__ uint32_t s_any;
+    uint32_t* s_bin = sh.bin;
+    uint32_t* s_scan = sh.scan;
+    uint32_t& s_max = sh.max;
+    uint32_t& s_any = sh.any;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_max = 0;
     s_bin[threadIdx.x] = 0;
@@ -238,15 +219,82 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageStat
     }
 }
 
+__global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageState img, int num_tiles)
+{
+    __shared__ TileOrderShared sh;
+    tile_order(g, img, num_tiles, sh);
+}
+
+// Grouped path, ONE launch (round 1 used three dependent ones, 22 us of mostly launch latency for ~1 MB):
+//   1. every workgroup turns 64 columns group_counts[*][t] into exclusive prefixes over the groups.  Wave w of
+//      the 16 owns the groups [w G, (w + 1) G), lane = tile: a row segment is one coalesced 256-byte read, the
+//      <= 16 counts of a thread stay in registers, the 16 partial sums per tile meet in LDS;
+//   2. the workgroup that arrives LAST at the header's counter (agent-scope release / acquire around one relaxed
+//      atomic, as the MI355X guide prescribes for inter-workgroup hand-offs) scans the tile totals into the
+//      ranges and builds the longest-first schedule and segment table -- 12 KB of work for one workgroup.
+// The counter is reset by the projection kernel of the same forward (the header is fresh memory every call).
+constexpr int SCAN_TILES = 64;   // tiles per workgroup
+constexpr int SCAN_MAX_PER_WAVE = BIN_MAX_GROUPS / 16;
+
+__global__ __launch_bounds__(1024) void tile_scan_fused_kernel(GeomState g, ImageState img, int num_tiles, int groups)
+{
+    __shared__ uint32_t s_part[16][SCAN_TILES];
+    __shared__ uint32_t s_scan16[16];
+    __shared__ uint32_t s_last;
+    __shared__ TileOrderShared s_order;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * SCAN_TILES + lane;
+    const int per = (groups + 15) / 16;
+    const int g0 = wave * per, g1 = min(groups, g0 + per);
+    uint32_t c[SCAN_MAX_PER_WAVE];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_MAX_PER_WAVE; i++) {
+        c[i] = (t < num_tiles && g0 + i < g1) ? img.group_counts[(size_t)(g0 + i) * num_tiles + t] : 0u;
+        sum += c[i];
+    }
+    s_part[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t v = s_part[w][lane];
+        if (w < wave) run += v;
+        total += v;
+    }
+    if (t < num_tiles) {
+#pragma unroll
+        for (int i = 0; i < SCAN_MAX_PER_WAVE; i++) {
+            if (g0 + i < g1) img.group_counts[(size_t)(g0 + i) * num_tiles + t] = run;
+            run += c[i];
+        }
+        if (wave == 0) img.tile_count[t] = total;
+    }
+    // ---- hand-off to the last workgroup
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t arrived = __hip_atomic_fetch_add(&g.hdr->scan_arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = arrived == gridDim.x - 1;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    tile_totals_scan(g, img, num_tiles, s_scan16);
+    __syncthreads();  // ranges are read back by the same workgroup (the barrier orders its global accesses)
+    tile_order(g, img, num_tiles, s_order);
+    if (threadIdx.x == 0) g.hdr->scan_arrivals = 0;
+}
+
 void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, int groups, hipStream_t stream)
 {
     if (groups > 0) {
-        hipLaunchKernelGGL(group_prefix_kernel, dim3((num_tiles + 255) / 256), dim3(256), 0, stream, img, num_tiles,
-                           groups);
-        hipLaunchKernelGGL(tile_totals_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
-    } else {
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
+        hipLaunchKernelGGL(tile_scan_fused_kernel, dim3((num_tiles + SCAN_TILES - 1) / SCAN_TILES), dim3(1024), 0, stream,
+                           g, img, num_tiles, groups);
+        return;
     }
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
 }
 

@@ -26,21 +26,12 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
     if (project_surfel(cam, p_world, quat, scale, o)) {
         tiles = o.tiles;
         radius = o.radius;
-        float rgb[3];
-        uint32_t clamp_mask = 0;
-        if (a.colors_precomp == nullptr) {
-            sh_forward(cam.sh_degree, p_world, cam.campos, a.shs + (size_t)idx * cam.sh_coeffs * 3, rgb, clamp_mask);
-        } else {
-            rgb[0] = a.colors_precomp[3 * idx];
-            rgb[1] = a.colors_precomp[3 * idx + 1];
-            rgb[2] = a.colors_precomp[3 * idx + 2];
-        }
+        // (q4 = colour and clamp mask is written by surfel_color_kernel)
         float4* rec = reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
         rec[0] = make_float4(o.T[0], o.T[1], o.T[2], o.T[3]);
         rec[1] = make_float4(o.T[4], o.T[5], o.T[6], o.T[7]);
         rec[2] = make_float4(o.T[8], o.center[0], o.center[1], a.opacities[idx]);
         rec[3] = make_float4(o.normal[0], o.normal[1], o.normal[2], o.depth);
-        rec[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
         float box[4];
         contribution_box(o.T, o.center[0], o.center[1], a.opacities[idx], box);
         rec[5] = make_float4(box[0], box[1], box[2], box[3]);
@@ -74,6 +65,7 @@ __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(Pre
     const Camera cam = load_camera(a.cam);
     const int num_tiles = cam.grid_x * cam.grid_y;
     for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) s_hist[t] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.geom.hdr->scan_arrivals = 0;  // (the header is fresh memory)
     __syncthreads();
     const int first = blockIdx.x * BIN_THREADS * a.iters;
     for (int it = 0; it < a.iters; it++) {
@@ -90,10 +82,63 @@ __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(Pre
     for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) row[t] = s_hist[t];
 }
 
+// View-dependent colour of every surfel (computeColorFromSH, forward.cu:20-71) -> record slot q4 (rgb, clamp
+// mask).  A kernel of its own: the 192-byte SH rows are the bulk of the forward's input (38 of 46 MB at 200 k
+// surfels), and a thread-per-surfel walk over them touches 64 cache lines per wave instruction (the projection
+// kernel, which read them in round 1, ran at 1.6 TB/s).  Here the 256 rows of a workgroup -- one contiguous
+// 48 KiB run -- are copied with coalesced 16-byte loads into an LDS tile with a 49-word row stride (odd: the
+// per-thread walk is conflict free), as the per-surfel backward does.  SH_LDS needs 16 coefficients and a
+// 16-byte aligned tensor; otherwise (and for colors_precomp) rows are read directly.
+constexpr int SH_ROW = 48, SH_STRIDE = 49;
+
+template <bool SH_LDS>
+__global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];  // [256][49] when SH_LDS
+    const int block_first = blockIdx.x * PRE_BLOCK;
+    const int idx = block_first + threadIdx.x;
+    const int rows = (a.P - block_first) < PRE_BLOCK ? (a.P - block_first) : PRE_BLOCK;
+    if (SH_LDS) {
+        const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
+        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
+            const float4 v = g4[i];
+            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
+            float* d = s_sh + r * SH_STRIDE + c;
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+        __syncthreads();
+    }
+    if (idx >= a.P) return;
+    float rgb[3];
+    uint32_t clamp_mask = 0;
+    if (a.colors_precomp == nullptr) {
+        const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+        const float campos[3] = {a.cam.campos[0], a.cam.campos[1], a.cam.campos[2]};
+        const float* sh = SH_LDS ? s_sh + threadIdx.x * SH_STRIDE : a.shs + (size_t)idx * a.cam.sh_coeffs * 3;
+        sh_forward(a.cam.sh_degree, p_world, campos, sh, rgb, clamp_mask);
+    } else {
+        rgb[0] = a.colors_precomp[3 * idx];
+        rgb[1] = a.colors_precomp[3 * idx + 1];
+        rgb[2] = a.colors_precomp[3 * idx + 2];
+    }
+    reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS)[4] =
+        make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
+}
+
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return;
     const int num_tiles = a.cam.grid_x * a.cam.grid_y;
+    const bool sh_lds = a.colors_precomp == nullptr && a.shs != nullptr && a.cam.sh_coeffs == 16 &&
+                        (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0;
+    if (sh_lds)
+        hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK),
+                           (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);
+    else
+        hipLaunchKernelGGL(surfel_color_kernel<false>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
     if (use_grouped_binning(num_tiles))
         hipLaunchKernelGGL(preprocess_fwd_grouped_kernel, dim3(bin_groups(a.P)), dim3(BIN_THREADS),
                            (size_t)num_tiles * sizeof(uint32_t), stream, a);
@@ -110,7 +155,6 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
 // over-fetch and 2.5x over-write).  Instead the run is copied with coalesced 16-byte loads into an
 // LDS tile with row stride 49 words (odd => the per-thread column walk is bank-conflict free), the
 // gradients are written back into the same tile and leave with coalesced 16-byte stores.
-constexpr int SH_ROW = 48, SH_STRIDE = 49;
 
 template <bool SH_LDS>
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs a)

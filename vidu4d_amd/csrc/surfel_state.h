@@ -57,7 +57,8 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t num_split_pos; // schedule positions [0, num_split_pos) hold every split tile
     uint32_t split_used;    // the forward blended long tiles segment-parallel (seg_data is valid)
     uint32_t truncated;     // a pixel was still unsaturated after the last segment the caller allowed (max_seg)
-    uint32_t pad[57];
+    uint32_t scan_arrivals; // workgroups of tile_scan_fused_kernel that have finished their columns (reset per forward)
+    uint32_t pad[56];
 };
 
 struct GeomState {
