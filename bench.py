@@ -17,6 +17,12 @@ only exchange the path has.  value = N * K * FRAMES_PER_STEP / max-over-ranks ti
 As in Stage3Trainer, the frames of a step are queued on separate HIP streams and the rasterizer's
 host wait for the pair count is deferred to one check per step (--frame-streams 0: one stream).
 
+`--gpus N` (N > 1) without a torchrun environment spawns the N ranks itself (python -m torch.distributed.run on
+127.0.0.1) and relays rank 0's line; it never prints an n_gpus: 1 line for N > 1.  After the contract's timed
+region of exactly K steps (-> "value"), `--repeats` further regions of K steps each give "repeats" (median,
+p10, p90 of images/s).  "fit_step" is the second figure of SURVEY.md 8(d): the full Stage-3 fitting step (bob
+warp + raster + losses + backward + clip + densify statistics + Adam) at the same size.
+
 Extra objects on the JSON line: "roofline" (dominant kernel: algorithmic bytes per launch /
 its average launch duration, measured with HIP events on the launch stream over extra steps of
 the same workload right after the timed region, frames serialised -- under the timed region's
@@ -97,6 +103,35 @@ def cpu_baseline(scene, n_images: int):
             "fwd_only_images_per_s": n_images / t_fwd}
 
 
+def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int):
+    """Second figure of SURVEY.md 8(d): images/s of the FULL Stage-3 fitting step (bob LBS warp with frozen,
+    randomly initialised warp / camera networks -> rasterize 2 frames -> losses -> backward -> gradient clip ->
+    densification statistics -> Adam) on an object-centric synthetic sequence of the same size."""
+    import numpy as np
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    frames = 120
+    m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=frames, device=dev)
+    d = rng.normal(size=(n_surfels, 3)).astype(np.float32)
+    pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(n_surfels, 1)).astype(np.float32) ** (1 / 3)
+    m.init_from_points(pts.astype(np.float32), rng.uniform(size=(n_surfels, 3)).astype(np.float32))
+    tr = Stage3Trainer(m)
+    batches = [synthetic_batch(m, [(2 * i) % frames, (2 * i + 1) % frames], H, W, seed=i) for i in range(8)]
+    for i in range(6):
+        tr.train_step(batches[i % 8])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.train_step(batches[i % 8])
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps,
+            "config": f"{n_surfels} surfels in a unit ball 3 units from the camera, {W}x{H}, 25 bones, 120 frames, "
+                      "warp / camera networks frozen (--gs_optim_warp=False), densify off"}
+
+
 def torch_cpu_baseline(scene, n_images: int, threads: int):
     """The pure-PyTorch CPU render BASELINE.json's north_star asks to be timed beside the GPU number
     (oracle/torch_render.py: vectorised forward, autograd backward)."""
@@ -154,6 +189,9 @@ def main():
                     help="frames timed on the pure-PyTorch CPU render (0 = skip; ~10-20 s each at 200k/512^2)")
     ap.add_argument("--no-stage-timers", action="store_true")
     ap.add_argument("--frame-streams", type=int, default=1, help="queue the frames of a step on separate HIP streams")
+    ap.add_argument("--repeats", type=int, default=5, help="further timed regions of --steps steps (median / p10 / p90)")
+    ap.add_argument("--fit-steps", type=int, default=30, help="steps of the full Stage-3 fitting loop timed for "
+                                                              "\"fit_step\" (0 = skip)")
     ap.add_argument("--_torch_cpu_child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--_threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -171,6 +209,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: start the ranks ourselves (one process per GPU over RCCL) and relay rank 0's line
+        import subprocess
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            sys.stderr.write(r.stdout[-2000:] + r.stderr[-4000:])
+            raise SystemExit(f"spawning {args.gpus} ranks failed (rc {r.returncode})")
+        print(lines[-1], flush=True)
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -237,14 +291,28 @@ def main():
         # the path's only exchange: canonical-surfel gradients, once per optimizer step.  (After the capacity
         # check, so that a repeated step on one rank cannot add a collective the other ranks do not make.)
         if use_distributed_exchange:
-            g_means, g_rot = grads
-            torch.cat([g_means.reshape(-1), opac.grad.reshape(-1), scales.grad.reshape(-1), g_rot.reshape(-1),
-                       shs.grad.reshape(-1)], out=flat)
+            # (the shared-parameter gradients already live in `flat`: their .grad tensors are views of it)
             dist.all_reduce(flat)
 
+    if use_dist:
+        # one persistent flat exchange buffer; the shared parameters' .grad are views of it (autograd accumulates
+        # into an existing .grad in place), the per-frame means / rotations gradients are summed straight into it
+        offs = {}
+        o = 0
+        for name, n in (("means", N * 3), ("opac", N), ("scales", N * 2), ("rot", N * 4), ("shs", N * 48)):
+            offs[name] = (o, o + n)
+            o += n
+        flat_view = {k: flat[a:b] for k, (a, b) in offs.items()}
+
     def step_once():
-        for t in (opac, scales, shs):
-            t.grad = None
+        if use_dist:
+            flat.zero_()
+            opac.grad = flat_view["opac"].view_as(opac)
+            scales.grad = flat_view["scales"].view_as(scales)
+            shs.grad = flat_view["shs"].view_as(shs)
+        else:
+            for t in (opac, scales, shs):
+                t.grad = None
         use_streams = mode["streams"]
         main = torch.cuda.current_stream(dev)
         ready = main.record_event() if use_streams else None
@@ -261,6 +329,10 @@ def main():
         if use_streams:
             for st in side:
                 main.wait_stream(st)
+        if use_dist:
+            torch.add(per_frame[0][0], per_frame[1][0], out=flat_view["means"].view(N, 3))
+            torch.add(per_frame[0][1], per_frame[1][1], out=flat_view["rot"].view(N, 4))
+            return None
         return sum(g[0] for g in per_frame), sum(g[1] for g in per_frame)
 
     def sync():
@@ -276,6 +348,14 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    rep_rates = []
+    for _ in range(max(0, args.repeats)):
+        sync()
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        rep_rates.append(world * args.steps * FRAMES_PER_STEP / (time.perf_counter() - r0))
     # Per-kernel launch durations for the roofline: HIP events on the launch stream around every stage
     # (vidu4d_surfel_profile_*), over further steps of the same workload with the frames of a step queued
     # one after the other.  In the timed region above two frames overlap on two streams, and an event
@@ -311,6 +391,12 @@ def main():
                    "parallelism": f"frame-parallel x{world}" + (" + RCCL all-reduce of surfel grads" if world > 1 else "")},
     }
 
+    if rep_rates:
+        import statistics
+        q = sorted(rep_rates)
+        pick = lambda f: q[min(len(q) - 1, max(0, int(round(f * (len(q) - 1)))))]  # noqa: E731
+        out["repeats"] = {"n": len(q), "unit": "images/s", "median": statistics.median(q), "p10": pick(0.1), "p90": pick(0.9),
+                          "min": q[0], "max": q[-1], "note": "this rank's clock; each region = --steps steps"}
     if rank == 0:
         # ---- roofline of the dominant kernel (live HIP-event stage timers, see above)
         from vidu4d_amd import _C
@@ -343,12 +429,21 @@ def main():
                     traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+            # what actually limits the kernel (rocprofv3 SQ counters of this command, tools/profile_round.sh ->
+            # profiles/pmc_traffic.json): the blend kernels are bound by VALU issue, not by HBM
+            limiter = {}
+            try:
+                limiter = json.load(open(tpath)).get(dom, {}).get("limiter", {})
+            except Exception:
+                limiter = {}
+            out["roofline"] = {"bound": limiter.get("bound", "hbm"), "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "limiter": limiter,
                                "avg_launch_ms": stages[dom]["ms_avg"],
                                "timing": "HIP events on the launch stream, %d extra steps after the timed region with "
                                          "the frames of a step serialised on one stream" % min(args.steps, 20),
                                "algorithmic_bytes_per_launch": stage_bytes(dom, N, R, W * H, T, K)}
+        if world == 1 and args.fit_steps > 0:
+            out["fit_step"] = fit_step_rate(dev, N, W, H, args.fit_steps)
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
         if world == 1 and args.torch_cpu_images > 0:

@@ -81,3 +81,82 @@ def test_frame_parallel_two_ranks_gloo():
         assert ok_grad, "all-reduced gradient is not the mean over ranks"
         assert same_size and identical, "replicas diverged through densify/prune"
     assert out[0][4] == out[1][4]
+
+
+# ---------------------------------------------------------------------------------------------
+class _TorchRasterizer(torch.nn.Module):
+    """CPU stand-in for the HIP rasterizer in THIS TEST ONLY: the pure-PyTorch oracle render
+    (oracle/torch_render.py, test infrastructure) behind the GaussianRasterizer call signature, so that whole
+    Stage-3 steps (warp -> render -> losses -> backward -> exchange -> clip -> densify -> Adam) can run on two
+    gloo ranks without a GPU.  The product never imports oracle/."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.rs = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        from oracle import torch_render as tr
+        rs = self.rs
+        color, radii, others, _ = tr.rasterize(means3D, opacities, scales, rotations, rs.viewmatrix, rs.campos, rs.bg,
+                                               rs.image_width, rs.image_height, rs.tanfovx, rs.tanfovy, rs.sh_degree,
+                                               shs=shs)
+        return color + 0.0 * means2D.sum(), radii, others
+
+
+def _train_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vidu4d_amd.gs import gaussian_renderer as gr
+        from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+        from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+        gr.GaussianRasterizer = _TorchRasterizer
+        torch.set_num_threads(2)
+        rng = np.random.default_rng(0)
+        torch.manual_seed(0)                       # identical networks and surfels on every rank
+        opts = dict(fg_motion="gs-bob", densify_from_iter=0, densification_interval=2, densify_grad_threshold=1e-9,
+                    opacity_reset_interval=1000, frame_streams=False)
+        m = DeformableSurfels(opts, num_frames=8, device="cpu")
+        n = 150
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        m.init_from_points(0.25 * d / np.linalg.norm(d, axis=1, keepdims=True), rng.uniform(size=(n, 3)).astype(np.float32))
+        with torch.no_grad():
+            m._opacity.fill_(1.0)
+            m._opacity[:20] = -10.0                # transparent: pruned by the densify step (opacity < 0.005)
+        tr = Stage3Trainer(m, opts)
+        H = W = 32
+        norms = []
+        for step in range(3):                      # step 2 densifies (interval 2, from 0)
+            ids = [(2 * (step * world + rank)) % 8, (2 * (step * world + rank) + 1) % 8]   # this rank's frames
+            batch = synthetic_batch(m, ids, H, W, seed=step)    # same targets per step, different frames per rank
+            tr.train_step(batch)
+            norms.append(float(torch.cat([p.detach().reshape(-1) for p in tr.surfel_params()]).norm()))
+        sig = torch.cat([p.detach().reshape(-1) for p in tr.surfel_params()])
+        sizes = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([sig.numel()]))
+        same = all(int(x) == sig.numel() for x in sizes)
+        identical = False
+        if same:
+            gathered = [torch.zeros_like(sig) for _ in range(world)]
+            dist.all_gather(gathered, sig)
+            identical = all(torch.equal(gathered[0], t) for t in gathered)
+        out[rank] = (same, identical, m._xyz.shape[0], norms)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_full_train_steps_keep_two_gloo_replicas_identical():
+    """Two ranks render DIFFERENT frames each step; after the one all-reduce per step (flat gradient buffer),
+    the clip, a densify / prune and Adam the replicas hold bit-identical surfels."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        same, identical, n, norms = out[r]
+        assert same and identical, "replicas diverged"
+        assert all(np.isfinite(norms))
+    assert out[0][2] == out[1][2] and out[0][2] != 150, "the densify step did not change the surfel count"

@@ -29,10 +29,10 @@ if stats:
 
 # 2. PMC passes: per-kernel mean counter value per launch
 SHORT = {"blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "emit_keys": "emit_keys",
-         "preprocess_fwd": "preprocess_fwd", "preprocess_bwd": "preprocess_bwd", "tile_sort_kernel": "tile_sort",
-         "tile_scan": "tile_scan", "tile_totals": "tile_scan", "group_prefix": "tile_scan", "tile_order": "tile_scan",
+         "preprocess_fwd": "preprocess_fwd", "surfel_color": "surfel_color", "preprocess_bwd": "preprocess_bwd",
+         "tile_sort_kernel": "tile_sort", "tile_scan": "tile_scan", "tile_order": "tile_scan",
          "blend_seg_T": "blend_seg_T", "blend_combine": "blend_combine"}
-STREAMING = {"preprocess_fwd", "preprocess_bwd"}  # wide coalesced streaming reads: FETCH_SIZE counts 1/2 (guide, HBM section)
+STREAMING = {"preprocess_fwd", "surfel_color", "preprocess_bwd"}  # wide coalesced streaming reads: FETCH_SIZE counts 1/2 (guide, HBM section)
 per = defaultdict(lambda: defaultdict(list))
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     path = find(counter, "*counter_collection.csv")
@@ -90,4 +90,14 @@ if sq:
             ns = max(dur[k], key=lambda t: t[1])[0] if dur.get(k) and k != "tile_scan" else float("nan")
             util = m["SQ_INSTS_VALU"] * 4.0 / (SIMDS * ns * CLK_GHZ) if ns == ns else float("nan")
             f.write(f"surfel::{k},{n}," + ",".join(f"{m[c]:.4g}" for c in cols) + f",{ns / 1e3:.1f},{util:.3f}\n")
+            if k in traffic and ns == ns:
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs: share of the kernel's duration (at the
+                # 2.4 GHz peak clock; the sustained clock is lower, so this is a lower bound) the VALUs were executing
+                busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * ns * CLK_GHZ)
+                hbm = traffic[k]["hbm_bytes_per_launch"] / (ns * 1e-9) / 8.0e12
+                traffic[k]["limiter"] = {"bound": "valu" if busy > 0.5 and hbm < 0.3 else ("hbm" if hbm >= 0.3 else "latency"),
+                                         "valu_busy_frac": round(busy, 3), "valu_insts_per_launch": m["SQ_INSTS_VALU"],
+                                         "counter_hbm_frac_of_8TBps": round(hbm, 4), "avg_duration_us": round(ns / 1e3, 1),
+                                         "source": f"rocprofv3 --pmc SQ_ACTIVE_INST_VALU ... ({tag}_pmc_sq.csv)"}
+    json.dump(traffic, open(os.path.join(summ, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in traffic.items()}))

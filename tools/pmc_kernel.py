@@ -26,7 +26,7 @@ GROUPS = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("kernel")
-    ap.add_argument("--bench-args", default="--steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --no-stage-timers --frame-streams 0")
+    ap.add_argument("--bench-args", default="--steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --no-stage-timers --frame-streams 0")
     ap.add_argument("--out", default="")
     ap.add_argument("--groups", default="0,1,2")
     args = ap.parse_args()

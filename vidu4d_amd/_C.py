@@ -128,7 +128,8 @@ def check_deferred() -> bool:
         if ev is not None:
             ev.synchronize()
         n = int(slot[0])
-        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
+        # (a slowly decaying maximum: the buffers shrink again after a prune)
+        _capacity_hint[key] = max(int(n * 1.25) + 4096, int(0.98 * _capacity_hint.get(key, 0)))
         if stat is not None:
             _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
         if int(slot[6]):  # the segment limit cut a tile short: this frame is incomplete, the next ones run unlimited
@@ -144,7 +145,7 @@ def _pinned_slot(device):
     # deferred forwards keep theirs until they have been checked, so the k-th pending forward of a stream
     # gets the k-th slot of that stream (the same ones every step)
     sid = torch.cuda.current_stream(device).cuda_stream
-    k = sum(1 for p in _pending if p[4][3] == str(device) and p[5] == sid) if _deferred else 0
+    k = sum(1 for p in _pending if p[4][2] == str(device) and p[5] == sid) if _deferred else 0
     key = (str(device), sid, k)
     if key not in _pinned:
         _pinned[key] = torch.zeros(8, dtype=torch.int32).pin_memory()  # Header words 0..7 (surfel_state.h)
@@ -200,7 +201,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.geom_buffer, a.geom_bytes = geom.data_ptr(), geom.numel()
     a.image_buffer, a.image_bytes = img.data_ptr(), img.numel()
     stream = _stream(dev)
-    key = (P, W, H, str(dev))
+    # Hints are keyed on the image shape and device only: the surfel count changes with every densify / prune,
+    # and the pair count, split depth and per-stream counters of the previous frames stay good guesses across it
+    # (keying on P leaked one entry -- with a device tensor and a pinned buffer -- per surfel count).
+    key = (W, H, str(dev))
     stat = None
     if _SPLIT == "auto":
         depth = _depth_hint.get(key, 0)

@@ -10,9 +10,12 @@ checkpoint's point count, the state dict is applied with strict=False, and the o
 restored (upstream comments that part out, :416-421) -- the surfel optimizer is rebuilt instead.
 Per-round `%03d-fg-gs.ply` files use GaussianModel.save_ply (attribute order of gaussian_model.py:189-220).
 
-Sub-module keys (warp, camera MLP) are carried under the same prefix; they load into this
-repository's modules where name and shape agree and are reported otherwise (the reference's warp
-modules are not re-implemented layer for layer)."""
+Sub-module keys (`warp.*`, `camera_mlp.*`) are the reference's, key for key (nets.py, bob_warp.py;
+tests/test_refpy_nets.py loads a state dict saved from the imported reference modules strict=True), so a
+Stage-2 checkpoint populates the bones and cameras Stage-3 is fitted against.  A checkpoint whose network
+tensors are absent or have other shapes (another number of videos / another video length than the model was
+built for) is an ERROR when the networks are frozen (--gs_optim_warp=False): fitting surfels against randomly
+initialised motion would run to completion and mean nothing."""
 from __future__ import annotations
 
 import os
@@ -48,7 +51,11 @@ def save_checkpoint(trainer, save_dir: str, round_count: int, save_freq: int = 1
     return path
 
 
-def load_checkpoint(load_path: str, model, trainer=None, map_location=None, reset_steps: bool = True) -> dict:
+NET_PREFIXES = ("warp.", "camera_mlp.")
+
+
+def load_checkpoint(load_path: str, model, trainer=None, map_location=None, reset_steps: bool = True,
+                    allow_random_networks: bool = False) -> dict:
     """Updates `model` in place; returns the checkpoint dict plus "missing_keys" / "unexpected_keys".
     reset_steps (the reference's flag, default True, config.py:139-143): the step counter restarts at 0
     -- Stage-3 on top of a Stage-2 checkpoint -- instead of resuming the checkpoint's schedule."""
@@ -71,6 +78,17 @@ def load_checkpoint(load_path: str, model, trainer=None, map_location=None, rese
     res = model.load_state_dict(usable, strict=False)
     ckpt["missing_keys"] = list(res.missing_keys)
     ckpt["unexpected_keys"] = sorted(set(fg) - set(usable))
+    net_missing = [k for k in res.missing_keys if k.startswith(NET_PREFIXES)]
+    net_mismatch = [k for k in fg if k.startswith(NET_PREFIXES) and k in own and own[k].shape != fg[k].shape]
+    ckpt["network_keys_not_loaded"] = net_missing + net_mismatch
+    frozen = trainer is not None and not trainer.optim_warp
+    if (net_missing or net_mismatch) and frozen and not allow_random_networks:
+        detail = "; ".join(f"{k}: checkpoint {tuple(fg[k].shape)} vs model {tuple(own[k].shape)}" for k in net_mismatch[:4])
+        raise RuntimeError(
+            f"{load_path}: {len(net_missing)} warp / camera tensors are missing and {len(net_mismatch)} have other "
+            f"shapes ({detail}) -- with --gs_optim_warp=False the surfels would be fitted against randomly "
+            "initialised bones and cameras.  Build the model with the checkpoint's frame_info (number of videos "
+            "and frames), train the networks (--gs_optim_warp=True) or pass allow_random_networks=True.")
     if trainer is not None:  # fresh optimizer over the re-created parameters, step counter from the file
         trainer.__init__(model, trainer.cfg.__dict__ | {"gs_optim_warp": trainer.optim_warp})
         trainer.current_steps = 0 if reset_steps else int(ckpt.get("current_steps", 0))

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from ..gs.cameras import KCamera
 from ..gs.gaussian_model import GaussianModel
-from ..gs.gaussian_renderer import render
+from ..gs.gaussian_renderer import GEOMETRY_KEYS, render
 from . import quat_transform as qt
 from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss
 from .lbs_fused import lbs_apply
@@ -119,9 +119,11 @@ class DeformableSurfels(GaussianModel):
         return rendered
 
     def get_gs_Kcamera(self, Kinvs, Hs, Ws):
-        """One camera per frame from the inverse intrinsics (:927-962).  The intrinsics come to the host
-        in one copy; cameras are cached on their six defining numbers (with --force_center_cam every
-        frame of a video shares them)."""
+        """One camera per frame from the inverse intrinsics (:927-962).  Cameras are built on the host from six
+        numbers and cached on them (with --force_center_cam every frame of a video shares them).  Hand the
+        intrinsics over as a HOST tensor (vidloader and synthetic_batch do): a device tensor has to be copied
+        back, which makes the host wait for all queued GPU work once per step (only skipped when the very same
+        tensor comes again)."""
         # the same intrinsics tensor as last time (same storage, not written since): same cameras, and no
         # device-to-host copy -- that copy would make the host wait for all queued GPU work every step
         tkey = (Kinvs.data_ptr(), Kinvs._version, tuple(Kinvs.shape), tuple(int(h) for h in Hs), tuple(int(w) for w in Ws))
@@ -131,16 +133,18 @@ class DeformableSurfels(GaussianModel):
         cams = []
         Kh = Kinvs.detach().float().cpu()
         cache = self.__dict__.setdefault("_camera_cache", {})
+        dev = self._xyz.device if hasattr(self, "_xyz") and isinstance(self._xyz, torch.Tensor) and self._xyz.numel() \
+            else Kinvs.device
         for i in range(Kh.shape[0]):
             Kinv, H, W = Kh[i], int(Hs[i]), int(Ws[i])
             left, right = Kinv[0, 2], Kinv[0, 2] + Kinv[0, 0] * W
             bottom, top = Kinv[1, 2], Kinv[1, 2] + Kinv[1, 1] * H
-            key = (H, W, float(left), float(right), float(top), float(bottom), str(Kinvs.device))
+            key = (H, W, float(left), float(right), float(top), float(bottom), str(dev))
             if key not in cache:
                 if len(cache) > 64:
                     cache.clear()
                 cache[key] = KCamera(H=H, W=W, left=left, right=right, top=top, bottom=bottom,
-                                     data_device=Kinvs.device)
+                                     data_device=dev)
             cams.append(cache[key])
         self.__dict__["_camera_last"] = (tkey, cams, Kinvs)  # (keeps the tensor alive: its address is the key)
         return cams
@@ -246,6 +250,11 @@ class DeformableSurfels(GaussianModel):
         # chain, not by throughput).  autograd replays each frame's backward on the stream of its
         # forward, so the backward kernels overlap the same way.  Per-frame results are unchanged.
         streams = self._frame_streams(M) if xyz_cam.is_cuda and self.opts.get("frame_streams", True) else None
+        if outputs is None or any(k in GEOMETRY_KEYS for k in outputs):
+            # the cached pixel-ray grid of a camera is shared by the frames that use it: build it here, on the
+            # main stream, before the per-frame streams fork (two streams must not race to create it)
+            for cam in cams:
+                cam.pixel_rays()
         if streams:
             main = torch.cuda.current_stream(xyz_cam.device)
             ready = main.record_event()

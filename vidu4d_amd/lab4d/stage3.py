@@ -103,14 +103,35 @@ class Stage3Trainer:
         self.gs_optimizer = torch.optim.Adam(groups, lr=c.learning_rate, eps=1e-15, fused=m._xyz.is_cuda)
         m.optimizer = self.gs_optimizer
         self._flat = None
+        self._pending_reduce = None
         # --gs_optim_warp=False (the README's Stage-3 command): warp and camera networks come from the
         # Stage-2 checkpoint and are never stepped (trainer.py:592-598).  Upstream still back-propagates
-        # into them; freezing them is results-equivalent for the surfels and skips the weight-gradient
-        # GEMMs and the (M,N,B,.) broadcast reductions of the warp backward.
-        self.optim_warp = bool((opts or model.opts).get("gs_optim_warp", False))
-        for mod in (m.warp, m.camera_mlp):
-            for prm in mod.parameters():
-                prm.requires_grad_(self.optim_warp)
+        # into them; freezing them is results-equivalent for the surfels up to the gradient clip (upstream's
+        # check_grad, :861-869, puts the unused warp gradients into the norm it clips by -- DESIGN.md §5) and skips
+        # the weight-gradient GEMMs and the (M,N,B,.) broadcast reductions of the warp backward.
+        o = opts or model.opts
+        self.optim_warp = bool(o.get("gs_optim_warp", False))
+        self.optim_warp_from = int(o.get("optim_warp_neus_iters", 12000))
+        net_params = [(n, prm) for mod_name, mod in (("warp", m.warp), ("camera_mlp", m.camera_mlp))
+                      for n, prm in ((f"{mod_name}.{k}", v) for k, v in mod.named_parameters())]
+        for _, prm in net_params:
+            prm.requires_grad_(self.optim_warp)
+        self.optimizer = self.scheduler = None
+        if self.optim_warp:
+            # the reference's second optimizer (trainer.py:177-286): AdamW(betas (0.9, 0.999), weight decay 1e-4), one
+            # group per tensor, 10x the base rate for the explicit parameters, linear one-cycle schedule; it is stepped
+            # once the surfels have had optim_warp_neus_iters steps (:592-598)
+            explicit = (".logibeta", ".logsigma", ".logscale", ".log_gauss", ".base_quat", ".shift")
+            groups, lrs = [], []
+            for n, prm in net_params:
+                groups.append({"params": [prm], "name": n})
+                lrs.append(c.learning_rate * (10.0 if any(n.endswith(e[1:]) or e in n for e in explicit) else 1.0))
+            total = max(2, int(o.get("num_rounds", 1)) * int(o.get("iters_per_round", 200)))
+            self.optimizer = torch.optim.AdamW(groups, lr=c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4)
+            self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
+                self.optimizer, lrs, total, pct_start=min(0.5, 2.0 / max(1, int(o.get("num_rounds", 1)))),
+                cycle_momentum=False, anneal_strategy="linear", div_factor=25.0, final_div_factor=1.0)
+        self._net_params = [prm for _, prm in net_params]
 
     # ---- the path's only exchange
     def surfel_params(self):
@@ -120,25 +141,58 @@ class Stage3Trainer:
             ps.append(m.learnable_bkgd)
         return ps
 
-    def allreduce_gradients(self):
-        """Mean of the surfel gradients over the ranks through one flat fp32 buffer."""
+    def exchanged_params(self):
+        """Everything the ranks must agree on after a step: the surfels, and the networks when they train."""
+        return self.surfel_params() + (self._net_params if self.optim_warp else [])
+
+    def bind_flat_gradients(self):
+        """Makes every exchanged parameter's .grad a view of ONE persistent fp32 buffer and zeroes it (this is
+        the step's zero_grad): autograd then accumulates straight into the buffer the all-reduce, the norm for
+        the clip and the fused Adam read -- no gather / scatter copies around the collective.  Re-bound every
+        step because densify / prune re-create the surfel parameters."""
+        ps = self.exchanged_params()
+        n = sum(p.numel() for p in ps)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != ps[0].device:
+            self._flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        else:
+            self._flat.zero_()
+        off = 0
+        for p in ps:
+            p.grad = self._flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        return self._flat
+
+    def allreduce_gradients(self, async_op: bool = False):
+        """Sum of the flat gradient buffer over the ranks (the mean is folded into clip_gradients).  With async_op
+        the collective is left in flight (RCCL runs it on its own stream) and `wait_gradients` joins it, so that
+        work that does not read the gradients -- the densification statistics -- overlaps it."""
         if self.world == 1:
             return
-        ps = self.surfel_params()
-        n = sum(p.numel() for p in ps)
-        if self._flat is None or self._flat.numel() != n:
-            self._flat = torch.empty(n, dtype=torch.float32, device=ps[0].device)
-        off = 0
-        for p in ps:
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            self._flat[off:off + p.numel()].copy_(g.reshape(-1))
-            off += p.numel()
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-        self._flat.div_(self.world)
-        off = 0
-        for p in ps:
-            p.grad = self._flat[off:off + p.numel()].view_as(p).clone()
-            off += p.numel()
+        if self._flat is None or any(p.grad is None or p.grad.untyped_storage().data_ptr() != self._flat.untyped_storage().data_ptr()
+                                     for p in self.exchanged_params()):
+            # gradients that were not produced into the flat buffer (a caller that set them by hand): gather them
+            ps = self.exchanged_params()
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
+            self.bind_flat_gradients()
+            for p, g_ in zip(ps, grads):
+                p.grad.copy_(g_)
+        self._pending_reduce = dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True)
+        if not async_op:
+            self.wait_gradients()
+
+    def wait_gradients(self):
+        if self._pending_reduce is not None:
+            self._pending_reduce.wait()
+            self._pending_reduce = None
+            self._flat.div_(self.world)
+
+    def clip_gradients(self, max_norm: float = 5.0):
+        """clip_grad_norm_ over the exchanged parameters (trainer.py:861-869), one norm over the flat buffer."""
+        if self._flat is None:
+            return torch.nn.utils.clip_grad_norm_(self.exchanged_params(), max_norm)
+        norm = torch.linalg.vector_norm(self._flat)
+        self._flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        return norm
 
     def _sync_densification_stats(self):
         if self.world == 1:
@@ -171,15 +225,16 @@ class Stage3Trainer:
             # one check per step: if a frame outgrew its buffer -- it then rendered only the background --
             # the gradients of this step are dropped and the step is replayed with exact buffers.
             from .. import _C
+            self.bind_flat_gradients()
             with _C.deferred_capacity_check():
                 losses = self._forward_backward(batch, step)
             if not _C.check_deferred():
-                self.gs_optimizer.zero_grad(set_to_none=True)
+                self.bind_flat_gradients()
                 losses = self._forward_backward(batch, step)
         else:
+            self.bind_flat_gradients()
             losses = self._forward_backward(batch, step)
-        self.allreduce_gradients()
-        torch.nn.utils.clip_grad_norm_(self.surfel_params(), 5.0)
+        self.allreduce_gradients(async_op=True)   # in flight while the statistics below are gathered
 
         with torch.no_grad():
             if step < c.densify_until_iter:
@@ -187,6 +242,9 @@ class Stage3Trainer:
                     vis, radii = m._visibility_filter_batch[i], m._radii_batch[i]
                     m.max_radii2D.copy_(torch.where(vis, torch.maximum(m.max_radii2D, radii.float()), m.max_radii2D))
                     m.add_densification_stats(m._viewspace_points_batch[i], vis)
+            self.wait_gradients()
+            self.clip_gradients(5.0)              # check_grad precedes the densification upstream (trainer.py:547)
+            if step < c.densify_until_iter:
                 gen = None
                 if step > c.densify_from_iter and step % c.densification_interval == 0:
                     self._sync_densification_stats()
@@ -205,8 +263,13 @@ class Stage3Trainer:
                     # holds the same surfels, so every rank prunes the same ones.
                     from ..simple_knn import radius_neighbor_count
                     m.prune_points(radius_neighbor_count(m.get_xyz, 0.004) <= 20)
+        # (parameters re-created by densify / prune / reset_opacity have no gradient and are skipped, as upstream)
         self.gs_optimizer.step()
-        self.gs_optimizer.zero_grad(set_to_none=True)
+        if self.optimizer is not None and step >= self.optim_warp_from:
+            self.optimizer.step()
+            self.scheduler.step()
+        for p in self.exchanged_params():
+            p.grad = None
         self.current_steps += 1
         return {k: v.detach() for k, v in losses.items()}
 
@@ -224,7 +287,8 @@ def synthetic_batch(model: DeformableSurfels, frame_ids, H: int, W: int, seed: i
     dev = model._xyz.device
     M = len(frame_ids)
     g = torch.Generator().manual_seed(seed)
-    return {"frameid": torch.as_tensor(frame_ids, device=dev), "Kinv": make_intrinsics_inv(M, H, W, device=dev),
+    # (Kinv stays on the host: cameras are built there, deformable_surfels.get_gs_Kcamera)
+    return {"frameid": torch.as_tensor(frame_ids, device=dev), "Kinv": make_intrinsics_inv(M, H, W, device="cpu"),
             "H": [H] * M, "W": [W] * M, "rgb": torch.rand(M, H, W, 3, generator=g).to(dev),
             "mask": (torch.rand(M, H, W, 1, generator=g) > 0.5).float().to(dev),
             "vis2d": torch.ones(M, H, W, 1, device=dev)}

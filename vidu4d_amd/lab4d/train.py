@@ -28,13 +28,14 @@ import torch
 STAGE3_FLAGS = dict(
     seqname="synthetic", logname="tmp", logroot="logdir", fg_motion="gs-bob", num_rounds=1, iters_per_round=200,
     load_path="", gs_init_mesh="", imgs_per_gpu=1, pixels_per_image=-1, eval_res=256, train_res=256,
-    rgb_loss_only=False, gs_optim_warp=False, data_prefix="full", force_center_cam=False, sh_degree=3,
+    rgb_loss_only=False, gs_optim_warp=True, data_prefix="full", force_center_cam=False, sh_degree=3,
     position_lr_init=5e-5, position_lr_final=5e-7, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
     feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3, rotation_lr=1e-3, percent_dense=0.01,
     densification_interval=100, densify_from_iter=500, densify_until_iter=15000, densify_grad_threshold=2e-4,
     opacity_reset_interval=3000, outlier_filtering_interval=2000, lambda_normal=0.05, lambda_dist=0.0,
     lambda_dssim=0.0, gs_learnable_bg=True, debug_cuda=False, learning_rate=5e-4, num_frames=120,
-    num_surfels=200000, seed=0, save_freq=10, data_root="database", intrinsics="", reset_steps=True)
+    num_surfels=200000, seed=0, save_freq=10, data_root="database", intrinsics="", reset_steps=True,
+    optim_warp_neus_iters=12000, allow_random_warp=False)
 
 
 def parse_flags(argv):
@@ -132,7 +133,8 @@ def main(argv=None):
     trainer = Stage3Trainer(model, opts)
     from . import checkpoint
     if opts["load_path"] and os.path.exists(opts["load_path"]):
-        info = checkpoint.load_checkpoint(opts["load_path"], model, trainer, reset_steps=opts["reset_steps"])
+        info = checkpoint.load_checkpoint(opts["load_path"], model, trainer, reset_steps=opts["reset_steps"],
+                                          allow_random_networks=opts["allow_random_warp"])
         say(f"loaded {opts['load_path']}: {model._xyz.shape[0]} surfels, step {trainer.current_steps}; "
             f"{len(info['unexpected_keys'])} checkpoint keys without a counterpart here")
     elif opts["load_path"]:

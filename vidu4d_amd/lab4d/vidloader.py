@@ -77,7 +77,7 @@ class SequenceData:
         K = K.expand(M, 4) if K.dim() == 1 else K
         Kinv = K2inv(K) @ K2mat(self.crop2raw[idx])
         dev = torch.device(device)
-        return {"frameid": torch.as_tensor(idx + frame_offset, device=dev), "Kinv": Kinv.to(dev), "H": [H] * M,
+        return {"frameid": torch.as_tensor(idx + frame_offset, device=dev), "Kinv": Kinv.cpu(), "H": [H] * M,
                 "W": [W] * M, "rgb": torch.from_numpy(rgb).to(dev), "mask": torch.from_numpy(ann[..., :1].copy()).to(dev),
                 "vis2d": torch.from_numpy(ann[..., 1:2].copy()).to(dev),
                 "is_detected": torch.as_tensor(self.is_detected[idx].astype(bool), device=dev)}
