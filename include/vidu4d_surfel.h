@@ -211,6 +211,20 @@ int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_q
                         const float* g_out_xyz, const float* g_out_rot, float* g_wT, float* g_xyz, float* g_rot,
                         void* stream);
 
+/* Skinning weights + blend + apply: replaces, on top of the above, SkinningField.forward's
+ * Gaussian-bone distances, the relu * 0.1 of the delta-skin MLP output and the softmax
+ * (lab4d/nnutils/skinning.py:89-142, lab4d/nnutils/warping.py:415-427).  Feature-major inputs: xbT (3B, N) bone
+ * coordinates x_bone / gauss, rawT (B, N) raw delta-MLP output or NULL; one evaluation of the weights serves the
+ * M <= 8 frames.  The backward writes g_xbT (3B, N), g_rawT (B, N) (NULL iff rawT is) and the gradients w.r.t. the
+ * canonical centres (N, 3) and orientations (N, 4) already summed over the frames. */
+int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
+                            const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
+                            const float* cam_t, float* out_xyz, float* out_rot, void* stream);
+int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
+                             const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
+                             const float* cam_t, const float* g_out_xyz, const float* g_out_rot, float* g_xbT,
+                             float* g_rawT, float* g_xyz, float* g_rot, void* stream);
+
 /* ---- mean squared distance of every point to its 3 nearest other points (exact): replaces
  *      simple-knn's distCUDA2 (gs/submodules/simple-knn/spatial.cu:15-25, simple_knn.cu:185-221), used
  *      once by GaussianModel.create_from_pcd (gs/scene/gaussian_model.py:134-136).  points (P,3),

@@ -385,6 +385,18 @@ def gen_warp(out_dir):
         A.update(warp_q=q, warp_t=t, xyz_cam=xyz_cam, rot_cam=rot_cam.reshape(M, N, 4), g_xyz=gx, g_rot=gr,
                  skin_entropy=holder._aux_dict["skin_entropy"], delta_skin=holder._aux_dict["delta_skin"])
 
+        # the same for the first two frames only (they share an instance code: what the frozen-network fast path,
+        # one skinning evaluation for all frames of a step, can represent)
+        xyz_l3 = xyz.clone().requires_grad_(True)
+        rot_l3 = rot.clone().requires_grad_(True)
+        s2 = {"field2cam": (cq[:2], ct[:2]), "t_articulation": (t_art[0][:2], t_art[1][:2]),
+              "rest_articulation": (rest_art[0][:2], rest_art[1][:2])}
+        xc2, rc2, _ = DeformableGaussian.forward_warp(holder, xyz_l3.reshape(1, N, 1, 3).expand(2, -1, -1, -1).contiguous(),
+                                                      rot_l3.reshape(1, N, 1, 4).expand(2, -1, -1, -1).contiguous(),
+                                                      frame_id[:2], inst_id[:2], s2, cache_aux_dict=False)
+        gx3, gr3 = torch.autograd.grad((xc2 * Gx[:2]).sum() + (rc2.reshape(2, N, 4) * Gr[:2]).sum(), (xyz_l3, rot_l3))
+        A.update(f2_xyz_cam=xc2, f2_rot_cam=rc2.reshape(2, N, 4), f2_g_xyz=gx3, f2_g_rot=gr3)
+
         # skinning field alone (forward warp: rest articulation, frame_id None)
         with torch.no_grad():
             art = (rest_art[0][:, None, None].expand(M, N, 1, -1, -1), rest_art[1][:, None, None].expand(M, N, 1, -1, -1))

@@ -75,7 +75,7 @@ def test_render_frames_fused_equals_unfused(gpu_device):
     H = W = 96
     out = {}
     for fused in (True, False):
-        m = _model(dev, seed=3, fused_warp=fused)
+        m = _model(dev, seed=3, fused_warp=fused, warp_aux=True)
         for mod in (m.warp, m.camera_mlp):
             for p in mod.parameters():
                 p.requires_grad_(False)

@@ -110,9 +110,37 @@ def test_fused_forward_warp_with_reference_weights(gpu_device):
             p.requires_grad_(False)
     fid, iid = a["frame_id"][:2], a["inst_id"][:2]
     assert m.fused_warp_ok(iid)
-    xyz_cam, rot_cam = m.forward_warp_fused(fid, iid)
-    close(xyz_cam, a["xyz_cam"][:2, :, 0], atol=1e-5)
-    close(rot_cam, a["rot_cam"][:2], atol=1e-5)
+    for fused_skin in (True, False):   # skin + blend + apply in one kernel / weights in torch, blend + apply in the kernel
+        m.opts["fused_skin"] = fused_skin
+        m._xyz.grad = m._rotation.grad = None
+        xyz_cam, rot_cam = m.forward_warp_fused(fid, iid)
+        close(xyz_cam, a["f2_xyz_cam"][:, :, 0], atol=1e-5)
+        close(rot_cam, a["f2_rot_cam"], atol=1e-5)
+        gx, gr = torch.autograd.grad((xyz_cam * a["Gx"][:2, :, 0]).sum() + (rot_cam * a["Gr"][:2]).sum(),
+                                     (m._xyz, m._rotation))
+        close(gx, a["f2_g_xyz"], rtol=5e-4, atol=5e-4)
+        close(gr, a["f2_g_rot"], rtol=2e-4, atol=2e-5)
+
+
+def test_lbs_skin_kernel_without_delta_field(gpu_device):
+    """rawT = NULL (bob-nosoft): Gaussian-bone distances only, against the torch softmax + reference-pinned blend."""
+    from vidu4d_amd.lab4d.lbs_fused import lbs_apply, lbs_skin_apply
+    a = _warp_fixture(gpu_device)
+    N, B = a["xyz"].shape[0], a["se3_r"].shape[1]
+    g = torch.Generator().manual_seed(5)
+    xbT = (torch.randn(3 * B, N, generator=g) * 1.5).to(gpu_device).requires_grad_(True)
+    xyz = a["xyz"].clone().requires_grad_(True)
+    rot = a["rot"].clone().requires_grad_(True)
+    se3 = (a["se3_r"], a["se3_d"])
+    ox, orot = lbs_skin_apply(xbT, None, se3, xyz, rot, a["cam_q"], a["cam_t"])
+    logits = -(xbT.view(B, 3, N) ** 2).sum(1).t()
+    rx, rrot = lbs_apply(logits.softmax(-1), se3, xyz, rot, a["cam_q"], a["cam_t"])
+    close(ox, rx, atol=1e-5), close(orot, rrot, atol=1e-5)
+    Gx, Gr = a["Gx"][:, :, 0], a["Gr"]
+    g1 = torch.autograd.grad((ox * Gx).sum() + (orot * Gr).sum(), (xbT, xyz, rot))
+    g2 = torch.autograd.grad((rx * Gx).sum() + (rrot * Gr).sum(), (xbT, xyz, rot))
+    for u, v in zip(g1, g2):
+        close(u, v, rtol=2e-4, atol=2e-4 * float(v.abs().max()))
 
 
 def test_kcamera_on_gpu(gpu_device):

@@ -181,6 +181,144 @@ __global__ __launch_bounds__(256) void lbs_kernel(int N, int B, const float* __r
     g_rot[4 * o + 3] = g_r.z;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Skinning weights + blend + apply in one kernel: per canonical surfel
+//   logit_b = -(|x_bone_b|^2 + 0.1 relu(raw_b))      Gaussian-bone distance + delta-skin MLP output
+//   w       = softmax_b(logit)                        (skinning.py:89-142, warping.py:415-427)
+// followed, for every frame of the step, by the blend / apply / camera transform of lbs_kernel.  In the forward
+// warp the weights do not depend on the frame, so ONE thread handles a surfel for all M frames: logits and softmax
+// are evaluated once, and the backward accumulates the weight gradients of the frames in registers before it
+// goes back through the softmax.  Inputs are feature-major -- xbT (3B, N) bone coordinates, rawT (B, N) raw MLP
+// output (or NULL: no delta field) -- so that every load of a wave is coalesced; these are exactly the layouts
+// the feature-major GEMMs of the delta MLP produce and consume (lab4d/lbs_fused.py).
+constexpr int MAX_FRAMES = 8;
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
+                                                       const float* __restrict__ rawT,
+                                                       const float* __restrict__ se3_qr,
+                                                       const float* __restrict__ se3_qd,
+                                                       const float* __restrict__ xyz, const float* __restrict__ rot,
+                                                       const float* __restrict__ cam_q,
+                                                       const float* __restrict__ cam_t, float* __restrict__ out_xyz,
+                                                       float* __restrict__ out_rot,
+                                                       const float* __restrict__ g_out_xyz,
+                                                       const float* __restrict__ g_out_rot,
+                                                       float* __restrict__ g_xbT, float* __restrict__ g_rawT,
+                                                       float* __restrict__ g_xyz, float* __restrict__ g_rot)
+{
+    __shared__ float s_q[MAX_FRAMES][2 * MAX_BONES * 4];
+    __shared__ unsigned long long s_sign[MAX_FRAMES][MAX_BONES];
+    for (int m = 0; m < M; m++) stage_frame(se3_qr, se3_qd, m, B, s_q[m], s_sign[m]);
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+
+    float w[MAX_BONES];
+    int anchor = 0;
+    float best = -3.0e38f;
+#pragma unroll 5
+    for (int b = 0; b < B; b++) {
+        const float x0 = xbT[(size_t)(3 * b) * N + n], x1 = xbT[(size_t)(3 * b + 1) * N + n],
+                    x2 = xbT[(size_t)(3 * b + 2) * N + n];
+        const float raw = rawT ? rawT[(size_t)b * N + n] : 0.f;
+        w[b] = -((x0 * x0 + x1 * x1 + x2 * x2) + 0.1f * fmaxf(raw, 0.f));
+        if (w[b] > best) {  // first maximum, like torch.argmax (the softmax keeps the order)
+            best = w[b];
+            anchor = b;
+        }
+    }
+    float sum = 0.f;
+    for (int b = 0; b < B; b++) {
+        w[b] = __expf(w[b] - best);
+        sum += w[b];
+    }
+    const float isum = 1.0f / sum;
+    for (int b = 0; b < B; b++) w[b] *= isum;
+
+    const Q p = qvec(xyz[3 * n], xyz[3 * n + 1], xyz[3 * n + 2]);
+    const Q r = ldq(rot + 4 * n);
+    float gw[MAX_BONES];
+    Q acc_p = {0, 0, 0, 0}, acc_r = {0, 0, 0, 0};
+    if (BACKWARD)
+        for (int b = 0; b < B; b++) gw[b] = 0.f;
+
+    for (int m = 0; m < M; m++) {
+        const float* sq = s_q[m];
+        const unsigned long long hemi = s_sign[m][anchor];
+        Q Qr = {0, 0, 0, 0}, Qd = {0, 0, 0, 0};
+        for (int b = 0; b < B; b++) {
+            const float ws = ((hemi >> b) & 1ull) ? w[b] : -w[b];
+            Qr = qadd(Qr, qscale(ldq(sq + b * 4), ws));
+            Qd = qadd(Qd, qscale(ldq(sq + MAX_BONES * 4 + b * 4), ws));
+        }
+        const float inv = 1.0f / sqrtf(qdot(Qr, Qr));
+        const Q q = qscale(Qr, inv), d = qscale(Qd, inv);
+        const Q tq = qscale(qmul(d, qconj(q)), 2.0f);
+        Q p1, px;
+        rotate(q, p, p1, px);
+        const Q xt = qvec(px.x + tq.x, px.y + tq.y, px.z + tq.z);
+        const Q rt = qmul(q, r);
+        const Q cq = ldq(cam_q + 4 * m);
+        const float* ct = cam_t + 3 * m;
+        Q c1, cx;
+        rotate(cq, xt, c1, cx);
+        const size_t o = (size_t)m * N + n;
+        if (!BACKWARD) {
+            out_xyz[3 * o] = cx.x + ct[0];
+            out_xyz[3 * o + 1] = cx.y + ct[1];
+            out_xyz[3 * o + 2] = cx.z + ct[2];
+            const Q rc = qmul(cq, rt);
+            out_rot[4 * o] = rc.w;
+            out_rot[4 * o + 1] = rc.x;
+            out_rot[4 * o + 2] = rc.y;
+            out_rot[4 * o + 3] = rc.z;
+            continue;
+        }
+        const Q g_xc = qvec(g_out_xyz[3 * o], g_out_xyz[3 * o + 1], g_out_xyz[3 * o + 2]);
+        const Q g_rc = ldq(g_out_rot + 4 * o);
+        Q g_cq_unused, g_xt;
+        rotate_bwd(cq, xt, c1, g_xc, g_cq_unused, g_xt);
+        g_xt.w = 0.f;
+        const Q g_rt = qmul(qconj(cq), g_rc);
+        Q g_q, g_p;
+        rotate_bwd(q, p, p1, g_xt, g_q, g_p);
+        g_q = qadd(g_q, qmul(g_rt, qconj(r)));
+        acc_r = qadd(acc_r, qmul(qconj(q), g_rt));
+        acc_p = qadd(acc_p, g_p);
+        const Q g_tq = qscale(g_xt, 2.0f);
+        const Q g_d = qmul(g_tq, q);
+        g_q = qadd(g_q, qconj(qmul(qconj(d), g_tq)));
+        const float gq_q = qdot(g_q, q), gd_d = qdot(g_d, d);
+        const Q g_Qr = qscale(qadd(g_q, qscale(q, -(gq_q + gd_d))), inv);
+        const Q g_Qd = qscale(g_d, inv);
+        for (int b = 0; b < B; b++) {
+            const float sgn = ((hemi >> b) & 1ull) ? 1.0f : -1.0f;
+            gw[b] += sgn * (qdot(g_Qr, ldq(sq + b * 4)) + qdot(g_Qd, ldq(sq + MAX_BONES * 4 + b * 4)));
+        }
+    }
+    if (!BACKWARD) return;
+    // back through the softmax and the logits
+    float dot = 0.f;
+    for (int b = 0; b < B; b++) dot += w[b] * gw[b];
+#pragma unroll 5
+    for (int b = 0; b < B; b++) {
+        const float g_logit = w[b] * (gw[b] - dot);
+        const float x0 = xbT[(size_t)(3 * b) * N + n], x1 = xbT[(size_t)(3 * b + 1) * N + n],
+                    x2 = xbT[(size_t)(3 * b + 2) * N + n];
+        g_xbT[(size_t)(3 * b) * N + n] = -2.0f * x0 * g_logit;
+        g_xbT[(size_t)(3 * b + 1) * N + n] = -2.0f * x1 * g_logit;
+        g_xbT[(size_t)(3 * b + 2) * N + n] = -2.0f * x2 * g_logit;
+        if (g_rawT) g_rawT[(size_t)b * N + n] = (rawT[(size_t)b * N + n] > 0.f) ? -0.1f * g_logit : 0.f;
+    }
+    g_xyz[3 * n] = acc_p.x;
+    g_xyz[3 * n + 1] = acc_p.y;
+    g_xyz[3 * n + 2] = acc_p.z;
+    g_rot[4 * n] = acc_r.w;
+    g_rot[4 * n + 1] = acc_r.x;
+    g_rot[4 * n + 2] = acc_r.y;
+    g_rot[4 * n + 3] = acc_r.z;
+}
+
 int check(int M, int N, int B)
 {
     if (M < 0 || N < 0 || B <= 0 || B > MAX_BONES) return VIDU4D_E_INVALID;
@@ -215,5 +353,37 @@ extern "C" int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const f
     (void)hipGetLastError();
     hipLaunchKernelGGL(lbs_kernel<true>, dim3((N + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, N, B, wT, se3_qr,
                        se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot, g_wT, g_xyz, g_rot);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}
+
+extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
+                                       const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
+                                       const float* cam_t, float* out_xyz, float* out_rot, void* stream)
+{
+    if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
+    if (M == 0 || N == 0) return VIDU4D_OK;
+    if (!xbT || !se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !out_xyz || !out_rot) return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(lbs_skin_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B, xbT, rawT,
+                       se3_qr, se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}
+
+extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
+                                        const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
+                                        const float* cam_t, const float* g_out_xyz, const float* g_out_rot,
+                                        float* g_xbT /*(3B,N)*/, float* g_rawT /*(B,N) or NULL*/, float* g_xyz /*(N,3)*/,
+                                        float* g_rot /*(N,4)*/, void* stream)
+{
+    if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
+    if (M == 0 || N == 0) return VIDU4D_OK;
+    if (!xbT || !se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !g_out_xyz || !g_out_rot || !g_xbT || !g_xyz ||
+        !g_rot || (rawT && !g_rawT))
+        return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B, xbT, rawT,
+                       se3_qr, se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot, g_xbT, g_rawT, g_xyz,
+                       g_rot);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }

@@ -70,6 +70,27 @@ class SkinningField(nn.Module):
         R, t = bone_frames if bone_frames is not None else self.bone_frames(bone2obj)
         return (torch.einsum("mbij,mnj->mnbi", R, xyz) + t[:, None]) / self.get_gauss()
 
+    def bone_affine(self, bone2obj):
+        """x_bone / gauss as ONE affine map of the canonical point for a single articulation ((1,B,4),(1,B,4)):
+        returns A (3B,3) and c (3B,) with x_boneT = A @ xyz^T + c[:, None]  (feature-major, row 3b + k)."""
+        R, t = self.bone_frames(bone2obj)
+        ig = 1.0 / self.get_gauss()                                  # (B,3)
+        A = (R[0] * ig[:, :, None]).reshape(-1, 3)
+        return A, (t[0] * ig).reshape(-1)
+
+    def delta_raw_T(self, xbT, frame_bias):
+        """Raw delta-skin MLP output in feature-major layout: xbT (3B,N) -> (B,N).  Same weights and arithmetic as
+        `forward` (first layer split into its coordinate columns and the per-frame bias), written as W @ X so that
+        the (B,N) result is what csrc/lbs.hip reads with coalesced loads."""
+        mlp = self.delta_field
+        assert self.num_freq_xyz == 0 and not any(0 < s < mlp.D for s in mlp.skips)
+        lin = mlp.linear_1[0]
+        h = F.relu(torch.addmm(frame_bias.reshape(-1, 1), lin.weight[:, :self.xyz_channels], xbT))
+        for i in range(1, mlp.D):
+            li = getattr(mlp, f"linear_{i + 1}")[0]
+            h = F.relu(torch.addmm(li.bias[:, None], li.weight, h))
+        return torch.addmm(mlp.linear_final.bias[:, None], mlp.linear_final.weight, h)
+
     def frame_bias(self, frame_id, inst_id, M, device):
         """(M or 1, W): the first layer applied to the per-frame part of its input (time code | instance code)."""
         te = self.time_embedding

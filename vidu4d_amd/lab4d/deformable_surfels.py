@@ -16,7 +16,7 @@ from ..gs.gaussian_model import GaussianModel
 from ..gs.gaussian_renderer import GEOMETRY_KEYS, render
 from . import quat_transform as qt
 from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss
-from .lbs_fused import lbs_apply
+from .lbs_fused import lbs_apply, lbs_skin_apply
 from .nets import CameraMLP, make_frame_info
 
 
@@ -173,7 +173,7 @@ class DeformableSurfels(GaussianModel):
         return inst_id is None or len(set(inst_id.tolist())) == 1
 
     def _frozen_warp_table(self):
-        params = [p for mod in (self.warp.articulation, self.camera_mlp) for p in mod.parameters()]
+        params = [p for mod in (self.warp, self.camera_mlp) for p in mod.parameters()]
         version = sum(p._version for p in params)
         tab = self.__dict__.get("_warp_table")
         if tab is None or tab["version"] != version:
@@ -183,8 +183,12 @@ class DeformableSurfels(GaussianModel):
                 se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
                 cq, ct = self.camera_mlp.get_vals(ids)
                 rest1 = (rest_art[0][:1].contiguous(), rest_art[1][:1].contiguous())
+                sm = self.warp.skinning_model
+                A, c0 = sm.bone_affine(rest1)
                 tab = {"version": version, "se3_qr": se3[0].contiguous(), "se3_qd": se3[1].contiguous(),
-                       "rest1": rest1, "bone_frames": self.warp.skinning_model.bone_frames(rest1),
+                       "rest1": rest1, "bone_frames": sm.bone_frames(rest1), "bone_A": A.contiguous(),
+                       "bone_c": c0.contiguous(),
+                       "frame_bias": sm.frame_bias(None, None, 1, ids.device) if sm.has_delta else None,
                        "cam_q": cq.contiguous(), "cam_t": ct.contiguous()}
             self.__dict__["_warp_table"] = tab
         return tab
@@ -212,15 +216,38 @@ class DeformableSurfels(GaussianModel):
             se3 = (tab["se3_qr"][frame_id], tab["se3_qd"][frame_id])
             rest1 = tab["rest1"]
             cq, ct = tab["cam_q"][frame_id], tab["cam_t"][frame_id]
-        frames = None if overrides else tab["bone_frames"]
-        skin, delta = w.skinning_model(self._xyz[None], rest1, None, None if inst_id is None else inst_id[:1],
-                                       bone_frames=frames)
-        xyz_cam, rot_cam = lbs_apply(skin[0].softmax(-1), se3, self._xyz, self._rotation, cq, ct)
+        sm = w.skinning_model
         M = frame_id.shape[0]
-        aux = {"skin_entropy": cross_entropy_skin_loss(skin)[..., None, None].expand(M, -1, -1, -1)}  # (M,N,1,1)
-        if delta is not None:
-            aux["delta_skin"] = delta.pow(2).mean(-1, keepdim=True)[..., None, :].expand(M, -1, -1, -1)
-        self._aux_dict = aux
+        iid = None if inst_id is None else inst_id[:1]
+        if overrides:
+            A, c0 = sm.bone_affine(rest1)
+            bias = sm.frame_bias(None, iid, 1, self._xyz.device) if sm.has_delta else None
+        else:
+            A, c0, bias = tab["bone_A"], tab["bone_c"], tab["frame_bias"]   # (bias: mean instance code)
+            if sm.has_delta and iid is not None:
+                bias = sm.frame_bias(None, iid, 1, self._xyz.device)
+        if M <= 8 and self.opts.get("fused_skin", True) and (not sm.has_delta or sm.num_freq_xyz == 0):
+            # bone coordinates and the delta MLP as feature-major GEMMs (4 library calls), everything else -- distances,
+            # relu * 0.1, softmax, blend, apply, camera, for all frames -- in one HIP kernel per direction
+            xbT = torch.addmm(c0[:, None], A, self._xyz.t())
+            rawT = sm.delta_raw_T(xbT, bias[0]) if sm.has_delta else None
+            xyz_cam, rot_cam = lbs_skin_apply(xbT, rawT, se3, self._xyz, self._rotation, cq, ct)
+            skin = delta = None
+        else:
+            frames = None if overrides else tab["bone_frames"]
+            skin, delta = sm(self._xyz[None], rest1, None, iid, bone_frames=frames)
+            xyz_cam, rot_cam = lbs_apply(skin[0].softmax(-1), se3, self._xyz, self._rotation, cq, ct)
+        # The warp's auxiliary terms (skin entropy, delta-skin magnitude) only feed regularisers that
+        # --rgb_loss_only drops (trainer.py:477-483): evaluated on request
+        if self.opts.get("warp_aux", False):
+            if skin is None:
+                skin, delta = sm(self._xyz[None], rest1, None, iid, bone_frames=None if overrides else tab["bone_frames"])
+            aux = {"skin_entropy": cross_entropy_skin_loss(skin)[..., None, None].expand(M, -1, -1, -1)}  # (M,N,1,1)
+            if delta is not None:
+                aux["delta_skin"] = delta.pow(2).mean(-1, keepdim=True)[..., None, :].expand(M, -1, -1, -1)
+            self._aux_dict = aux
+        else:
+            self._aux_dict = {}
         return xyz_cam, rot_cam
 
     def _frame_streams(self, M):
