@@ -25,7 +25,7 @@ warp + raster + losses + backward + clip + densify statistics + Adam) at the sam
 
 Extra objects on the JSON line: "roofline" (dominant kernel: algorithmic bytes per launch /
 its average launch duration, measured with HIP events on the launch stream over extra steps of
-the same workload right after the timed region, frames serialised -- under the timed region's
+the same workload (run before the warm-up and the timed region), frames serialised -- under the timed region's
 two-stream overlap an event pair does not measure a launch duration) and "cpu_baseline" (the CPU
 oracle timed on this box's host cores, rank 0, N = 1 only).
 """
@@ -340,6 +340,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # ---- Per-kernel launch durations for the roofline: HIP events on the launch stream around every stage
+    # (vidu4d_surfel_profile_*), over steps of the same workload run BEFORE the warm-up and the timed region, with
+    # the frames of a step queued one after the other.  In the timed region two frames overlap on two streams, and an event
+    # pair around a kernel then measures that kernel sharing the GPU with another frame's kernels -- not
+    # a launch duration (rocprofv3's kernel trace, which serialises, would not agree with it either).
+    if not args.no_stage_timers:
+        mode["streams"] = False
+        for _ in range(3):  # (capacity hints settle, allocator pools fill)
+            step()
+        sync()
+        _lib.profile_read(reset=True)
+        _lib.profile_enable(True)
+        for _ in range(min(args.steps, 20)):
+            step()
+        sync()
+        _lib.profile_enable(False)
+        mode["streams"] = bool(args.frame_streams)
     for _ in range(args.warmup):
         step()
     sync()
@@ -356,20 +373,6 @@ def main():
             step()
         sync()
         rep_rates.append(world * args.steps * FRAMES_PER_STEP / (time.perf_counter() - r0))
-    # Per-kernel launch durations for the roofline: HIP events on the launch stream around every stage
-    # (vidu4d_surfel_profile_*), over further steps of the same workload with the frames of a step queued
-    # one after the other.  In the timed region above two frames overlap on two streams, and an event
-    # pair around a kernel then measures that kernel sharing the GPU with another frame's kernels -- not
-    # a launch duration (rocprofv3's kernel trace, which serialises, would not agree with it either).
-    if not args.no_stage_timers:
-        mode["streams"] = False
-        _lib.profile_read(reset=True)
-        _lib.profile_enable(True)
-        for _ in range(min(args.steps, 20)):
-            step()
-        sync()
-        _lib.profile_enable(False)
-        mode["streams"] = bool(args.frame_streams)
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -439,8 +442,8 @@ def main():
             out["roofline"] = {"bound": limiter.get("bound", "hbm"), "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "limiter": limiter,
                                "avg_launch_ms": stages[dom]["ms_avg"],
-                               "timing": "HIP events on the launch stream, %d extra steps after the timed region with "
-                                         "the frames of a step serialised on one stream" % min(args.steps, 20),
+                               "timing": "HIP events on the launch stream, %d extra steps before the warm-up / timed region "
+                                         "with the frames of a step serialised on one stream" % min(args.steps, 20),
                                "algorithmic_bytes_per_launch": stage_bytes(dom, N, R, W * H, T, K)}
         if world == 1 and args.fit_steps > 0:
             out["fit_step"] = fit_step_rate(dev, N, W, H, args.fit_steps)

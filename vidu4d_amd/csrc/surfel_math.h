@@ -474,6 +474,11 @@ SURFEL_HD bool eval_pair_flat(const float Tu[3], const float Tv[3], const float 
 // projected centre so that fp32 cancellation stays far below the safety margin.  If that conic is
 // not an ellipse in front of the camera plane the box is unbounded.  Margin: 1 px + 0.2 %.
 // This only prunes work: pixels inside the box still run the exact per-pixel test.
+#ifndef SURFEL_BOX_MARGIN_PX
+#define SURFEL_BOX_MARGIN_PX 0.02f
+#endif
+constexpr float BOX_MARGIN_PX = SURFEL_BOX_MARGIN_PX;
+
 SURFEL_HD void contribution_box(const float T[9], float cx, float cy, float opacity, float box[4])
 {
     const float BIG = 3.0e38f;
@@ -511,7 +516,7 @@ SURFEL_HD void contribution_box(const float T[9], float cx, float cy, float opac
         x0 = y0 = -BIG;
         x1 = y1 = BIG;
     }
-    const float mx = 1.0f + 2e-3f * (x1 - x0), my = 1.0f + 2e-3f * (y1 - y0);
+    const float mx = BOX_MARGIN_PX + 2e-3f * (x1 - x0), my = BOX_MARGIN_PX + 2e-3f * (y1 - y0);
     box[0] = x0 - mx;
     box[1] = y0 - my;
     box[2] = x1 + mx;
