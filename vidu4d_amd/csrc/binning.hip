@@ -375,26 +375,31 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
 // <4, true>: 4 wave64, lists up to TILE_SORT_CAP are sorted inside LDS, longer ones ping-pong through
 // global memory (unless `skip_long`: then the <16, false> launch takes them -- 16 wave64 per tile,
 // global ping-pong only; the long tiles are the first positions of the longest-first schedule).
-template <int WAVES, bool IN_LDS>
+// CAP: list length the LDS ping-pong holds.  Two in-LDS launches share the tiles by length: <4, true, 1024>
+// (16 KiB + counters: 8 workgroups per CU, all 1024 tiles of a 512^2 frame resident at once) takes the lists up
+// to 1024 entries, <4, true, TILE_SORT_CAP> (56 KiB: 2 per CU) the longer ones; a workgroup whose tile belongs
+// to the other launch exits at once.  (One launch with the large buffers ran the typical 600-entry lists of
+// the headline scene in two rounds of 512 workgroups: 42 us instead of 25.)
+template <int WAVES, bool IN_LDS, int CAP>
 __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
                                                               const uint32_t* __restrict__ ranges,
                                                               const uint32_t* num_ptr, int64_t capacity,
                                                               uint64_t* entries, uint64_t* scratch,
                                                               uint32_t* __restrict__ point_list, int id_bytes,
-                                                              int skip_long)
+                                                              int skip_long, int min_len)
 {
     constexpr int THREADS = WAVES * 64;
-    __shared__ uint64_t s_buf[IN_LDS ? 2 : 1][IN_LDS ? TILE_SORT_CAP : 1];
+    __shared__ uint64_t s_buf[IN_LDS ? 2 : 1][IN_LDS ? CAP : 1];
     __shared__ uint32_t s_cnt[WAVES][256];  // per-wave digit counts, then per-wave destination cursors
     __shared__ uint32_t s_scan[16];
     if ((int64_t)*num_ptr > capacity) return;
     const uint32_t tile = tile_order[blockIdx.x];  // longest list first
     const uint32_t start = ranges[2 * tile];
     const int n = (int)(ranges[2 * tile + 1] - start);
-    if (n == 0) return;
-    if (IN_LDS ? (skip_long && n > TILE_SORT_CAP) : n <= TILE_SORT_CAP) return;
+    if (n == 0 || n < min_len) return;
+    if (IN_LDS ? ((skip_long || CAP < TILE_SORT_CAP) && n > CAP) : n <= TILE_SORT_CAP) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool in_lds = IN_LDS && n <= TILE_SORT_CAP;
+    const bool in_lds = IN_LDS && n <= CAP;
     uint64_t* A;
     uint64_t* B;
     if (in_lds) {
@@ -473,11 +478,15 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
     if (long_pass) {
         // the long tiles lead the schedule, but it is sorted by length CLASS only (a long tile may sit behind
         // shorter ones of its class), so every position gets a workgroup; the short ones exit at once
-        hipLaunchKernelGGL((tile_sort_kernel<16, false>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order,
-                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0);
+        hipLaunchKernelGGL((tile_sort_kernel<16, false, 1>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order,
+                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0, 0);
     }
-    hipLaunchKernelGGL((tile_sort_kernel<4, true>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order, img.ranges,
-                       &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, long_pass ? 1 : 0);
+    constexpr int SMALL_CAP = 1024;
+    hipLaunchKernelGGL((tile_sort_kernel<4, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
+                       img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes,
+                       long_pass ? 1 : 0, SMALL_CAP + 1);
+    hipLaunchKernelGGL((tile_sort_kernel<4, true, SMALL_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
+                       img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 1, 0);
 }
 
 }  // namespace surfel
