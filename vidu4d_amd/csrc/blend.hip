@@ -651,14 +651,18 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
                 const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) &&
                                 contributor < s.last_contributor;  // (outside pixels have last_contributor 0)
                 if (!__any(ok)) continue;
-                float g[ACC_FLOATS];
-#pragma unroll
-                for (int i = 0; i < ACC_FLOATS; i++) g[i] = 0.f;
+                // recurrences under the lane mask; the gradient products for every lane (zeros where !ok: no
+                // register zeroing, no second divergent region)
+                PairGrad pg;
+                pg.w = pg.dL_dalpha = pg.dL_dz = 0.f;
                 if (ok) {
                     const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                     const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                    bwd_pair(s, e, Tw, q2.w, nrm, rgb, pixx, pixy, contributor + 1 == s.median_contributor, g);
+                    pg = bwd_pair_core(s, e, nrm, rgb, contributor + 1 == s.median_contributor);
                 }
+                e.sanitise(ok);
+                float g[ACC_FLOATS];
+                bwd_pair_geometry(s, e, pg, Tw, q2.w, pixx, pixy, g);
                 float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
                                g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
                 const float r16 = wave_reduce_scatter16(v, lane);

@@ -371,6 +371,17 @@ struct PairEval {
     float dx, dy;
     float rho3d, rho2d;
     float depth, G, alpha;
+    // a pair that failed the tests may hold inf / NaN here (pz == 0, rho = NaN): make the factors the gradient
+    // products use finite, so that zero recurrence outputs give zero contributions
+    SURFEL_HD void sanitise(bool ok)
+    {
+        sx = ok ? sx : 0.f;
+        sy = ok ? sy : 0.f;
+        ipz = ok ? ipz : 0.f;
+        G = ok ? G : 0.f;
+        rho3d = ok ? rho3d : 0.f;  // (takes the homography branch, whose entries are all products with the above)
+        rho2d = ok ? rho2d : 1.f;
+    }
 };
 
 SURFEL_HD float fast_exp(float x)
@@ -637,15 +648,17 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
     return r;
 }
 
-// Gradient contributions of one (pixel, surfel) pair, in AccSlot order (backward.cu:325-446).
-SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float opacity, const float normal[3],
-                        const float rgb[3], float pixx, float pixy, bool is_median, float g[ACC_FLOATS])
+// Gradient contributions of one (pixel, surfel) pair, in AccSlot order (backward.cu:325-446), from the pair's
+// recurrence outputs `pg`.  Every entry is linear in (pg.w, pg.dL_dalpha, pg.dL_dz): a pair that does not
+// contribute passes pg = 0 and `e` with finite sx, sy, ipz, G (PairEval::sanitise) and gets exact zeros without
+// a branch.  The six dL/dTu, dL/dTv sums are accumulated with the OPPOSITE sign (+dk, +dl: the negations are
+// seven VALU instructions per pair); surfel_backward flips them back (exact).
+SURFEL_HD void bwd_pair_geometry(const BwdPixel& s, const PairEval& e, const PairGrad& pg, const float Tw[3],
+                                 float opacity, float pixx, float pixy, float g[ACC_FLOATS])
 {
-    const float dLdpix[3] = {s.dL_dpixel[0], s.dL_dpixel[1], s.dL_dpixel[2]};
-    const PairGrad pg = bwd_pair_core(s, e, normal, rgb, is_median);
     const float G = e.G, dL_dz = pg.dL_dz;
     for (int ch = 0; ch < 3; ch++) {
-        g[A_RGB + ch] = pg.w * dLdpix[ch];
+        g[A_RGB + ch] = pg.w * s.dL_dpixel[ch];
         g[A_NRM + ch] = pg.w * s.dL_dnormal2D[ch];
     }
     const float dL_dG = opacity * pg.dL_dalpha;  // straight-through the 0.99 clamp (backward.cu:400)
@@ -660,12 +673,12 @@ SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float
         // dL_dk = l x dL_dp ; dL_dl = dL_dp x k
         const float dkx = e.ly * dpz - e.lz * dpy, dky = e.lz * dpx - e.lx * dpz, dkz = e.lx * dpy - e.ly * dpx;
         const float dlx = dpy * e.kz - dpz * e.ky, dly = dpz * e.kx - dpx * e.kz, dlz = dpx * e.ky - dpy * e.kx;
-        g[A_T + 0] = -dkx;
-        g[A_T + 1] = -dky;
-        g[A_T + 2] = -dkz;
-        g[A_T + 3] = -dlx;
-        g[A_T + 4] = -dly;
-        g[A_T + 5] = -dlz;
+        g[A_T + 0] = dkx;  // (sign: see above)
+        g[A_T + 1] = dky;
+        g[A_T + 2] = dkz;
+        g[A_T + 3] = dlx;
+        g[A_T + 4] = dly;
+        g[A_T + 5] = dlz;
         g[A_T + 6] = pixx * dkx + pixy * dlx + dL_dz * e.sx;
         g[A_T + 7] = pixx * dky + pixy * dly + dL_dz * e.sy;
         g[A_T + 8] = pixx * dkz + pixy * dlz + dL_dz;
@@ -677,6 +690,13 @@ SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float
         g[A_M2D + 0] = dL_dG * (-G * 2.0f * e.dx);
         g[A_M2D + 1] = dL_dG * (-G * 2.0f * e.dy);
     }
+}
+
+SURFEL_HD void bwd_pair(BwdPixel& s, const PairEval& e, const float Tw[3], float opacity, const float normal[3],
+                        const float rgb[3], float pixx, float pixy, bool is_median, float g[ACC_FLOATS])
+{
+    const PairGrad pg = bwd_pair_core(s, e, normal, rgb, is_median);
+    bwd_pair_geometry(s, e, pg, Tw, opacity, pixx, pixy, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -712,8 +732,8 @@ SURFEL_HD void surfel_backward(const Camera& cam, const float p_world[3], const 
     const float dL_dd = (df[0] * f[0] + df[1] * f[1] + df[2] * f[2]) * (-1.0f / d);
     for (int c = 0; c < 3; c++) dT3[c] += dL_dd * (sgn[c] * T3[c] * 2.0f);
     for (int c = 0; c < 3; c++) {
-        o.dT[c] = acc[A_T + c] + dT0[c];
-        o.dT[3 + c] = acc[A_T + 3 + c] + dT1[c];
+        o.dT[c] = dT0[c] - acc[A_T + c];  // (the blend kernel accumulates these six with the opposite sign)
+        o.dT[3 + c] = dT1[c] - acc[A_T + 3 + c];
         o.dT[6 + c] = acc[A_T + 6 + c] + dT3[c];
     }
     const float z = T[8];
