@@ -200,7 +200,7 @@ def install_environment():
     sys.modules["lab4d"] = pkg
     # ---- reference modules whose import graph is irrelevant to the functions called below
     for name in ("lab4d.nnutils.multifields", "lab4d.nnutils.intrinsics", "lab4d.engine.train_utils",
-                 "lab4d.utils.render_utils", "lab4d.nnutils.util", "lab4d.utils.numpy_utils", "preprocess",
+                 "lab4d.utils.render_utils", "lab4d.nnutils.util", "preprocess",
                  "preprocess.scripts", "lab4d.nnutils.appearance", "lab4d.nnutils.visibility",
                  "lab4d.utils.decorator", "gs.arguments", "gs.scene.dataset_readers", "gs.utils.camera_utils",
                  "lab4d.utils.vis_utils", "lab4d.engine.trainer", "lab4d.engine.trainer_ddp", "lab4d.export",
@@ -691,6 +691,34 @@ def gen_losses(out_dir):
     npz(os.path.join(out_dir, "refpy_losses.npz"), **out)
 
 
+def gen_vidloader(out_dir):
+    """lab4d/dataloader/vidloader.py:48-372 (VidDataset) and data_utils.py:13-31, :151-334 (FrameInfo,
+    section_to_dataset / load_config, get_data_info, load_small_files) reading the tiny sequence that
+    tests/golden/dataset_fixture.py writes."""
+    import configparser
+    import importlib.util
+    import tempfile
+    import types
+    spec = importlib.util.spec_from_file_location("dataset_fixture", os.path.join(HERE, "dataset_fixture.py"))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    from lab4d.dataloader import data_utils
+    from lab4d.dataloader.vidloader import VidDataset
+    with tempfile.TemporaryDirectory() as root:
+        cfg_path = fx.write_dataset(root, seed=0)
+        config = configparser.RawConfigParser()
+        config.read(cfg_path)
+        opts = dict(fx.OPTS, dataset_constructor=VidDataset)
+        datasets = [data_utils.section_to_dataset(opts, config, v) for v in range(len(fx.VIDEOS))]
+
+        def info(dss):
+            loader = types.SimpleNamespace(dataset=types.SimpleNamespace(datasets=dss))
+            return data_utils.get_data_info(loader)[0]
+        arrays = fx.collect(datasets, info)
+    npz(os.path.join(out_dir, "refpy_vidloader.npz"), **arrays)
+    print("vidloader:", len(arrays), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
@@ -702,7 +730,7 @@ def main():
     dsr = install_environment()
     import torch
     torch.set_num_threads(1)  # bit-reproducible reductions
-    todo = args.only.split(",") if args.only else ["quat", "warp", "camera", "render", "densify", "losses"]
+    todo = args.only.split(",") if args.only else ["quat", "warp", "camera", "render", "densify", "losses", "vidloader"]
     if "quat" in todo:
         gen_quat(args.out)
     if "warp" in todo:
@@ -714,6 +742,8 @@ def main():
         gen_densify(args.out)
     if "losses" in todo:
         gen_losses(args.out)
+    if "vidloader" in todo:
+        gen_vidloader(args.out)
     print("stubbed third-party modules:", sorted(set(n.split(".")[0] for n in _FallbackStubFinder.stubbed)))
 
 

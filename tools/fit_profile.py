@@ -23,6 +23,8 @@ t0 = time.perf_counter(); K = 10
 for i in range(K): tr.train_step(batches[i % 4])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 print(f"FIT_STEP 200k/512^2 radius {RADIUS}, 2 frames/step: {dt*1e3:.2f} ms/step = {2/dt:.1f} images/s")
+if os.environ.get("FIT_NO_TORCH_PROF", "0") == "1":
+    sys.exit(0)
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for i in range(3): tr.train_step(batches[i % 4])
     torch.cuda.synchronize()

@@ -33,7 +33,10 @@
 namespace surfel {
 
 constexpr int FWD_BATCH = 256;  // list entries staged per round (one per thread)
-constexpr int BWD_BATCH = 128;
+#ifndef SURFEL_BWD_BATCH
+#define SURFEL_BWD_BATCH 128
+#endif
+constexpr int BWD_BATCH = SURFEL_BWD_BATCH;
 
 struct TileCoord {
     int tile, tx, ty;

@@ -8,6 +8,7 @@ Out of scope here (auxiliary losses dropped by --rgb_loss_only, trainer.py:477-4
 feature matching / reprojection, flow rendering, bone-density visualisation."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -65,6 +66,9 @@ class DeformableSurfels(GaussianModel):
         if synthetic_cam:  # no camera prior: every frame looks at the object from 3 units away
             rtmat = torch.eye(4).repeat(int(self.frame_offset_raw[-1]), 1, 1)
             rtmat[:, 2, 3] = 3.0
+        else:  # dataset cameras: translations enter at the field's scale (deformable_gaussian.py:93, :123)
+            rtmat = torch.as_tensor(np.asarray(rtmat), dtype=torch.float32).clone()
+            rtmat[..., :3, 3] *= float(opts.get("init_scale", 0.1))
         self.camera_mlp = CameraMLP(rtmat, frame_info=frame_info)
         if synthetic_cam:
             self.camera_mlp.base_init()

@@ -11,9 +11,10 @@ rounds of `iters_per_round` steps with a `%03d-fg-gs.ply` export per round, mult
 What runs here is the Stage-3 hot path only: surfels initialised from `--gs_init_mesh` (or a
 synthetic proxy when the file is absent), the bob warp, the MI355X rasterizer, the surfel optimizer
 and densify cadence, frame-parallel over the ranks torchrun starts, `ckpt_%04d.pth` / `ckpt_latest.pth`
-every `--save_freq` rounds and `--load_path` in the reference's layout (checkpoint.py).  Frames come
-from `<data_root>/processed/...` (vidloader.py) when `--intrinsics fx,fy,cx,cy` is given and the
-sequence is there; otherwise the targets are synthetic frames and the run says so.  Stage-2 and
+every `--save_freq` rounds and `--load_path` in the reference's layout (checkpoint.py).  Frames, intrinsics,
+frame offsets and the camera prior come from `<data_root>/configs/<seqname>.config` + `<data_root>/processed/...`
+(vidloader.py, the reference's layout) when they exist, else from one video given `--intrinsics fx,fy,cx,cy`;
+otherwise the targets are synthetic frames and the run says so.  Stage-2 and
 evaluation are outside this build.  Flags of the reference that do not concern this path are
 accepted and listed as ignored, so the reference's command lines keep working."""
 from __future__ import annotations
@@ -35,7 +36,8 @@ STAGE3_FLAGS = dict(
     opacity_reset_interval=3000, outlier_filtering_interval=2000, lambda_normal=0.05, lambda_dist=0.0,
     lambda_dssim=0.0, gs_learnable_bg=True, debug_cuda=False, learning_rate=5e-4, num_frames=120,
     num_surfels=200000, seed=0, save_freq=10, data_root="database", intrinsics="", reset_steps=True,
-    optim_warp_neus_iters=12000, allow_random_warp=False)
+    optim_warp_neus_iters=12000, allow_random_warp=False, feature_type="dinov2", delta_list="2,4,8",
+    init_scale=0.1)
 
 
 def parse_flags(argv):
@@ -128,7 +130,27 @@ def main(argv=None):
         d = rng.normal(size=(n, 3)).astype(np.float32)
         pts = 0.25 * d / np.linalg.norm(d, axis=1, keepdims=True)
         say(f"--gs_init_mesh not found: initialising {n} surfels on a synthetic proxy sphere")
-    model = DeformableSurfels(opts, num_frames=opts["num_frames"], device=dev)
+    # ---- data: the reference's database/configs/<seqname>.config + database/processed/... when present
+    # (data_utils.py:121-148), else one video given --intrinsics, else synthetic frames
+    datasets = data_info = data = None
+    config_path = os.path.join(opts["data_root"], "configs", opts["seqname"] + ".config")
+    prefix = f"{opts['data_prefix']}-{opts['train_res']}"
+    if os.path.exists(config_path):
+        from . import vidloader
+        try:
+            datasets = vidloader.config_to_datasets(
+                dict(seqname=opts["seqname"], data_prefix=prefix, feature_type=opts["feature_type"],
+                     delta_list=[int(d) for d in str(opts["delta_list"]).split(",") if d], pixels_per_image=-1,
+                     load_pair=False), config_path=config_path)
+            data_info = vidloader.get_data_info(datasets)
+            data_info["rtmat"] = data_info["rtmat"][data_info["vis_info"]["fg"]]  # (multifields.py:82)
+            opts["num_frames"] = int(data_info["total_frames"])
+            frame_table = [(v, i) for v, ds in enumerate(datasets) for i in range(ds.frame_info.num_frames)]
+            say(f"{config_path}: {len(datasets)} video(s), {len(frame_table)} frames ({prefix})")
+        except (FileNotFoundError, KeyError, ValueError) as e:
+            say(f"{config_path} not usable ({e}): falling back")
+            datasets = data_info = None
+    model = DeformableSurfels(opts, num_frames=opts["num_frames"], device=dev, data_info=data_info)
     model.init_from_points(pts, rng.uniform(size=(n, 3)).astype(np.float32))
     trainer = Stage3Trainer(model, opts)
     from . import checkpoint
@@ -139,20 +161,18 @@ def main(argv=None):
             f"{len(info['unexpected_keys'])} checkpoint keys without a counterpart here")
     elif opts["load_path"]:
         say(f"--load_path {opts['load_path']} not found: starting from the initialisation")
-    data = None
     droot = os.path.join(opts["data_root"], "processed")
-    if opts["intrinsics"] and os.path.isdir(droot):
+    if datasets is None and opts["intrinsics"] and os.path.isdir(droot):
         from .vidloader import SequenceData
         try:
-            data = SequenceData(droot, opts["seqname"] if "-" in opts["seqname"][-5:] else opts["seqname"] + "-0000",
-                                f"{opts['data_prefix']}-{opts['train_res']}")
+            data = SequenceData(droot, opts["seqname"] if "-" in opts["seqname"][-5:] else opts["seqname"] + "-0000", prefix)
             K = [float(x) for x in opts["intrinsics"].split(",")]
             say(f"reading {len(data)} frames of {data.seq} ({data.prefix}) from {droot}")
         except (FileNotFoundError, ValueError) as e:
             say(f"dataset not usable ({e}): falling back to synthetic frames")
             data = None
     res = opts["train_res"] if opts["pixels_per_image"] == -1 else opts["eval_res"]
-    if data is None:
+    if data is None and datasets is None:
         say(f"no --intrinsics / processed data for this sequence: fitting synthetic {res}x{res} frames "
             f"({opts['num_frames']} frames, {2 * opts['imgs_per_gpu']} per GPU per step, {world} GPU(s))")
     logdir = os.path.join(opts["logroot"], f"{opts['seqname']}-{opts['logname']}")
@@ -165,7 +185,10 @@ def main(argv=None):
         for _ in range(opts["iters_per_round"]):
             first = (step * per_step * world + rank * per_step) % opts["num_frames"]
             ids = [(first + k) % opts["num_frames"] for k in range(per_step)]
-            if data is not None:
+            if datasets is not None:
+                batch = vidloader.stage3_batch(datasets, data_info, [frame_table[i % len(frame_table)] for i in ids],
+                                               device=dev)
+            elif data is not None:
                 batch = data.frame_batch([i % len(data) for i in ids], K, device=dev)
             else:
                 batch = synthetic_batch(model, ids, res, res, seed=step)
