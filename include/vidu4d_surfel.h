@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 2
+#define VIDU4D_SURFEL_ABI 3
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -249,6 +249,53 @@ int vidu4d_post_backward(int W, int H, const float* allmap, const float* surf_de
                          const float* rays_o, const float* view3x3, float depth_ratio, const float* g_rend_normal,
                          const float* g_depth_median, const float* g_depth_expected, const float* g_surf_depth,
                          const float* g_surf_normal, float* g_allmap, void* stream);
+
+/* ---- the surfel optimizer's update: replaces the per-group launches of torch.optim.Adam(eps=1e-15) that
+ *      Trainer.optimizer_init builds with one parameter group per surfel attribute (lab4d/engine/trainer.py:240-255)
+ *      by ONE launch over all groups.  Update rule of torch/optim/adam.py (no amsgrad, no weight decay); the caller
+ *      owns the step counts and passes 1 - beta1^t and sqrt(1 - beta2^t) per tensor; the betas are doubles so that
+ *      1 - beta is rounded to fp32 once, as torch does.  `tensors` is a HOST array. ---- */
+#define VIDU4D_ADAM_MAX_TENSORS 8
+typedef struct Vidu4dAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    float lr;
+    float bias_correction1;      /* 1 - beta1^step */
+    float bias_correction2_sqrt; /* sqrt(1 - beta2^step) */
+} Vidu4dAdamTensor;
+int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps, void* stream);
+
+/* ---- densify_and_prune on the device: replaces GaussianModel.densify_and_clone / densify_and_split / prune_points
+ *      and the optimizer surgery under them (gs/scene/gaussian_model.py:270-356, :384-448).
+ *  plan:  per surfel, from grad_accum / denom (N), log-scales (N,2), opacity logits (N): counts (3,N) int32 =
+ *         {the original survives, its clone exists and survives, its two split copies exist and survive}.
+ *         dense_extent = percent_dense * extent; big_world = 0.1 * extent, or < 0 when the caller passes no
+ *         max_screen_size (the world-size criterion is tied to it upstream, :443-446).
+ *  apply: with the inclusive prefix sums of the three count rows and their totals, writes every attribute (and, where
+ *         given, its two Adam moments: kept for surviving originals, zero for new rows) in the reference's row order
+ *         [originals | clones | first split copies | second split copies].  Split copies get
+ *         xyz + R(rotation) (draw * (sx, sy, 0)) and log(scale / 1.6); `draws` (2,N,3) holds unit normal draws per
+ *         source surfel and copy (or, draws_are_scaled != 0, the already scaled samples).  src_row (rows) int32 and
+ *         kind (rows) uint8 are scratch the caller provides; `attrs` is a HOST array. ---- */
+#define VIDU4D_DENSIFY_MAX_ATTRS 8
+typedef struct Vidu4dDensifyAttr {
+    const float* src;   /* (N, width) */
+    float* dst;         /* (rows, width) */
+    const float* src_m; /* Adam exp_avg of src, or NULL (no optimizer state) */
+    float* dst_m;
+    const float* src_v; /* Adam exp_avg_sq */
+    float* dst_v;
+    int width;
+} Vidu4dDensifyAttr;
+int vidu4d_densify_plan(int N, const float* grad_accum, const float* denom, const float* scaling, const float* opacity,
+                        float grad_threshold, float dense_extent, float min_opacity, float big_world, int32_t* counts,
+                        void* stream);
+int vidu4d_densify_apply(int N, const int32_t* inclusive_counts, int n_orig, int n_clone, int n_split, int n_attrs,
+                         const Vidu4dDensifyAttr* attrs, int xyz_attr, int scaling_attr, int rotation_attr,
+                         const float* draws, int draws_are_scaled, int32_t* src_row, uint8_t* kind, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,8 @@ def test_header_symbols_exported():
 def test_struct_layout_matches_header():
     """ctypes mirrors must have the field order of the C structs."""
     hdr = open(os.path.join(ROOT, "include", "vidu4d_surfel.h")).read()
-    for cname, struct in (("Vidu4dSurfelForwardArgs", _lib.ForwardArgs), ("Vidu4dSurfelBackwardArgs", _lib.BackwardArgs)):
+    for cname, struct in (("Vidu4dSurfelForwardArgs", _lib.ForwardArgs), ("Vidu4dSurfelBackwardArgs", _lib.BackwardArgs),
+                          ("Vidu4dAdamTensor", _lib.AdamTensor), ("Vidu4dDensifyAttr", _lib.DensifyAttr)):
         body = hdr[hdr.index("typedef struct " + cname):hdr.index("} " + cname + ";")]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

@@ -1,0 +1,114 @@
+"""csrc/optim.hip against torch: SurfelAdam vs torch.optim.Adam (the optimizer the reference builds,
+lab4d/engine/trainer.py:240-255), and the device-side densify_and_prune vs GaussianModel.densify_and_prune (itself pinned
+against the imported reference by tests/golden/refpy_densify.npz) on a larger random model."""
+import copy
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_surfel_adam_matches_torch_adam(gpu_device):
+    from vidu4d_amd.gs.surfel_optim import SurfelAdam
+    dev = gpu_device
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = [(5000, 3), (5000, 1, 3), (5000, 15, 3), (5000, 1), (5000, 2), (5000, 4), (5000, 16), (3,), (1025,)]
+    lrs = [5e-5, 2.5e-3, 1.25e-4, 0.05, 5e-3, 1e-3, 2.5e-3, 2.5e-3, 1e-2]
+    a = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = SurfelAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(a, lrs))], lr=5e-4, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=5e-4, eps=1e-15)
+    for step in range(6):
+        for i, (p, q) in enumerate(zip(a, b)):
+            if step == 2 and i == 3:
+                p.grad = q.grad = None  # a parameter without gradient is skipped; its step count stays behind
+                continue
+            gr = (torch.randn(p.shape, generator=g) * (10.0 ** (i - 4))).to(dev)
+            if step == 4:
+                gr[::7] = 0.0  # exact zeros: v stays tiny, the eps = 1e-15 regime
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step(), ob.step()
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), (i, float((p - q).abs().max()))
+        sa, sb = oa.state[p], ob.state[q]
+        assert float(sa["step"]) == float(sb["step"])
+        for k in ("exp_avg", "exp_avg_sq"):  # (entries that cancel to ~0 are compared at the tensor's scale)
+            assert torch.allclose(sa[k], sb[k], rtol=5e-6, atol=1e-6 * float(sb[k].abs().max())), (i, k)
+    # same state_dict layout as torch's (checkpoint.py stores it as is)
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["param_groups"][0]["eps"] == 1e-15
+
+
+def _model(dev, n, seed, with_state=True):
+    from vidu4d_amd.gs.gaussian_model import GaussianModel
+    from vidu4d_amd.gs.surfel_optim import SurfelAdam
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    gm = GaussianModel(3, device=dev)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    gm._xyz = torch.nn.Parameter(r(n, 3))
+    gm._features_dc = torch.nn.Parameter(r(n, 1, 3))
+    gm._features_rest = torch.nn.Parameter(r(n, 15, 3))
+    gm._opacity = torch.nn.Parameter(r(n, 1) * 3.0 - 2.0)  # sigmoid below 0.005 for some
+    gm._scaling = torch.nn.Parameter(r(n, 2) * 1.2 - 4.0)  # around percent_dense * extent = 0.01, a few above 0.1
+    gm._rotation = torch.nn.Parameter(r(n, 4))
+    gm._regist_feat = torch.nn.Parameter(r(n, 16))
+    gm.percent_dense = 0.01
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "regist_feat")
+    ps = (gm._xyz, gm._features_dc, gm._features_rest, gm._opacity, gm._scaling, gm._rotation, gm._regist_feat)
+    gm.optimizer = SurfelAdam([{"params": [p], "lr": 1e-3, "name": nm} for nm, p in zip(names, ps)], lr=5e-4, eps=1e-15)
+    if with_state:
+        for nm, p in zip(names, ps):
+            if nm == "opacity":
+                continue  # as after reset_opacity: no Adam state
+            gm.optimizer.state[p] = {"step": torch.tensor(7.0), "exp_avg": r(*p.shape), "exp_avg_sq": r(*p.shape).abs()}
+    gm.xyz_gradient_accum = (torch.rand(n, 1, generator=g) * 1e-3).to(dev)
+    gm.denom = torch.randint(0, 3, (n, 1), generator=g).float().to(dev)  # zeros -> NaN / inf gradients
+    gm.max_radii2D = (torch.rand(n, generator=g) * 40).to(dev)
+    return gm, names
+
+
+@pytest.mark.parametrize("screen", [20, None])
+def test_device_side_densify_equals_the_python_path(gpu_device, screen):
+    from vidu4d_amd.gs.surfel_optim import densify_and_prune_fused
+    dev = gpu_device
+    n = 20000
+    a, names = _model(dev, n, seed=11)
+    b, _ = _model(dev, n, seed=11)
+    g = a.xyz_gradient_accum / a.denom
+    g[g.isnan()] = 0.0
+    sel = (g.squeeze(-1) >= 2e-4) & (a.get_scaling.max(dim=1).values > a.percent_dense * 1.0)
+    n_sel = int(sel.sum())
+    assert 100 < n_sel < n
+    stds = torch.cat([a.get_scaling[sel].repeat(2, 1), torch.zeros(2 * n_sel, 1, device=dev)], dim=-1)
+    samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=torch.Generator(device=dev).manual_seed(1))
+    a.densify_and_prune(2e-4, 0.005, 1.0, screen, samples=samples)
+    densify_and_prune_fused(b, 2e-4, 0.005, 1.0, screen, samples=samples)
+    assert a._xyz.shape[0] == b._xyz.shape[0] and a._xyz.shape[0] != n
+    get = lambda m: (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation, m._regist_feat)  # noqa: E731
+    for nm, p, q in zip(names, get(a), get(b)):
+        if nm in ("xyz", "scaling"):
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-6), nm
+        else:
+            assert torch.equal(p, q), nm
+        sa, sb = a.optimizer.state.get(p), b.optimizer.state.get(q)
+        assert (sa is None) == (sb is None), nm
+        if sa is not None:
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), nm
+            assert float(sa["step"]) == float(sb["step"]) == 7.0
+        assert b.optimizer.param_groups[names.index(nm)]["params"][0] is q
+    for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+
+
+def test_device_side_densify_draws_its_own_samples(gpu_device):
+    """Without `samples`: unit normal draws per (copy, source surfel), scaled by the surfel's extent in its plane."""
+    from vidu4d_amd.gs.surfel_optim import densify_and_prune_fused
+    dev = gpu_device
+    b, _ = _model(dev, 20000, seed=5, with_state=False)
+    xyz0, sc0 = b._xyz.detach().clone(), b.get_scaling.detach().clone()
+    densify_and_prune_fused(b, 2e-4, 0.005, 1.0, 20, generator=torch.Generator(device=dev).manual_seed(9))
+    n = b._xyz.shape[0]
+    assert n != 20000 and torch.isfinite(b._xyz).all() and b.denom.shape == (n, 1)
+    assert len(b.optimizer.state) == 0

@@ -162,6 +162,12 @@ def test_densify_prune_surgery_on_gpu(gpu_device):
     H.check_densify(gpu_device)
 
 
+def test_device_side_densify_and_hip_adam_match_the_reference_model(gpu_device):
+    """The same fixture through csrc/optim.hip: densify_and_prune_fused (plan / index / gather kernels) and SurfelAdam
+    (one launch for all groups) against gs/scene/gaussian_model.py + torch.optim.Adam of the imported reference."""
+    H.check_densify(gpu_device, fused=True)
+
+
 @pytest.mark.parametrize("case", H.LOSS_CASES)
 def test_stage3_losses_on_gpu(gpu_device, case):
     H.check_losses(case, gpu_device)

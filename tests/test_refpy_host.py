@@ -174,7 +174,7 @@ def _params(gm):
     return {g["name"]: g["params"][0] for g in gm.optimizer.param_groups}
 
 
-def check_densify(dev):
+def check_densify(dev, fused=False):
     from vidu4d_amd.gs.gaussian_model import GaussianModel
     r = load("refpy_densify.npz", dev)
     gm = GaussianModel(3, device=dev)
@@ -195,8 +195,11 @@ def check_densify(dev):
     gm._opacity, gm._scaling, gm._rotation, gm._regist_feat = P["opacity"], P["scaling"], P["rotation"], P["regist_feat"]
     lr = dict(xyz=5e-5, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, regist_feat=2.5e-3,
               bg_rgb=2.5e-3)
-    gm.optimizer = torch.optim.Adam([{"params": [P[n]], "lr": lr[n], "name": n} for n in GROUPS + ("bg_rgb",)],
-                                    lr=5e-4, eps=1e-15)
+    if fused:  # the HIP optimizer + device-side densification (csrc/optim.hip)
+        from vidu4d_amd.gs.surfel_optim import SurfelAdam as Adam
+    else:
+        Adam = torch.optim.Adam
+    gm.optimizer = Adam([{"params": [P[n]], "lr": lr[n], "name": n} for n in GROUPS + ("bg_rgb",)], lr=5e-4, eps=1e-15)
     for n, p in P.items():
         gm.optimizer.state[p] = {"step": torch.tensor(2.0), "exp_avg": r[f"pre_m_{n}"].clone(),
                                  "exp_avg_sq": r[f"pre_v_{n}"].clone()}
@@ -208,7 +211,11 @@ def check_densify(dev):
     close(gm.denom, r["stats_denom"], rtol=0, atol=0)
     gm.max_radii2D = r["pre_max_radii2D"].clone()
 
-    gm.densify_and_prune(2e-4, 0.005, 1.0, 20, samples=r["split_samples"])
+    if fused:
+        from vidu4d_amd.gs.surfel_optim import densify_and_prune_fused
+        densify_and_prune_fused(gm, 2e-4, 0.005, 1.0, 20, samples=r["split_samples"])
+    else:
+        gm.densify_and_prune(2e-4, 0.005, 1.0, 20, samples=r["split_samples"])
     after = _params(gm)
     for n in GROUPS + ("bg_rgb",):
         close(after[n], r[f"post_{n}"], what="post_" + n, rtol=1e-5, atol=1e-6)

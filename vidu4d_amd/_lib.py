@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ForwardArgs(C.Structure):
@@ -27,6 +27,23 @@ class ForwardArgs(C.Structure):
         ("geom_buffer", C.c_void_p), ("geom_bytes", C.c_size_t), ("image_buffer", C.c_void_p),
         ("image_bytes", C.c_size_t), ("segment_split", C.c_int), ("depth_used", C.c_void_p),
     ]
+
+
+class AdamTensor(C.Structure):
+    """struct Vidu4dAdamTensor"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_int64), ("lr", C.c_float), ("bias_correction1", C.c_float),
+                ("bias_correction2_sqrt", C.c_float)]
+
+
+class DensifyAttr(C.Structure):
+    """struct Vidu4dDensifyAttr"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_m", C.c_void_p), ("dst_m", C.c_void_p),
+                ("src_v", C.c_void_p), ("dst_v", C.c_void_p), ("width", C.c_int)]
+
+
+ADAM_MAX_TENSORS = 8
+DENSIFY_MAX_ATTRS = 8
 
 
 class BackwardArgs(C.Structure):
@@ -79,6 +96,10 @@ SYMBOLS = {
     "vidu4d_radius_count": (C.c_int, [C.c_int, _P, C.c_float, _P, _P]),
     "vidu4d_post_forward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
     "vidu4d_post_backward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P]),
+    "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,
+                                       C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
 }
 
 STATE = dict(num_rendered=0, records=1, tiles_touched=2, point_list=3, sorted_keys=4, ranges=5, final_T=6,

@@ -1,0 +1,136 @@
+"""The surfel optimizer and the densification step on the HIP path (csrc/optim.hip).
+
+`SurfelAdam` IS a torch.optim.Adam -- same constructor, param_groups, per-parameter state {"step", "exp_avg",
+"exp_avg_sq"} and state_dict, so GaussianModel's optimizer surgery and the checkpoint format are untouched -- whose
+step() updates every group with one launch instead of one multi-tensor launch per group (the reference builds one
+group per surfel attribute because each has its own learning rate: lab4d/engine/trainer.py:240-255).
+
+`densify_and_prune_fused` produces what GaussianModel.densify_and_prune (gs/scene/gaussian_model.py:434-448 with
+:270-356, :384-432 under it) produces -- same rows in the same order, same optimizer-state handling -- from three
+launches and one host read of the new surfel count."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+class SurfelAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, foreach=False, fused=False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise RuntimeError("SurfelAdam: closures are not supported")
+        batches = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue  # (freshly re-created parameters are skipped, as torch does)
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("SurfelAdam: contiguous fp32 HIP parameters required")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                t = float(st["step"])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                rec = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                      p.numel(), float(group["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t))
+                batches.setdefault((p.device, b1, b2, group["eps"]), []).append((rec, g))
+        lib = _lib.load()
+        for (dev, b1, b2, eps), items in batches.items():
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for i in range(0, len(items), _lib.ADAM_MAX_TENSORS):
+                chunk = items[i:i + _lib.ADAM_MAX_TENSORS]
+                arr = (_lib.AdamTensor * len(chunk))(*[c[0] for c in chunk])
+                _lib.check(lib.vidu4d_adam_step(len(chunk), arr, b1, b2, eps, stream), "adam step")
+        return None
+
+
+_ATTRS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "regist_feat")
+
+
+def densify_and_prune_fused(gm, max_grad, min_opacity, extent, max_screen_size, generator=None, samples=None):
+    """In-place equivalent of gm.densify_and_prune(...) for a GaussianModel on a HIP device.  `samples`
+    (tests): the (2 * n_selected, 3) scaled draws the Python path would be given."""
+    dev = gm._xyz.device
+    if not gm._xyz.is_cuda:
+        raise RuntimeError("densify_and_prune_fused: HIP tensors required")
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    N = gm._xyz.shape[0]
+    groups = {g["name"]: g for g in gm.optimizer.param_groups if g["name"] in _ATTRS}
+    names = [n for n in _ATTRS if n in groups]
+    if N == 0:
+        return
+    counts = torch.empty(3, N, dtype=torch.int32, device=dev)
+    accum, denom = gm.xyz_gradient_accum.contiguous(), gm.denom.contiguous()
+    _lib.check(lib.vidu4d_densify_plan(N, accum.data_ptr(), denom.data_ptr(), gm._scaling.data_ptr(),
+                                       gm._opacity.data_ptr(), float(max_grad), float(gm.percent_dense * extent),
+                                       float(min_opacity), float(0.1 * extent) if max_screen_size else -1.0,
+                                       counts.data_ptr(), stream), "densify plan")
+    inc = torch.cumsum(counts, dim=1, dtype=torch.int32)
+    n_orig, n_clone, n_split = (int(v) for v in inc[:, -1].tolist())  # the one host read of this step
+    rows = n_orig + n_clone + 2 * n_split
+    if samples is not None:
+        # the Python path's layout: row k / n_sel + k = first / second copy of the k-th split-selected surfel
+        # (selected BEFORE the final prune); re-indexed by source surfel here
+        g = accum / denom
+        g[g.isnan()] = 0.0
+        sel = (g.squeeze(-1) >= max_grad) & (gm.get_scaling.max(dim=1).values > gm.percent_dense * extent)
+        draws = torch.zeros(2, N, 3, device=dev)
+        draws[:, sel] = samples.to(dev).view(2, -1, 3)
+        scaled = 1
+    else:
+        draws = torch.randn(2, N, 3, device=dev, generator=generator)
+        scaled = 0
+    src_row = torch.empty(max(rows, 1), dtype=torch.int32, device=dev)
+    kind = torch.empty(max(rows, 1), dtype=torch.uint8, device=dev)
+    recs, new_params, new_states, keep_alive = [], {}, {}, []
+    for name in names:
+        old = groups[name]["params"][0]
+        width = old[0].numel() if N else 1
+        src = old.detach().contiguous()
+        dst = torch.empty((rows,) + tuple(old.shape[1:]), dtype=torch.float32, device=dev)
+        st = gm.optimizer.state.get(old)
+        has = st is not None and "exp_avg" in st
+        if has:
+            m, v = st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()
+            dm, dv = torch.empty_like(dst), torch.empty_like(dst)
+            new_states[name] = (dm, dv)
+            keep_alive += [m, v]
+        recs.append(_lib.DensifyAttr(src.data_ptr(), dst.data_ptr(), m.data_ptr() if has else None,
+                                     dm.data_ptr() if has else None, v.data_ptr() if has else None,
+                                     dv.data_ptr() if has else None, width))
+        new_params[name] = dst
+        keep_alive.append(src)
+    arr = (_lib.DensifyAttr * len(recs))(*recs)
+    _lib.check(lib.vidu4d_densify_apply(N, inc.data_ptr(), n_orig, n_clone, n_split, len(recs), arr, names.index("xyz"),
+                                        names.index("scaling"), names.index("rotation"), draws.data_ptr(), scaled,
+                                        src_row.data_ptr(), kind.data_ptr(), stream), "densify apply")
+    # ---- re-key the optimizer exactly as _resize_groups does
+    out = {}
+    for name in names:
+        group = groups[name]
+        old = group["params"][0]
+        st = gm.optimizer.state.pop(old, None)
+        new = nn.Parameter(new_params[name].requires_grad_(True))
+        if st is not None:
+            if name in new_states:
+                st["exp_avg"], st["exp_avg_sq"] = new_states[name]
+            gm.optimizer.state[new] = st
+        group["params"][0] = new
+        out[name] = new
+    gm._assign(out)
+    gm.xyz_gradient_accum = torch.zeros(rows, 1, device=dev)
+    gm.denom = torch.zeros(rows, 1, device=dev)
+    gm.max_radii2D = torch.zeros(rows, device=dev)

@@ -99,8 +99,13 @@ class Stage3Trainer:
         ]
         if c.gs_learnable_bg:
             groups.append({"params": [m.learnable_bkgd], "lr": c.feature_lr, "name": "bg_rgb"})
-        # one multi-tensor kernel per step on the GPU (same update rule as the reference's Adam)
-        self.gs_optimizer = torch.optim.Adam(groups, lr=c.learning_rate, eps=1e-15, fused=m._xyz.is_cuda)
+        # on the GPU: ONE launch per step for all groups (csrc/optim.hip; same update rule and state layout as the
+        # reference's torch.optim.Adam)
+        if m._xyz.is_cuda:
+            from ..gs.surfel_optim import SurfelAdam
+            self.gs_optimizer = SurfelAdam(groups, lr=c.learning_rate, eps=1e-15)
+        else:
+            self.gs_optimizer = torch.optim.Adam(groups, lr=c.learning_rate, eps=1e-15)
         m.optimizer = self.gs_optimizer
         self._flat = None
         self._pending_reduce = None
@@ -250,10 +255,15 @@ class Stage3Trainer:
                     self._sync_densification_stats()
                     gen = torch.Generator(device=m._xyz.device).manual_seed(1000003 * step + 17)
                     size_threshold = 20 if step > c.opacity_reset_interval else None
-                    m.densify_and_prune(c.densify_grad_threshold, 0.005, m.cameras_extent, size_threshold, generator=gen)
+                    if m._xyz.is_cuda:  # decisions, row gather and moment surgery on the device (csrc/optim.hip)
+                        from ..gs.surfel_optim import densify_and_prune_fused
+                        densify = lambda *a, **k: densify_and_prune_fused(m, *a, **k)  # noqa: E731
+                    else:
+                        densify = m.densify_and_prune
+                    densify(c.densify_grad_threshold, 0.005, m.cameras_extent, size_threshold, generator=gen)
                     if step % (10 * c.densification_interval) == 0:
-                        m.densify_and_prune(c.densify_grad_threshold * 0.1, 0.002, m.cameras_extent * 100,
-                                            size_threshold, generator=gen)
+                        densify(c.densify_grad_threshold * 0.1, 0.002, m.cameras_extent * 100, size_threshold,
+                                generator=gen)
                 if step % c.opacity_reset_interval == 0:  # (step 0 included, as upstream: trainer.py:570)
                     m.reset_opacity()
                 if (m._xyz.is_cuda and c.densify_from_iter < step < c.outlier_stop_iter
