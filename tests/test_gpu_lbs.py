@@ -88,3 +88,72 @@ def test_render_frames_fused_equals_unfused(gpu_device):
     for a, b in zip(out[True], out[False]):
         scale = max(1e-3, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 1e-3 * scale, (float((a - b).abs().max()), scale)
+
+
+def _skinning_field(dev, B, D, seed, frames=12):
+    from vidu4d_amd.lab4d.bob_warp import SkinningField
+    from vidu4d_amd.lab4d.nets import make_frame_info
+    torch.manual_seed(seed)
+    sm = SkinningField(num_coords=B, frame_info=make_frame_info([0, frames]), num_inst=1, D=D, W=64).to(dev)
+    with torch.no_grad():  # untrained output layers are ~0: give every layer weights that matter
+        for p in sm.delta_field.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+    for p in sm.parameters():
+        p.requires_grad_(False)
+    return sm
+
+
+@pytest.mark.parametrize("N,B,D", [(5000, 25, 2), (193, 25, 2), (1000, 7, 1), (64, 32, 4), (1, 25, 3)])
+def test_skin_field_kernel_matches_the_torch_path(gpu_device, N, B, D):
+    """csrc/skin_field.hip (bone map + delta-skin MLP, one thread per surfel) against addmm + SkinningField.delta_raw_T
+    (themselves checked against the imported reference SkinningField in test_refpy_nets / test_gpu_refpy)."""
+    from vidu4d_amd.lab4d import quat_transform as qt
+    from vidu4d_amd.lab4d.lbs_fused import prepare_skin_field, skin_field, skin_field_supported
+    dev = gpu_device
+    sm = _skinning_field(dev, B, D, seed=N + B)
+    assert skin_field_supported(sm)
+    g = torch.Generator().manual_seed(3)
+    rest = qt.quaternion_translation_to_dual_quaternion(
+        torch.nn.functional.normalize(torch.randn(1, B, 4, generator=g), dim=-1).to(dev), (0.2 * torch.randn(1, B, 3, generator=g)).to(dev))
+    A, c0 = sm.bone_affine(rest)
+    bias = sm.frame_bias(None, None, 1, dev)
+    xyz0 = (0.3 * torch.randn(N, 3, generator=g)).to(dev)
+    Gx, Gr = torch.randn(3 * B, N, generator=g).to(dev), torch.randn(B, N, generator=g).to(dev)
+    res = {}
+    for name in ("fused", "torch"):
+        xyz = xyz0.clone().requires_grad_(True)
+        if name == "fused":
+            xbT, rawT = skin_field(xyz, bias[0], prepare_skin_field(sm, A, c0))
+        else:
+            xbT = torch.addmm(c0[:, None], A, xyz.t())
+            rawT = sm.delta_raw_T(xbT, bias[0])
+        ((xbT * Gx).sum() + (rawT * Gr).sum()).backward()
+        res[name] = [t.detach().cpu().numpy() for t in (xbT, rawT, xyz.grad)]
+    for a, b, what in zip(res["fused"], res["torch"], ("xbT", "rawT", "g_xyz")):
+        scale = max(1e-3, float(np.abs(b).max()))
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 3e-5 * scale, (what, np.abs(a - b).max(), scale)
+    # relu masks really differ between surfels and the output is not degenerate
+    assert float(np.abs(res["torch"][1]).max()) > 1e-2
+
+
+def test_skin_field_is_what_the_fused_warp_runs(gpu_device):
+    """DeformableSurfels.forward_warp_fused: skin-field kernel on == off (library GEMMs), values and gradients."""
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    dev = gpu_device
+    out = {}
+    for flag in (True, False):
+        torch.manual_seed(0)
+        m = DeformableSurfels(dict(fg_motion="gs-bob", fused_skin_field=flag), num_frames=8, device=dev)
+        with torch.no_grad():
+            for p in m.warp.skinning_model.delta_field.parameters():
+                p.add_(0.2 * torch.randn_like(p))
+        for p in list(m.warp.parameters()) + list(m.camera_mlp.parameters()):
+            p.requires_grad_(False)
+        rng = np.random.default_rng(1)
+        m.init_from_points(rng.normal(size=(3000, 3)).astype(np.float32) * 0.2, rng.uniform(size=(3000, 3)).astype(np.float32))
+        x, r = m.forward_warp_fused(torch.tensor([1, 5], device=dev))
+        (x.sum() + (r * r).sum()).backward()
+        out[flag] = (x.detach(), r.detach(), m._xyz.grad.clone(), m._rotation.grad.clone())
+    for a, b in zip(out[True], out[False]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))

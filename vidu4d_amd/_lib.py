@@ -42,6 +42,14 @@ class DensifyAttr(C.Structure):
                 ("src_v", C.c_void_p), ("dst_v", C.c_void_p), ("width", C.c_int)]
 
 
+class SkinFieldArgs(C.Structure):
+    """struct Vidu4dSkinFieldArgs"""
+    _fields_ = [("N", C.c_int), ("B", C.c_int), ("W", C.c_int), ("D", C.c_int)] + [
+        (n, C.c_void_p) for n in ("xyz", "bone_A", "bone_c", "w_in_T", "b_in", "w_hid_T", "b_hid", "w_out_T", "b_out",
+                                  "w_in", "w_hid", "w_out", "xbT", "rawT", "g_xbT", "g_rawT", "g_xyz")]
+
+
+SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
 ADAM_MAX_TENSORS = 8
 DENSIFY_MAX_ATTRS = 8
 
@@ -96,6 +104,8 @@ SYMBOLS = {
     "vidu4d_radius_count": (C.c_int, [C.c_int, _P, C.c_float, _P, _P]),
     "vidu4d_post_forward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
     "vidu4d_post_backward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "vidu4d_skin_field_forward": (C.c_int, [C.POINTER(SkinFieldArgs), _P]),
+    "vidu4d_skin_field_backward": (C.c_int, [C.POINTER(SkinFieldArgs), _P]),
     "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libvidu4d_surfel.so")
-SOURCES = ["preprocess.hip", "binning.hip", "blend.hip", "quaternion.hip", "lbs.hip", "knn.hip", "post.hip", "optim.hip", "capi.hip"]
+SOURCES = ["preprocess.hip", "binning.hip", "blend.hip", "quaternion.hip", "lbs.hip", "knn.hip", "post.hip", "optim.hip", "skin_field.hip", "capi.hip"]
 HEADERS = ["surfel_math.h", "surfel_state.h", os.path.join(INCLUDE, "vidu4d_surfel.h")]
 ARCH = "gfx950"
 # -munsafe-fp-atomics: hardware global_atomic_add_f32 / ds_add_f32 instead of CAS loops.
@@ -26,7 +26,8 @@ FLAGS = [f for f in FLAGS if f]
 # Per-file extras.  blend.hip: clang's SLP vectoriser turns pairs of scalar fp32 ops into v_pk_* but
 # pays for it with v_mov_b32 to assemble the register pairs -- 266 vs 248 VALU instructions in the
 # backward inner loop (and 125 vs 110 VGPRs); the kernels are VALU-issue bound, so it is switched off.
-EXTRA_FLAGS = {"blend.hip": ["-fno-slp-vectorize"]}
+# skin_field.hip: same reason (its inner loops are v_fmac with an SGPR weight; v_pk_fma needs the weights in VGPRs).
+EXTRA_FLAGS = {"blend.hip": ["-fno-slp-vectorize"], "skin_field.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

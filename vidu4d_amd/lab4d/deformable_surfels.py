@@ -17,7 +17,7 @@ from ..gs.gaussian_model import GaussianModel
 from ..gs.gaussian_renderer import GEOMETRY_KEYS, render
 from . import quat_transform as qt
 from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss
-from .lbs_fused import lbs_apply, lbs_skin_apply
+from .lbs_fused import lbs_apply, lbs_skin_apply, prepare_skin_field, skin_field, skin_field_supported
 from .nets import CameraMLP, make_frame_info
 
 
@@ -233,8 +233,19 @@ class DeformableSurfels(GaussianModel):
         if M <= 8 and self.opts.get("fused_skin", True) and (not sm.has_delta or sm.num_freq_xyz == 0):
             # bone coordinates and the delta MLP as feature-major GEMMs (4 library calls), everything else -- distances,
             # relu * 0.1, softmax, blend, apply, camera, for all frames -- in one HIP kernel per direction
-            xbT = torch.addmm(c0[:, None], A, self._xyz.t())
-            rawT = sm.delta_raw_T(xbT, bias[0]) if sm.has_delta else None
+            if self.opts.get("fused_skin_field", True) and skin_field_supported(sm):
+                # ... and with frozen weights those GEMMs too: one thread carries a surfel through bone map and MLP
+                # (csrc/skin_field.hip), no hidden activation ever reaches HBM
+                if overrides:
+                    sf_tab = prepare_skin_field(sm, A, c0)
+                else:
+                    sf_tab = tab.get("skin_field")
+                    if sf_tab is None:
+                        sf_tab = tab["skin_field"] = prepare_skin_field(sm, A, c0)
+                xbT, rawT = skin_field(self._xyz, bias[0].detach(), sf_tab)
+            else:
+                xbT = torch.addmm(c0[:, None], A, self._xyz.t())
+                rawT = sm.delta_raw_T(xbT, bias[0]) if sm.has_delta else None
             xyz_cam, rot_cam = lbs_skin_apply(xbT, rawT, se3, self._xyz, self._rotation, cq, ct)
             skin = delta = None
         else:

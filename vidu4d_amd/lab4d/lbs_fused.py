@@ -115,3 +115,98 @@ def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t):
     """xbT (3B,N) Gaussian-bone coordinates; rawT (B,N) raw output of the delta-skin MLP or None; se3 = (qr, qd)
     each (M,B,4), M <= 8; xyz (N,3); rot (N,4); cam_q (M,4), cam_t (M,3).  -> xyz_cam (M,N,3), rot_cam (M,N,4)."""
     return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Bone coordinates + delta-skin MLP in one kernel per direction (csrc/skin_field.hip)
+def skin_field_supported(sm) -> bool:
+    """True when SkinningField `sm` has the shape csrc/skin_field.hip is written for (the bob field: width 64,
+    no positional encoding of the bone coordinates, no skip connection inside the stack) and frozen weights."""
+    lim = _lib.SKIN_FIELD
+    if not sm.has_delta or sm.num_freq_xyz != 0:
+        return False
+    mlp = sm.delta_field
+    B = sm.log_gauss.shape[0]
+    if mlp.W != lim["width"] or not (1 <= mlp.D <= lim["max_hidden"]) or any(0 < s_ < mlp.D for s_ in mlp.skips):
+        return False
+    if 3 * B > lim["in_max"] or B > lim["out_max"] or sm.xyz_channels != 3 * B:
+        return False
+    return not any(p.requires_grad for p in sm.parameters())
+
+
+def prepare_skin_field(sm, A, c0) -> dict:
+    """Device arrays in the layout Vidu4dSkinFieldArgs documents (zero-padded, both orientations), from the
+    SkinningField's weights and the rest pose's bone map x_bone = A xyz + c0."""
+    lim = _lib.SKIN_FIELD
+    W, IN, OUT = lim["width"], lim["in_max"], lim["out_max"]
+    mlp = sm.delta_field
+    dev = A.device
+    B3 = A.shape[0]
+    with torch.no_grad():
+        def pad(t, shape):
+            out = torch.zeros(shape, dtype=torch.float32, device=dev)
+            out[tuple(slice(0, n) for n in t.shape)] = t.float()
+            return out
+
+        w1 = mlp.linear_1[0].weight[:, :B3]                       # (W, 3B): the coordinate columns
+        hid = [getattr(mlp, f"linear_{i + 1}")[0] for i in range(1, mlp.D)]
+        wo, bo = mlp.linear_final.weight, mlp.linear_final.bias    # (B, W), (B)
+        tab = {"B": wo.shape[0], "D": mlp.D,
+               "bone_A": pad(A, (IN, 3)), "bone_c": pad(c0, (IN,)),
+               "w_in": pad(w1, (W, IN)), "w_in_T": pad(w1.t(), (IN, W)),
+               "w_out": pad(wo, (OUT, W)), "w_out_T": pad(wo.t(), (W, OUT)), "b_out": pad(bo, (OUT,))}
+        if hid:
+            tab["w_hid"] = torch.stack([l_.weight for l_ in hid]).float().contiguous()
+            tab["w_hid_T"] = torch.stack([l_.weight.t() for l_ in hid]).float().contiguous()
+            tab["b_hid"] = torch.stack([l_.bias for l_ in hid]).float().contiguous()
+    return tab
+
+
+def _skin_field_args(tab, N, xyz, b_in, **ptrs):
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    a = _lib.SkinFieldArgs()
+    a.N, a.B, a.W, a.D = N, tab["B"], _lib.SKIN_FIELD["width"], tab["D"]
+    a.xyz, a.b_in = xyz.data_ptr(), b_in.data_ptr()
+    for k in ("bone_A", "bone_c", "w_in_T", "w_hid_T", "b_hid", "w_out_T", "b_out", "w_in", "w_hid", "w_out"):
+        setattr(a, k, p(tab.get(k)))
+    for k, v in ptrs.items():
+        setattr(a, k, p(v))
+    return a
+
+
+class _SkinField(Function):
+    @staticmethod
+    def forward(ctx, xyz, b_in, tab):
+        if not xyz.is_cuda:
+            raise RuntimeError("skin_field: HIP tensors required")
+        if b_in.requires_grad:
+            raise RuntimeError("skin_field: the first-layer bias (time / instance code) requires grad; the fused path "
+                               "treats the skinning network as constant")
+        N = xyz.shape[0]
+        x, b = _c(xyz), _c(b_in).reshape(-1)
+        xbT = torch.empty(3 * tab["B"], N, dtype=torch.float32, device=xyz.device)
+        rawT = torch.empty(tab["B"], N, dtype=torch.float32, device=xyz.device)
+        a = _skin_field_args(tab, N, x, b, xbT=xbT, rawT=rawT)
+        _lib.check(_lib.load().vidu4d_skin_field_forward(a, torch.cuda.current_stream(xyz.device).cuda_stream),
+                   "skin field forward")
+        ctx.save_for_backward(x, b)
+        ctx.tab = tab
+        return xbT, rawT
+
+    @staticmethod
+    def backward(ctx, g_xbT, g_rawT):
+        x, b = ctx.saved_tensors
+        tab, N = ctx.tab, x.shape[0]
+        g_xbT = None if g_xbT is None else _c(g_xbT)
+        g_rawT = torch.zeros(tab["B"], N, device=x.device) if g_rawT is None else _c(g_rawT)
+        g_xyz = torch.empty(N, 3, dtype=torch.float32, device=x.device)
+        a = _skin_field_args(tab, N, x, b, g_xbT=g_xbT, g_rawT=g_rawT, g_xyz=g_xyz)
+        _lib.check(_lib.load().vidu4d_skin_field_backward(a, torch.cuda.current_stream(x.device).cuda_stream),
+                   "skin field backward")
+        return g_xyz, None, None
+
+
+def skin_field(xyz, b_in, tab):
+    """xyz (N,3) canonical centres; b_in (W,) first-layer bias of the step (SkinningField.frame_bias); tab from
+    prepare_skin_field.  -> xbT (3B,N) Gaussian-bone coordinates, rawT (B,N) raw delta-skin output."""
+    return _SkinField.apply(xyz, b_in, tab)
