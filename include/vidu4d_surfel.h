@@ -230,13 +230,14 @@ int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, const float*
  *      lab4d/nnutils/skinning.py:89-142, as called by SkinningWarp.forward with the rest articulation and the mean
  *      time code, lab4d/nnutils/warping.py:415-427).  Feature-major outputs xbT (3B, N), rawT (B, N): the inputs of
  *      vidu4d_lbs_skin_*.  Bones and weights are constants (frozen networks); the backward returns d/d xyz only.
- *      All weight arrays are device pointers prepared by the caller, zero-padded to the MAX sizes below:
- *        bone_A (IN_MAX, 3), bone_c (IN_MAX): x_bone = A xyz + c, 3 rows per bone;
- *        w_in_T (IN_MAX, W) k-major / w_in (W, IN_MAX): first layer, coordinate columns; b_in (W): its bias plus
- *        its time- and instance-code columns applied to the step's code vector;
- *        w_hid_T / w_hid (D-1, W, W), b_hid (D-1, W): further hidden layers (k-major / row-major);
- *        w_out_T (W, OUT_MAX) k-major / w_out (OUT_MAX, W), b_out (OUT_MAX): output layer.  ReLU after every hidden
- *        layer, none after the output (the caller's relu(.) * 0.1 is part of vidu4d_lbs_skin_*). ---- */
+ *      All weight arrays are device pointers in the network's own row-major (out, in) layout, zero-padded to the
+ *      sizes below:
+ *        bone_A (3B, 3), bone_c (3B): x_bone = A xyz + c, 3 rows per bone;
+ *        w_in (W, IN_MAX): first layer, coordinate columns; b_in (W): its bias plus its time- and instance-code
+ *        columns applied to the step's code vector;
+ *        w_hid (D-1, W, W), b_hid (D-1, W): further hidden layers;  w_out (OUT_MAX, W), b_out (OUT_MAX): output layer.
+ *      ReLU after every hidden layer, none after the output (the caller's relu(.) * 0.1 is part of
+ *      vidu4d_lbs_skin_*).  Runs on v_mfma_f32_32x32x2_f32 (exact fp32). ---- */
 #define VIDU4D_SKIN_FIELD_WIDTH 64
 #define VIDU4D_SKIN_FIELD_IN_MAX 96
 #define VIDU4D_SKIN_FIELD_OUT_MAX 32
@@ -246,15 +247,12 @@ typedef struct Vidu4dSkinFieldArgs {
     const float* xyz;
     const float* bone_A;
     const float* bone_c;
-    const float* w_in_T;
+    const float* w_in;
     const float* b_in;
-    const float* w_hid_T;
-    const float* b_hid;
-    const float* w_out_T;
-    const float* b_out;
-    const float* w_in;   /* backward only, as are the next two */
     const float* w_hid;
+    const float* b_hid;
     const float* w_out;
+    const float* b_out;
     float* xbT;          /* forward outputs */
     float* rawT;
     const float* g_xbT;  /* backward inputs: gradient w.r.t. xbT (may be NULL) and rawT */

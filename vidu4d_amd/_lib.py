@@ -45,8 +45,8 @@ class DensifyAttr(C.Structure):
 class SkinFieldArgs(C.Structure):
     """struct Vidu4dSkinFieldArgs"""
     _fields_ = [("N", C.c_int), ("B", C.c_int), ("W", C.c_int), ("D", C.c_int)] + [
-        (n, C.c_void_p) for n in ("xyz", "bone_A", "bone_c", "w_in_T", "b_in", "w_hid_T", "b_hid", "w_out_T", "b_out",
-                                  "w_in", "w_hid", "w_out", "xbT", "rawT", "g_xbT", "g_rawT", "g_xyz")]
+        (n, C.c_void_p) for n in ("xyz", "bone_A", "bone_c", "w_in", "b_in", "w_hid", "b_hid", "w_out", "b_out", "xbT",
+                                  "rawT", "g_xbT", "g_rawT", "g_xyz")]
 
 
 SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)

@@ -26,8 +26,7 @@ FLAGS = [f for f in FLAGS if f]
 # Per-file extras.  blend.hip: clang's SLP vectoriser turns pairs of scalar fp32 ops into v_pk_* but
 # pays for it with v_mov_b32 to assemble the register pairs -- 266 vs 248 VALU instructions in the
 # backward inner loop (and 125 vs 110 VGPRs); the kernels are VALU-issue bound, so it is switched off.
-# skin_field.hip: same reason (its inner loops are v_fmac with an SGPR weight; v_pk_fma needs the weights in VGPRs).
-EXTRA_FLAGS = {"blend.hip": ["-fno-slp-vectorize"], "skin_field.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"blend.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -9,17 +9,26 @@
 // arrives here folded into that layer's bias.)  Outputs are feature-major -- xbT (3B, N), rawT (B, N) -- which is what
 // csrc/lbs.hip (distances, softmax, blend, apply, camera) reads with coalesced loads.
 //
-// Upstream this is five library GEMMs + activations forward (every hidden activation, 51 MB each at 200k surfels,
-// goes through HBM) and as many again backward.  Here one thread carries one surfel through the whole network:
-//   * the weights are wave-uniform, so they are fetched with scalar loads and enter v_fma_f32 as the SGPR operand: the
-//     inner loops are pure FMA issue (fp32 has the same peak on the vector and the matrix pipes of CDNA4, so MFMA
-//     would buy nothing here and would need a layout shuffle between layers);
-//   * the hidden vector of a thread lives in a PRIVATE LDS column between layers (the next layer walks it with a
-//     uniform index, which registers cannot do): no barrier anywhere;
-//   * HBM traffic is the inputs and outputs only (12 B in, 4 (3B + B) B out per surfel).
-// The backward recomputes the forward (cheaper than storing it), keeps the ReLU masks as bits and returns the
-// gradient with respect to the canonical centres only: bones and network weights are constants of Stage-3
-// (--gs_optim_warp=False); a caller that trains them uses the torch path.
+// Upstream this is five library GEMMs + activations forward (every hidden activation, 51 MB each at 200k surfels, goes
+// through HBM) and as many again backward.  This is the one GEMM-shaped piece of the hot path, so it runs on the matrix
+// cores: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bitwise an fmaf chain, no precision trade).
+//
+//   * A wave owns a tile of 32 surfels = the 32 columns of every MFMA; a layer's 64 outputs are two 32-row blocks.
+//   * The C/D layout of this MFMA puts row (v&3) + 8 (v>>2) of a block into register v of lanes 0-31 and that row + 4
+//     into the same register of lanes 32-63 -- exactly the shape of a B operand (lanes 0-31: k0, lanes 32-63: k1) for
+//     the k-pair (row, row + 4).  The contraction order is free, so the NEXT layer simply contracts over these pairs:
+//     the accumulator registers of one layer (after bias + ReLU) ARE the B operands of the next.  No transposition, no
+//     LDS round trip, no cross-lane traffic between layers, forward or backward.
+//   * The weights are the A operands.  Each workgroup stages them once into LDS already arranged per MFMA ("stream"
+//     m holds, for lane l, the weight of output row l&31 and the contraction index that lane half l>>5 supplies), so an
+//     A operand is one conflict-free ds_read_b32; the 16 waves of a workgroup share them and loop over tiles.
+//   * HBM traffic is inputs and outputs only: 12 B in, 4 (3B + B) B out per surfel.
+// (A first version carried one surfel per thread with scalar-loaded weights as SGPR FMA operands; at 2.5 waves per SIMD
+// its 40 KB weight stream per wave through the scalar cache held it to 18 TFLOP/s -- 244 us forward at 200k surfels.)
+//
+// The backward recomputes the forward (cheaper than storing it), keeps the ReLU masks as bits and returns the gradient
+// with respect to the canonical centres only: bones and network weights are constants of Stage-3 (--gs_optim_warp=False);
+// a caller that trains them uses the torch path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,146 +36,290 @@
 
 namespace {
 
-constexpr int W = VIDU4D_SKIN_FIELD_WIDTH;       // hidden width
-constexpr int IN_MAX = VIDU4D_SKIN_FIELD_IN_MAX;  // padded 3B
-constexpr int OUT_MAX = VIDU4D_SKIN_FIELD_OUT_MAX;  // padded B
+constexpr int W = VIDU4D_SKIN_FIELD_WIDTH;          // hidden width: two row blocks of 32
+constexpr int IN_MAX = VIDU4D_SKIN_FIELD_IN_MAX;    // padded 3B: three row blocks
+constexpr int OUT_MAX = VIDU4D_SKIN_FIELD_OUT_MAX;  // padded B: one row block
 constexpr int MAX_HIDDEN = VIDU4D_SKIN_FIELD_MAX_HIDDEN;
-constexpr int WAVE = 64;
+constexpr int THREADS = 512;  // 8 waves share the staged weights; 2 waves per SIMD leave each 256 registers
+constexpr int T1_MAX = IN_MAX / 2, T3_MAX = OUT_MAX / 2;
+static_assert(W == 64 && IN_MAX == 96 && OUT_MAX == 32, "row-block structure");
 
-// Weights, biases and bone matrices are read-only for the whole launch and every index into them is wave-uniform:
-// viewed through the constant address space they are fetched by the scalar unit (s_load_dwordx8/x16 through the
-// scalar cache) and enter the FMAs as SGPR operands, instead of 64 lanes loading the same address.
-typedef const float __attribute__((address_space(4))) * UniformPtr;
-__device__ __forceinline__ UniformPtr uniform(const float* p) { return (UniformPtr)(uintptr_t)p; }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float relu_bit(float v, uint64_t& mask, int j)
+__device__ __forceinline__ int rowv(int v, int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c)
 {
-    const bool on = v > 0.f;
-    mask |= on ? (1ull << j) : 0ull;
-    return on ? v : 0.f;
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// acc[j] += sum_k wT[k][j] * lds[k]   (k-major weights, `rows` uniform)
-template <int J>
-__device__ __forceinline__ void layer_from_lds(float (&acc)[J], const float* w, const float* lds_col, int rows)
+// Schedule hint for the unrolled layer loops: N LDS reads (the A operands of the next step), then N MFMAs, repeated.
+// Without it the scheduler hoists all 64-96 operand reads of a layer to its top and spills the accumulators.
+template <int N>
+__device__ __forceinline__ void interleave_reads_and_mfmas()
 {
-    UniformPtr wT = uniform(w);
-#pragma unroll 1
-    for (int k = 0; k < rows; k++) {
-        const float hk = lds_col[k * WAVE];
-        UniformPtr wk = wT + (size_t)k * J;
+    __builtin_amdgcn_sched_group_barrier(0x100, N, 0);  // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, N, 0);  // MFMA
+}
+
+// LDS plan (floats).  Streams are [m][64 lanes].
+struct Plan {
+    int T1, T3;            // k-pairs of the first layer (ceil(3B / 2)) and of the output gradient (ceil(B / 2))
+    int s_in, s_hid, s_out;          // forward streams
+    int t_out, t_hid, t_in;          // backward streams
+    int bias, bone;                  // (D + 1) * 64 bias floats; IN_MAX float4 bone rows
+    int total;
+};
+
+__host__ __device__ inline Plan make_plan(int B, int D, bool backward)
+{
+    Plan p;
+    p.T1 = (3 * B + 1) / 2;
+    p.T3 = (B + 1) / 2;
+    int o = 0;
+    p.s_in = o;
+    o += p.T1 * 2 * 64;
+    p.s_hid = o;
+    o += (D - 1) * 64 * 64;
+    p.s_out = o;
+    o += backward ? 0 : 32 * 64;
+    p.t_out = o;
+    o += backward ? p.T3 * 2 * 64 : 0;
+    p.t_hid = o;
+    o += backward ? (D - 1) * 64 * 64 : 0;
+    p.t_in = o;
+    o += backward ? 32 * 3 * 64 : 0;
+    p.bias = o;
+    o += (D + 1) * 64;
+    p.bone = o;
+    o += IN_MAX * 4;
+    p.total = o;
+    return p;
+}
+
+template <bool BACKWARD>
+__device__ void stage(const Vidu4dSkinFieldArgs& a, const Plan& p, float* lds)
+{
+    const int B3 = 3 * a.B;
+    for (int e = threadIdx.x; e < p.T1 * 2 * 64; e += THREADS) {
+        const int l = e & 63, m = e >> 6, ob = m & 1, t = m >> 1;
+        const int k = t + p.T1 * (l >> 5);
+        lds[p.s_in + e] = k < B3 ? a.w_in[(32 * ob + (l & 31)) * IN_MAX + k] : 0.f;
+    }
+    for (int e = threadIdx.x; e < (a.D - 1) * 64 * 64; e += THREADS) {
+        const int l = e & 63, m = (e >> 6) & 63, layer = e >> 12, ob = m & 1, sv = m >> 1;
+        const int src = 32 * (sv >> 4) + rowv(sv & 15, l >> 5), out = 32 * ob + (l & 31);
+        const float* w = a.w_hid + (size_t)layer * W * W;
+        lds[p.s_hid + e] = w[out * W + src];
+        if (BACKWARD) lds[p.t_hid + e] = w[src * W + out];
+    }
+    if (!BACKWARD) {
+        for (int e = threadIdx.x; e < 32 * 64; e += THREADS) {
+            const int l = e & 63, sv = e >> 6;
+            lds[p.s_out + e] = a.w_out[(l & 31) * W + 32 * (sv >> 4) + rowv(sv & 15, l >> 5)];  // (rows >= B are zero)
+        }
+    } else {
+        for (int e = threadIdx.x; e < p.T3 * 2 * 64; e += THREADS) {
+            const int l = e & 63, m = e >> 6, ob = m & 1, t = m >> 1;
+            const int j = t + p.T3 * (l >> 5);
+            lds[p.t_out + e] = j < a.B ? a.w_out[j * W + 32 * ob + (l & 31)] : 0.f;
+        }
+        for (int e = threadIdx.x; e < 32 * 3 * 64; e += THREADS) {
+            const int l = e & 63, m = e >> 6, ob = m % 3, sv = m / 3;
+            lds[p.t_in + e] = a.w_in[(32 * (sv >> 4) + rowv(sv & 15, l >> 5)) * IN_MAX + 32 * ob + (l & 31)];
+        }
+    }
+    for (int e = threadIdx.x; e < (a.D + 1) * 64; e += THREADS) {
+        const int layer = e >> 6, j = e & 63;
+        lds[p.bias + e] = layer == 0 ? a.b_in[j] : (layer < a.D ? a.b_hid[(layer - 1) * W + j] : (j < OUT_MAX ? a.b_out[j] : 0.f));
+    }
+    for (int e = threadIdx.x; e < IN_MAX; e += THREADS) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < B3) r = make_float4(a.bone_A[3 * e], a.bone_A[3 * e + 1], a.bone_A[3 * e + 2], a.bone_c[e]);
+        reinterpret_cast<float4*>(lds + p.bone)[e] = r;
+    }
+    __syncthreads();
+}
+
+// acc = bias of `layer` in the D layout
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[2], const float* lds, const Plan& p, int layer, int half)
+{
 #pragma unroll
-        for (int j = 0; j < J; j++) acc[j] = fmaf(wk[j], hk, acc[j]);
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[ob][v] = lds[p.bias + layer * 64 + 32 * ob + rowv(v, half)];
+}
+
+__device__ __forceinline__ uint32_t relu_tiles(f32x16 (&h)[2])
+{
+    uint32_t mask = 0;
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const bool on = h[ob][v] > 0.f;
+            mask |= on ? (1u << (16 * ob + v)) : 0u;
+            h[ob][v] = on ? h[ob][v] : 0.f;
+        }
+    return mask;
+}
+
+// Hidden layers of the forward for one tile; h = last hidden activations (D layout), masks[l] = active units of layer l.
+__device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, const Plan& p, const float* lds, int lane,
+                                               int n, bool valid, float x, float y, float z, float* xbT_out,
+                                               f32x16 (&h)[2], uint32_t (&masks)[MAX_HIDDEN])
+{
+    const int half = lane >> 5;
+    load_bias(h, lds, p, 0, half);
+    const float4* bone = reinterpret_cast<const float4*>(lds + p.bone);
+#pragma unroll 2
+    for (int t = 0; t < p.T1; t++) {
+        const int k = t + p.T1 * half;
+        const float4 bc = bone[k < IN_MAX ? k : IN_MAX - 1];
+        const float xb = (k < 3 * a.B) ? fmaf(bc.x, x, fmaf(bc.y, y, fmaf(bc.z, z, bc.w))) : 0.f;
+        if (xbT_out && valid && k < 3 * a.B) xbT_out[(size_t)k * a.N + n] = xb;
+        const float* s = lds + p.s_in + (t * 2) * 64 + lane;
+        h[0] = mfma(s[0], xb, h[0]);
+        h[1] = mfma(s[64], xb, h[1]);
+    }
+    masks[0] = relu_tiles(h);
+#pragma unroll 1
+    for (int layer = 1; layer < a.D; layer++) {
+        f32x16 acc[2];
+        load_bias(acc, lds, p, layer, half);
+        const float* s = lds + p.s_hid + (layer - 1) * 64 * 64 + lane;
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const float b = h[sb][v];
+                acc[0] = mfma(s[((sb * 16 + v) * 2) * 64], b, acc[0]);
+                acc[1] = mfma(s[((sb * 16 + v) * 2 + 1) * 64], b, acc[1]);
+                interleave_reads_and_mfmas<2>();
+            }
+        masks[layer] = relu_tiles(acc);
+        h[0] = acc[0];
+        h[1] = acc[1];
     }
 }
 
-// hidden layers 1..D of the forward; on return the last hidden vector is in the thread's LDS column.
-// masks[l] = which units of hidden layer l are active.
-__device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, float x, float y, float z, float* lds_col,
-                                               uint64_t (&masks)[MAX_HIDDEN], float* xbT_out, int n)
+template <bool BACKWARD>
+__global__ __launch_bounds__(THREADS) void skin_field_kernel(Vidu4dSkinFieldArgs a)
 {
-    float acc[W];
-    UniformPtr b_in = uniform(a.b_in), A = uniform(a.bone_A), c = uniform(a.bone_c), w_in_T = uniform(a.w_in_T);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Plan p = make_plan(a.B, a.D, BACKWARD);
+    stage<BACKWARD>(a, p, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int tiles = (a.N + 31) / 32;
+    // (tile = (round * waves + wave) * workgroups + workgroup: a partial last round is spread over all CUs and SIMDs)
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < tiles; tile += gridDim.x * (THREADS / 64)) {
+        const int n = tile * 32 + (lane & 31);
+        const bool valid = n < a.N;
+        const int nn = valid ? n : a.N - 1;
+        const float x = a.xyz[3 * nn], y = a.xyz[3 * nn + 1], z = a.xyz[3 * nn + 2];
+        f32x16 h[2];
+        uint32_t masks[MAX_HIDDEN];
+        hidden_forward(a, p, lds, lane, n, valid, x, y, z, BACKWARD ? nullptr : a.xbT, h, masks);
+        if (!BACKWARD) {
+            f32x16 out;
 #pragma unroll
-    for (int j = 0; j < W; j++) acc[j] = b_in[j];
+            for (int v = 0; v < 16; v++) out[v] = lds[p.bias + a.D * 64 + rowv(v, half)];
+            const float* s = lds + p.s_out + lane;
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    out = mfma(s[(sb * 16 + v) * 64], h[sb][v], out);
+                    interleave_reads_and_mfmas<1>();
+                }
+            if (valid) {
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    const int j = rowv(v, half);
+                    if (j < a.B) a.rawT[(size_t)j * a.N + n] = out[v];
+                }
+            }
+            continue;
+        }
+        // ---- backward: d raw -> d h_D
+        f32x16 g[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) g[ob][v] = 0.f;
+        {
+            const float* s = lds + p.t_out + lane;
+#pragma unroll 2
+            for (int t = 0; t < p.T3; t++) {
+                const int j = t + p.T3 * half;
+                const float gj = j < a.B ? a.g_rawT[(size_t)j * a.N + nn] : 0.f;
+                g[0] = mfma(s[(t * 2) * 64], gj, g[0]);
+                g[1] = mfma(s[(t * 2 + 1) * 64], gj, g[1]);
+            }
+        }
 #pragma unroll 1
-    for (int k = 0; k < 3 * a.B; k++) {
-        const float xb = fmaf(A[3 * k], x, fmaf(A[3 * k + 1], y, fmaf(A[3 * k + 2], z, c[k])));
-        if (xbT_out) xbT_out[(size_t)k * a.N + n] = xb;
-        UniformPtr wk = w_in_T + (size_t)k * W;
+        for (int layer = a.D - 1; layer >= 1; layer--) {
+            const uint32_t m = masks[layer];
+            f32x16 acc[2];
 #pragma unroll
-        for (int j = 0; j < W; j++) acc[j] = fmaf(wk[j], xb, acc[j]);
-    }
-    masks[0] = 0;
+            for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-    for (int j = 0; j < W; j++) lds_col[j * WAVE] = relu_bit(acc[j], masks[0], j);
-#pragma unroll 1
-    for (int l = 1; l < a.D; l++) {
+                for (int v = 0; v < 16; v++) acc[ob][v] = 0.f;
+            const float* s = lds + p.t_hid + (layer - 1) * 64 * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < W; j++) acc[j] = uniform(a.b_hid)[(l - 1) * W + j];
-        layer_from_lds<W>(acc, a.w_hid_T + (size_t)(l - 1) * W * W, lds_col, W);
-        uint64_t m = 0;
+            for (int sb = 0; sb < 2; sb++)
 #pragma unroll
-        for (int j = 0; j < W; j++) lds_col[j * WAVE] = relu_bit(acc[j], m, j);
-        masks[l] = m;
-    }
-}
-
-__global__ __launch_bounds__(WAVE) void skin_field_fwd_kernel(Vidu4dSkinFieldArgs a)
-{
-    __shared__ float lds[W * WAVE];
-    const int n = blockIdx.x * WAVE + threadIdx.x;
-    const bool live = n < a.N;
-    const int nn = live ? n : a.N - 1;  // (idle lanes of the last wave repeat its last surfel and store nothing)
-    float* lds_col = lds + threadIdx.x;
-    const float x = a.xyz[3 * nn], y = a.xyz[3 * nn + 1], z = a.xyz[3 * nn + 2];
-    uint64_t masks[MAX_HIDDEN];
-    hidden_forward(a, x, y, z, lds_col, masks, live ? a.xbT : nullptr, nn);
-    float out[OUT_MAX];
+                for (int v = 0; v < 16; v++) {
+                    const float b = ((m >> (16 * sb + v)) & 1u) ? g[sb][v] : 0.f;
+                    acc[0] = mfma(s[((sb * 16 + v) * 2) * 64], b, acc[0]);
+                    acc[1] = mfma(s[((sb * 16 + v) * 2 + 1) * 64], b, acc[1]);
+                    interleave_reads_and_mfmas<2>();
+                }
+            g[0] = acc[0];
+            g[1] = acc[1];
+        }
+        // ---- d h_1 -> d x_bone (three row blocks), starting from what the skinning kernel passes for x_bone itself
+        f32x16 gx[3];
 #pragma unroll
-    for (int j = 0; j < OUT_MAX; j++) out[j] = uniform(a.b_out)[j];
-    layer_from_lds<OUT_MAX>(out, a.w_out_T, lds_col, W);
-    if (live) {
+        for (int ob = 0; ob < 3; ob++)
 #pragma unroll
-        for (int j = 0; j < OUT_MAX; j++)
-            if (j < a.B) a.rawT[(size_t)j * a.N + n] = out[j];
-    }
-}
-
-__global__ __launch_bounds__(WAVE) void skin_field_bwd_kernel(Vidu4dSkinFieldArgs a)
-{
-    __shared__ float lds[W * WAVE];
-    const int n = blockIdx.x * WAVE + threadIdx.x;
-    const bool live = n < a.N;
-    const int nn = live ? n : a.N - 1;
-    float* lds_col = lds + threadIdx.x;
-    const float x = a.xyz[3 * nn], y = a.xyz[3 * nn + 1], z = a.xyz[3 * nn + 2];
-    uint64_t masks[MAX_HIDDEN];
-    hidden_forward(a, x, y, z, lds_col, masks, nullptr, nn);
-
-    // d raw -> d h_D : rows of w_out (B, W)
-    float g[W];
+            for (int v = 0; v < 16; v++) {
+                const int k = 32 * ob + rowv(v, half);
+                gx[ob][v] = (a.g_xbT && k < 3 * a.B) ? a.g_xbT[(size_t)k * a.N + nn] : 0.f;
+            }
+        {
+            const uint32_t m = masks[0];
+            const float* s = lds + p.t_in + lane;
 #pragma unroll
-    for (int k = 0; k < W; k++) g[k] = 0.f;
-#pragma unroll 1
-    for (int j = 0; j < a.B; j++) {
-        const float gj = a.g_rawT[(size_t)j * a.N + nn];
-        UniformPtr wj = uniform(a.w_out) + (size_t)j * W;
+            for (int sb = 0; sb < 2; sb++)
 #pragma unroll
-        for (int k = 0; k < W; k++) g[k] = fmaf(wj[k], gj, g[k]);
-    }
-#pragma unroll 1
-    for (int l = a.D - 1; l >= 1; l--) {
-        const uint64_t m = masks[l];
+                for (int v = 0; v < 16; v++) {
+                    const float b = ((m >> (16 * sb + v)) & 1u) ? g[sb][v] : 0.f;
 #pragma unroll
-        for (int k = 0; k < W; k++) lds_col[k * WAVE] = ((m >> k) & 1ull) ? g[k] : 0.f;
+                    for (int ob = 0; ob < 3; ob++) gx[ob] = mfma(s[((sb * 16 + v) * 3 + ob) * 64], b, gx[ob]);
+                    interleave_reads_and_mfmas<3>();
+                }
+        }
+        // ---- x_bone = A xyz + c: d xyz = A^T d x_bone; this lane holds 48 of the surfel's rows, its partner the others
+        const float4* bone = reinterpret_cast<const float4*>(lds + p.bone);
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < W; k++) g[k] = 0.f;
-        layer_from_lds<W>(g, a.w_hid + (size_t)(l - 1) * W * W, lds_col, W);  // rows j of w_hid (W, W): sum_j w[j][k] g_j
-    }
-    {
-        const uint64_t m = masks[0];
+        for (int ob = 0; ob < 3; ob++)
 #pragma unroll
-        for (int k = 0; k < W; k++) lds_col[k * WAVE] = ((m >> k) & 1ull) ? g[k] : 0.f;
-    }
-    // d h_1 -> d x_bone (rows of w_in (W, IN_MAX)), plus what the skinning kernel passes for x_bone itself
-    float gx[IN_MAX];
-#pragma unroll
-    for (int k = 0; k < IN_MAX; k++) gx[k] = (k < 3 * a.B && a.g_xbT) ? a.g_xbT[(size_t)k * a.N + nn] : 0.f;
-    layer_from_lds<IN_MAX>(gx, a.w_in, lds_col, W);
-    // x_bone = A xyz + c
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    UniformPtr A = uniform(a.bone_A);
-#pragma unroll
-    for (int k = 0; k < IN_MAX; k++) {
-        g0 = fmaf(A[3 * k], gx[k], g0);
-        g1 = fmaf(A[3 * k + 1], gx[k], g1);
-        g2 = fmaf(A[3 * k + 2], gx[k], g2);
-    }
-    if (live) {
-        a.g_xyz[3 * n] = g0;
-        a.g_xyz[3 * n + 1] = g1;
-        a.g_xyz[3 * n + 2] = g2;
+            for (int v = 0; v < 16; v++) {
+                const float4 bc = bone[32 * ob + rowv(v, half)];  // (rows >= 3B are zero)
+                g0 = fmaf(bc.x, gx[ob][v], g0);
+                g1 = fmaf(bc.y, gx[ob][v], g1);
+                g2 = fmaf(bc.z, gx[ob][v], g2);
+            }
+        g0 += __shfl_xor(g0, 32, 64);
+        g1 += __shfl_xor(g1, 32, 64);
+        g2 += __shfl_xor(g2, 32, 64);
+        if (valid && half == 0) {
+            a.g_xyz[3 * n] = g0;
+            a.g_xyz[3 * n + 1] = g1;
+            a.g_xyz[3 * n + 2] = g2;
+        }
     }
 }
 
@@ -175,29 +328,39 @@ int check_args(const Vidu4dSkinFieldArgs* a, bool backward)
     if (!a || a->N < 0 || a->B <= 0 || a->B > OUT_MAX || 3 * a->B > IN_MAX || a->W != W || a->D < 1 || a->D > MAX_HIDDEN)
         return VIDU4D_E_INVALID;
     if (a->N == 0) return VIDU4D_OK;
-    if (!a->xyz || !a->bone_A || !a->bone_c || !a->w_in_T || !a->b_in || !a->w_out_T || !a->b_out) return VIDU4D_E_INVALID;
-    if (a->D > 1 && (!a->w_hid_T || !a->b_hid)) return VIDU4D_E_INVALID;
+    if (!a->xyz || !a->bone_A || !a->bone_c || !a->w_in || !a->b_in || !a->w_out || !a->b_out) return VIDU4D_E_INVALID;
+    if (a->D > 1 && (!a->w_hid || !a->b_hid)) return VIDU4D_E_INVALID;
     if (!backward) return (a->xbT && a->rawT) ? VIDU4D_OK : VIDU4D_E_INVALID;
-    if (!a->w_in || !a->w_out || (a->D > 1 && !a->w_hid) || !a->g_rawT || !a->g_xyz) return VIDU4D_E_INVALID;
-    return VIDU4D_OK;
+    return (a->g_rawT && a->g_xyz) ? VIDU4D_OK : VIDU4D_E_INVALID;
+}
+
+template <bool BACKWARD>
+int launch(const Vidu4dSkinFieldArgs* a, void* stream)
+{
+    const int rc = check_args(a, BACKWARD);
+    if (rc != VIDU4D_OK || a->N == 0) return rc;
+    const Plan p = make_plan(a->B, a->D, BACKWARD);
+    const size_t bytes = (size_t)p.total * sizeof(float);
+    static bool attr_set = false;  // (one attribute call per template instance; idempotent, benign if raced)
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skin_field_kernel<BACKWARD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return VIDU4D_E_HIP;
+        attr_set = true;
+    }
+    if (bytes > 160 * 1024) return VIDU4D_E_UNSUPPORTED;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int tiles = (a->N + 31) / 32, per_wg = THREADS / 64;
+    int grid = (tiles + per_wg - 1) / per_wg;
+    if (grid > cus) grid = cus;  // one resident workgroup per CU, waves loop over tiles
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(skin_field_kernel<BACKWARD>, dim3(grid), dim3(THREADS), bytes, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
 }  // namespace
 
-extern "C" int vidu4d_skin_field_forward(const Vidu4dSkinFieldArgs* a, void* stream)
-{
-    const int rc = check_args(a, false);
-    if (rc != VIDU4D_OK || a->N == 0) return rc;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(skin_field_fwd_kernel, dim3((a->N + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, *a);
-    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
-}
+extern "C" int vidu4d_skin_field_forward(const Vidu4dSkinFieldArgs* a, void* stream) { return launch<false>(a, stream); }
 
-extern "C" int vidu4d_skin_field_backward(const Vidu4dSkinFieldArgs* a, void* stream)
-{
-    const int rc = check_args(a, true);
-    if (rc != VIDU4D_OK || a->N == 0) return rc;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(skin_field_bwd_kernel, dim3((a->N + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, *a);
-    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
-}
+extern "C" int vidu4d_skin_field_backward(const Vidu4dSkinFieldArgs* a, void* stream) { return launch<true>(a, stream); }

@@ -135,8 +135,8 @@ def skin_field_supported(sm) -> bool:
 
 
 def prepare_skin_field(sm, A, c0) -> dict:
-    """Device arrays in the layout Vidu4dSkinFieldArgs documents (zero-padded, both orientations), from the
-    SkinningField's weights and the rest pose's bone map x_bone = A xyz + c0."""
+    """Device arrays in the layout Vidu4dSkinFieldArgs documents (row-major, zero-padded), from the SkinningField's
+    weights and the rest pose's bone map x_bone = A xyz + c0."""
     lim = _lib.SKIN_FIELD
     W, IN, OUT = lim["width"], lim["in_max"], lim["out_max"]
     mlp = sm.delta_field
@@ -151,13 +151,10 @@ def prepare_skin_field(sm, A, c0) -> dict:
         w1 = mlp.linear_1[0].weight[:, :B3]                       # (W, 3B): the coordinate columns
         hid = [getattr(mlp, f"linear_{i + 1}")[0] for i in range(1, mlp.D)]
         wo, bo = mlp.linear_final.weight, mlp.linear_final.bias    # (B, W), (B)
-        tab = {"B": wo.shape[0], "D": mlp.D,
-               "bone_A": pad(A, (IN, 3)), "bone_c": pad(c0, (IN,)),
-               "w_in": pad(w1, (W, IN)), "w_in_T": pad(w1.t(), (IN, W)),
-               "w_out": pad(wo, (OUT, W)), "w_out_T": pad(wo.t(), (W, OUT)), "b_out": pad(bo, (OUT,))}
+        tab = {"B": wo.shape[0], "D": mlp.D, "bone_A": A.float().contiguous(), "bone_c": c0.float().contiguous(),
+               "w_in": pad(w1, (W, IN)), "w_out": pad(wo, (OUT, W)), "b_out": pad(bo, (OUT,))}
         if hid:
             tab["w_hid"] = torch.stack([l_.weight for l_ in hid]).float().contiguous()
-            tab["w_hid_T"] = torch.stack([l_.weight.t() for l_ in hid]).float().contiguous()
             tab["b_hid"] = torch.stack([l_.bias for l_ in hid]).float().contiguous()
     return tab
 
@@ -167,7 +164,7 @@ def _skin_field_args(tab, N, xyz, b_in, **ptrs):
     a = _lib.SkinFieldArgs()
     a.N, a.B, a.W, a.D = N, tab["B"], _lib.SKIN_FIELD["width"], tab["D"]
     a.xyz, a.b_in = xyz.data_ptr(), b_in.data_ptr()
-    for k in ("bone_A", "bone_c", "w_in_T", "w_hid_T", "b_hid", "w_out_T", "b_out", "w_in", "w_hid", "w_out"):
+    for k in ("bone_A", "bone_c", "w_in", "w_hid", "b_hid", "w_out", "b_out"):
         setattr(a, k, p(tab.get(k)))
     for k, v in ptrs.items():
         setattr(a, k, p(v))
