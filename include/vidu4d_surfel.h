@@ -334,6 +334,42 @@ int vidu4d_densify_apply(int N, const int32_t* inclusive_counts, int n_orig, int
                          const Vidu4dDensifyAttr* attrs, int xyz_attr, int scaling_attr, int rotation_attr,
                          const float* draws, int draws_are_scaled, int32_t* src_row, uint8_t* kind, void* stream);
 
+/* ---- Stage-3 loss terms straight from the rasterizer's planes, and their gradients straight into the planes the
+ *      rasterizer's backward consumes: replaces the elementwise / reduction chain of dvr_model.compute_recon_loss,
+ *      mask_losses, get_mask_balance_wt, compute_reg_loss (distortion term) and apply_loss_weights for the surfel
+ *      field under --rgb_loss_only (lab4d/engine/model.py:586-693, :835-842, :895-1012) together with the learnable-
+ *      background composite in front of it (lab4d/nnutils/deformable_gaussian.py:1216-1218).
+ *      color[m] (3,H,W), allmap[m] (8,H,W): the rasterizer outputs of frame m (M <= 8); bkgd (3) learnable background
+ *      or NULL; rgb (M,H,W,3), mask / vis2d (M,H,W,1) targets; det (M) 1/0 per frame or NULL.  losses (4) =
+ *      {rgb, mask, dist, 0}, each already multiplied by its weight.  sums (32 floats) and partials
+ *      (VIDU4D_LOSS_BLOCKS * 16 floats) are scratch that must stay untouched between forward and backward.
+ *      The backward takes g_losses (4, device) and writes every plane of g_color[m] / g_allmap[m] and g_bkgd (3). ---- */
+#define VIDU4D_LOSS_MAX_FRAMES 8
+#define VIDU4D_LOSS_BLOCKS 512
+#define VIDU4D_LOSS_SUMS_FLOATS 32
+typedef struct Vidu4dStage3LossArgs {
+    int M, H, W;
+    const float* color[VIDU4D_LOSS_MAX_FRAMES];
+    const float* allmap[VIDU4D_LOSS_MAX_FRAMES];
+    const float* bkgd;
+    const float* rgb;
+    const float* mask;
+    const float* vis2d;
+    const float* det;
+    float lambda_dssim, rgb_wt, mask_wt, dist_wt;
+    float* sums;
+    float* partials;
+    float* losses;
+} Vidu4dStage3LossArgs;
+typedef struct Vidu4dStage3LossGrads {
+    float* g_color[VIDU4D_LOSS_MAX_FRAMES];
+    float* g_allmap[VIDU4D_LOSS_MAX_FRAMES];
+    float* g_bkgd;
+} Vidu4dStage3LossGrads;
+int vidu4d_stage3_loss_forward(const Vidu4dStage3LossArgs* args, void* stream);
+int vidu4d_stage3_loss_backward(const Vidu4dStage3LossArgs* args, const float* g_losses,
+                                const Vidu4dStage3LossGrads* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

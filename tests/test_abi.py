@@ -27,7 +27,9 @@ def test_struct_layout_matches_header():
     """ctypes mirrors must have the field order of the C structs."""
     hdr = open(os.path.join(ROOT, "include", "vidu4d_surfel.h")).read()
     for cname, struct in (("Vidu4dSurfelForwardArgs", _lib.ForwardArgs), ("Vidu4dSurfelBackwardArgs", _lib.BackwardArgs),
-                          ("Vidu4dAdamTensor", _lib.AdamTensor), ("Vidu4dDensifyAttr", _lib.DensifyAttr)):
+                          ("Vidu4dAdamTensor", _lib.AdamTensor), ("Vidu4dDensifyAttr", _lib.DensifyAttr),
+                          ("Vidu4dSkinFieldArgs", _lib.SkinFieldArgs), ("Vidu4dStage3LossArgs", _lib.Stage3LossArgs),
+                          ("Vidu4dStage3LossGrads", _lib.Stage3LossGrads)):
         body = hdr[hdr.index("typedef struct " + cname):hdr.index("} " + cname + ";")]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -36,7 +38,7 @@ def test_struct_layout_matches_header():
             if not decl:
                 continue
             for part in decl.split(","):
-                names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
+                names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", re.sub(r"\[.*?\]", "", part).strip())[0])
         assert names == [f[0] for f in struct._fields_], cname
 
 

@@ -49,6 +49,24 @@ class SkinFieldArgs(C.Structure):
                                   "rawT", "g_xbT", "g_rawT", "g_xyz")]
 
 
+LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 8, 512, 32
+
+
+class Stage3LossArgs(C.Structure):
+    """struct Vidu4dStage3LossArgs"""
+    _fields_ = [("M", C.c_int), ("H", C.c_int), ("W", C.c_int), ("color", C.c_void_p * LOSS_MAX_FRAMES),
+                ("allmap", C.c_void_p * LOSS_MAX_FRAMES), ("bkgd", C.c_void_p), ("rgb", C.c_void_p),
+                ("mask", C.c_void_p), ("vis2d", C.c_void_p), ("det", C.c_void_p), ("lambda_dssim", C.c_float),
+                ("rgb_wt", C.c_float), ("mask_wt", C.c_float), ("dist_wt", C.c_float), ("sums", C.c_void_p),
+                ("partials", C.c_void_p), ("losses", C.c_void_p)]
+
+
+class Stage3LossGrads(C.Structure):
+    """struct Vidu4dStage3LossGrads"""
+    _fields_ = [("g_color", C.c_void_p * LOSS_MAX_FRAMES), ("g_allmap", C.c_void_p * LOSS_MAX_FRAMES),
+                ("g_bkgd", C.c_void_p)]
+
+
 SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
 ADAM_MAX_TENSORS = 8
 DENSIFY_MAX_ATTRS = 8
@@ -106,6 +124,8 @@ SYMBOLS = {
     "vidu4d_post_backward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "vidu4d_skin_field_forward": (C.c_int, [C.POINTER(SkinFieldArgs), _P]),
     "vidu4d_skin_field_backward": (C.c_int, [C.POINTER(SkinFieldArgs), _P]),
+    "vidu4d_stage3_loss_forward": (C.c_int, [C.POINTER(Stage3LossArgs), _P]),
+    "vidu4d_stage3_loss_backward": (C.c_int, [C.POINTER(Stage3LossArgs), _P, C.POINTER(Stage3LossGrads), _P]),
     "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,

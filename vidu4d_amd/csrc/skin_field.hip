@@ -41,7 +41,6 @@ constexpr int IN_MAX = VIDU4D_SKIN_FIELD_IN_MAX;    // padded 3B: three row bloc
 constexpr int OUT_MAX = VIDU4D_SKIN_FIELD_OUT_MAX;  // padded B: one row block
 constexpr int MAX_HIDDEN = VIDU4D_SKIN_FIELD_MAX_HIDDEN;
 constexpr int THREADS = 512;  // 8 waves share the staged weights; 2 waves per SIMD leave each 256 registers
-constexpr int T1_MAX = IN_MAX / 2, T3_MAX = OUT_MAX / 2;
 static_assert(W == 64 && IN_MAX == 96 && OUT_MAX == 32, "row-block structure");
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -172,7 +171,6 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
     const int half = lane >> 5;
     load_bias(h, lds, p, 0, half);
     const float4* bone = reinterpret_cast<const float4*>(lds + p.bone);
-#pragma unroll 2
     for (int t = 0; t < p.T1; t++) {
         const int k = t + p.T1 * half;
         const float4 bc = bone[k < IN_MAX ? k : IN_MAX - 1];
@@ -249,7 +247,6 @@ __global__ __launch_bounds__(THREADS) void skin_field_kernel(Vidu4dSkinFieldArgs
             for (int v = 0; v < 16; v++) g[ob][v] = 0.f;
         {
             const float* s = lds + p.t_out + lane;
-#pragma unroll 2
             for (int t = 0; t < p.T3; t++) {
                 const int j = t + p.T3 * half;
                 const float gj = j < a.B ? a.g_rawT[(size_t)j * a.N + nn] : 0.f;

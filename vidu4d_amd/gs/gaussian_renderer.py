@@ -58,6 +58,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                                                scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}
+    if outputs is not None and "allmap" in outputs:  # (extension: the raw auxiliary planes, for the fused loss)
+        rets["allmap"] = allmap
 
     render_alpha = allmap[1:2]
     if outputs is not None and not any(k in GEOMETRY_KEYS for k in outputs):

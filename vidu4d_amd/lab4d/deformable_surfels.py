@@ -118,6 +118,8 @@ class DeformableSurfels(GaussianModel):
             if override_xyz is not None:
                 del self._override_xyz
                 del self._override_rotation
+        if outputs is not None and "raw" in outputs:
+            return rendered  # (the caller composites the learnable background itself: lab4d/loss_fused.py)
         if hasattr(self, "learnable_bkgd"):
             rendered["render"] = rendered["render"] + (1 - rendered["acc"]) * self.learnable_bkgd[:, None, None]
         return rendered
@@ -286,6 +288,12 @@ class DeformableSurfels(GaussianModel):
             xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
         cams = self.get_gs_Kcamera(Kinv, H, W)
         stacked, per_frame = {}, {"viewspace_points": [], "visibility_filter": [], "radii": []}
+        # outputs containing "raw": the per-frame colour / auxiliary planes are handed out as they leave the rasterizer
+        # (out["raw"] = [(color (3,H,W), allmap (8,H,W))], no learnable-background composite, no permute / stack)
+        raw = outputs is not None and "raw" in outputs
+        raw_frames = []
+        if raw:
+            outputs = tuple(outputs) + ("allmap",)
         # Frames of a step are independent until the loss: each one is queued on its own HIP stream so
         # that the tile workgroups of all frames are resident together (an object-centric frame fills
         # only a fraction of the 256 CUs, and its blend kernels are bound by the longest tile's serial
@@ -311,6 +319,9 @@ class DeformableSurfels(GaussianModel):
             else:
                 r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i],
                                      outputs=outputs)
+            if raw:
+                raw_frames.append((r.pop("render"), r.pop("allmap")))
+                r.pop("acc", None), r.pop("rend_dist", None)
             for k, v in r.items():
                 if k in per_frame:
                     per_frame[k].append(v)
@@ -323,8 +334,11 @@ class DeformableSurfels(GaussianModel):
         self._viewspace_points_batch = per_frame["viewspace_points"]
         self._visibility_filter_batch = per_frame["visibility_filter"]
         self._radii_batch = per_frame["radii"]
-        out["rendered"] = out["render"]
-        out["mask"] = out["acc"]
+        if raw:
+            out["raw"] = raw_frames
+        else:
+            out["rendered"] = out["render"]
+            out["mask"] = out["acc"]
         return out
 
 

@@ -1,0 +1,74 @@
+"""Stage-3 loss terms from the rasterizer's planes in five launches (csrc/loss.hip) instead of ~80: the same arithmetic
+as stage3.compute_losses (which tests/golden/refpy_losses.npz pins against lab4d/engine/model.py:586-693, :835-842,
+:895-1012) applied to the per-frame (3,H,W) colour and (8,H,W) auxiliary planes, with the learnable-background
+composite of DeformableGaussian.render_view (deformable_gaussian.py:1216-1218) in front."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+class _Stage3Loss(Function):
+    @staticmethod
+    def forward(ctx, cfg, targets, bkgd, *planes):
+        M = len(planes) // 2
+        colors, allmaps = planes[:M], planes[M:]
+        dev = colors[0].device
+        if not colors[0].is_cuda:
+            raise RuntimeError("stage3_loss: HIP tensors required")
+        if M > _lib.LOSS_MAX_FRAMES:
+            raise RuntimeError(f"stage3_loss: at most {_lib.LOSS_MAX_FRAMES} frames per call")
+        H, W = colors[0].shape[-2:]
+        keep = [t.detach().float().contiguous() for t in colors + allmaps]
+        tg = {k: targets[k].detach().float().contiguous() for k in ("rgb", "mask", "vis2d")}
+        if tuple(tg["rgb"].shape) != (M, H, W, 3) or tg["mask"].numel() != M * H * W or tg["vis2d"].numel() != M * H * W:
+            raise RuntimeError("stage3_loss: targets must be rgb (M,H,W,3), mask / vis2d (M,H,W,1) of the rendered size")
+        det = targets.get("is_detected")
+        det = None if det is None else det.detach().float().contiguous()
+        bg = None if bkgd is None else bkgd.detach().float().contiguous()
+        a = _lib.Stage3LossArgs()
+        a.M, a.H, a.W = M, H, W
+        for m in range(M):
+            a.color[m], a.allmap[m] = keep[m].data_ptr(), keep[M + m].data_ptr()
+        a.bkgd = None if bg is None else bg.data_ptr()
+        a.rgb, a.mask, a.vis2d = tg["rgb"].data_ptr(), tg["mask"].data_ptr(), tg["vis2d"].data_ptr()
+        a.det = None if det is None else det.data_ptr()
+        a.lambda_dssim, a.rgb_wt, a.mask_wt, a.dist_wt = cfg["lambda_dssim"], cfg["rgb_wt"], cfg["mask_wt"], cfg["dist_wt"]
+        sums = torch.empty(_lib.LOSS_SUMS_FLOATS, dtype=torch.float32, device=dev)
+        partials = torch.empty(_lib.LOSS_BLOCKS * 16, dtype=torch.float32, device=dev)
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        a.sums, a.partials, a.losses = sums.data_ptr(), partials.data_ptr(), losses.data_ptr()
+        _lib.check(_lib.load().vidu4d_stage3_loss_forward(a, torch.cuda.current_stream(dev).cuda_stream), "stage3 loss forward")
+        ctx.args, ctx.M, ctx.has_bg = a, M, bg is not None
+        ctx.keep = (keep, tg, det, bg, sums, partials, losses)  # everything the argument struct points to
+        return losses
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        keep = ctx.keep[0]
+        M, dev = ctx.M, keep[0].device
+        g = g_losses.detach().float().contiguous()
+        g_color = [torch.empty_like(keep[m]) for m in range(M)]
+        g_allmap = [torch.empty_like(keep[M + m]) for m in range(M)]
+        g_bg = torch.empty(3, dtype=torch.float32, device=dev) if ctx.has_bg else None
+        o = _lib.Stage3LossGrads()
+        for m in range(M):
+            o.g_color[m], o.g_allmap[m] = g_color[m].data_ptr(), g_allmap[m].data_ptr()
+        o.g_bkgd = None if g_bg is None else g_bg.data_ptr()
+        _lib.check(_lib.load().vidu4d_stage3_loss_backward(ctx.args, g.data_ptr(), o, torch.cuda.current_stream(dev).cuda_stream),
+                   "stage3 loss backward")
+        return (None, None, g_bg) + tuple(g_color) + tuple(g_allmap)
+
+
+def stage3_loss(colors, allmaps, bkgd, batch: dict, step: int, cfg) -> dict:
+    """colors / allmaps: per-frame (3,H,W) / (8,H,W) rasterizer outputs (BEFORE the learnable-background composite);
+    bkgd: the (3,) learnable background or None; batch as for compute_losses.  -> {"rgb", "mask", "dist_loss"}: the
+    same weighted terms compute_losses returns for them."""
+    lam_d = float(cfg.lambda_dist) if step > 8000 else 0.0
+    c = dict(lambda_dssim=float(cfg.lambda_dssim), rgb_wt=float(cfg.rgb_wt), mask_wt=float(cfg.mask_wt), dist_wt=lam_d)
+    out = _Stage3Loss.apply(c, batch, bkgd, *colors, *allmaps)
+    return {"rgb": out[0], "mask": out[1], "dist_loss": out[2]}

@@ -212,9 +212,18 @@ class Stage3Trainer:
         m = self.model
         # the depth / normal maps are only read by the regularisers, whose weights are 0 until step 8000
         need_geometry = step > 8000 and (self.cfg.lambda_normal != 0.0)
-        outputs = None if need_geometry else ("render", "acc", "rend_dist")
-        rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=outputs)
-        losses = compute_losses(rendered, batch, step, self.cfg)
+        M = int(batch["frameid"].shape[0])
+        if m._xyz.is_cuda and not need_geometry and M <= 8 and m.opts.get("fused_loss", True):
+            # colour / silhouette / distortion terms and their gradient planes in five launches (csrc/loss.hip)
+            from .loss_fused import stage3_loss
+            rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=("raw",))
+            colors, allmaps = zip(*rendered["raw"])
+            losses = stage3_loss(colors, allmaps, getattr(m, "learnable_bkgd", None), batch, step, self.cfg)
+            losses["normal_loss"] = torch.zeros((), device=m._xyz.device)
+        else:
+            outputs = None if need_geometry else ("render", "acc", "rend_dist")
+            rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=outputs)
+            losses = compute_losses(rendered, batch, step, self.cfg)
         total = sum(losses.values())
         total.backward()
         return losses
