@@ -175,7 +175,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--surfels", type=int, default=200_000)
     ap.add_argument("--res", type=int, default=512, help="image width (and height unless --height is given)")
     ap.add_argument("--height", type=int, default=0)
