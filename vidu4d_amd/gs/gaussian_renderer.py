@@ -23,7 +23,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     elementwise launches per frame, twice that in the backward) is skipped and those keys are absent."""
     xyz = pc.get_xyz
     # dummy (N,3) tensor whose .grad receives the screen-space densification statistic (:29-33)
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype).requires_grad_(True)  # (a leaf: .grad is kept)
     try:
         screenspace_points.retain_grad()
     except Exception:

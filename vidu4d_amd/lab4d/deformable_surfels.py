@@ -105,6 +105,29 @@ class DeformableSurfels(GaussianModel):
     def get_xyz(self):
         return self._override_xyz if hasattr(self, "_override_xyz") else self._xyz
 
+    # The frames of a step share the canonical appearance: the activated copies (one exp, one sigmoid, one (N,16,3)
+    # concatenation of the SH rows) are made once per step by render_frames, not once per frame; autograd sums
+    # the frames' gradients into them.
+    def _shared(self, key, make):
+        cache = self.__dict__.get("_step_cache")
+        if cache is None:
+            return make()
+        if key not in cache:
+            cache[key] = make()
+        return cache[key]
+
+    @property
+    def get_scaling(self):
+        return self._shared("scaling", lambda: self.scaling_activation(self._scaling))
+
+    @property
+    def get_opacity(self):
+        return self._shared("opacity", lambda: self.opacity_activation(self._opacity))
+
+    @property
+    def get_features(self):
+        return self._shared("features", lambda: torch.cat((self._features_dc, self._features_rest), dim=1))
+
     def render_view(self, view, override_xyz=None, override_rotation=None, override_color=None, override_bkgd=None,
                     outputs=None):
         if override_xyz is not None:
@@ -267,6 +290,17 @@ class DeformableSurfels(GaussianModel):
             self._aux_dict = {}
         return xyz_cam, rot_cam
 
+    @staticmethod
+    def _collect_frame(r, raw, raw_frames, per_frame, stacked):
+        if raw:
+            raw_frames.append((r.pop("render"), r.pop("allmap")))
+            r.pop("acc", None), r.pop("rend_dist", None)
+        for k, v in r.items():
+            if k in per_frame:
+                per_frame[k].append(v)
+            else:
+                stacked.setdefault(k, []).append(v.permute(1, 2, 0))
+
     def _frame_streams(self, M):
         if M < 2:
             return None
@@ -280,12 +314,12 @@ class DeformableSurfels(GaussianModel):
         keeps the per-frame screen-space tensors the densification statistics need."""
         M = frame_id.shape[0]
         if self.fused_warp_ok(inst_id):
-            xyz_cam, rot_cam = self.forward_warp_fused(frame_id, inst_id, samples_dict)
-            xyz_cam = xyz_cam[:, :, None]
+            xyz_cam, rot_cam = self.forward_warp_fused(frame_id, inst_id, samples_dict)  # (M,N,3), (M,N,4)
         else:
             xyz = self._xyz[None, :, None].expand(M, -1, -1, -1)
             rot = self._rotation[None].expand(M, -1, -1)
             xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
+            xyz_cam = xyz_cam.squeeze(2)
         cams = self.get_gs_Kcamera(Kinv, H, W)
         stacked, per_frame = {}, {"viewspace_points": [], "visibility_filter": [], "radii": []}
         # outputs containing "raw": the per-frame colour / auxiliary planes are handed out as they leave the rasterizer
@@ -305,28 +339,31 @@ class DeformableSurfels(GaussianModel):
             # main stream, before the per-frame streams fork (two streams must not race to create it)
             for cam in cams:
                 cam.pixel_rays()
+        # (unbind, not xyz_cam[i]: its backward is ONE stack of the frames' gradients instead of a zero-filled full
+        # tensor plus a copy plus an add per frame)
+        frame_xyz, frame_rot = xyz_cam.unbind(0), rot_cam.unbind(0)
+        self.__dict__["_step_cache"] = {}
+        shared = (self.get_scaling, self.get_opacity, self.get_features)  # made here, on the main stream
         if streams:
             main = torch.cuda.current_stream(xyz_cam.device)
             ready = main.record_event()
-        for i in range(M):
-            if streams:
-                streams[i].wait_event(ready)
-                with torch.cuda.stream(streams[i]):
-                    r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i],
-                                         outputs=outputs)
-                    for v in r.values():
-                        v.record_stream(main)
-            else:
-                r = self.render_view(cams[i], override_xyz=xyz_cam[i, :, 0], override_rotation=rot_cam[i],
-                                     outputs=outputs)
-            if raw:
-                raw_frames.append((r.pop("render"), r.pop("allmap")))
-                r.pop("acc", None), r.pop("rend_dist", None)
-            for k, v in r.items():
-                if k in per_frame:
-                    per_frame[k].append(v)
+        try:
+            for i in range(M):
+                if streams:
+                    streams[i].wait_event(ready)
+                    with torch.cuda.stream(streams[i]):
+                        for t in shared:
+                            t.record_stream(streams[i])
+                        r = self.render_view(cams[i], override_xyz=frame_xyz[i], override_rotation=frame_rot[i],
+                                             outputs=outputs)
+                        for v in r.values():
+                            v.record_stream(main)
                 else:
-                    stacked.setdefault(k, []).append(v.permute(1, 2, 0))
+                    r = self.render_view(cams[i], override_xyz=frame_xyz[i], override_rotation=frame_rot[i],
+                                         outputs=outputs)
+                self._collect_frame(r, raw, raw_frames, per_frame, stacked)
+        finally:
+            self.__dict__.pop("_step_cache", None)
         if streams:
             for st in streams[:M]:
                 main.wait_stream(st)
