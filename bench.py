@@ -360,6 +360,11 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # (the cyclic collector is kept out of the timed regions: a generation-2 pass over torch's Python objects takes
+    # milliseconds, as long as several steps)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -373,6 +378,7 @@ def main():
             step()
         sync()
         rep_rates.append(world * args.steps * FRAMES_PER_STEP / (time.perf_counter() - r0))
+    gc.enable()
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
