@@ -240,6 +240,58 @@ def test_headline_size_vs_oracle_and_properties(gpu_device):
     assert int((ranges[:, 1] - ranges[:, 0]).sum()) == R
 
 
+def test_largest_configuration_properties(gpu_device):
+    """BASELINE.json configs[4] at its FULL size -- 1 M surfels, 1920x1080 (8160 tiles, partial bottom row) -- through
+    size-independent properties (the CPU oracle would need a minute): pair count == sum of the tile counts of the
+    visible surfels, ranges partition the list, keys ascending with the tile id in the high word, alpha == 1 - T,
+    bit-identical repeat, every gradient finite and the backward LINEAR in the upstream gradients."""
+    from vidu4d_amd import _C
+    dev = gpu_device
+    W, H, P = 1920, 1080, 1_000_000
+    sc = make_scene(P, W, H, seed=4)
+    d, shs, cols, out = _native_forward(sc, dev)
+    R, color, others, radii, geom, binning, img = out
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    touched = _state("tiles_touched", out, sc, torch.int32, P).astype(np.int64)
+    assert R == int(touched[to_np(radii) > 0].sum()) and R > P
+    ranges = _state("ranges", out, sc, torch.int32, 2 * T).view(np.uint32).reshape(-1, 2).astype(np.int64)
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.sum()) == R and (lens >= 0).all()
+    nz = lens > 0
+    assert np.array_equal(np.sort(ranges[nz, 0]), np.concatenate([[0], np.cumsum(lens[nz][np.argsort(ranges[nz, 0])])[:-1]]))
+    keys = _state("sorted_keys", out, sc, torch.int64, R).view(np.uint64)
+    assert (np.diff(keys.astype(np.int64)) >= 0).all()
+    tile_of = (keys >> np.uint64(32)).astype(np.int64)
+    assert np.array_equal(np.bincount(tile_of, minlength=T), lens)
+    plist = _state("point_list", out, sc, torch.int32, R).view(np.uint32)
+    assert int(plist.max()) < P and (to_np(radii)[plist[:: max(1, R // 100000)]] > 0).all()
+    fT = _state("final_T", out, sc, torch.float32, 3 * W * H).reshape(3, H, W)
+    assert np.allclose(to_np(others[1]), 1.0 - fT[0], atol=1e-6) and np.isfinite(to_np(color)).all()
+    _, _, _, out2 = _native_forward(sc, dev)
+    assert out2[0] == R and torch.equal(color, out2[1]) and torch.equal(others, out2[2]) and torch.equal(radii, out2[3])
+
+    empty = torch.empty(0, device=dev)
+
+    def bwd(dc, do):
+        return _C.rasterize_gaussians_backward(d.bg, d.means3D, radii, cols, d.scales, d.rotations, 1.0, empty, d.viewmatrix,
+                                               d.projmatrix, sc.tanfovx, sc.tanfovy, dc, do, shs, sc.sh_degree, d.campos, geom,
+                                               R, binning, img, False)
+    g = torch.Generator().manual_seed(0)
+    dc1, dc2 = (torch.randn(3, H, W, generator=g).to(dev) for _ in range(2))
+    do1, do2 = (torch.randn(8, H, W, generator=g).to(dev) for _ in range(2))
+    do1[5] = do2[5] = 0  # (the median-depth plane is a selection, linear too, but keep the check about the sums)
+    ga, gb = bwd(dc1, do1), bwd(dc2, do2)
+    gc = bwd(2.0 * dc1 - 0.5 * dc2, 2.0 * do1 - 0.5 * do2)
+    for a, b, c in zip(ga, gb, gc):
+        if not c.numel():
+            continue
+        assert torch.isfinite(c).all()
+        want = 2.0 * a - 0.5 * b
+        scale = float(want.abs().max()) + 1e-30
+        bad = ((c - want).abs() > 2e-4 * scale).float().mean()
+        assert float(bad) <= 1e-5, float(bad)  # (atomic summation order differs between runs: fp32 re-association only)
+
+
 def test_partial_tiles_1080p_slice(gpu_device):
     """cfg-E geometry (height not a multiple of 16, 13 tile bits) at a reduced surfel count."""
     sc = make_scene(60_000, 1920, 1080, seed=77)
