@@ -159,7 +159,31 @@ def test_skin_field_is_what_the_fused_warp_runs(gpu_device):
         rng = np.random.default_rng(1)
         m.init_from_points(rng.normal(size=(3000, 3)).astype(np.float32) * 0.2, rng.uniform(size=(3000, 3)).astype(np.float32))
         x, r = m.forward_warp_fused(torch.tensor([1, 5], device=dev))
-        (x.sum() + (r * r).sum()).backward()
+        G = torch.randn(r.shape, generator=torch.Generator().manual_seed(4)).to(dev)  # (|r| = 1: r * r would be constant)
+        (x.sum() + (r * G).sum()).backward()
         out[flag] = (x.detach(), r.detach(), m._xyz.grad.clone(), m._rotation.grad.clone())
     for a, b in zip(out[True], out[False]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+
+
+def test_lbs_skin_unit_rotation_equals_normalize_after(gpu_device):
+    """lbs_skin_apply(unit_rot=True) == F.normalize(lbs_skin_apply(...)[1]) with its backward (the renderer's rotation
+    activation, gs/scene/gaussian_model.py:57, fused into the kernel)."""
+    from vidu4d_amd.lab4d.lbs_fused import lbs_skin_apply
+    dev = gpu_device
+    M, N, B = 2, 3000, 25
+    qr, qd, logits, xyz, rot, cq, ct = _inputs(dev, M, N, B, seed=5)
+    g = torch.Generator().manual_seed(2)
+    xbT0 = (0.5 * torch.randn(3 * B, N, generator=g)).to(dev)
+    gx, gr = torch.randn(M, N, 3, generator=g).to(dev), torch.randn(M, N, 4, generator=g).to(dev)
+    res = {}
+    for unit in (True, False):
+        xb, x, r = (t.clone().requires_grad_(True) for t in (xbT0, xyz, 2.5 * rot))
+        ox, orot = lbs_skin_apply(xb, None, (qr, qd), x, r, cq, ct, unit_rot=unit)
+        if not unit:
+            orot = torch.nn.functional.normalize(orot, dim=-1)
+        ((ox * gx).sum() + (orot * gr).sum()).backward()
+        res[unit] = [t.detach() for t in (ox, orot, xb.grad, x.grad, r.grad)]
+    for a, b in zip(res[True], res[False]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-6 * float(b.abs().max()))
+    assert torch.allclose(res[True][1].norm(dim=-1), torch.ones(M, N, device=dev), atol=1e-6)

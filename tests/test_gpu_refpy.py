@@ -110,6 +110,7 @@ def test_fused_forward_warp_with_reference_weights(gpu_device):
             p.requires_grad_(False)
     fid, iid = a["frame_id"][:2], a["inst_id"][:2]
     assert m.fused_warp_ok(iid)
+    m.opts["fused_rot_activation"] = False  # the reference's forward_warp returns the orientations un-normalised
     for fused_skin in (True, False):   # skin + blend + apply in one kernel / weights in torch, blend + apply in the kernel
         m.opts["fused_skin"] = fused_skin
         m._xyz.grad = m._rotation.grad = None
@@ -120,6 +121,10 @@ def test_fused_forward_warp_with_reference_weights(gpu_device):
                                      (m._xyz, m._rotation))
         close(gx, a["f2_g_xyz"], rtol=5e-4, atol=5e-4)
         close(gr, a["f2_g_rot"], rtol=2e-4, atol=2e-5)
+    # default: the renderer's rotation activation (F.normalize, gaussian_model.py:57) is applied inside the kernel
+    m.opts["fused_skin"], m.opts["fused_rot_activation"] = True, True
+    _, rot_unit = m.forward_warp_fused(fid, iid)
+    close(rot_unit, torch.nn.functional.normalize(a["f2_rot_cam"], dim=-1), atol=1e-5)
 
 
 def test_lbs_skin_kernel_without_delta_field(gpu_device):

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
                                                        const float* __restrict__ g_out_xyz,
                                                        const float* __restrict__ g_out_rot,
                                                        float* __restrict__ g_xbT, float* __restrict__ g_rawT,
-                                                       float* __restrict__ g_xyz, float* __restrict__ g_rot)
+                                                       float* __restrict__ g_xyz, float* __restrict__ g_rot,
+                                                       int unit_rot)
 {
     __shared__ float s_q[MAX_FRAMES][2 * MAX_BONES * 4];
     __shared__ unsigned long long s_sign[MAX_FRAMES][MAX_BONES];
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
             out_xyz[3 * o] = cx.x + ct[0];
             out_xyz[3 * o + 1] = cx.y + ct[1];
             out_xyz[3 * o + 2] = cx.z + ct[2];
-            const Q rc = qmul(cq, rt);
+            Q rc = qmul(cq, rt);
+            if (unit_rot) rc = qscale(rc, 1.0f / fmaxf(sqrtf(qdot(rc, rc)), 1e-12f));  // F.normalize (eps = 1e-12)
             out_rot[4 * o] = rc.w;
             out_rot[4 * o + 1] = rc.x;
             out_rot[4 * o + 2] = rc.y;
@@ -275,7 +277,14 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
             continue;
         }
         const Q g_xc = qvec(g_out_xyz[3 * o], g_out_xyz[3 * o + 1], g_out_xyz[3 * o + 2]);
-        const Q g_rc = ldq(g_out_rot + 4 * o);
+        Q g_rc = ldq(g_out_rot + 4 * o);
+        if (unit_rot) {  // back through v / max(|v|, eps)
+            const Q rc = qmul(cq, rt);
+            const float nrm = sqrtf(qdot(rc, rc));
+            const float invn = 1.0f / fmaxf(nrm, 1e-12f);
+            const Q u = qscale(rc, invn);
+            g_rc = nrm > 1e-12f ? qscale(qadd(g_rc, qscale(u, -qdot(u, g_rc))), invn) : qscale(g_rc, invn);
+        }
         Q g_cq_unused, g_xt;
         rotate_bwd(cq, xt, c1, g_xc, g_cq_unused, g_xt);
         g_xt.w = 0.f;
@@ -358,7 +367,7 @@ extern "C" int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const f
 
 extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                                        const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
-                                       const float* cam_t, float* out_xyz, float* out_rot, void* stream)
+                                       const float* cam_t, float* out_xyz, float* out_rot, int unit_rot, void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
@@ -366,7 +375,7 @@ extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, co
     (void)hipGetLastError();
     hipLaunchKernelGGL(lbs_skin_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B, xbT, rawT,
                        se3_qr, se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       nullptr);
+                       nullptr, unit_rot);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
@@ -374,7 +383,7 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
                                         const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                                         const float* cam_t, const float* g_out_xyz, const float* g_out_rot,
                                         float* g_xbT /*(3B,N)*/, float* g_rawT /*(B,N) or NULL*/, float* g_xyz /*(N,3)*/,
-                                        float* g_rot /*(N,4)*/, void* stream)
+                                        float* g_rot /*(N,4)*/, int unit_rot, void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
@@ -384,6 +393,6 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
     (void)hipGetLastError();
     hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B, xbT, rawT,
                        se3_qr, se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot, g_xbT, g_rawT, g_xyz,
-                       g_rot);
+                       g_rot, unit_rot);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }

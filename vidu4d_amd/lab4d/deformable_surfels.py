@@ -98,6 +98,8 @@ class DeformableSurfels(GaussianModel):
     @property
     def get_rotation(self):
         if hasattr(self, "_override_rotation"):
+            if self.__dict__.get("_override_rotation_is_unit", False):
+                return self._override_rotation  # (activated by the warp kernel: lbs_skin_apply(unit_rot=True))
             return self.rotation_activation(self._override_rotation)
         return self.rotation_activation(self._rotation)
 
@@ -229,6 +231,7 @@ class DeformableSurfels(GaussianModel):
         direction (csrc/lbs.hip).  -> xyz_cam (M,N,3), rot_cam (M,N,4)."""
         samples_dict = samples_dict or {}
         w = self.warp
+        self.__dict__["_warp_rot_is_unit"] = False
         overrides = any(k in samples_dict for k in ("rest_articulation", "t_articulation", "field2cam"))
         if overrides:
             if "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
@@ -271,7 +274,11 @@ class DeformableSurfels(GaussianModel):
             else:
                 xbT = torch.addmm(c0[:, None], A, self._xyz.t())
                 rawT = sm.delta_raw_T(xbT, bias[0]) if sm.has_delta else None
-            xyz_cam, rot_cam = lbs_skin_apply(xbT, rawT, se3, self._xyz, self._rotation, cq, ct)
+            # (the renderer's rotation activation -- F.normalize per frame, 6 launches forward and backward -- is
+            # applied inside the kernel: render_frames hands these orientations on as already activated)
+            unit = bool(self.opts.get("fused_rot_activation", True))
+            xyz_cam, rot_cam = lbs_skin_apply(xbT, rawT, se3, self._xyz, self._rotation, cq, ct, unit_rot=unit)
+            self.__dict__["_warp_rot_is_unit"] = unit
             skin = delta = None
         else:
             frames = None if overrides else tab["bone_frames"]
@@ -315,7 +322,9 @@ class DeformableSurfels(GaussianModel):
         M = frame_id.shape[0]
         if self.fused_warp_ok(inst_id):
             xyz_cam, rot_cam = self.forward_warp_fused(frame_id, inst_id, samples_dict)  # (M,N,3), (M,N,4)
+            rot_is_unit = self.__dict__.pop("_warp_rot_is_unit", False)
         else:
+            rot_is_unit = False
             xyz = self._xyz[None, :, None].expand(M, -1, -1, -1)
             rot = self._rotation[None].expand(M, -1, -1)
             xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
@@ -343,6 +352,7 @@ class DeformableSurfels(GaussianModel):
         # tensor plus a copy plus an add per frame)
         frame_xyz, frame_rot = xyz_cam.unbind(0), rot_cam.unbind(0)
         self.__dict__["_step_cache"] = {}
+        self.__dict__["_override_rotation_is_unit"] = rot_is_unit
         shared = (self.get_scaling, self.get_opacity, self.get_features)  # made here, on the main stream
         if streams:
             main = torch.cuda.current_stream(xyz_cam.device)
@@ -364,6 +374,7 @@ class DeformableSurfels(GaussianModel):
                 self._collect_frame(r, raw, raw_frames, per_frame, stacked)
         finally:
             self.__dict__.pop("_step_cache", None)
+            self.__dict__.pop("_override_rotation_is_unit", None)
         if streams:
             for st in streams[:M]:
                 main.wait_stream(st)

@@ -67,7 +67,7 @@ class _LbsSkinApply(Function):
     apply -> camera, for all frames, one kernel per direction (csrc/lbs.hip lbs_skin_kernel)."""
 
     @staticmethod
-    def forward(ctx, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t):
+    def forward(ctx, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, unit_rot=False):
         if not xyz.is_cuda:
             raise RuntimeError("lbs_skin_apply: HIP tensors required")
         for t, name in ((se3_qr, "se3"), (se3_qd, "se3"), (cam_q, "field2cam"), (cam_t, "field2cam")):
@@ -82,9 +82,10 @@ class _LbsSkinApply(Function):
         out_rot = torch.empty(M, N, 4, dtype=torch.float32, device=xyz.device)
         lib = _lib.load()
         ptr = [None if a is None else a.data_ptr() for a in args]
-        _lib.check(lib.vidu4d_lbs_skin_forward(M, N, B, *ptr, out_xyz.data_ptr(), out_rot.data_ptr(),
+        _lib.check(lib.vidu4d_lbs_skin_forward(M, N, B, *ptr, out_xyz.data_ptr(), out_rot.data_ptr(), int(unit_rot),
                                                torch.cuda.current_stream(xyz.device).cuda_stream), "lbs skin forward")
         ctx.has_raw = rawT is not None
+        ctx.unit_rot = bool(unit_rot)
         ctx.save_for_backward(*[a for a in args if a is not None])
         ctx.dims = (M, N, B)
         return out_xyz, out_rot
@@ -106,15 +107,17 @@ class _LbsSkinApply(Function):
         ptr = [None if a is None else a.data_ptr() for a in saved]
         _lib.check(lib.vidu4d_lbs_skin_backward(M, N, B, *ptr, g_xyz_out.data_ptr(), g_rot_out.data_ptr(), g_xbT.data_ptr(),
                                                 None if g_rawT is None else g_rawT.data_ptr(), g_xyz.data_ptr(),
-                                                g_rot.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                                                g_rot.data_ptr(), int(ctx.unit_rot),
+                                                torch.cuda.current_stream(dev).cuda_stream),
                    "lbs skin backward")
-        return g_xbT, g_rawT, None, None, g_xyz, g_rot, None, None
+        return g_xbT, g_rawT, None, None, g_xyz, g_rot, None, None, None
 
 
-def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t):
+def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False):
     """xbT (3B,N) Gaussian-bone coordinates; rawT (B,N) raw output of the delta-skin MLP or None; se3 = (qr, qd)
-    each (M,B,4), M <= 8; xyz (N,3); rot (N,4); cam_q (M,4), cam_t (M,3).  -> xyz_cam (M,N,3), rot_cam (M,N,4)."""
-    return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t)
+    each (M,B,4), M <= 8; xyz (N,3); rot (N,4); cam_q (M,4), cam_t (M,3).  -> xyz_cam (M,N,3), rot_cam (M,N,4);
+    unit_rot: rot_cam comes out normalised (F.normalize, the renderer's rotation activation, fused in)."""
+    return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot)
 
 
 # ---------------------------------------------------------------------------------------------------------------
