@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void lbs_kernel(int N, int B, const float* __r
 // the feature-major GEMMs of the delta MLP produce and consume (lab4d/lbs_fused.py).
 constexpr int MAX_FRAMES = 8;
 
-template <bool BACKWARD>
+// BCAP: compile-time bound of the bone loops (32 for the bob field's 25 bones: fully unrolled, the per-bone weights and
+// weight gradients stay in registers; the 64-bone instance indexes them dynamically, i.e. through scratch memory).
+template <bool BACKWARD, int BCAP>
 __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
                                                        const float* __restrict__ rawT,
                                                        const float* __restrict__ se3_qr,
@@ -214,11 +216,12 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
 
-    float w[MAX_BONES];
+    float w[BCAP];
     int anchor = 0;
     float best = -3.0e38f;
-#pragma unroll 5
-    for (int b = 0; b < B; b++) {
+#pragma unroll
+    for (int b = 0; b < BCAP; b++) {
+        if (b >= B) break;
         const float x0 = xbT[(size_t)(3 * b) * N + n], x1 = xbT[(size_t)(3 * b + 1) * N + n],
                     x2 = xbT[(size_t)(3 * b + 2) * N + n];
         const float raw = rawT ? rawT[(size_t)b * N + n] : 0.f;
@@ -229,25 +232,28 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
         }
     }
     float sum = 0.f;
-    for (int b = 0; b < B; b++) {
+    _Pragma("unroll") for (int b = 0; b < BCAP; b++) {
+        if (b >= B) break;
         w[b] = __expf(w[b] - best);
         sum += w[b];
     }
     const float isum = 1.0f / sum;
-    for (int b = 0; b < B; b++) w[b] *= isum;
+    _Pragma("unroll") for (int b = 0; b < BCAP; b++)
+        if (b < B) w[b] *= isum;
 
     const Q p = qvec(xyz[3 * n], xyz[3 * n + 1], xyz[3 * n + 2]);
     const Q r = ldq(rot + 4 * n);
-    float gw[MAX_BONES];
+    float gw[BCAP];
     Q acc_p = {0, 0, 0, 0}, acc_r = {0, 0, 0, 0};
     if (BACKWARD)
-        for (int b = 0; b < B; b++) gw[b] = 0.f;
+        _Pragma("unroll") for (int b = 0; b < BCAP; b++) gw[b] = 0.f;
 
     for (int m = 0; m < M; m++) {
         const float* sq = s_q[m];
         const unsigned long long hemi = s_sign[m][anchor];
         Q Qr = {0, 0, 0, 0}, Qd = {0, 0, 0, 0};
-        for (int b = 0; b < B; b++) {
+        _Pragma("unroll") for (int b = 0; b < BCAP; b++) {
+            if (b >= B) break;
             const float ws = ((hemi >> b) & 1ull) ? w[b] : -w[b];
             Qr = qadd(Qr, qscale(ldq(sq + b * 4), ws));
             Qd = qadd(Qd, qscale(ldq(sq + MAX_BONES * 4 + b * 4), ws));
@@ -300,7 +306,8 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
         const float gq_q = qdot(g_q, q), gd_d = qdot(g_d, d);
         const Q g_Qr = qscale(qadd(g_q, qscale(q, -(gq_q + gd_d))), inv);
         const Q g_Qd = qscale(g_d, inv);
-        for (int b = 0; b < B; b++) {
+        _Pragma("unroll") for (int b = 0; b < BCAP; b++) {
+            if (b >= B) break;
             const float sgn = ((hemi >> b) & 1ull) ? 1.0f : -1.0f;
             gw[b] += sgn * (qdot(g_Qr, ldq(sq + b * 4)) + qdot(g_Qd, ldq(sq + MAX_BONES * 4 + b * 4)));
         }
@@ -308,9 +315,11 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
     if (!BACKWARD) return;
     // back through the softmax and the logits
     float dot = 0.f;
-    for (int b = 0; b < B; b++) dot += w[b] * gw[b];
-#pragma unroll 5
-    for (int b = 0; b < B; b++) {
+    _Pragma("unroll") for (int b = 0; b < BCAP; b++)
+        if (b < B) dot += w[b] * gw[b];
+#pragma unroll
+    for (int b = 0; b < BCAP; b++) {
+        if (b >= B) break;
         const float g_logit = w[b] * (gw[b] - dot);
         const float x0 = xbT[(size_t)(3 * b) * N + n], x1 = xbT[(size_t)(3 * b + 1) * N + n],
                     x2 = xbT[(size_t)(3 * b + 2) * N + n];
@@ -373,9 +382,14 @@ extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, co
     if (M == 0 || N == 0) return VIDU4D_OK;
     if (!xbT || !se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !out_xyz || !out_rot) return VIDU4D_E_INVALID;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(lbs_skin_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B, xbT, rawT,
-                       se3_qr, se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, unit_rot);
+    if (B <= 32)
+        hipLaunchKernelGGL((lbs_skin_kernel<false, 32>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B,
+                           xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, unit_rot);
+    else
+        hipLaunchKernelGGL((lbs_skin_kernel<false, MAX_BONES>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M,
+                           N, B, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr, unit_rot);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
@@ -391,8 +405,13 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
         !g_rot || (rawT && !g_rawT))
         return VIDU4D_E_INVALID;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B, xbT, rawT,
-                       se3_qr, se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot, g_xbT, g_rawT, g_xyz,
-                       g_rot, unit_rot);
+    if (B <= 32)
+        hipLaunchKernelGGL((lbs_skin_kernel<true, 32>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B,
+                           xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot, g_xbT,
+                           g_rawT, g_xyz, g_rot, unit_rot);
+    else
+        hipLaunchKernelGGL((lbs_skin_kernel<true, MAX_BONES>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N,
+                           B, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot,
+                           g_xbT, g_rawT, g_xyz, g_rot, unit_rot);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
