@@ -40,7 +40,10 @@ constexpr int W = VIDU4D_SKIN_FIELD_WIDTH;          // hidden width: two row blo
 constexpr int IN_MAX = VIDU4D_SKIN_FIELD_IN_MAX;    // padded 3B: three row blocks
 constexpr int OUT_MAX = VIDU4D_SKIN_FIELD_OUT_MAX;  // padded B: one row block
 constexpr int MAX_HIDDEN = VIDU4D_SKIN_FIELD_MAX_HIDDEN;
-constexpr int THREADS = 512;  // 8 waves share the staged weights; 2 waves per SIMD leave each 256 registers
+// waves per workgroup share the staged weights: 16 (4 per SIMD, <= 128 registers each) forward, 8 (2 per SIMD, <= 256
+// registers) backward
+template <bool BACKWARD>
+constexpr int threads_of() { return BACKWARD ? 512 : 1024; }
 static_assert(W == 64 && IN_MAX == 96 && OUT_MAX == 32, "row-block structure");
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -99,6 +102,7 @@ __host__ __device__ inline Plan make_plan(int B, int D, bool backward)
 template <bool BACKWARD>
 __device__ void stage(const Vidu4dSkinFieldArgs& a, const Plan& p, float* lds)
 {
+    constexpr int THREADS = threads_of<BACKWARD>();
     const int B3 = 3 * a.B;
     for (int e = threadIdx.x; e < p.T1 * 2 * 64; e += THREADS) {
         const int l = e & 63, m = e >> 6, ob = m & 1, t = m >> 1;
@@ -202,8 +206,9 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
 }
 
 template <bool BACKWARD>
-__global__ __launch_bounds__(THREADS) void skin_field_kernel(Vidu4dSkinFieldArgs a)
+__global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu4dSkinFieldArgs a)
 {
+    constexpr int THREADS = threads_of<BACKWARD>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const Plan p = make_plan(a.B, a.D, BACKWARD);
     stage<BACKWARD>(a, p, lds);
@@ -348,6 +353,7 @@ int launch(const Vidu4dSkinFieldArgs* a, void* stream)
     if (bytes > 160 * 1024) return VIDU4D_E_UNSUPPORTED;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    constexpr int THREADS = threads_of<BACKWARD>();
     const int tiles = (a->N + 31) / 32, per_wg = THREADS / 64;
     int grid = (tiles + per_wg - 1) / per_wg;
     if (grid > cus) grid = cus;  // one resident workgroup per CU, waves loop over tiles
