@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 4
+#define VIDU4D_SURFEL_ABI 5
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -105,7 +105,23 @@ typedef struct Vidu4dSurfelForwardArgs {
     uint32_t* depth_used;            /* optional device counter (or NULL): atomic max of the deepest list position
                                         any pixel of the frame blended, i.e. the serial chain length of the
                                         unsplit blend.  Callers use it to decide segment_split for later frames. */
+    /* ---- stacked frames (the reference renders the frames of a step one after the other,
+     * lab4d/nnutils/deformable_gaussian.py:1175-1228).  frames > 1: ONE launch set rasterizes `frames` frames that
+     * share opacities / scales / shs (P rows) but have their own centres and orientations -- means3D (frames,P,3),
+     * rotations (frames,P,4), radii (frames,P) -- and cameras: frame f uses frame_viewmatrix[f], frame_campos[f],
+     * frame_tan_fovx/y[f] (viewmatrix / campos / tan_fov* above are ignored).  Outputs are plane-major over the frames:
+     * out_color (3,frames,H,W), out_others (8,frames,H,W).  geom_buffer must hold vidu4d_surfel_geom_bytes(frames * P),
+     * image_buffer vidu4d_surfel_image_bytes_frames(W,H,frames).  Every per-frame result equals what a single-frame
+     * call gives for that frame (same tile lists, same blend order).  colors_precomp, if used, is (frames,P,3).
+     * frames <= 1: the fields below are ignored. */
+    int frames;
+    const float* frame_viewmatrix[8];
+    const float* frame_campos[8];
+    float frame_tan_fovx[8];
+    float frame_tan_fovy[8];
 } Vidu4dSurfelForwardArgs;
+#define VIDU4D_SURFEL_MAX_FRAMES 8
+size_t vidu4d_surfel_image_bytes_frames(int width, int height, int frames);
 
 int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* args, void* stream);
 /* Blocking device->host read of num_rendered (the reference's cudaMemcpy, rasterizer_impl.cu:282). */
@@ -151,6 +167,15 @@ typedef struct Vidu4dSurfelBackwardArgs {
     float* dL_drotations;            /* (P,4) */
     int segment_split;               /* !=0: walk long tile lists segment-parallel; takes effect only when the
                                         forward that filled the buffers ran with segment_split != 0 */
+    /* ---- stacked frames, as in the forward.  Inputs dL_dout_color (3,frames,H,W), dL_dout_others (8,frames,H,W);
+     * per-frame outputs dL_dmeans2D / dL_dmeans3D (frames,P,3), dL_drotations (frames,P,4), dL_dcolors (frames,P,3),
+     * dL_dtransMat (frames,P,9); the gradients of what the frames share -- dL_dopacity (P,1), dL_dscales (P,2),
+     * dL_dsh (P,M,3) -- are the SUMS over the frames.  workspace: vidu4d_surfel_backward_workspace_bytes(frames * P). */
+    int frames;
+    const float* frame_viewmatrix[8];
+    const float* frame_campos[8];
+    float frame_tan_fovx[8];
+    float frame_tan_fovy[8];
 } Vidu4dSurfelBackwardArgs;
 
 int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* args, void* stream);

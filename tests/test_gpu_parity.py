@@ -508,3 +508,59 @@ def test_segment_limit_reports_truncation_and_replay_is_exact(gpu_device, monkey
             assert out[5]._vidu4d_split == 1 and _C.check_deferred()
         for a, b in ((out[1], ref[1]), (out[2], ref[2])):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("F,split", [(2, "0"), (3, "1"), (2, "auto")])
+def test_stacked_frames_equal_single_frame_calls(gpu_device, monkeypatch, F, split):
+    """F frames in ONE launch set (frame || tile keys) == F single-frame calls: integers (radii, sorted lists
+    per tile, ranges, n_contrib) identical, images identical, gradients equal up to the order of the atomic sums; the
+    shared parameters' gradients are the sums over the frames."""
+    import diff_surfel_rasterization as dsr
+    from vidu4d_amd import _C
+    from vidu4d_amd.synthetic import frame_motion
+    monkeypatch.setattr(_C, "_SPLIT", split)
+    dev = gpu_device
+    W, H, N = 176, 120, 6000   # (partial tiles in both directions)
+    sc = make_scene(N, W, H, seed=21, sigma_px=6.0).to(dev)
+    frames = [frame_motion(sc, 3 * f, 12) for f in range(F)]
+    views = []
+    for f in range(F):  # a different camera per frame: a small rotation about y and a different field of view
+        ang = 0.05 * f
+        R = torch.eye(4, device=dev)
+        R[0, 0] = R[2, 2] = float(np.cos(ang))
+        R[0, 2], R[2, 0] = float(np.sin(ang)), -float(np.sin(ang))
+        vm = (sc.viewmatrix.t() @ R).t().contiguous()
+        views.append(dsr.GaussianRasterizationSettings(H, W, sc.tanfovx * (1 + 0.1 * f), sc.tanfovy * (1 + 0.1 * f), sc.bg, 1.0, vm,
+                                                       sc.projmatrix, sc.sh_degree, torch.linalg.inv(vm.t())[:3, 3].contiguous(),
+                                                       False, False))
+    dc, do = make_upstream_grads(W, H)
+    g = torch.Generator().manual_seed(1)
+    dcs = [(dc * (1 + 0.3 * f)).to(dev) for f in range(F)]
+    dos = [(do * (1 - 0.2 * f)).to(dev) for f in range(F)]
+    shared = lambda: [t.clone().requires_grad_(True) for t in (sc.opacities, sc.scales, sc.shs)]  # noqa: E731
+    # ---- F single-frame calls
+    o1, s1, h1 = shared()
+    singles, states = [], []
+    for f in range(F):
+        m = frames[f].means3D.clone().requires_grad_(True)
+        r = frames[f].rotations.clone().requires_grad_(True)
+        m2 = torch.zeros_like(m, requires_grad=True)
+        color, radii, allmap = dsr.GaussianRasterizer(views[f])(means3D=m, means2D=m2, opacities=o1, shs=h1, scales=s1, rotations=r)
+        torch.autograd.backward([color, allmap], [dcs[f], dos[f]])
+        singles.append((color.detach(), radii, allmap.detach(), m.grad, r.grad, m2.grad))
+    # ---- one stacked call
+    o2, s2, h2 = shared()
+    M3 = torch.stack([fr.means3D for fr in frames]).requires_grad_(True)
+    R4 = torch.stack([fr.rotations for fr in frames]).requires_grad_(True)
+    M2 = torch.zeros_like(M3, requires_grad=True)
+    color, radii, allmap = dsr.rasterize_frames(M3, M2, h2, o2, s2, R4, views)
+    assert color.shape == (3, F, H, W) and allmap.shape == (8, F, H, W) and radii.shape == (F, N)
+    torch.autograd.backward([color, allmap], [torch.stack(dcs, 1), torch.stack(dos, 1)])
+    for f in range(F):
+        c, rd, am, gm, gr, gm2 = singles[f]
+        assert torch.equal(radii[f], rd), f
+        assert torch.equal(color[:, f], c) and torch.equal(allmap[:, f], am), f
+        for a, b, what in ((M3.grad[f], gm, "means3D"), (R4.grad[f], gr, "rotations"), (M2.grad[f], gm2, "means2D")):
+            assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), (f, what)
+    for a, b, what in ((o2.grad, o1.grad, "opacity"), (s2.grad, s1.grad, "scales"), (h2.grad, h1.grad, "sh")):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), what

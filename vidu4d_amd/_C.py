@@ -152,11 +152,35 @@ def _pinned_slot(device):
     return _pinned[key]
 
 
+def _set_frame_cams(args, frame_cams, keep):
+    """Stacked frames: per-frame (viewmatrix, campos, tan_fovx, tan_fovy) into the argument struct."""
+    args.frames = len(frame_cams)
+    for f, (vm, cp, tfx, tfy) in enumerate(frame_cams):
+        vm, cp = _f32c(vm, "viewmatrix"), _f32c(cp, "campos")
+        keep += [vm, cp]
+        args.frame_viewmatrix[f], args.frame_campos[f] = vm.data_ptr(), cp.data_ptr()
+        args.frame_tan_fovx[f], args.frame_tan_fovy[f] = float(tfx), float(tfy)
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
-    """-> (num_rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer)"""
+                        prefiltered, debug, frame_cams=None):
+    """-> (num_rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer)
+
+    frame_cams (extension): a list of F <= 8 (viewmatrix, campos, tan_fovx, tan_fovy) -- F frames that
+    share opacity / scales / sh are rasterized by one launch set: means3D (F,P,3), rotations (F,P,4) -> out_color
+    (3,F,H,W), out_others (8,F,H,W), radii (F,P); viewmatrix / campos / tan_fov* arguments are ignored."""
     lib = _lib.load()
+    F = 1 if frame_cams is None else len(frame_cams)
+    if frame_cams is not None:
+        if not 1 <= F <= 8:
+            raise RuntimeError("frame_cams: 1 to 8 frames")
+        if means3D.ndim != 3 or means3D.shape[0] != F or rotations.ndim != 3 or rotations.shape[0] != F:
+            raise RuntimeError("stacked frames: means3D (F, num_points, 3) and rotations (F, num_points, 4) required")
+        means3D, rotations = means3D.reshape(-1, 3), rotations.reshape(-1, 4)
+        viewmatrix, campos, tan_fovx, tan_fovy = frame_cams[0]
+        if projmatrix is None or not projmatrix.numel():
+            projmatrix = viewmatrix
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if scales.ndim != 2 or scales.shape[1] != 2:
@@ -166,7 +190,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     _check_cuda(background, means3D, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, sh,
                 campos)
     dev = means3D.device
-    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    P, H, W = means3D.shape[0] // F, int(image_height), int(image_width)  # (P: surfels per frame)
     means3D = _f32c(means3D, "means3D")
     scales = _f32c(scales, "scales")
     rotations = _f32c(rotations, "rotations")
@@ -182,13 +206,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if colors.numel():
         colors = _f32c(colors, "colors")
 
-    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    out_others = torch.empty((8, H, W), dtype=torch.float32, device=dev)
-    radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    geom = torch.empty((lib.vidu4d_surfel_geom_bytes(P),), dtype=torch.uint8, device=dev)
-    img = torch.empty((lib.vidu4d_surfel_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+    plane = (H, W) if frame_cams is None else (F, H, W)
+    out_color = torch.empty((3,) + plane, dtype=torch.float32, device=dev)
+    out_others = torch.empty((8,) + plane, dtype=torch.float32, device=dev)
+    radii = torch.empty((P,) if frame_cams is None else (F, P), dtype=torch.int32, device=dev)
+    geom = torch.empty((lib.vidu4d_surfel_geom_bytes(P * F),), dtype=torch.uint8, device=dev)
+    img = torch.empty((lib.vidu4d_surfel_image_bytes_frames(W, H, F),), dtype=torch.uint8, device=dev)
 
     a = _lib.ForwardArgs()
+    keep = []
+    if frame_cams is not None and F > 1:
+        _set_frame_cams(a, frame_cams, keep)
     a.P, a.D, a.M, a.width, a.height = P, int(degree), M, W, H
     a.tan_fovx, a.tan_fovy = float(tan_fovx), float(tan_fovy)
     a.scale_modifier = float(scale_modifier)
@@ -204,7 +232,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # Hints are keyed on the image shape and device only: the surfel count changes with every densify / prune,
     # and the pair count, split depth and per-stream counters of the previous frames stay good guesses across it
     # (keying on P leaked one entry -- with a device tensor and a pinned buffer -- per surfel count).
-    key = (W, H, str(dev))
+    key = (W, H, str(dev)) if F == 1 else (W, H, str(dev), F)
     stat = None
     if _SPLIT == "auto":
         depth = _depth_hint.get(key, 0)
@@ -283,31 +311,42 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 binning_capacity=None, segment_split=None):
-    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations)"""
+                                 binning_capacity=None, segment_split=None, frame_cams=None):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations)
+
+    frame_cams: as in rasterize_gaussians (means3D (F,P,3), rotations (F,P,4), radii (F,P), dL_dout_color (3,F,H,W),
+    dL_dout_others (8,F,H,W)); per-frame gradients come back (F,P,.), those of opacity / scales / sh summed over the
+    frames."""
     lib = _lib.load()
+    F = 1 if frame_cams is None else len(frame_cams)
+    if frame_cams is not None:
+        means3D, rotations = means3D.reshape(-1, 3), rotations.reshape(-1, 4)
+        viewmatrix, campos, tan_fovx, tan_fovy = frame_cams[0]
+        if projmatrix is None or not projmatrix.numel():
+            projmatrix = viewmatrix
     _check_cuda(background, means3D, radii, colors, scales, rotations, viewmatrix, projmatrix, sh, campos, geomBuffer,
                 binningBuffer, imageBuffer)
     dev = means3D.device
-    P = means3D.shape[0]
-    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    P = means3D.shape[0] // F  # (surfels per frame)
+    H, W = dL_dout_color.shape[-2], dL_dout_color.shape[-1]
     M = sh.shape[1] if sh.numel() else 0
     opt = dict(dtype=torch.float32, device=dev)
-    dL_dmeans3D = torch.empty((P, 3), **opt)
-    dL_dmeans2D = torch.empty((P, 3), **opt)
-    dL_dcolors = torch.empty((P, 3), **opt)
+    lead = (P,) if frame_cams is None else (F, P)
+    dL_dmeans3D = torch.empty(lead + (3,), **opt)
+    dL_dmeans2D = torch.empty(lead + (3,), **opt)
+    dL_dcolors = torch.empty(lead + (3,), **opt)
     dL_dopacity = torch.empty((P, 1), **opt)
-    dL_dtransMat = torch.empty((P, 9), **opt)
+    dL_dtransMat = torch.empty(lead + (9,), **opt)
     dL_dsh = torch.empty((P, M, 3), **opt)
     dL_dscales = torch.empty((P, 2), **opt)
-    dL_drotations = torch.empty((P, 4), **opt)
+    dL_drotations = torch.empty(lead + (4,), **opt)
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
     if binning_capacity is None:
         binning_capacity = getattr(binningBuffer, "_vidu4d_capacity", None)
     if binning_capacity is None:
         binning_capacity = max(int(R), 1)
-    ws = torch.empty((lib.vidu4d_surfel_backward_workspace_bytes(P),), dtype=torch.uint8, device=dev)
+    ws = torch.empty((lib.vidu4d_surfel_backward_workspace_bytes(P * F),), dtype=torch.uint8, device=dev)
     means3D = _f32c(means3D, "means3D")
     scales = _f32c(scales, "scales")
     rotations = _f32c(rotations, "rotations")
@@ -323,6 +362,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         colors = _f32c(colors, "colors")
 
     b = _lib.BackwardArgs()
+    keep = []
+    if frame_cams is not None and F > 1:
+        _set_frame_cams(b, frame_cams, keep)
     b.P, b.D, b.M, b.width, b.height = P, int(degree), M, W, H
     b.tan_fovx, b.tan_fovy, b.scale_modifier, b.debug = float(tan_fovx), float(tan_fovy), float(scale_modifier), int(
         bool(debug))
@@ -359,11 +401,11 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     return present
 
 
-def read_state(what: str, fwd_inputs: dict, geomBuffer, binningBuffer, imgBuffer, P, W, H, dtype, max_count):
-    """Test helper: copies one internal array (see _lib.STATE) to a host tensor."""
+def read_state(what: str, fwd_inputs: dict, geomBuffer, binningBuffer, imgBuffer, P, W, H, dtype, max_count, frames=1):
+    """Test helper: copies one internal array (see _lib.STATE) to a host tensor (frames > 1: P per frame)."""
     lib = _lib.load()
     a = _lib.ForwardArgs()
-    a.P, a.width, a.height = P, W, H
+    a.P, a.width, a.height, a.frames = P, W, H, frames
     a.geom_buffer, a.geom_bytes = geomBuffer.data_ptr(), geomBuffer.numel()
     a.image_buffer, a.image_bytes = imgBuffer.data_ptr(), imgBuffer.numel()
     cap = getattr(binningBuffer, "_vidu4d_capacity", 0)

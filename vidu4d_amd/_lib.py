@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ForwardArgs(C.Structure):
@@ -26,6 +26,8 @@ class ForwardArgs(C.Structure):
         ("campos", C.c_void_p), ("out_color", C.c_void_p), ("out_others", C.c_void_p), ("radii", C.c_void_p),
         ("geom_buffer", C.c_void_p), ("geom_bytes", C.c_size_t), ("image_buffer", C.c_void_p),
         ("image_bytes", C.c_size_t), ("segment_split", C.c_int), ("depth_used", C.c_void_p),
+        ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
+        ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
     ]
 
 
@@ -86,6 +88,8 @@ class BackwardArgs(C.Structure):
         ("dL_dmeans2D", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dopacity", C.c_void_p),
         ("dL_dmeans3D", C.c_void_p), ("dL_dtransMat", C.c_void_p), ("dL_dsh", C.c_void_p),
         ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("segment_split", C.c_int),
+        ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
+        ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
     ]
 
 
@@ -96,6 +100,7 @@ SYMBOLS = {
     "vidu4d_last_error": (C.c_char_p, []),
     "vidu4d_surfel_geom_bytes": (C.c_size_t, [C.c_int]),
     "vidu4d_surfel_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vidu4d_surfel_image_bytes_frames": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vidu4d_surfel_binning_bytes": (C.c_size_t, [C.c_int64]),
     "vidu4d_surfel_backward_workspace_bytes": (C.c_size_t, [C.c_int]),
     "vidu4d_surfel_forward_plan": (C.c_int, [C.POINTER(ForwardArgs), _P]),

@@ -316,9 +316,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, 
     tile_rect(q2.y, q2.z, radius, cam.grid_x, cam.grid_y, x0, y0, x1, y1);
     const uint64_t entry = ((uint64_t)__float_as_uint(q3.w) << 32) | (uint32_t)idx;
     const int slice = blockIdx.x & (TILE_SLICES - 1);  // same slice the count came from (same launch geometry)
+    const int tile0 = cam.frames > 1 ? (idx / cam.frame_surfels) * cam.grid_x * cam.grid_y : 0;  // (stacked frames)
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
-            const size_t b = (size_t)(y * cam.grid_x + x) * TILE_SLICES + slice;
+            const size_t b = (size_t)(tile0 + y * cam.grid_x + x) * TILE_SLICES + slice;
             const uint32_t pos = img.tile_base[b] + atomicAdd(&img.tile_count[b], 1u);
             entries[pos] = entry;
         }
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraPa
         if (blockIdx.x == 0 && threadIdx.x == 0) g.hdr->overflow = 1;
         return;
     }
-    const int num_tiles = cam.grid_x * cam.grid_y;
+    const int frame_tiles = cam.grid_x * cam.grid_y, num_tiles = frame_tiles * cam.frames;
     const uint32_t* row = img.group_counts + (size_t)blockIdx.x * num_tiles;
     for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) s_cur[t] = img.ranges[2 * t] + row[t];
     __syncthreads();
@@ -352,8 +353,9 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraPa
         int x0, y0, x1, y1;
         tile_rect(q2.y, q2.z, radius, cam.grid_x, cam.grid_y, x0, y0, x1, y1);
         const uint64_t entry = ((uint64_t)__float_as_uint(q3.w) << 32) | (uint32_t)idx;
+        uint32_t* cur = s_cur + (cam.frames > 1 ? (idx / cam.frame_surfels) * frame_tiles : 0);
         for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) entries[atomicAdd(&s_cur[y * cam.grid_x + x], 1u)] = entry;
+            for (int x = x0; x < x1; x++) entries[atomicAdd(&cur[y * cam.grid_x + x], 1u)] = entry;
     }
 }
 
@@ -363,7 +365,7 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
     if (P <= 0) return;
     if (grouped)
         hipLaunchKernelGGL(emit_keys_grouped_kernel, dim3(bin_groups(P)), dim3(BIN_THREADS),
-                           (size_t)cam.grid_x * cam.grid_y * sizeof(uint32_t), stream, cam, P, bin_iters(P), radii, g,
+                           (size_t)total_tiles(cam) * sizeof(uint32_t), stream, cam, P, bin_iters(P), radii, g,
                            img, b.entries, capacity);
     else
         hipLaunchKernelGGL(emit_keys_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, cam, P, radii, g, img,

@@ -43,6 +43,18 @@ struct TileCoord {
     bool valid;
 };
 
+// Stacked frames (surfel_state.h): the tile grid handed to these kernels is `frames` grids of one frame on top of each
+// other (grid_y = frames * ceil(H / 16)), image planes are (frames, H, W).  Makes tc.ty the row inside its frame and
+// returns the offset of that frame in a plane; `plane` = distance between two planes.  One frame: 0 and H * W.
+__device__ __forceinline__ size_t frame_of_tile(TileCoord& tc, int W, int H, int grid_y_total, size_t& plane)
+{
+    const int fgy = (H + TILE - 1) / TILE;
+    const int frame = tc.ty / fgy;
+    tc.ty -= frame * fgy;
+    plane = (size_t)W * H * (size_t)(grid_y_total / fgy);
+    return (size_t)frame * W * H;
+}
+
 // Stages one surfel record (q0..q4) into LDS slot `slot` and returns q5, the contribution box.
 __device__ __forceinline__ float4 stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
 {
@@ -184,7 +196,9 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
     if (overflow || blockIdx.x >= hdr->num_segments) return;
     const WorkItem wk = find_work<true>(hdr, img, grid_x, grid_y, false);
     if (wk.seg >= max_seg) return;
-    const TileCoord tc = wk.tc;
+    TileCoord tc = wk.tc;
+    size_t plane_unused;
+    (void)frame_of_tile(tc, W, H, grid_y, plane_unused);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
     const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
@@ -230,7 +244,9 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
     const bool overflow = (int64_t)hdr->num_rendered > capacity;
     const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
-    const TileCoord tc = wk.tc;
+    TileCoord tc = wk.tc;
+    size_t plane;
+    const size_t frame_base = frame_of_tile(tc, W, H, grid_y, plane);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
     const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
         return;
     }
     if (inside)
-        write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
+        write_pixel(s, plane, frame_base + (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
     report_depth(depth_used, s.last_contributor);
 }
 
@@ -347,8 +363,14 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     const int nseg_all = (int)((img.ranges[2 * tile + 1] - img.ranges[2 * tile] + SEG_LEN - 1) / SEG_LEN);
     const int nseg = nseg_all < max_seg ? nseg_all : max_seg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = (tile % grid_x) * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = (tile / grid_x) * TILE + (wave >> 1) * 8 + (lane >> 3);
+    TileCoord tc;
+    tc.tile = tile;
+    tc.tx = tile % grid_x;
+    tc.ty = tile / grid_x;
+    size_t plane;
+    const size_t frame_base = frame_of_tile(tc, W, H, grid_y, plane);
+    const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     FwdPixel s;
     float T_raw = 1.0f;
     for (int q = 0; q < nseg; q++) {
@@ -376,7 +398,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
         }
     }
     if (px < W && py < H)
-        write_pixel(s, (size_t)H * W, (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
+        write_pixel(s, plane, frame_base + (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
 
     report_depth(depth_used, s.last_contributor);
     // the caller's segment limit cut this tile short and this pixel had not saturated yet: its values are
@@ -417,11 +439,11 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
                       float* out_others, uint32_t* depth_used, hipStream_t stream)
 {
-    const int tiles = cam.grid_x * cam.grid_y;
+    const int tiles = total_tiles(cam), grid_y = cam.grid_y * cam.frames;  // (stacked frames: a taller tile grid)
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
         hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                           cam.grid_y, g.hdr, img, point_list, capacity, 0, g.rec, background, b.seg_data, out_color,
+                           grid_y, g.hdr, img, point_list, capacity, 0, g.rec, background, b.seg_data, out_color,
                            out_others, depth_used);
         return;
     }
@@ -430,13 +452,13 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     // number of positions that hold split tiles is not bounded by capacity / SPLIT_MIN.
     const int segs = (int)seg_capacity(capacity);
     const int split_tiles = tiles;
-    hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, cam.grid_y,
+    hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y,
                        g.hdr, img, point_list, capacity, max_seg, g.rec, b.seg_data);
     hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                       cam.grid_y, g.hdr, img, point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color,
+                       grid_y, g.hdr, img, point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color,
                        out_others, depth_used);
     hipLaunchKernelGGL(blend_combine_kernel, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                       cam.grid_y, g.hdr, img, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used);
+                       grid_y, g.hdr, img, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,14 +564,16 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     // (a forward that ran unsplit left no segment state: every tile is then walked whole)
     const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, SPLIT && !hdr->split_used);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
-    const TileCoord tc = wk.tc;
+    TileCoord tc = wk.tc;
+    size_t HW;  // (distance between planes: frames * H * W)
+    const size_t frame_base = frame_of_tile(tc, W, H, grid_y, HW);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
     const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
     const uint32_t r0 = ranges[2 * tc.tile];
-    const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
+    const size_t pid = frame_base + (size_t)py * W + px;
     const int seg_begin = (SPLIT && wk.seg >= 0) ? wk.seg * SEG_LEN : 0;
 
     BwdPixel s;
@@ -691,14 +715,14 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
 
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
 {
-    const int tiles = a.cam.grid_x * a.cam.grid_y;
+    const int tiles = total_tiles(a.cam), grid_y = a.cam.grid_y * a.cam.frames;
     if (a.split && a.seg_data)
         hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), 0, stream,
-                           a.cam.W, a.cam.H, a.cam.grid_x, a.cam.grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec,
+                           a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec,
                            a.background, a.seg_data, a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc);
     else
         hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x,
-                           a.cam.grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0,
+                           grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0,
                            a.dL_dcolor, a.dL_dothers, a.acc);
 }
 

@@ -125,6 +125,11 @@ extern "C" size_t vidu4d_surfel_image_bytes(int width, int height)
     ImageState s;
     return carve_image(nullptr, width < 0 ? 0 : width, height < 0 ? 0 : height, s);
 }
+extern "C" size_t vidu4d_surfel_image_bytes_frames(int width, int height, int frames)
+{
+    ImageState s;
+    return carve_image(nullptr, width < 0 ? 0 : width, height < 0 ? 0 : height, s, frames < 1 ? 1 : frames);
+}
 extern "C" size_t vidu4d_surfel_binning_bytes(int64_t capacity)
 {
     BinState b;
@@ -133,6 +138,36 @@ extern "C" size_t vidu4d_surfel_binning_bytes(int64_t capacity)
 extern "C" size_t vidu4d_surfel_backward_workspace_bytes(int P)
 {
     return (size_t)(P < 0 ? 0 : P) * ACC_FLOATS * sizeof(float) + 256;
+}
+
+// frames of a (possibly stacked) call, total surfel rows, camera with the per-frame views
+template <typename Args>
+static int frames_of(const Args* a) { return a->frames > 1 ? a->frames : 1; }
+template <typename Args>
+static CameraParams camera_of(const Args* a)
+{
+    const int F = frames_of(a);
+    CameraParams c = make_camera_params(F > 1 ? a->frame_viewmatrix[0] : a->viewmatrix, F > 1 ? a->frame_campos[0] : a->campos,
+                                        a->width, a->height, F > 1 ? a->frame_tan_fovx[0] : a->tan_fovx,
+                                        F > 1 ? a->frame_tan_fovy[0] : a->tan_fovy, a->D, a->M);
+    if (F > 1) {
+        c.frames = F;
+        c.frame_surfels = a->P;
+        for (int f = 0; f < F; f++)
+            set_frame_camera(c, f, a->frame_viewmatrix[f], a->frame_campos[f], a->frame_tan_fovx[f], a->frame_tan_fovy[f]);
+    }
+    return c;
+}
+template <typename Args>
+static int check_frames(const Args* a)
+{
+    if (a->frames <= 1) return VIDU4D_OK;
+    if (a->frames > MAX_STACKED_FRAMES) return fail(VIDU4D_E_INVALID, "at most %d stacked frames", MAX_STACKED_FRAMES);
+    if ((int64_t)a->P * a->frames > 0x7fffffffll) return fail(VIDU4D_E_INVALID, "frames * P exceeds 2^31");
+    for (int f = 0; f < a->frames; f++)
+        if (!a->frame_viewmatrix[f] || !a->frame_campos[f] || !(a->frame_tan_fovx[f] > 0.f) || !(a->frame_tan_fovy[f] > 0.f))
+            return fail(VIDU4D_E_INVALID, "camera of stacked frame %d is incomplete", f);
+    return VIDU4D_OK;
 }
 
 static int check_forward(const Vidu4dSurfelForwardArgs* a)
@@ -147,12 +182,16 @@ static int check_forward(const Vidu4dSurfelForwardArgs* a)
         return fail(VIDU4D_E_INVALID, "provide exactly one of shs / colors_precomp");
     if (a->shs && (a->M <= 0 || a->M > 16 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M))
         return fail(VIDU4D_E_INVALID, "bad SH configuration D=%d M=%d", a->D, a->M);
-    if (!(a->tan_fovx > 0.f) || !(a->tan_fovy > 0.f)) return fail(VIDU4D_E_INVALID, "tan_fov must be > 0");
+    const int F = frames_of(a);
+    if (int rc = check_frames(a)) return rc;
+    if (F == 1 && (!(a->tan_fovx > 0.f) || !(a->tan_fovy > 0.f))) return fail(VIDU4D_E_INVALID, "tan_fov must be > 0");
     if (!a->out_color || !a->out_others || !a->background) return fail(VIDU4D_E_INVALID, "output/background pointer is NULL");
-    if (a->P > 0 && (!a->means3D || !a->opacities || !a->scales || !a->rotations || !a->radii || !a->viewmatrix || !a->campos))
+    if (a->P > 0 && (!a->means3D || !a->opacities || !a->scales || !a->rotations || !a->radii ||
+                     (F == 1 && (!a->viewmatrix || !a->campos))))
         return fail(VIDU4D_E_INVALID, "an input pointer is NULL");
-    if (!a->geom_buffer || a->geom_bytes < vidu4d_surfel_geom_bytes(a->P)) return fail(VIDU4D_E_BUFFER, "geom_buffer too small");
-    if (!a->image_buffer || a->image_bytes < vidu4d_surfel_image_bytes(a->width, a->height)) return fail(VIDU4D_E_BUFFER, "image_buffer too small");
+    if (!a->geom_buffer || a->geom_bytes < vidu4d_surfel_geom_bytes(a->P * F)) return fail(VIDU4D_E_BUFFER, "geom_buffer too small");
+    if (!a->image_buffer || a->image_bytes < vidu4d_surfel_image_bytes_frames(a->width, a->height, F))
+        return fail(VIDU4D_E_BUFFER, "image_buffer too small");
     return VIDU4D_OK;
 }
 
@@ -163,6 +202,15 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(uint4* p, size_t n16)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+__global__ __launch_bounds__(256) void zero_fill_f32_kernel(float* p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+static void zero_fill_f32(float* p, size_t n, hipStream_t stream)  // any alignment / count
+{
+    if (n) hipLaunchKernelGGL(zero_fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n);
 }
 static void zero_fill(void* p, size_t bytes, hipStream_t stream)  // p 16-byte aligned, bytes a multiple of 16
 {
@@ -179,11 +227,12 @@ extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void
     if (rc) return rc;
     GeomState g;
     ImageState img;
-    carve_geom((char*)a->geom_buffer, a->P, g);
-    carve_image((char*)a->image_buffer, a->width, a->height, img);
+    const int F = frames_of(a), P = a->P * F;  // (stacked frames: F * P surfel rows, F tile grids)
+    carve_geom((char*)a->geom_buffer, P, g);
+    carve_image((char*)a->image_buffer, a->width, a->height, img, F);
     PreprocessArgs pa;
-    pa.cam = make_camera_params(a->viewmatrix, a->campos, a->width, a->height, a->tan_fovx, a->tan_fovy, a->D, a->M);
-    pa.P = a->P;
+    pa.cam = camera_of(a);
+    pa.P = P;
     pa.means3D = a->means3D;
     pa.scales = a->scales;
     pa.rotations = a->rotations;
@@ -194,8 +243,8 @@ extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void
     pa.geom = g;
     pa.tile_count = img.tile_count;
     pa.group_counts = img.group_counts;
-    pa.iters = bin_iters(a->P);
-    const int num_tiles = pa.cam.grid_x * pa.cam.grid_y;
+    pa.iters = bin_iters(P);
+    const int num_tiles = total_tiles(pa.cam);
     const bool grouped = use_grouped_binning(num_tiles);
     {
         StageTimer t(ST_PREPROCESS, stream);
@@ -206,7 +255,7 @@ extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void
     STAGE_CHECK(a->debug, stream, "preprocess");
     {
         StageTimer t(ST_SCAN, stream);
-        launch_tile_scan(g, img, num_tiles, grouped ? bin_groups(a->P) : 0, stream);
+        launch_tile_scan(g, img, num_tiles, grouped ? bin_groups(P) : 0, stream);
     }
     STAGE_CHECK(a->debug, stream, "tile_scan");
     return VIDU4D_OK;
@@ -217,7 +266,7 @@ extern "C" int vidu4d_surfel_num_rendered(const Vidu4dSurfelForwardArgs* a, void
     hipStream_t stream = (hipStream_t)stream_;
     if (!a || !out || !a->geom_buffer) return fail(VIDU4D_E_INVALID, "NULL argument");
     GeomState g;
-    carve_geom((char*)a->geom_buffer, a->P, g);
+    carve_geom((char*)a->geom_buffer, a->P * frames_of(a), g);
     uint32_t r = 0;
     HIP_TRY(hipMemcpyAsync(&r, &g.hdr->num_rendered, sizeof(r), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -239,20 +288,20 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     GeomState g;
     ImageState img;
     BinState b;
-    carve_geom((char*)a->geom_buffer, a->P, g);
-    carve_image((char*)a->image_buffer, a->width, a->height, img);
+    const int F = frames_of(a), P = a->P * F;
+    carve_geom((char*)a->geom_buffer, P, g);
+    carve_image((char*)a->image_buffer, a->width, a->height, img, F);
     carve_binning((char*)binning, capacity, b);
-    const CameraParams cam =
-        make_camera_params(a->viewmatrix, a->campos, a->width, a->height, a->tan_fovx, a->tan_fovy, a->D, a->M);
+    const CameraParams cam = camera_of(a);
     if (capacity > 0) {
         {
             StageTimer t(ST_EMIT, stream);
-            launch_emit_keys(cam, a->P, a->radii, g, img, b, capacity, use_grouped_binning(cam.grid_x * cam.grid_y), stream);
+            launch_emit_keys(cam, P, a->radii, g, img, b, capacity, use_grouped_binning(total_tiles(cam)), stream);
         }
         STAGE_CHECK(a->debug, stream, "emit_keys");
         {
             StageTimer t(ST_SORT, stream);
-            launch_tile_sort(g, img, b, cam.grid_x * cam.grid_y, a->P, capacity, a->segment_split != 0, stream);
+            launch_tile_sort(g, img, b, total_tiles(cam), P, capacity, a->segment_split != 0, stream);
         }
         STAGE_CHECK(a->debug, stream, "tile_sort");
     }
@@ -275,27 +324,29 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     if (a->P < 0 || a->width <= 0 || a->height <= 0) return fail(VIDU4D_E_INVALID, "bad sizes");
     if (a->transMat_precomp) return fail(VIDU4D_E_UNSUPPORTED, "transMat_precomp is not supported (see forward)");
     if (a->P == 0) return VIDU4D_OK;
+    const int F = frames_of(a), P = a->P * F;
+    if (int rc = check_frames(a)) return rc;
     if (!a->geom_buffer || !a->image_buffer || !a->workspace || !a->dL_dout_color || !a->dL_dout_others ||
-        !a->means3D || !a->radii || !a->scales || !a->rotations || !a->viewmatrix || !a->campos || !a->background)
+        !a->means3D || !a->radii || !a->scales || !a->rotations || (F == 1 && (!a->viewmatrix || !a->campos)) || !a->background)
         return fail(VIDU4D_E_INVALID, "an input pointer is NULL");
     if (!a->dL_dmeans2D || !a->dL_dcolors || !a->dL_dopacity || !a->dL_dmeans3D || !a->dL_dtransMat ||
         !a->dL_dscales || !a->dL_drotations || (a->shs && !a->dL_dsh))
         return fail(VIDU4D_E_INVALID, "an output pointer is NULL");
-    if (a->workspace_bytes < vidu4d_surfel_backward_workspace_bytes(a->P)) return fail(VIDU4D_E_BUFFER, "workspace too small");
+    if (a->workspace_bytes < vidu4d_surfel_backward_workspace_bytes(P)) return fail(VIDU4D_E_BUFFER, "workspace too small");
     if (a->binning_capacity > 0 && !a->binning_buffer) return fail(VIDU4D_E_INVALID, "binning_buffer is NULL");
 
     BackwardArgs ba;
-    ba.cam = make_camera_params(a->viewmatrix, a->campos, a->width, a->height, a->tan_fovx, a->tan_fovy, a->D, a->M);
+    ba.cam = camera_of(a);
     BinState b;
-    carve_geom((char*)a->geom_buffer, a->P, ba.geom);
-    carve_image((char*)a->image_buffer, a->width, a->height, ba.img);
+    carve_geom((char*)a->geom_buffer, P, ba.geom);
+    carve_image((char*)a->image_buffer, a->width, a->height, ba.img, F);
     carve_binning((char*)a->binning_buffer, a->binning_capacity, b);
     ba.point_list = a->binning_capacity > 0 ? b.point_list : nullptr;
     ba.seg_data = a->binning_capacity > 0 ? b.seg_data : nullptr;
     ba.capacity = a->binning_capacity;
     ba.split = a->segment_split != 0 && a->binning_capacity > 0;
     ba.max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
-    ba.P = a->P;
+    ba.P = P;
     ba.background = a->background;
     ba.means3D = a->means3D;
     ba.radii = a->radii;
@@ -318,7 +369,12 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
 
     {
         StageTimer t(ST_BWD_ZERO, stream);
-        zero_fill(ba.acc, (size_t)a->P * ACC_FLOATS * sizeof(float), stream);
+        zero_fill(ba.acc, (size_t)P * ACC_FLOATS * sizeof(float), stream);
+        if (F > 1) {  // the frames ADD their gradients of the shared parameters (preprocess_bwd_kernel)
+            zero_fill_f32(a->dL_dopacity, (size_t)a->P, stream);
+            zero_fill_f32(a->dL_dscales, (size_t)a->P * 2, stream);
+            if (a->dL_dsh) zero_fill_f32(a->dL_dsh, (size_t)a->P * a->M * 3, stream);
+        }
     }
     {
         StageTimer t(ST_BLEND_BWD, stream);
@@ -354,20 +410,22 @@ extern "C" int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* a, const 
     GeomState g;
     ImageState img;
     BinState b;
-    carve_geom((char*)a->geom_buffer, a->P, g);
-    carve_image((char*)a->image_buffer, a->width, a->height, img);
+    const int F = frames_of(a);  // (stacked frames: every array is F times as long, frame-major)
+    const size_t Ptot = (size_t)a->P * F;
+    carve_geom((char*)a->geom_buffer, (int)Ptot, g);
+    carve_image((char*)a->image_buffer, a->width, a->height, img, F);
     carve_binning((char*)binning, capacity, b);
-    const int gx = (a->width + TILE - 1) / TILE, gy = (a->height + TILE - 1) / TILE;
+    const int gx = (a->width + TILE - 1) / TILE, gy = ((a->height + TILE - 1) / TILE) * F;
     uint32_t R = 0;
     HIP_TRY(hipMemcpyAsync(&R, &g.hdr->num_rendered, sizeof(R), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    const size_t hw = (size_t)a->width * a->height;
+    const size_t hw = (size_t)a->width * a->height * F;
     const void* src = nullptr;
     size_t n = 0, esz = 4;
     switch (what) {
         case VIDU4D_STATE_NUM_RENDERED: src = &g.hdr->num_rendered; n = 1; break;
-        case VIDU4D_STATE_RECORDS: src = g.rec; n = (size_t)a->P * REC_FLOATS; break;
-        case VIDU4D_STATE_TILES_TOUCHED: src = g.tiles_touched; n = (size_t)a->P; break;
+        case VIDU4D_STATE_RECORDS: src = g.rec; n = Ptot * REC_FLOATS; break;
+        case VIDU4D_STATE_TILES_TOUCHED: src = g.tiles_touched; n = Ptot; break;
         case VIDU4D_STATE_POINT_LIST: src = b.point_list; n = R; break;
         case VIDU4D_STATE_SORTED_KEYS: src = b.entries; n = R; esz = 8; break;
         case VIDU4D_STATE_RANGES: src = img.ranges; n = (size_t)gx * gy * 2; break;

@@ -13,11 +13,23 @@
 
 namespace surfel {
 
+// Frame of a (stacked) surfel index and its row in the arrays the frames share.
+struct FrameIndex {
+    int frame, shared;
+};
+__device__ __forceinline__ FrameIndex frame_index(const CameraParams& cam, int idx)
+{
+    if (cam.frames <= 1) return FrameIndex{0, idx};
+    const int f = idx / cam.frame_surfels;
+    return FrameIndex{f, idx - f * cam.frame_surfels};
+}
+
 // Projection of surfel idx; writes record / radius / tile count and returns the tile rect.
-__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const Camera& cam, int idx, Projected& o)
+__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const Camera& cam, int idx, int shared,
+                                                   Projected& o)
 {
     const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
+    const float2 sc = reinterpret_cast<const float2*>(a.scales)[shared];
     const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
     const float scale[2] = {sc.x, sc.y};
     const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -30,10 +42,11 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         float4* rec = reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
         rec[0] = make_float4(o.T[0], o.T[1], o.T[2], o.T[3]);
         rec[1] = make_float4(o.T[4], o.T[5], o.T[6], o.T[7]);
-        rec[2] = make_float4(o.T[8], o.center[0], o.center[1], a.opacities[idx]);
+        const float opacity = a.opacities[shared];
+        rec[2] = make_float4(o.T[8], o.center[0], o.center[1], opacity);
         rec[3] = make_float4(o.normal[0], o.normal[1], o.normal[2], o.depth);
         float box[4];
-        contribution_box(o.T, o.center[0], o.center[1], a.opacities[idx], box);
+        contribution_box(o.T, o.center[0], o.center[1], opacity, box);
         rec[5] = make_float4(box[0], box[1], box[2], box[3]);
     }
     a.radii[idx] = radius;
@@ -45,14 +58,16 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const Camera cam = load_camera(a.cam);
     if (idx >= a.P) return;
+    const FrameIndex fi = frame_index(a.cam, idx);
+    const Camera cam = load_camera(a.cam, fi.frame);
     Projected o;
-    if (preprocess_one(a, cam, idx, o)) {
+    if (preprocess_one(a, cam, idx, fi.shared, o)) {
         const int slice = blockIdx.x & (TILE_SLICES - 1);
+        const int tile0 = fi.frame * cam.grid_x * cam.grid_y;
         for (int y = o.y0; y < o.y1; y++)
             for (int x = o.x0; x < o.x1; x++)
-                atomicAdd(&a.tile_count[(y * cam.grid_x + x) * TILE_SLICES + slice], 1u);
+                atomicAdd(&a.tile_count[(size_t)(tile0 + y * cam.grid_x + x) * TILE_SLICES + slice], 1u);
     }
 }
 
@@ -62,8 +77,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(PreprocessArg
 __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(PreprocessArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
-    const Camera cam = load_camera(a.cam);
-    const int num_tiles = cam.grid_x * cam.grid_y;
+    const int frame_tiles = a.cam.grid_x * a.cam.grid_y, num_tiles = frame_tiles * a.cam.frames;
     for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) s_hist[t] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.geom.hdr->scan_arrivals = 0;  // (the header is fresh memory)
     __syncthreads();
@@ -71,10 +85,14 @@ __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(Pre
     for (int it = 0; it < a.iters; it++) {
         const int idx = first + it * BIN_THREADS + threadIdx.x;
         if (idx < a.P) {
+            const FrameIndex fi = frame_index(a.cam, idx);
+            const Camera cam = load_camera(a.cam, fi.frame);
             Projected o;
-            if (preprocess_one(a, cam, idx, o))
+            if (preprocess_one(a, cam, idx, fi.shared, o)) {
+                uint32_t* hist = s_hist + fi.frame * frame_tiles;
                 for (int y = o.y0; y < o.y1; y++)
-                    for (int x = o.x0; x < o.x1; x++) atomicAdd(&s_hist[y * cam.grid_x + x], 1u);
+                    for (int x = o.x0; x < o.x1; x++) atomicAdd(&hist[y * cam.grid_x + x], 1u);
+            }
         }
     }
     __syncthreads();
@@ -95,9 +113,15 @@ template <bool SH_LDS>
 __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];  // [256][49] when SH_LDS
-    const int block_first = blockIdx.x * PRE_BLOCK;
-    const int idx = block_first + threadIdx.x;
-    const int rows = (a.P - block_first) < PRE_BLOCK ? (a.P - block_first) : PRE_BLOCK;
+    // workgroups are laid out per frame (pre_blocks(N) each): the SH rows of a workgroup are 256 consecutive rows of
+    // the array the frames share
+    const int N = a.cam.frames > 1 ? a.cam.frame_surfels : a.P;
+    const int per_frame = pre_blocks(N);
+    const int frame = blockIdx.x / per_frame;
+    const int block_first = (blockIdx.x - frame * per_frame) * PRE_BLOCK;  // (row in the shared arrays)
+    const int shared = block_first + threadIdx.x;
+    const int idx = frame * N + shared;
+    const int rows = (N - block_first) < PRE_BLOCK ? (N - block_first) : PRE_BLOCK;
     if (SH_LDS) {
         const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
         for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
@@ -111,13 +135,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs 
         }
         __syncthreads();
     }
-    if (idx >= a.P) return;
+    if (shared >= N) return;
     float rgb[3];
     uint32_t clamp_mask = 0;
     if (a.colors_precomp == nullptr) {
         const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-        const float campos[3] = {a.cam.campos[0], a.cam.campos[1], a.cam.campos[2]};
-        const float* sh = SH_LDS ? s_sh + threadIdx.x * SH_STRIDE : a.shs + (size_t)idx * a.cam.sh_coeffs * 3;
+        const float* cp = a.cam.fc[frame].campos;
+        const float campos[3] = {cp[0], cp[1], cp[2]};
+        const float* sh = SH_LDS ? s_sh + threadIdx.x * SH_STRIDE : a.shs + (size_t)shared * a.cam.sh_coeffs * 3;
         sh_forward(a.cam.sh_degree, p_world, campos, sh, rgb, clamp_mask);
     } else {
         rgb[0] = a.colors_precomp[3 * idx];
@@ -131,14 +156,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return;
-    const int num_tiles = a.cam.grid_x * a.cam.grid_y;
+    const int num_tiles = total_tiles(a.cam);
     const bool sh_lds = a.colors_precomp == nullptr && a.shs != nullptr && a.cam.sh_coeffs == 16 &&
                         (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0;
+    const int color_blocks = a.cam.frames > 1 ? a.cam.frames * pre_blocks(a.cam.frame_surfels) : pre_blocks(a.P);
     if (sh_lds)
-        hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK),
+        hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(color_blocks), dim3(PRE_BLOCK),
                            (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);
     else
-        hipLaunchKernelGGL(surfel_color_kernel<false>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(surfel_color_kernel<false>, dim3(color_blocks), dim3(PRE_BLOCK), 0, stream, a);
     if (use_grouped_binning(num_tiles))
         hipLaunchKernelGGL(preprocess_fwd_grouped_kernel, dim3(bin_groups(a.P)), dim3(BIN_THREADS),
                            (size_t)num_tiles * sizeof(uint32_t), stream, a);
@@ -156,15 +182,24 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
 // LDS tile with row stride 49 words (odd => the per-thread column walk is bank-conflict free), the
 // gradients are written back into the same tile and leave with coalesced 16-byte stores.
 
+// Stacked frames (cam.frames > 1): workgroups are laid out per frame like the colour kernel's; gradients of what the
+// frames share (opacity, scale, SH rows) are ADDED to arrays the caller zero-filled -- the SH tile leaves with
+// lane-contiguous float atomics (merged per cache line by the memory side, as the blend backward's flush) -- while the
+// per-frame outputs (centres, orientations, screen-space statistic, colours, homography) are plain stores.
 template <bool SH_LDS>
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];  // [256][49] when SH_LDS
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const Camera cam = load_camera(a.cam);
+    const bool stacked = a.cam.frames > 1;
+    const int N = stacked ? a.cam.frame_surfels : a.P;
+    const int per_frame = pre_blocks(N);
+    const int frame = blockIdx.x / per_frame;
+    const int block_first = (blockIdx.x - frame * per_frame) * PRE_BLOCK;  // (row in the shared arrays)
+    const int shared = block_first + threadIdx.x;
+    const int idx = frame * N + shared;
+    const Camera cam = load_camera(a.cam, frame);
     const int M = cam.sh_coeffs;
-    const int block_first = blockIdx.x * PRE_BLOCK;
-    const int rows = (a.P - block_first) < PRE_BLOCK ? (a.P - block_first) : PRE_BLOCK;
+    const int rows = (N - block_first) < PRE_BLOCK ? (N - block_first) : PRE_BLOCK;
     if (SH_LDS) {
         const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
         for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
@@ -178,23 +213,25 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
         }
         __syncthreads();
     }
-    const bool live = idx < a.P;
+    const bool live = shared < N;
     const bool visible = live && a.radii[idx] > 0;
     float* sh_row = s_sh + threadIdx.x * SH_STRIDE;  // SH_LDS: this thread's private row (read, then overwritten)
-    float* dsh = (a.dL_dsh && live) ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+    float* dsh = (a.dL_dsh && live) ? a.dL_dsh + (size_t)shared * M * 3 : nullptr;
     if (live && !visible) {
         for (int k = 0; k < 3; k++) {
             a.dL_dmeans3D[3 * idx + k] = 0.f;
             a.dL_dmeans2D[3 * idx + k] = 0.f;
             a.dL_dcolors[3 * idx + k] = 0.f;
         }
-        a.dL_dopacity[idx] = 0.f;
         for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = 0.f;
-        a.dL_dscales[2 * idx] = a.dL_dscales[2 * idx + 1] = 0.f;
         for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = 0.f;
+        if (!stacked) {
+            a.dL_dopacity[shared] = 0.f;
+            a.dL_dscales[2 * shared] = a.dL_dscales[2 * shared + 1] = 0.f;
+        }
         if (SH_LDS) {
             for (int k = 0; k < SH_ROW; k++) sh_row[k] = 0.f;
-        } else if (dsh) {
+        } else if (dsh && !stacked) {
             for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
         }
     }
@@ -222,7 +259,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
             clamp_mask = __float_as_uint(q4.w);
         }
         const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-        const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
+        const float2 sc = reinterpret_cast<const float2*>(a.scales)[shared];
         const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
         const float scale[2] = {sc.x, sc.y};
         const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -235,9 +272,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
             if (SH_LDS) {
                 // in place: coefficient k is read before gradient k is stored over it
                 sh_backward(cam.sh_degree, M, p_world, cam.campos, sh_row, clamp_mask, dcol, sh_row, dmean);
-            } else {
-                sh_backward(cam.sh_degree, M, p_world, cam.campos, a.shs + (size_t)idx * M * 3, clamp_mask, dcol, dsh,
+            } else if (!stacked) {
+                sh_backward(cam.sh_degree, M, p_world, cam.campos, a.shs + (size_t)shared * M * 3, clamp_mask, dcol, dsh,
                             dmean);
+            } else {
+                float tmp[SH_ROW];
+                for (int k = 0; k < 3 * M; k++) tmp[k] = 0.f;
+                sh_backward(cam.sh_degree, M, p_world, cam.campos, a.shs + (size_t)shared * M * 3, clamp_mask, dcol, tmp,
+                            dmean);
+                for (int k = 0; k < 3 * M; k++)
+                    if (tmp[k] != 0.f) atomicAdd(dsh + k, tmp[k]);
             }
         }
         for (int k = 0; k < 3; k++) {
@@ -245,21 +289,35 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
             a.dL_dmeans2D[3 * idx + k] = o.dmean2D[k];
             a.dL_dcolors[3 * idx + k] = dcol[k];
         }
-        a.dL_dopacity[idx] = acc[A_OPAC];
         for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = o.dT[k];
-        a.dL_dscales[2 * idx] = o.dscale[0];
-        a.dL_dscales[2 * idx + 1] = o.dscale[1];
         for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = o.drot[k];
+        if (!stacked) {
+            a.dL_dopacity[shared] = acc[A_OPAC];
+            a.dL_dscales[2 * shared] = o.dscale[0];
+            a.dL_dscales[2 * shared + 1] = o.dscale[1];
+        } else {
+            atomicAdd(a.dL_dopacity + shared, acc[A_OPAC]);
+            atomicAdd(a.dL_dscales + 2 * shared, o.dscale[0]);
+            atomicAdd(a.dL_dscales + 2 * shared + 1, o.dscale[1]);
+        }
     }
     if (SH_LDS) {
         if (visible && a.shs == nullptr)
             for (int k = 0; k < SH_ROW; k++) sh_row[k] = 0.f;
         __syncthreads();
-        float4* o4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)block_first * SH_ROW);
-        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
-            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
-            const float* d = s_sh + r * SH_STRIDE + c;
-            o4[i] = make_float4(d[0], d[1], d[2], d[3]);
+        if (!stacked) {
+            float4* o4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)block_first * SH_ROW);
+            for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
+                const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
+                const float* d = s_sh + r * SH_STRIDE + c;
+                o4[i] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        } else {
+            float* out = a.dL_dsh + (size_t)block_first * SH_ROW;
+            for (int i = threadIdx.x; i < rows * SH_ROW; i += PRE_BLOCK) {
+                const float v = s_sh[(i / SH_ROW) * SH_STRIDE + i % SH_ROW];
+                if (v != 0.f) atomicAdd(out + i, v);
+            }
         }
     }
 }
@@ -270,11 +328,12 @@ void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream)
     const bool sh_lds = a.shs != nullptr && a.dL_dsh != nullptr && a.cam.sh_coeffs == 16 &&
                         (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0;
+    const int blocks = a.cam.frames > 1 ? a.cam.frames * pre_blocks(a.cam.frame_surfels) : pre_blocks(a.P);
     if (sh_lds)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK),
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(PRE_BLOCK),
                            (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);
     else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(PRE_BLOCK), 0, stream, a);
 }
 
 __global__ void mark_visible_kernel(int P, const float* means3D, const float* vm, uint8_t* present)

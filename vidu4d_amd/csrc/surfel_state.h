@@ -95,7 +95,7 @@ inline void carve(char*& p, T*& out, size_t count)
     p = reinterpret_cast<char*>(out + count);
 }
 
-inline int pre_blocks(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
+__host__ __device__ inline int pre_blocks(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
 // grouped binning geometry: each 1024-thread workgroup walks bin_iters(P) x 1024 consecutive surfels
 inline int bin_iters(int P)
 {
@@ -115,11 +115,11 @@ inline size_t carve_geom(char* base, int P, GeomState& g)
     return (size_t)(p - base) + 256;
 }
 
-inline size_t carve_image(char* base, int W, int H, ImageState& s)
+inline size_t carve_image(char* base, int W, int H, ImageState& s, int frames = 1)
 {
     char* p = base;
-    const size_t hw = (size_t)W * H;
-    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const size_t hw = (size_t)W * H * frames;
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE) * frames;
     carve(p, s.final_T, 3 * hw);
     carve(p, s.n_contrib, 2 * hw);
     carve(p, s.ranges, 2 * tiles);
@@ -146,11 +146,25 @@ inline size_t carve_binning(char* base, int64_t capacity, BinState& b)
 // Camera as passed to kernels: scalars by value, view matrix and camera position stay in device
 // memory (they are device tensors at the reference boundary) and are fetched with wave-uniform
 // loads at kernel start -- no host round trip.
+//
+// Frame stacking ("frame || tile keys"): `frames` > 1 frames of one optimizer step are rasterized by ONE
+// launch set.  Frame f owns the surfels [f * frame_surfels, (f + 1) * frame_surfels) of the per-surfel arrays (its
+// warped centres / orientations; opacity, scale and SH rows are shared and indexed modulo frame_surfels) and the tiles
+// [f * T, (f + 1) * T), T = grid_x * grid_y, of every per-tile array; W, H, grid_x, grid_y describe ONE frame, image planes
+// are (frames, H, W).  Nothing moves between frames: the binning, the sort and the blend see a taller tile grid.
+constexpr int MAX_STACKED_FRAMES = 8;
+struct FrameCamera {
+    const float* view;
+    const float* campos;
+    float focal_x, focal_y, tan_fovx, tan_fovy;
+};
 struct CameraParams {
-    const float* view;    // (4,4) device
+    const float* view;    // (4,4) device   (frame 0)
     const float* campos;  // (3) device
     float focal_x, focal_y, cx, cy, tan_fovx, tan_fovy;
     int W, H, grid_x, grid_y, sh_degree, sh_coeffs;
+    int frames, frame_surfels;
+    FrameCamera fc[MAX_STACKED_FRAMES];
 };
 
 inline CameraParams make_camera_params(const float* view_dev, const float* campos_dev, int W, int H, float tfx,
@@ -171,23 +185,34 @@ inline CameraParams make_camera_params(const float* view_dev, const float* campo
     c.cy = (float)((double)(float)H / 2.0);
     c.sh_degree = D;
     c.sh_coeffs = M;
+    c.frames = 1;
+    c.frame_surfels = 0;
+    for (int f = 0; f < MAX_STACKED_FRAMES; f++) c.fc[f] = FrameCamera{view_dev, campos_dev, c.focal_x, c.focal_y, tfx, tfy};
     return c;
 }
 
+// frame f of a stacked launch: its own view matrix, camera centre and field of view
+inline void set_frame_camera(CameraParams& c, int f, const float* view_dev, const float* campos_dev, float tfx, float tfy)
+{
+    c.fc[f] = FrameCamera{view_dev, campos_dev, c.W / (2.0f * tfx), c.H / (2.0f * tfy), tfx, tfy};
+}
+inline int total_tiles(const CameraParams& c) { return c.grid_x * c.grid_y * c.frames; }
+
 #if defined(__HIPCC__)
-__device__ __forceinline__ Camera load_camera(const CameraParams& p)
+__device__ __forceinline__ Camera load_camera(const CameraParams& p, int frame = 0)
 {
     Camera c;
+    const FrameCamera fc = p.fc[frame];
 #pragma unroll
-    for (int k = 0; k < 16; k++) c.view[k] = p.view[k];
+    for (int k = 0; k < 16; k++) c.view[k] = fc.view[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) c.campos[k] = p.campos[k];
-    c.focal_x = p.focal_x;
-    c.focal_y = p.focal_y;
+    for (int k = 0; k < 3; k++) c.campos[k] = fc.campos[k];
+    c.focal_x = fc.focal_x;
+    c.focal_y = fc.focal_y;
     c.cx = p.cx;
     c.cy = p.cy;
-    c.tan_fovx = p.tan_fovx;
-    c.tan_fovy = p.tan_fovy;
+    c.tan_fovx = fc.tan_fovx;
+    c.tan_fovy = fc.tan_fovy;
     c.W = p.W;
     c.H = p.H;
     c.grid_x = p.grid_x;
