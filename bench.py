@@ -189,6 +189,9 @@ def main():
                     help="frames timed on the pure-PyTorch CPU render (0 = skip; ~10-20 s each at 200k/512^2)")
     ap.add_argument("--no-stage-timers", action="store_true")
     ap.add_argument("--frame-streams", type=int, default=1, help="queue the frames of a step on separate HIP streams")
+    ap.add_argument("--stacked", type=int, default=1, help="1 (default): the frames of a step through ONE launch set "
+                                                            "(dsr.rasterize_frames, frame || tile keys); 0: one call per "
+                                                            "frame, on separate HIP streams with --frame-streams 1")
     ap.add_argument("--repeats", type=int, default=5, help="further timed regions of --steps steps (median / p10 / p90)")
     ap.add_argument("--fit-steps", type=int, default=30, help="steps of the full Stage-3 fitting loop timed for "
                                                               "\"fit_step\" (0 = skip)")
@@ -304,7 +307,36 @@ def main():
             o += n
         flat_view = {k: flat[a:b] for k, (a, b) in offs.items()}
 
+    rs_frames = [rs] * FRAMES_PER_STEP
+    dc_st, do_st = torch.stack([dc] * FRAMES_PER_STEP, 1).contiguous(), torch.stack([do] * FRAMES_PER_STEP, 1).contiguous()
+
+    def stacked_frames():
+        """The step's frames as one stacked call (frame || tile keys)."""
+        ids = [(counter["slot"] + k) % len(frames) for k in range(FRAMES_PER_STEP)]
+        counter["slot"] += FRAMES_PER_STEP
+        m = torch.stack([means[i] for i in ids]).requires_grad_(True)
+        r = torch.stack([rots[i] for i in ids]).requires_grad_(True)
+        m2d = torch.zeros_like(m, requires_grad=True)
+        color, radii, allmap = dsr.rasterize_frames(m, m2d, shs_f, opac_f, scales_f, r, rs_frames)
+        torch.autograd.backward([color, allmap], [dc_st, do_st])
+        return m.grad, r.grad
+
     def step_once():
+        if args.stacked:
+            if use_dist:
+                flat.zero_()
+                opac.grad = flat_view["opac"].view_as(opac)
+                scales.grad = flat_view["scales"].view_as(scales)
+                shs.grad = flat_view["shs"].view_as(shs)
+            else:
+                for t in (opac, scales, shs):
+                    t.grad = None
+            gm, gr = stacked_frames()
+            if use_dist:
+                torch.sum(gm, 0, out=flat_view["means"].view(N, 3))
+                torch.sum(gr, 0, out=flat_view["rot"].view(N, 4))
+                return None
+            return gm.sum(0), gr.sum(0)
         if use_dist:
             flat.zero_()
             opac.grad = flat_view["opac"].view_as(opac)
@@ -397,7 +429,9 @@ def main():
                                f"{W}x{H}, SH degree 3, {args.frames} frames sharded one-frame-per-GPU, "
                                f"{FRAMES_PER_STEP} frames per step per GPU",
                    "scene": args.scene, "surfels": N, "width": W, "height": H, "frames": args.frames, "frames_per_step": FRAMES_PER_STEP,
-                   "parallelism": f"frame-parallel x{world}" + (" + RCCL all-reduce of surfel grads" if world > 1 else "")},
+                   "parallelism": f"frame-parallel x{world}" + (" + RCCL all-reduce of surfel grads" if world > 1 else ""),
+                   "frames_of_a_step": "one stacked launch set" if args.stacked else
+                                       ("one call per frame, separate HIP streams" if args.frame_streams else "one call per frame")},
     }
 
     if rep_rates:
@@ -430,7 +464,10 @@ def main():
             out["stage_ms_avg"] = {k: (round(v["ms_avg"], 4) if v["ms_avg"] is not None else None) for k, v in stages.items()}
             dom = max((k for k in stages if stages[k]["launches"]), key=lambda k: stages[k]["ms_total"])
             avg_s = stages[dom]["ms_avg"] * 1e-3
-            ach = stage_bytes(dom, N, R, W * H, T, K) / avg_s / 1e9
+            # units one launch processes: the frames of a step when they go through one stacked launch set
+            units = FRAMES_PER_STEP if args.stacked else 1
+            launch_bytes = units * stage_bytes(dom, N, R, W * H, T, K)
+            ach = launch_bytes / avg_s / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
@@ -448,9 +485,10 @@ def main():
             out["roofline"] = {"bound": limiter.get("bound", "hbm"), "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "limiter": limiter,
                                "avg_launch_ms": stages[dom]["ms_avg"],
-                               "timing": "HIP events on the launch stream, %d extra steps before the warm-up / timed region "
-                                         "with the frames of a step serialised on one stream" % min(args.steps, 20),
-                               "algorithmic_bytes_per_launch": stage_bytes(dom, N, R, W * H, T, K)}
+                               "timing": "HIP events on the launch stream, %d extra steps before the warm-up / timed region"
+                                         % min(args.steps, 20) +
+                                         ("" if args.stacked else " with the frames of a step serialised on one stream"),
+                               "frames_per_launch": units, "algorithmic_bytes_per_launch": launch_bytes}
         if world == 1 and args.fit_steps > 0:
             out["fit_step"] = fit_step_rate(dev, N, W, H, args.fit_steps)
         if world == 1 and args.cpu_images > 0:

@@ -370,7 +370,9 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     {
         StageTimer t(ST_BWD_ZERO, stream);
         zero_fill(ba.acc, (size_t)P * ACC_FLOATS * sizeof(float), stream);
-        if (F > 1) {  // the frames ADD their gradients of the shared parameters (preprocess_bwd_kernel)
+        const bool sums_in_kernel = a->shs && a->dL_dsh && a->M == 16 && ((uintptr_t)a->shs & 15) == 0 &&
+                                    ((uintptr_t)a->dL_dsh & 15) == 0;  // (preprocess_bwd_stacked_kernel's condition)
+        if (F > 1 && !sums_in_kernel) {  // the frames ADD their gradients of the shared parameters (preprocess_bwd_kernel)
             zero_fill_f32(a->dL_dopacity, (size_t)a->P, stream);
             zero_fill_f32(a->dL_dscales, (size_t)a->P * 2, stream);
             if (a->dL_dsh) zero_fill_f32(a->dL_dsh, (size_t)a->P * a->M * 3, stream);

@@ -322,12 +322,123 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
     }
 }
 
+// Stacked frames with the LDS-staged SH rows: one thread per CANONICAL surfel walks the frames, so that the gradients of
+// what the frames share (opacity, scale, SH row) are summed in registers in frame order and stored once -- no atomics,
+// no zero fill; the per-frame outputs are written as in the single-frame kernel.
+__global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_stacked_kernel(BackwardArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];  // [256][49]
+    const int N = a.cam.frame_surfels, F = a.cam.frames;
+    const int block_first = blockIdx.x * PRE_BLOCK;
+    const int shared = block_first + threadIdx.x;
+    const int rows = (N - block_first) < PRE_BLOCK ? (N - block_first) : PRE_BLOCK;
+    {
+        const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
+        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
+            const float4 v = g4[i];
+            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
+            float* d = s_sh + r * SH_STRIDE + c;
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+        __syncthreads();
+    }
+    const bool live = shared < N;
+    float* sh_row = s_sh + threadIdx.x * SH_STRIDE;
+    float g_sh[SH_ROW];
+#pragma unroll
+    for (int k = 0; k < SH_ROW; k++) g_sh[k] = 0.f;
+    float g_opacity = 0.f, g_scale0 = 0.f, g_scale1 = 0.f;
+    const float2 sc = live ? reinterpret_cast<const float2*>(a.scales)[shared] : make_float2(0.f, 0.f);
+    const float scale[2] = {sc.x, sc.y};
+#pragma unroll 1
+    for (int f = 0; f < F && live; f++) {
+        const int idx = f * N + shared;
+        if (!(a.radii[idx] > 0)) {
+            for (int k = 0; k < 3; k++) {
+                a.dL_dmeans3D[3 * idx + k] = 0.f;
+                a.dL_dmeans2D[3 * idx + k] = 0.f;
+                a.dL_dcolors[3 * idx + k] = 0.f;
+            }
+            for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = 0.f;
+            for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = 0.f;
+            continue;
+        }
+        const Camera cam = load_camera(a.cam, f);
+        float acc[ACC_FLOATS];
+        {
+            const float4* p = reinterpret_cast<const float4*>(a.acc + (size_t)idx * ACC_FLOATS);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const float4 v = p[k];
+                acc[4 * k] = v.x;
+                acc[4 * k + 1] = v.y;
+                acc[4 * k + 2] = v.z;
+                acc[4 * k + 3] = v.w;
+            }
+        }
+        float T[9];
+        uint32_t clamp_mask;
+        {
+            const float4* r = reinterpret_cast<const float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2], q4 = r[4];
+            T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q0.w;
+            T[4] = q1.x; T[5] = q1.y; T[6] = q1.z; T[7] = q1.w;
+            T[8] = q2.x;
+            clamp_mask = __float_as_uint(q4.w);
+        }
+        const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+        SurfelGrads o;
+        surfel_backward(cam, p_world, quat, scale, T, acc, o);
+        float dmean[3] = {o.dmean3D[0], o.dmean3D[1], o.dmean3D[2]};
+        const float dcol[3] = {acc[A_RGB], acc[A_RGB + 1], acc[A_RGB + 2]};
+        float tmp[SH_ROW];
+        sh_backward(cam.sh_degree, 16, p_world, cam.campos, sh_row, clamp_mask, dcol, tmp, dmean);
+#pragma unroll
+        for (int k = 0; k < SH_ROW; k++) g_sh[k] += tmp[k];
+        g_opacity += acc[A_OPAC];
+        g_scale0 += o.dscale[0];
+        g_scale1 += o.dscale[1];
+        for (int k = 0; k < 3; k++) {
+            a.dL_dmeans3D[3 * idx + k] = dmean[k];
+            a.dL_dmeans2D[3 * idx + k] = o.dmean2D[k];
+            a.dL_dcolors[3 * idx + k] = dcol[k];
+        }
+        for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = o.dT[k];
+        for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = o.drot[k];
+    }
+    if (live) {
+        a.dL_dopacity[shared] = g_opacity;
+        a.dL_dscales[2 * shared] = g_scale0;
+        a.dL_dscales[2 * shared + 1] = g_scale1;
+    }
+    __syncthreads();  // (every thread is done reading the coefficients of the tile)
+#pragma unroll
+    for (int k = 0; k < SH_ROW; k++) sh_row[k] = g_sh[k];
+    __syncthreads();
+    float4* o4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)block_first * SH_ROW);
+    for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
+        const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
+        const float* d = s_sh + r * SH_STRIDE + c;
+        o4[i] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+}
+
 void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return;
     const bool sh_lds = a.shs != nullptr && a.dL_dsh != nullptr && a.cam.sh_coeffs == 16 &&
                         (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0;
+    if (a.cam.frames > 1 && sh_lds) {
+        hipLaunchKernelGGL(preprocess_bwd_stacked_kernel, dim3(pre_blocks(a.cam.frame_surfels)), dim3(PRE_BLOCK),
+                           (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);
+        return;
+    }
     const int blocks = a.cam.frames > 1 ? a.cam.frames * pre_blocks(a.cam.frame_surfels) : pre_blocks(a.P);
     if (sh_lds)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(PRE_BLOCK),
