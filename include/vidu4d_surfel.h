@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 5
+#define VIDU4D_SURFEL_ABI 6
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -387,6 +387,9 @@ typedef struct Vidu4dStage3LossArgs {
     float* sums;
     float* partials;
     float* losses;
+    int64_t plane_stride;   /* floats between two planes of color[m] / allmap[m] and of the gradient planes; 0 = H*W.
+                               M*H*W when the frames come from one stacked rasterizer call ((3,M,H,W) / (8,M,H,W)
+                               tensors, color[m] = base + m*H*W) */
 } Vidu4dStage3LossArgs;
 typedef struct Vidu4dStage3LossGrads {
     float* g_color[VIDU4D_LOSS_MAX_FRAMES];

@@ -92,6 +92,35 @@ def test_fused_loss_with_learnable_background_matches_torch(gpu_device, M, H, W,
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-12)
 
 
+def test_trainer_step_stacked_frames_equal_per_frame_calls(gpu_device):
+    """One Stage3Trainer step with the frames through one stacked launch set / one rasterizer call per frame (both with
+    the fused loss): same losses, same gradients, same densification statistics."""
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    dev = gpu_device
+    out = {}
+    for flag in (True, False):
+        torch.manual_seed(0)
+        rng = np.random.default_rng(2)
+        m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=10**6, stacked_frames=flag, frame_streams=False),
+                              num_frames=8, device=dev)
+        m.init_from_points(rng.normal(size=(4000, 3)).astype(np.float32) * 0.25, rng.uniform(size=(4000, 3)).astype(np.float32))
+        tr = Stage3Trainer(m)
+        batch = synthetic_batch(m, [1, 4, 6], 64, 48, seed=3)
+        tr.bind_flat_gradients()
+        losses = tr._forward_backward(batch, 10)
+        stats = [(m._viewspace_points_batch[i].grad.clone(), m._radii_batch[i].clone(), m._visibility_filter_batch[i].clone())
+                 for i in range(3)]
+        out[flag] = ({k: float(v) for k, v in losses.items()}, tr._flat.clone(), stats)
+    for k in ("rgb", "mask"):
+        assert abs(out[True][0][k] - out[False][0][k]) <= 1e-6 * abs(out[False][0][k]) + 1e-9, k
+    a, b = out[True][1], out[False][1]
+    assert torch.allclose(a, b, rtol=1e-3, atol=2e-6 * float(b.abs().max()))
+    for (ga, ra, va), (gb, rb, vb) in zip(out[True][2], out[False][2]):
+        assert torch.equal(ra, rb) and torch.equal(va, vb)
+        assert torch.allclose(ga, gb, rtol=1e-3, atol=2e-6 * float(gb.abs().max()))
+
+
 def test_trainer_step_fused_loss_equals_torch_loss(gpu_device):
     """One Stage3Trainer step with the fused loss on / off: same loss values, same surfel gradients."""
     from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ForwardArgs(C.Structure):
@@ -60,7 +60,7 @@ class Stage3LossArgs(C.Structure):
                 ("allmap", C.c_void_p * LOSS_MAX_FRAMES), ("bkgd", C.c_void_p), ("rgb", C.c_void_p),
                 ("mask", C.c_void_p), ("vis2d", C.c_void_p), ("det", C.c_void_p), ("lambda_dssim", C.c_float),
                 ("rgb_wt", C.c_float), ("mask_wt", C.c_float), ("dist_wt", C.c_float), ("sums", C.c_void_p),
-                ("partials", C.c_void_p), ("losses", C.c_void_p)]
+                ("partials", C.c_void_p), ("losses", C.c_void_p), ("plane_stride", C.c_int64)]
 
 
 class Stage3LossGrads(C.Structure):

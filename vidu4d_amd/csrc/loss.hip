@@ -65,10 +65,11 @@ __device__ __forceinline__ Pixel load_pixel(const Vidu4dStage3LossArgs& a, size_
     Pixel q;
     const float* col = a.color[m];
     const float* aux = a.allmap[m];
-    q.a = aux[HW + p];
-    q.dist = aux[6 * HW + p];
+    const size_t PS = a.plane_stride ? (size_t)a.plane_stride : HW;
+    q.a = aux[PS + p];
+    q.dist = aux[6 * PS + p];
     for (int c = 0; c < 3; c++) {
-        q.r[c] = col[c * HW + p] + (1.0f - q.a) * (a.bkgd ? a.bkgd[c] : 0.f);
+        q.r[c] = col[c * PS + p] + (1.0f - q.a) * (a.bkgd ? a.bkgd[c] : 0.f);
         q.t[c] = a.rgb[3 * e + c];
     }
     q.mf = a.mask[e];
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3Loss
                                                                float* partial)
 {
     const size_t HW = (size_t)a.H * a.W, total = HW * a.M;
+    const size_t PS = a.plane_stride ? (size_t)a.plane_stride : HW;
     const float numel = (float)total;
     const float* S = a.sums;
     const float g_rgb = g[0] * a.rgb_wt * S[D_RGB_COEF] * (1.0f - a.lambda_dssim) / (3.0f * numel);  // per |r - t| entry
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3Loss
             const float diff = q.r[c] - q.t[c];
             const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);  // (torch: d|x|/dx = sign(x), 0 at 0; NaN stays NaN)
             const float gr = (q.v > 0.f) ? g_rgb * (diff != diff ? diff : sgn) : 0.f;
-            gc[c * HW + p] = gr;
+            gc[c * PS + p] = gr;
             if (a.bkgd) {
                 ga -= gr * a.bkgd[c];
                 bg[c] += gr * (1.0f - q.a);
@@ -206,10 +208,10 @@ __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3Loss
         }
         float* gm = o.g_allmap[m];
         gm[p] = 0.f;
-        gm[HW + p] = ga;
-        for (int k = 2; k < 6; k++) gm[k * HW + p] = 0.f;
-        gm[6 * HW + p] = g_dist;
-        gm[7 * HW + p] = 0.f;
+        gm[PS + p] = ga;
+        for (int k = 2; k < 6; k++) gm[k * PS + p] = 0.f;
+        gm[6 * PS + p] = g_dist;
+        gm[7 * PS + p] = 0.f;
     }
     block_partials<3>(bg, partial + blockIdx.x * 16);
 }

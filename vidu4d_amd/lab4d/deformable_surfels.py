@@ -297,6 +297,42 @@ class DeformableSurfels(GaussianModel):
             self._aux_dict = {}
         return xyz_cam, rot_cam
 
+    class _FrameGrad:
+        """viewspace_points of one frame of a stacked call: `.grad` is that frame's slice of the stacked statistic."""
+
+        def __init__(self, parent, index):
+            self._parent, self._index = parent, index
+
+        @property
+        def grad(self):
+            g = self._parent.grad
+            return None if g is None else g[self._index]
+
+    def _render_frames_stacked(self, cams, xyz_cam, rot_cam, rot_is_unit):
+        """All frames of the step through ONE launch set (diff_surfel_rasterization.rasterize_frames: stacked tile
+        grids).  -> {"raw_stacked": (color (3,M,H,W), allmap (8,M,H,W))}; frame i is [:, i]."""
+        from ..diff_surfel_rasterization import GaussianRasterizationSettings, rasterize_frames
+        settings = []
+        for cam in cams:
+            tan = cam.__dict__.get("_raster_tanfov")
+            if tan is None:  # fp32 tan of the fp32 field of view, as render() (gs/gaussian_renderer/__init__.py:36-37)
+                tan = cam.__dict__["_raster_tanfov"] = tuple(
+                    float(torch.tan(torch.as_tensor(f, dtype=torch.float32).cpu() * 0.5)) for f in (cam.FoVx, cam.FoVy))
+            settings.append(GaussianRasterizationSettings(
+                image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=tan[0], tanfovy=tan[1],
+                bg=self.background_feat, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                projmatrix=cam.full_proj_transform, sh_degree=self.active_sh_degree, campos=cam.camera_center,
+                prefiltered=False, debug=False))
+        rotations = rot_cam if rot_is_unit else self.rotation_activation(rot_cam, dim=-1)
+        screen = torch.zeros_like(xyz_cam).requires_grad_(True)  # (a leaf: its .grad is the densification statistic)
+        color, radii, allmap = rasterize_frames(xyz_cam, screen, self.get_features, self.get_opacity, self.get_scaling,
+                                                rotations, settings)
+        M = xyz_cam.shape[0]
+        self._viewspace_points_batch = [self._FrameGrad(screen, i) for i in range(M)]
+        self._visibility_filter_batch = [radii[i] > 0 for i in range(M)]
+        self._radii_batch = [radii[i] for i in range(M)]
+        return {"raw_stacked": (color, allmap)}
+
     @staticmethod
     def _collect_frame(r, raw, raw_frames, per_frame, stacked):
         if raw:
@@ -330,6 +366,9 @@ class DeformableSurfels(GaussianModel):
             xyz_cam, rot_cam, _ = self.forward_warp(xyz, rot, frame_id, inst_id, samples_dict)
             xyz_cam = xyz_cam.squeeze(2)
         cams = self.get_gs_Kcamera(Kinv, H, W)
+        if (outputs is not None and tuple(outputs) == ("raw",) and xyz_cam.is_cuda and self.opts.get("stacked_frames", True)
+                and 1 <= M <= 8 and len({(int(h), int(w)) for h, w in zip(H, W)}) == 1):
+            return self._render_frames_stacked(cams, xyz_cam, rot_cam, rot_is_unit)
         stacked, per_frame = {}, {"viewspace_points": [], "visibility_filter": [], "radii": []}
         # outputs containing "raw": the per-frame colour / auxiliary planes are handed out as they leave the rasterizer
         # (out["raw"] = [(color (3,H,W), allmap (8,H,W))], no learnable-background composite, no permute / stack)

@@ -15,15 +15,24 @@ from .. import _lib
 class _Stage3Loss(Function):
     @staticmethod
     def forward(ctx, cfg, targets, bkgd, *planes):
-        M = len(planes) // 2
-        colors, allmaps = planes[:M], planes[M:]
-        dev = colors[0].device
-        if not colors[0].is_cuda:
+        stacked = len(planes) == 2 and planes[0].dim() == 4  # (3,M,H,W), (8,M,H,W) from one stacked rasterizer call
+        if stacked:
+            M = planes[0].shape[1]
+            dev = planes[0].device
+        else:
+            M = len(planes) // 2
+            dev = planes[0].device
+        if not planes[0].is_cuda:
             raise RuntimeError("stage3_loss: HIP tensors required")
         if M > _lib.LOSS_MAX_FRAMES:
             raise RuntimeError(f"stage3_loss: at most {_lib.LOSS_MAX_FRAMES} frames per call")
-        H, W = colors[0].shape[-2:]
-        keep = [t.detach().float().contiguous() for t in colors + allmaps]
+        H, W = planes[0].shape[-2:]
+        keep = [t.detach().float().contiguous() for t in planes]
+        if stacked:  # per-frame base pointers into the stacked tensors, planes M*H*W apart
+            colors = [keep[0][:, m] for m in range(M)]
+            allmaps = [keep[1][:, m] for m in range(M)]
+        else:
+            colors, allmaps = keep[:M], keep[M:]
         tg = {k: targets[k].detach().float().contiguous() for k in ("rgb", "mask", "vis2d")}
         if tuple(tg["rgb"].shape) != (M, H, W, 3) or tg["mask"].numel() != M * H * W or tg["vis2d"].numel() != M * H * W:
             raise RuntimeError("stage3_loss: targets must be rgb (M,H,W,3), mask / vis2d (M,H,W,1) of the rendered size")
@@ -32,8 +41,9 @@ class _Stage3Loss(Function):
         bg = None if bkgd is None else bkgd.detach().float().contiguous()
         a = _lib.Stage3LossArgs()
         a.M, a.H, a.W = M, H, W
+        a.plane_stride = M * H * W if stacked else 0
         for m in range(M):
-            a.color[m], a.allmap[m] = keep[m].data_ptr(), keep[M + m].data_ptr()
+            a.color[m], a.allmap[m] = colors[m].data_ptr(), allmaps[m].data_ptr()
         a.bkgd = None if bg is None else bg.data_ptr()
         a.rgb, a.mask, a.vis2d = tg["rgb"].data_ptr(), tg["mask"].data_ptr(), tg["vis2d"].data_ptr()
         a.det = None if det is None else det.data_ptr()
@@ -43,7 +53,7 @@ class _Stage3Loss(Function):
         losses = torch.empty(4, dtype=torch.float32, device=dev)
         a.sums, a.partials, a.losses = sums.data_ptr(), partials.data_ptr(), losses.data_ptr()
         _lib.check(_lib.load().vidu4d_stage3_loss_forward(a, torch.cuda.current_stream(dev).cuda_stream), "stage3 loss forward")
-        ctx.args, ctx.M, ctx.has_bg = a, M, bg is not None
+        ctx.args, ctx.M, ctx.has_bg, ctx.stacked = a, M, bg is not None, stacked
         ctx.keep = (keep, tg, det, bg, sums, partials, losses)  # everything the argument struct points to
         return losses
 
@@ -52,8 +62,13 @@ class _Stage3Loss(Function):
         keep = ctx.keep[0]
         M, dev = ctx.M, keep[0].device
         g = g_losses.detach().float().contiguous()
-        g_color = [torch.empty_like(keep[m]) for m in range(M)]
-        g_allmap = [torch.empty_like(keep[M + m]) for m in range(M)]
+        if ctx.stacked:
+            full = [torch.empty_like(keep[0]), torch.empty_like(keep[1])]
+            g_color = [full[0][:, m] for m in range(M)]
+            g_allmap = [full[1][:, m] for m in range(M)]
+        else:
+            g_color = [torch.empty_like(keep[m]) for m in range(M)]
+            g_allmap = [torch.empty_like(keep[M + m]) for m in range(M)]
         g_bg = torch.empty(3, dtype=torch.float32, device=dev) if ctx.has_bg else None
         o = _lib.Stage3LossGrads()
         for m in range(M):
@@ -61,14 +76,20 @@ class _Stage3Loss(Function):
         o.g_bkgd = None if g_bg is None else g_bg.data_ptr()
         _lib.check(_lib.load().vidu4d_stage3_loss_backward(ctx.args, g.data_ptr(), o, torch.cuda.current_stream(dev).cuda_stream),
                    "stage3 loss backward")
+        if ctx.stacked:
+            return (None, None, g_bg, full[0], full[1])
         return (None, None, g_bg) + tuple(g_color) + tuple(g_allmap)
 
 
 def stage3_loss(colors, allmaps, bkgd, batch: dict, step: int, cfg) -> dict:
-    """colors / allmaps: per-frame (3,H,W) / (8,H,W) rasterizer outputs (BEFORE the learnable-background composite);
+    """colors / allmaps: per-frame (3,H,W) / (8,H,W) rasterizer outputs (BEFORE the learnable-background composite),
+    or the (3,M,H,W) / (8,M,H,W) tensors of one stacked call (diff_surfel_rasterization.rasterize_frames);
     bkgd: the (3,) learnable background or None; batch as for compute_losses.  -> {"rgb", "mask", "dist_loss"}: the
     same weighted terms compute_losses returns for them."""
     lam_d = float(cfg.lambda_dist) if step > 8000 else 0.0
     c = dict(lambda_dssim=float(cfg.lambda_dssim), rgb_wt=float(cfg.rgb_wt), mask_wt=float(cfg.mask_wt), dist_wt=lam_d)
-    out = _Stage3Loss.apply(c, batch, bkgd, *colors, *allmaps)
+    if isinstance(colors, torch.Tensor):
+        out = _Stage3Loss.apply(c, batch, bkgd, colors, allmaps)
+    else:
+        out = _Stage3Loss.apply(c, batch, bkgd, *colors, *allmaps)
     return {"rgb": out[0], "mask": out[1], "dist_loss": out[2]}

@@ -217,7 +217,10 @@ class Stage3Trainer:
             # colour / silhouette / distortion terms and their gradient planes in five launches (csrc/loss.hip)
             from .loss_fused import stage3_loss
             rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=("raw",))
-            colors, allmaps = zip(*rendered["raw"])
+            if "raw_stacked" in rendered:   # the frames came out of one stacked launch set: (3,M,H,W), (8,M,H,W)
+                colors, allmaps = rendered["raw_stacked"]
+            else:
+                colors, allmaps = zip(*rendered["raw"])
             losses = stage3_loss(colors, allmaps, getattr(m, "learnable_bkgd", None), batch, step, self.cfg)
             losses["normal_loss"] = torch.zeros((), device=m._xyz.device)
         else:
