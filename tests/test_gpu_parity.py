@@ -510,7 +510,7 @@ def test_segment_limit_reports_truncation_and_replay_is_exact(gpu_device, monkey
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
-@pytest.mark.parametrize("F,split", [(2, "0"), (3, "1"), (2, "auto")])
+@pytest.mark.parametrize("F,split", [(2, "0"), (3, "1"), (2, "auto"), (1, "0"), (8, "0")])
 def test_stacked_frames_equal_single_frame_calls(gpu_device, monkeypatch, F, split):
     """F frames in ONE launch set (frame || tile keys) == F single-frame calls: integers (radii, sorted lists
     per tile, ranges, n_contrib) identical, images identical, gradients equal up to the order of the atomic sums; the
@@ -564,3 +564,15 @@ def test_stacked_frames_equal_single_frame_calls(gpu_device, monkeypatch, F, spl
             assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), (f, what)
     for a, b, what in ((o2.grad, o1.grad, "opacity"), (s2.grad, s1.grad, "scales"), (h2.grad, h1.grad, "sh")):
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), what
+
+
+def test_stacked_frames_without_surfels(gpu_device):
+    """P == 0 through the stacked entry point: background only, as rasterize_points.cu:105 for one frame."""
+    import diff_surfel_rasterization as dsr
+    dev = gpu_device
+    sc = make_scene(10, 64, 48, seed=1).to(dev)
+    rs = dsr.GaussianRasterizationSettings(48, 64, sc.tanfovx, sc.tanfovy, sc.bg, 1.0, sc.viewmatrix, sc.projmatrix, 3,
+                                           sc.campos, False, False)
+    e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+    color, radii, allmap = dsr.rasterize_frames(e(2, 0, 3), e(2, 0, 3), e(0, 16, 3), e(0, 1), e(0, 2), e(2, 0, 4), [rs, rs])
+    assert color.shape == (3, 2, 48, 64) and radii.shape == (2, 0) and float(color.abs().max()) == 0.0
