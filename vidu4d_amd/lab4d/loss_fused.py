@@ -55,13 +55,22 @@ class _Stage3Loss(Function):
         _lib.check(_lib.load().vidu4d_stage3_loss_forward(a, torch.cuda.current_stream(dev).cuda_stream), "stage3 loss forward")
         ctx.args, ctx.M, ctx.has_bg, ctx.stacked = a, M, bg is not None, stacked
         ctx.keep = (keep, tg, det, bg, sums, partials, losses)  # everything the argument struct points to
-        return losses
+        # three scalar outputs (views of the kernel's output vector): indexing ONE output tensor afterwards would cost a
+        # zero-filled (4,) tensor, a copy and an add per term in the backward
+        return losses[0], losses[1], losses[2]
 
     @staticmethod
-    def backward(ctx, g_losses):
+    def backward(ctx, g_rgb, g_mask, g_dist):
         keep = ctx.keep[0]
         M, dev = ctx.M, keep[0].device
-        g = g_losses.detach().float().contiguous()
+        zero = None
+        parts = []
+        for t in (g_rgb, g_mask, g_dist):
+            if t is None:
+                zero = torch.zeros((), dtype=torch.float32, device=dev) if zero is None else zero
+                t = zero
+            parts.append(t.detach().float().reshape(()))
+        g = torch.stack(parts + [parts[0]])  # (4,) device vector the kernel reads (the fourth term is unused)
         if ctx.stacked:
             full = [torch.empty_like(keep[0]), torch.empty_like(keep[1])]
             g_color = [full[0][:, m] for m in range(M)]
@@ -89,7 +98,7 @@ def stage3_loss(colors, allmaps, bkgd, batch: dict, step: int, cfg) -> dict:
     lam_d = float(cfg.lambda_dist) if step > 8000 else 0.0
     c = dict(lambda_dssim=float(cfg.lambda_dssim), rgb_wt=float(cfg.rgb_wt), mask_wt=float(cfg.mask_wt), dist_wt=lam_d)
     if isinstance(colors, torch.Tensor):
-        out = _Stage3Loss.apply(c, batch, bkgd, colors, allmaps)
+        rgb, mask, dist = _Stage3Loss.apply(c, batch, bkgd, colors, allmaps)
     else:
-        out = _Stage3Loss.apply(c, batch, bkgd, *colors, *allmaps)
-    return {"rgb": out[0], "mask": out[1], "dist_loss": out[2]}
+        rgb, mask, dist = _Stage3Loss.apply(c, batch, bkgd, *colors, *allmaps)
+    return {"rgb": rgb, "mask": mask, "dist_loss": dist}
