@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 6
+#define VIDU4D_SURFEL_ABI 7
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -318,11 +318,14 @@ int vidu4d_post_backward(int W, int H, const float* allmap, const float* surf_de
  *      Trainer.optimizer_init builds with one parameter group per surfel attribute (lab4d/engine/trainer.py:240-255)
  *      by ONE launch over all groups.  Update rule of torch/optim/adam.py (no amsgrad, no weight decay); the caller
  *      owns the step counts and passes 1 - beta1^t and sqrt(1 - beta2^t) per tensor; the betas are doubles so that
- *      1 - beta is rounded to fp32 once, as torch does.  `tensors` is a HOST array. ---- */
+ *      1 - beta is rounded to fp32 once, as torch does.  grad_scale (device scalar or NULL): every gradient is multiplied
+ *      by it on the way in -- the coefficient of torch.nn.utils.clip_grad_norm_ (lab4d/engine/trainer.py:861-869),
+ *      which upstream applies in a pass of its own; zero_grads != 0: the gradient arrays are left zero-filled (the next
+ *      step's zero_grad), `grad` is then written to.  `tensors` is a HOST array. ---- */
 #define VIDU4D_ADAM_MAX_TENSORS 8
 typedef struct Vidu4dAdamTensor {
     float* param;
-    const float* grad;
+    float* grad;        /* read; zero-filled afterwards when zero_grads is set */
     float* exp_avg;
     float* exp_avg_sq;
     int64_t numel;
@@ -330,7 +333,8 @@ typedef struct Vidu4dAdamTensor {
     float bias_correction1;      /* 1 - beta1^step */
     float bias_correction2_sqrt; /* sqrt(1 - beta2^step) */
 } Vidu4dAdamTensor;
-int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps, void* stream);
+int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
+                     const float* grad_scale, int zero_grads, void* stream);
 
 /* ---- densify_and_prune on the device: replaces GaussianModel.densify_and_clone / densify_and_split / prune_points
  *      and the optimizer surgery under them (gs/scene/gaussian_model.py:270-356, :384-448).

@@ -112,3 +112,61 @@ def test_device_side_densify_draws_its_own_samples(gpu_device):
     n = b._xyz.shape[0]
     assert n != 20000 and torch.isfinite(b._xyz).all() and b.denom.shape == (n, 1)
     assert len(b.optimizer.state) == 0
+
+
+def test_surfel_adam_scales_and_zeroes_gradients_in_the_same_pass(gpu_device):
+    """grad_scale (the clip coefficient as a device scalar) and zero_grads folded into the one launch == scaling the
+    gradients first, stepping, zeroing afterwards."""
+    from vidu4d_amd.gs.surfel_optim import SurfelAdam
+    dev = gpu_device
+    g = torch.Generator().manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in [(3000, 3), (3000, 15, 3), (7,)]]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = SurfelAdam([{"params": [p], "lr": 1e-2 * (i + 1)} for i, p in enumerate(a)], eps=1e-15)
+    ob = SurfelAdam([{"params": [p], "lr": 1e-2 * (i + 1)} for i, p in enumerate(b)], eps=1e-15)
+    coef = torch.tensor(0.37, device=dev)
+    for _ in range(3):
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, generator=g).to(dev)
+            p.grad, q.grad = gr.clone(), gr * coef
+        oa.step(grad_scale=coef, zero_grads=True)
+        ob.step()
+        for p in a:
+            assert float(p.grad.abs().max()) == 0.0
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+
+
+def test_trainer_folds_clip_and_zero_fill_into_adam(gpu_device, monkeypatch):
+    """Stage3Trainer's optimizer phase with the clip's scaling and the flat buffer's zero fill inside the Adam launch ==
+    with the separate passes, on the SAME gradients (a whole training run is not comparable entry by entry: Adam with
+    eps = 1e-15 turns the rounding noise of the blend's atomic sums into +-lr for entries whose gradient is ~0)."""
+    import numpy as np
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    dev = gpu_device
+
+    def make():
+        torch.manual_seed(0)
+        rng = np.random.default_rng(4)
+        m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=8, device=dev)
+        m.init_from_points(rng.normal(size=(3000, 3)).astype(np.float32) * 0.25, rng.uniform(size=(3000, 3)).astype(np.float32))
+        return m, Stage3Trainer(m)
+    m1, t1 = make()
+    m2, t2 = make()
+    batch = synthetic_batch(m1, [1, 5], 48, 48, seed=2)
+    for rep in range(2):
+        t1.bind_flat_gradients()
+        t1._forward_backward(batch, rep)
+        t2.bind_flat_gradients()
+        t2._flat.copy_(t1._flat)
+        monkeypatch.setattr(Stage3Trainer, "_fold_clip_into_adam", lambda self: self is t1)
+        for t in (t1, t2):
+            t.clip_gradients(5.0)
+            t._optimizer_step(rep)
+        assert t1.__dict__.get("_flat_is_zero") is True and float(t1._flat.abs().max()) == 0.0
+        for a, b in zip(t1.surfel_params(), t2.surfel_params()):
+            assert torch.allclose(a, b, rtol=0, atol=1e-7 * float(b.abs().max()) + 1e-12), float((a - b).abs().max())
+        for t in (t1, t2):
+            for p in t.exchanged_params():
+                p.grad = None

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ForwardArgs(C.Structure):
@@ -131,7 +131,7 @@ SYMBOLS = {
     "vidu4d_skin_field_backward": (C.c_int, [C.POINTER(SkinFieldArgs), _P]),
     "vidu4d_stage3_loss_forward": (C.c_int, [C.POINTER(Stage3LossArgs), _P]),
     "vidu4d_stage3_loss_backward": (C.c_int, [C.POINTER(Stage3LossArgs), _P, C.POINTER(Stage3LossGrads), _P]),
-    "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P]),
+    "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,
                                        C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),

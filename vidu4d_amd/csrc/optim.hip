@@ -28,6 +28,8 @@ struct AdamLaunch {
     unsigned first_block[VIDU4D_ADAM_MAX_TENSORS + 1];
     int n;
     float beta2, one_minus_beta1, one_minus_beta2, eps;
+    const float* grad_scale;
+    int zero_grads;
 };
 
 constexpr int ADAM_PER_THREAD = 4;
@@ -44,13 +46,14 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
     const Vidu4dAdamTensor t = a.t[k];
     const float step_size = t.lr / t.bias_correction1;
     const float w = a.one_minus_beta1, w2 = a.one_minus_beta2;
+    const float gs = a.grad_scale ? *a.grad_scale : 1.0f;
     const int64_t base = (int64_t)(blockIdx.x - a.first_block[k]) * ADAM_PER_BLOCK + threadIdx.x;
     float g[ADAM_PER_THREAD], m[ADAM_PER_THREAD], v[ADAM_PER_THREAD], p[ADAM_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < ADAM_PER_THREAD; j++) {
         const int64_t e = base + j * 256;
         if (e < t.numel) {
-            g[j] = t.grad[e];
+            g[j] = a.grad_scale ? t.grad[e] * gs : t.grad[e];
             m[j] = t.exp_avg[e];
             v[j] = t.exp_avg_sq[e];
             p[j] = t.param[e];
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
             const float mn = fmaf(w, g[j] - m[j], m[j]);  // lerp with weight < 0.5 (ATen/native/Lerp.h)
             const float vn = fmaf(w2 * g[j], g[j], a.beta2 * v[j]);
             const float denom = sqrtf(vn) / t.bias_correction2_sqrt + a.eps;
+            if (a.zero_grads) t.grad[e] = 0.f;
             t.exp_avg[e] = mn;
             t.exp_avg_sq[e] = vn;
             t.param[e] = p[j] - step_size * (mn / denom);
@@ -193,7 +197,8 @@ __global__ __launch_bounds__(256) void densify_gather_kernel(DensifyLaunch L)
 
 }  // namespace
 
-extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps, void* stream)
+extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
+                                const float* grad_scale, int zero_grads, void* stream)
 {
     if (n < 0 || n > VIDU4D_ADAM_MAX_TENSORS || (n && !tensors)) return VIDU4D_E_INVALID;
     AdamLaunch a;
@@ -202,6 +207,8 @@ extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double b
     a.one_minus_beta1 = (float)(1.0 - beta1);
     a.one_minus_beta2 = (float)(1.0 - beta2);
     a.eps = (float)eps;
+    a.grad_scale = grad_scale;
+    a.zero_grads = zero_grads;
     unsigned blocks = 0;
     for (int i = 0; i < n; i++) {
         const Vidu4dAdamTensor& t = tensors[i];

@@ -24,7 +24,9 @@ class SurfelAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, foreach=False, fused=False)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=None, zero_grads=False):
+        """grad_scale: device scalar the gradients are multiplied by on the way in (the clip coefficient, instead of a
+        pass of its own over the gradients); zero_grads: leave the gradient arrays zero-filled."""
         if closure is not None:
             raise RuntimeError("SurfelAdam: closures are not supported")
         batches = {}
@@ -42,6 +44,8 @@ class SurfelAdam(torch.optim.Adam):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 t = float(st["step"])
+                if zero_grads and not p.grad.is_contiguous():
+                    raise RuntimeError("SurfelAdam: zero_grads needs contiguous gradients")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 rec = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                       p.numel(), float(group["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t))
@@ -52,7 +56,8 @@ class SurfelAdam(torch.optim.Adam):
             for i in range(0, len(items), _lib.ADAM_MAX_TENSORS):
                 chunk = items[i:i + _lib.ADAM_MAX_TENSORS]
                 arr = (_lib.AdamTensor * len(chunk))(*[c[0] for c in chunk])
-                _lib.check(lib.vidu4d_adam_step(len(chunk), arr, b1, b2, eps, stream), "adam step")
+                _lib.check(lib.vidu4d_adam_step(len(chunk), arr, b1, b2, eps, None if grad_scale is None else grad_scale.data_ptr(),
+                                                int(bool(zero_grads)), stream), "adam step")
         return None
 
 

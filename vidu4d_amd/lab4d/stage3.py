@@ -159,7 +159,7 @@ class Stage3Trainer:
         n = sum(p.numel() for p in ps)
         if self._flat is None or self._flat.numel() != n or self._flat.device != ps[0].device:
             self._flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
-        else:
+        elif not self.__dict__.pop("_flat_is_zero", False):  # (the one-launch Adam left it zero-filled)
             self._flat.zero_()
         off = 0
         for p in ps:
@@ -196,8 +196,33 @@ class Stage3Trainer:
         if self._flat is None:
             return torch.nn.utils.clip_grad_norm_(self.exchanged_params(), max_norm)
         norm = torch.linalg.vector_norm(self._flat)
-        self._flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        if self._fold_clip_into_adam():
+            self._clip_coef = coef  # the surfel Adam multiplies the gradients by it on the way in (csrc/optim.hip)
+        else:
+            self._flat.mul_(coef)
         return norm
+
+    def _fold_clip_into_adam(self):
+        """The clip's scaling pass and the next step's zero fill ride along in the one-launch Adam when nothing but that
+        Adam reads the gradients after the clip: surfels on the GPU, frozen networks."""
+        from ..gs.surfel_optim import SurfelAdam
+        return isinstance(self.gs_optimizer, SurfelAdam) and self.optimizer is None
+
+    def _optimizer_step(self, step: int):
+        """The surfel Adam (and, once it is due, the networks' optimizer) on the clipped gradients."""
+        coef = self.__dict__.pop("_clip_coef", None)
+        if coef is not None:
+            # every exchanged gradient is a live view of the flat buffer unless a parameter was re-created this step
+            # (densify / prune / reset_opacity): only then is the buffer not left zero-filled
+            whole = all(p.grad is not None for p in self.exchanged_params())
+            self.gs_optimizer.step(grad_scale=coef, zero_grads=whole)
+            self._flat_is_zero = whole
+        else:
+            self.gs_optimizer.step()
+        if self.optimizer is not None and step >= self.optim_warp_from:
+            self.optimizer.step()
+            self.scheduler.step()
 
     def _sync_densification_stats(self):
         if self.world == 1:
@@ -286,10 +311,7 @@ class Stage3Trainer:
                     from ..simple_knn import radius_neighbor_count
                     m.prune_points(radius_neighbor_count(m.get_xyz, 0.004) <= 20)
         # (parameters re-created by densify / prune / reset_opacity have no gradient and are skipped, as upstream)
-        self.gs_optimizer.step()
-        if self.optimizer is not None and step >= self.optim_warp_from:
-            self.optimizer.step()
-            self.scheduler.step()
+        self._optimizer_step(step)
         for p in self.exchanged_params():
             p.grad = None
         self.current_steps += 1
