@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 7
+#define VIDU4D_SURFEL_ABI 8
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -285,6 +285,8 @@ typedef struct Vidu4dSkinFieldArgs {
     const float* g_xbT;  /* backward inputs: gradient w.r.t. xbT (may be NULL) and rawT */
     const float* g_rawT;
     float* g_xyz;        /* backward output (N, 3) */
+    uint32_t* relu_masks; /* optional, D * 64 * ceil(N / 32) words: the forward records which hidden units are active,
+                             the backward then skips its recomputation of the hidden layers (NULL: it recomputes) */
 } Vidu4dSkinFieldArgs;
 int vidu4d_skin_field_forward(const Vidu4dSkinFieldArgs* args, void* stream);
 int vidu4d_skin_field_backward(const Vidu4dSkinFieldArgs* args, void* stream);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ForwardArgs(C.Structure):
@@ -48,7 +48,7 @@ class SkinFieldArgs(C.Structure):
     """struct Vidu4dSkinFieldArgs"""
     _fields_ = [("N", C.c_int), ("B", C.c_int), ("W", C.c_int), ("D", C.c_int)] + [
         (n, C.c_void_p) for n in ("xyz", "bone_A", "bone_c", "w_in", "b_in", "w_hid", "b_hid", "w_out", "b_out", "xbT",
-                                  "rawT", "g_xbT", "g_rawT", "g_xyz")]
+                                  "rawT", "g_xbT", "g_rawT", "g_xyz", "relu_masks")]
 
 
 LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 8, 512, 32

@@ -170,7 +170,8 @@ __device__ __forceinline__ uint32_t relu_tiles(f32x16 (&h)[2])
 // Hidden layers of the forward for one tile; h = last hidden activations (D layout), masks[l] = active units of layer l.
 __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, const Plan& p, const float* lds, int lane,
                                                int n, bool valid, float x, float y, float z, float* xbT_out,
-                                               f32x16 (&h)[2], uint32_t (&masks)[MAX_HIDDEN])
+                                               f32x16 (&h)[2], uint32_t (&masks)[MAX_HIDDEN], uint32_t* mask_out,
+                                               size_t mask_stride)
 {
     const int half = lane >> 5;
     load_bias(h, lds, p, 0, half);
@@ -185,6 +186,7 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
         h[1] = mfma(s[64], xb, h[1]);
     }
     masks[0] = relu_tiles(h);
+    if (mask_out) mask_out[0] = masks[0];
 #pragma unroll 1
     for (int layer = 1; layer < a.D; layer++) {
         f32x16 acc[2];
@@ -200,6 +202,7 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
                 interleave_reads_and_mfmas<2>();
             }
         masks[layer] = relu_tiles(acc);
+        if (mask_out) mask_out[layer * mask_stride] = masks[layer];
         h[0] = acc[0];
         h[1] = acc[1];
     }
@@ -222,7 +225,15 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
         const float x = a.xyz[3 * nn], y = a.xyz[3 * nn + 1], z = a.xyz[3 * nn + 2];
         f32x16 h[2];
         uint32_t masks[MAX_HIDDEN];
-        hidden_forward(a, p, lds, lane, n, valid, x, y, z, BACKWARD ? nullptr : a.xbT, h, masks);
+        // relu_masks[layer][tile][lane]: with them the backward needs no forward at all
+        uint32_t* mask_slot = a.relu_masks ? a.relu_masks + (size_t)tile * 64 + lane : nullptr;
+        const size_t mask_layer_stride = (size_t)tiles * 64;
+        if (BACKWARD && mask_slot) {
+            for (int l = 0; l < a.D; l++) masks[l] = mask_slot[l * mask_layer_stride];
+        } else {
+            hidden_forward(a, p, lds, lane, n, valid, x, y, z, BACKWARD ? nullptr : a.xbT, h, masks,
+                           BACKWARD ? nullptr : mask_slot, mask_layer_stride);
+        }
         if (!BACKWARD) {
             f32x16 out;
 #pragma unroll

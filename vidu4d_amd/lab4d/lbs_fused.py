@@ -186,21 +186,23 @@ class _SkinField(Function):
         x, b = _c(xyz), _c(b_in).reshape(-1)
         xbT = torch.empty(3 * tab["B"], N, dtype=torch.float32, device=xyz.device)
         rawT = torch.empty(tab["B"], N, dtype=torch.float32, device=xyz.device)
-        a = _skin_field_args(tab, N, x, b, xbT=xbT, rawT=rawT)
+        # which hidden units are active, per layer / 32-surfel tile / lane: spares the backward its recomputation
+        masks = torch.empty(tab["D"] * 64 * ((N + 31) // 32), dtype=torch.int32, device=xyz.device)
+        a = _skin_field_args(tab, N, x, b, xbT=xbT, rawT=rawT, relu_masks=masks)
         _lib.check(_lib.load().vidu4d_skin_field_forward(a, torch.cuda.current_stream(xyz.device).cuda_stream),
                    "skin field forward")
-        ctx.save_for_backward(x, b)
+        ctx.save_for_backward(x, b, masks)
         ctx.tab = tab
         return xbT, rawT
 
     @staticmethod
     def backward(ctx, g_xbT, g_rawT):
-        x, b = ctx.saved_tensors
+        x, b, masks = ctx.saved_tensors
         tab, N = ctx.tab, x.shape[0]
         g_xbT = None if g_xbT is None else _c(g_xbT)
         g_rawT = torch.zeros(tab["B"], N, device=x.device) if g_rawT is None else _c(g_rawT)
         g_xyz = torch.empty(N, 3, dtype=torch.float32, device=x.device)
-        a = _skin_field_args(tab, N, x, b, g_xbT=g_xbT, g_rawT=g_rawT, g_xyz=g_xyz)
+        a = _skin_field_args(tab, N, x, b, g_xbT=g_xbT, g_rawT=g_rawT, g_xyz=g_xyz, relu_masks=masks)
         _lib.check(_lib.load().vidu4d_skin_field_backward(a, torch.cuda.current_stream(x.device).cuda_stream),
                    "skin field backward")
         return g_xyz, None, None
