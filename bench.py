@@ -462,6 +462,8 @@ def main():
             prof = _lib.profile_read(reset=True)
             stages = {k: {"ms_total": ms, "launches": n, "ms_avg": (ms / n if n else None)} for k, (ms, n) in prof.items()}
             out["stage_ms_avg"] = {k: (round(v["ms_avg"], 4) if v["ms_avg"] is not None else None) for k, v in stages.items()}
+            # (a stacked launch covers all frames of a step: divide by this for per-frame kernel time)
+            out["stage_frames_per_launch"] = FRAMES_PER_STEP if args.stacked else 1
             dom = max((k for k in stages if stages[k]["launches"]), key=lambda k: stages[k]["ms_total"])
             avg_s = stages[dom]["ms_avg"] * 1e-3
             # units one launch processes: the frames of a step when they go through one stacked launch set
