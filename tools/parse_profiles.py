@@ -91,12 +91,17 @@ if sq:
             util = m["SQ_INSTS_VALU"] * 4.0 / (SIMDS * ns * CLK_GHZ) if ns == ns else float("nan")
             f.write(f"surfel::{k},{n}," + ",".join(f"{m[c]:.4g}" for c in cols) + f",{ns / 1e3:.1f},{util:.3f}\n")
             if k in traffic and ns == ns:
-                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs: share of the kernel's duration (at the
-                # 2.4 GHz peak clock; the sustained clock is lower, so this is a lower bound) the VALUs were executing
-                busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * ns * CLK_GHZ)
+                # Share of the VALU issue capacity the kernel's wave64 VALU instructions take, bracketed: a plain
+                # instruction issues every 2.4 cycles per SIMD on this chip (tools/ubench/valu_rate.hip; DPP adds 6,
+                # lane swaps / transcendentals 8), the nominal figure is 4.  Clock: 2.4 GHz peak (SQ_BUSY_CYCLES / 32
+                # shader engines / duration gives the sustained one, ~2.26 GHz under these kernels).
+                lo = m["SQ_INSTS_VALU"] * 2.4 / (SIMDS * ns * CLK_GHZ)
+                hi = m["SQ_INSTS_VALU"] * 4.0 / (SIMDS * ns * CLK_GHZ)
+                clk = m["SQ_BUSY_CYCLES"] / 32.0 / ns if m["SQ_BUSY_CYCLES"] == m["SQ_BUSY_CYCLES"] else float("nan")
                 hbm = traffic[k]["hbm_bytes_per_launch"] / (ns * 1e-9) / 8.0e12
-                traffic[k]["limiter"] = {"bound": "valu" if busy > 0.5 and hbm < 0.3 else ("hbm" if hbm >= 0.3 else "latency"),
-                                         "valu_busy_frac": round(busy, 3), "valu_insts_per_launch": m["SQ_INSTS_VALU"],
+                traffic[k]["limiter"] = {"bound": "valu" if lo > 0.4 and hbm < 0.3 else ("hbm" if hbm >= 0.3 else "latency"),
+                                         "valu_issue_frac_at_2.4_cycles": round(lo, 3), "valu_issue_frac_at_4_cycles": round(hi, 3),
+                                         "sustained_clock_ghz": round(clk, 2), "valu_insts_per_launch": m["SQ_INSTS_VALU"],
                                          "counter_hbm_frac_of_8TBps": round(hbm, 4), "avg_duration_us": round(ns / 1e3, 1),
                                          "source": f"rocprofv3 --pmc SQ_ACTIVE_INST_VALU ... ({tag}_pmc_sq.csv)"}
     json.dump(traffic, open(os.path.join(summ, "pmc_traffic.json"), "w"), indent=1)
