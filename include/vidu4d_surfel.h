@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 8
+#define VIDU4D_SURFEL_ABI 9
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -338,6 +338,17 @@ typedef struct Vidu4dAdamTensor {
 int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
                      const float* grad_scale, int zero_grads, void* stream);
 
+/* ---- the gradient clip's norm and coefficient: torch.nn.utils.clip_grad_norm_(params, max_norm) as Trainer.check_grad
+ *      calls it (lab4d/engine/trainer.py:861-869) is a norm per tensor, a stack, a norm, an add, a division, a clamp and
+ *      a multiply per tensor; here ONE launch reads the n gradient arrays (grads[i], numel[i]; HOST arrays, n <=
+ *      VIDU4D_CLIP_MAX_TENSORS) and writes out[0] = the 2-norm over all of them, out[1] = min(1, max_norm / (norm + 1e-6))
+ *      -- the factor vidu4d_adam_step takes as grad_scale.  workspace: VIDU4D_CLIP_WORKSPACE_FLOATS device floats whose
+ *      FIRST word is zero at entry (the kernel leaves it zero again); partial sums are added in a fixed order. ---- */
+#define VIDU4D_CLIP_MAX_TENSORS 16
+#define VIDU4D_CLIP_WORKSPACE_FLOATS 1056
+int vidu4d_grad_clip_coef(int n, const float* const* grads, const int64_t* numel, float max_norm, float* workspace,
+                          float* out, void* stream);
+
 /* ---- densify_and_prune on the device: replaces GaussianModel.densify_and_clone / densify_and_split / prune_points
  *      and the optimizer surgery under them (gs/scene/gaussian_model.py:270-356, :384-448).
  *  plan:  per surfel, from grad_accum / denom (N), log-scales (N,2), opacity logits (N): counts (3,N) int32 =
@@ -374,9 +385,10 @@ int vidu4d_densify_apply(int N, const int32_t* inclusive_counts, int n_orig, int
  *      background composite in front of it (lab4d/nnutils/deformable_gaussian.py:1216-1218).
  *      color[m] (3,H,W), allmap[m] (8,H,W): the rasterizer outputs of frame m (M <= 8); bkgd (3) learnable background
  *      or NULL; rgb (M,H,W,3), mask / vis2d (M,H,W,1) targets; det (M) 1/0 per frame or NULL.  losses (4) =
- *      {rgb, mask, dist, 0}, each already multiplied by its weight.  sums (32 floats) and partials
+ *      {rgb, mask, dist, rgb + mask + dist}, each term already multiplied by its weight.  sums (32 floats) and partials
  *      (VIDU4D_LOSS_BLOCKS * 16 floats) are scratch that must stay untouched between forward and backward.
- *      The backward takes g_losses (4, device) and writes every plane of g_color[m] / g_allmap[m] and g_bkgd (3). ---- */
+ *      The backward takes g_losses (4, device: upstream gradients of the three terms and of their sum, the latter is
+ *      added to each) and writes every plane of g_color[m] / g_allmap[m] and g_bkgd (3). ---- */
 #define VIDU4D_LOSS_MAX_FRAMES 8
 #define VIDU4D_LOSS_BLOCKS 512
 #define VIDU4D_LOSS_SUMS_FLOATS 32

@@ -30,9 +30,10 @@ def _planes(rendered, mask, dist):
     return colors, allmaps
 
 
+@pytest.mark.parametrize("through_total", [False, True])
 @pytest.mark.parametrize("case", LOSS_CASES)
-def test_fused_loss_matches_the_reference_numbers(gpu_device, case):
-    from vidu4d_amd.lab4d.loss_fused import stage3_loss
+def test_fused_loss_matches_the_reference_numbers(gpu_device, case, through_total):
+    from vidu4d_amd.lab4d.loss_fused import stage3_loss, unit_gradient
     dev = gpu_device
     r = load("refpy_losses.npz", dev)
     step = int(r[f"{case}_step"])
@@ -42,7 +43,12 @@ def test_fused_loss_matches_the_reference_numbers(gpu_device, case):
     losses = stage3_loss(colors, allmaps, None, batch, step, _cfg())
     for k in ("rgb", "mask", "dist_loss"):
         close(losses[k], r[f"{case}_loss_{k}"], what=f"{case}:{k}", rtol=2e-5, atol=1e-8)
-    sum(losses.values()).backward()
+    terms = losses["rgb"] + losses["mask"] + losses["dist_loss"]
+    assert float(losses["total"]) == float(terms) or (terms.isnan() and losses["total"].isnan())
+    if through_total:  # the kernel's own sum, started from the cached unit gradient (what Stage3Trainer does)
+        losses["total"].backward(gradient=unit_gradient(dev))
+    else:
+        terms.backward()
     g_r = torch.stack([c.grad.permute(1, 2, 0) for c in colors])
     g_m = torch.stack([a.grad[1][..., None] for a in allmaps])
     g_d = torch.stack([a.grad[6][..., None] for a in allmaps])

@@ -170,3 +170,65 @@ def test_trainer_folds_clip_and_zero_fill_into_adam(gpu_device, monkeypatch):
         for t in (t1, t2):
             for p in t.exchanged_params():
                 p.grad = None
+
+
+@pytest.mark.parametrize("sizes,scale", [([(200000, 3), (200000, 15, 3), (200000, 1), (3,)], 1e-3), ([(7,)], 50.0),
+                                          ([(1023, 5)] * 18, 1.0), ([(4, 4), (0, 3), (5,)], 1e-8)])
+def test_clip_coefficient_kernel_matches_torch(gpu_device, sizes, scale):
+    """csrc/optim.hip::clip_kernel (one launch: norm over all tensors + the clamp) == torch.nn.utils.clip_grad_norm_
+    as Trainer.check_grad calls it (lab4d/engine/trainer.py:861-869); called twice: the workspace counter is left clean."""
+    from vidu4d_amd.gs.surfel_optim import clip_coef
+    g = torch.Generator().manual_seed(len(sizes))
+    grads = [(torch.randn(*s, generator=g) * scale).to(gpu_device) for s in sizes]
+    params = [torch.nn.Parameter(torch.zeros_like(t)) for t in grads]
+    for p, t in zip(params, grads):
+        p.grad = t.clone()
+    ref_norm = torch.nn.utils.clip_grad_norm_(params, 5.0)
+    ref_coef = min(1.0, 5.0 / (float(ref_norm) + 1e-6))
+    for _ in range(2):
+        norm, coef = clip_coef(grads, 5.0)
+        assert abs(float(norm) - float(ref_norm)) <= 2e-6 * float(ref_norm) + 1e-30
+        assert abs(float(coef) - ref_coef) <= 2e-6 * ref_coef
+    scaled = [t * coef for t in grads]
+    for p, t in zip(params, scaled):
+        if t.numel():
+            assert torch.allclose(p.grad, t, rtol=1e-5, atol=0)
+
+
+def test_train_step_on_one_rank_leaves_the_gradients_unbound(gpu_device):
+    """One rank, frozen networks: train_step takes the gradients as autograd hands them over (no flat buffer, no
+    accumulation passes), clips through the one-launch kernel and steps; a second trainer on the bound path takes the
+    same step from the same gradients."""
+    import numpy as np
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    dev = gpu_device
+
+    def make():
+        torch.manual_seed(0)
+        rng = np.random.default_rng(4)
+        m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=8, device=dev)
+        m.init_from_points(rng.normal(size=(3000, 3)).astype(np.float32) * 0.25, rng.uniform(size=(3000, 3)).astype(np.float32))
+        return m, Stage3Trainer(m)
+    m1, t1 = make()
+    m2, t2 = make()
+    assert not t1._flat_needed()
+    batch = synthetic_batch(m1, [1, 5], 48, 48, seed=2)
+    t1.begin_gradients()
+    assert t1._flat is None
+    t1._forward_backward(batch, 0)
+    grads = [p.grad for p in t1.exchanged_params()]
+    assert sum(g is not None for g in grads) >= 6  # (a parameter nothing reads, regist_feat, gets none: skipped by Adam)
+    t2.bind_flat_gradients()
+    for p, g_ in zip(t2.exchanged_params(), grads):
+        if g_ is not None:
+            p.grad.copy_(g_)
+    for t in (t1, t2):
+        t.clip_gradients(5.0)
+        t._optimizer_step(0)
+    # (the norm's partial sums are grouped differently over seven arrays than over one: the coefficient may differ by an ulp)
+    for a, b in zip(t1.surfel_params(), t2.surfel_params()):
+        assert torch.allclose(a, b, rtol=0, atol=1e-7 * float(b.abs().max()) + 1e-12), float((a - b).abs().max())
+    # and the public entry point runs on that path
+    out = t1.train_step(batch)
+    assert t1._flat is None and all(torch.isfinite(v) for v in out.values())

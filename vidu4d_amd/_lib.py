@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ForwardArgs(C.Structure):
@@ -71,6 +71,8 @@ class Stage3LossGrads(C.Structure):
 
 SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
 ADAM_MAX_TENSORS = 8
+CLIP_MAX_TENSORS = 16
+CLIP_WORKSPACE_FLOATS = 1056
 DENSIFY_MAX_ATTRS = 8
 
 
@@ -132,6 +134,7 @@ SYMBOLS = {
     "vidu4d_stage3_loss_forward": (C.c_int, [C.POINTER(Stage3LossArgs), _P]),
     "vidu4d_stage3_loss_backward": (C.c_int, [C.POINTER(Stage3LossArgs), _P, C.POINTER(Stage3LossGrads), _P]),
     "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P]),
+    "vidu4d_grad_clip_coef": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, _P, _P, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,
                                        C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),

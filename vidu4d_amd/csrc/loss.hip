@@ -170,11 +170,12 @@ __global__ __launch_bounds__(64) void loss_reduce2_kernel(Vidu4dStage3LossArgs a
     const bool pos = s[S_MASK_N] > 0.f;
     S[D_MASK_USE_POS] = pos ? 1.f : 0.f;
     S[D_MASK_INV] = pos ? 1.0f / s[S_MASK_N] : 1.0f / numel;
-    a.losses[1] = (pos ? s[S_MASK_POS] / s[S_MASK_N] : s[S_MASK_ALL] / numel) * a.mask_wt;
-    a.losses[3] = 0.f;
+    const float mask_term = (pos ? s[S_MASK_POS] / s[S_MASK_N] : s[S_MASK_ALL] / numel) * a.mask_wt;
+    a.losses[1] = mask_term;
+    a.losses[3] = (a.losses[0] + mask_term) + a.losses[2];  // the sum the trainer back-propagates (losses[0], [2]: reduce1)
 }
 
-// g (4): upstream gradients of the four terms.  Writes g_color[m] (3,H,W), g_allmap[m] (8,H,W) completely and the
+// g (4): upstream gradients of the three terms and, g[3], of their sum losses[3] (added to each).  Writes g_color[m] (3,H,W), g_allmap[m] (8,H,W) completely and the
 // per-block partials of d / d learnable_bkgd.
 __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3LossArgs a, const float* g, Vidu4dStage3LossGrads o,
                                                                float* partial)
@@ -183,10 +184,10 @@ __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3Loss
     const size_t PS = a.plane_stride ? (size_t)a.plane_stride : HW;
     const float numel = (float)total;
     const float* S = a.sums;
-    const float g_rgb = g[0] * a.rgb_wt * S[D_RGB_COEF] * (1.0f - a.lambda_dssim) / (3.0f * numel);  // per |r - t| entry
-    const float g_mask = g[1] * a.mask_wt * S[D_MASK_INV];
+    const float g_rgb = (g[0] + g[3]) * a.rgb_wt * S[D_RGB_COEF] * (1.0f - a.lambda_dssim) / (3.0f * numel);  // per |r - t| entry
+    const float g_mask = (g[1] + g[3]) * a.mask_wt * S[D_MASK_INV];
     const bool only_pos = S[D_MASK_USE_POS] != 0.f;
-    const float g_dist = a.dist_wt != 0.f ? g[2] * a.dist_wt / numel : 0.f;
+    const float g_dist = a.dist_wt != 0.f ? (g[2] + g[3]) * a.dist_wt / numel : 0.f;
     float bg[3] = {0.f, 0.f, 0.f};
     for (size_t e = (size_t)blockIdx.x * THREADS + threadIdx.x; e < total; e += (size_t)BLOCKS * THREADS) {
         const int m = (int)(e / HW);

@@ -74,6 +74,68 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ gradient clip
+constexpr int CLIP_BLOCKS = 1024;
+struct ClipLaunch {
+    const float* g[VIDU4D_CLIP_MAX_TENSORS];
+    int64_t numel[VIDU4D_CLIP_MAX_TENSORS];
+    int n;
+    float max_norm;
+    float* workspace;  // [0] arrival counter (as unsigned), [32 .. 32 + CLIP_BLOCKS) block partials
+    float* out;
+};
+
+// Every block strides over every tensor; the block that arrives last adds the CLIP_BLOCKS partials in index order (in
+// double), so the result does not depend on the arrival order.
+__global__ __launch_bounds__(256) void clip_kernel(ClipLaunch a)
+{
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int64_t stride = (int64_t)CLIP_BLOCKS * 256;
+    for (int k = 0; k < a.n; k++) {
+        const float* __restrict__ g = a.g[k];
+        const int64_t n = a.numel[k];
+        int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; e + 3 * stride < n; e += 4 * stride) {
+            const float v0 = g[e], v1 = g[e + stride], v2 = g[e + 2 * stride], v3 = g[e + 3 * stride];
+            s0 = fmaf(v0, v0, s0);
+            s1 = fmaf(v1, v1, s1);
+            s2 = fmaf(v2, v2, s2);
+            s3 = fmaf(v3, v3, s3);
+        }
+        for (; e < n; e += stride) s0 = fmaf(g[e], g[e], s0);
+    }
+    float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    __shared__ float s_part[4];
+    __shared__ bool s_last;
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    unsigned* counter = reinterpret_cast<unsigned*>(a.workspace);
+    float* partial = a.workspace + 32;
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        __threadfence();
+        s_last = atomicAdd(counter, 1u) == (unsigned)(CLIP_BLOCKS - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double t = 0.0;
+    for (int i = threadIdx.x; i < CLIP_BLOCKS; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ double s_t[256];
+    s_t[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 256; i++) tot += s_t[i];
+        const float norm = (float)sqrt(tot);
+        a.out[0] = norm;
+        a.out[1] = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
+        *counter = 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ densify
 __device__ __forceinline__ float sigmoid_like_torch(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -224,6 +286,28 @@ extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double b
     if (!blocks) return VIDU4D_OK;
     (void)hipGetLastError();
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}
+
+extern "C" int vidu4d_grad_clip_coef(int n, const float* const* grads, const int64_t* numel, float max_norm,
+                                     float* workspace, float* out, void* stream)
+{
+    static_assert(VIDU4D_CLIP_WORKSPACE_FLOATS >= 32 + CLIP_BLOCKS, "clip workspace");
+    if (n < 0 || n > VIDU4D_CLIP_MAX_TENSORS || (n && (!grads || !numel)) || !workspace || !out) return VIDU4D_E_INVALID;
+    ClipLaunch a;
+    a.n = 0;
+    for (int i = 0; i < n; i++) {
+        if (numel[i] < 0 || (numel[i] && !grads[i])) return VIDU4D_E_INVALID;
+        if (numel[i] == 0) continue;
+        a.g[a.n] = grads[i];
+        a.numel[a.n] = numel[i];
+        a.n++;
+    }
+    a.max_norm = max_norm;
+    a.workspace = workspace;
+    a.out = out;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(clip_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 

@@ -308,6 +308,21 @@ class DeformableSurfels(GaussianModel):
             g = self._parent.grad
             return None if g is None else g[self._index]
 
+    class _Visible:
+        """visibility_filter of the frames of a stacked call, made when somebody asks (`radii > 0` is a launch per
+        frame that only the densification statistics read)."""
+
+        def __init__(self, radii):
+            self._radii, self._made = radii, {}
+
+        def __len__(self):
+            return self._radii.shape[0]
+
+        def __getitem__(self, i):
+            if i not in self._made:
+                self._made[i] = self._radii[i] > 0
+            return self._made[i]
+
     def _render_frames_stacked(self, cams, xyz_cam, rot_cam, rot_is_unit):
         """All frames of the step through ONE launch set (diff_surfel_rasterization.rasterize_frames: stacked tile
         grids).  -> {"raw_stacked": (color (3,M,H,W), allmap (8,M,H,W))}; frame i is [:, i]."""
@@ -324,12 +339,17 @@ class DeformableSurfels(GaussianModel):
                 projmatrix=cam.full_proj_transform, sh_degree=self.active_sh_degree, campos=cam.camera_center,
                 prefiltered=False, debug=False))
         rotations = rot_cam if rot_is_unit else self.rotation_activation(rot_cam, dim=-1)
-        screen = torch.zeros_like(xyz_cam).requires_grad_(True)  # (a leaf: its .grad is the densification statistic)
+        # a leaf whose .grad is the densification statistic; the rasterizer never reads its values (upstream passes zeros),
+        # so every step's leaf shares one cached buffer instead of zero-filling a new one
+        buf = self.__dict__.get("_screen_buf")
+        if buf is None or buf.shape != xyz_cam.shape or buf.device != xyz_cam.device:
+            buf = self.__dict__["_screen_buf"] = torch.zeros_like(xyz_cam)
+        screen = buf.detach().requires_grad_(True)
         color, radii, allmap = rasterize_frames(xyz_cam, screen, self.get_features, self.get_opacity, self.get_scaling,
                                                 rotations, settings)
         M = xyz_cam.shape[0]
         self._viewspace_points_batch = [self._FrameGrad(screen, i) for i in range(M)]
-        self._visibility_filter_batch = [radii[i] > 0 for i in range(M)]
+        self._visibility_filter_batch = self._Visible(radii)
         self._radii_batch = [radii[i] for i in range(M)]
         return {"raw_stacked": (color, allmap)}
 

@@ -12,6 +12,19 @@ from torch.autograd import Function
 from .. import _lib
 
 
+_unit_cache: dict = {}
+
+
+def unit_gradient(device):
+    """A cached device scalar 1.0 to start the backward from (`total.backward(gradient=unit_gradient(dev))`): no
+    ones_like launch per step, and _Stage3Loss.backward recognises it and reads a cached (0, 0, 0, 1) vector."""
+    key = str(device)
+    if key not in _unit_cache:
+        _unit_cache[key] = (torch.ones((), dtype=torch.float32, device=device),
+                            torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float32, device=device))
+    return _unit_cache[key][0]
+
+
 class _Stage3Loss(Function):
     @staticmethod
     def forward(ctx, cfg, targets, bkgd, *planes):
@@ -55,22 +68,29 @@ class _Stage3Loss(Function):
         _lib.check(_lib.load().vidu4d_stage3_loss_forward(a, torch.cuda.current_stream(dev).cuda_stream), "stage3 loss forward")
         ctx.args, ctx.M, ctx.has_bg, ctx.stacked = a, M, bg is not None, stacked
         ctx.keep = (keep, tg, det, bg, sums, partials, losses)  # everything the argument struct points to
-        # three scalar outputs (views of the kernel's output vector): indexing ONE output tensor afterwards would cost a
-        # zero-filled (4,) tensor, a copy and an add per term in the backward
-        return losses[0], losses[1], losses[2]
+        # four scalar outputs (views of the kernel's output vector: the three terms and their sum): indexing ONE output
+        # tensor afterwards would cost a zero-filled (4,) tensor, a copy and an add per term in the backward, and summing
+        # the terms in torch two launches forward and two backward
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1], losses[2], losses[3]
 
     @staticmethod
-    def backward(ctx, g_rgb, g_mask, g_dist):
+    def backward(ctx, g_rgb, g_mask, g_dist, g_total):
         keep = ctx.keep[0]
         M, dev = ctx.M, keep[0].device
-        zero = None
-        parts = []
-        for t in (g_rgb, g_mask, g_dist):
-            if t is None:
-                zero = torch.zeros((), dtype=torch.float32, device=dev) if zero is None else zero
-                t = zero
-            parts.append(t.detach().float().reshape(()))
-        g = torch.stack(parts + [parts[0]])  # (4,) device vector the kernel reads (the fourth term is unused)
+        unit = _unit_cache.get(str(dev))
+        if (g_rgb is None and g_mask is None and g_dist is None and g_total is not None and unit is not None
+                and g_total.data_ptr() == unit[0].data_ptr()):
+            g = unit[1]  # the usual case: total.backward(gradient=unit_gradient(dev)), nothing to assemble
+        else:
+            zero = None
+            parts = []
+            for t in (g_rgb, g_mask, g_dist, g_total):
+                if t is None:
+                    zero = torch.zeros((), dtype=torch.float32, device=dev) if zero is None else zero
+                    t = zero
+                parts.append(t.detach().float().reshape(()))
+            g = torch.stack(parts)  # (4,) device vector the kernel reads
         if ctx.stacked:
             full = [torch.empty_like(keep[0]), torch.empty_like(keep[1])]
             g_color = [full[0][:, m] for m in range(M)]
@@ -94,11 +114,12 @@ def stage3_loss(colors, allmaps, bkgd, batch: dict, step: int, cfg) -> dict:
     """colors / allmaps: per-frame (3,H,W) / (8,H,W) rasterizer outputs (BEFORE the learnable-background composite),
     or the (3,M,H,W) / (8,M,H,W) tensors of one stacked call (diff_surfel_rasterization.rasterize_frames);
     bkgd: the (3,) learnable background or None; batch as for compute_losses.  -> {"rgb", "mask", "dist_loss"}: the
-    same weighted terms compute_losses returns for them."""
+    same weighted terms compute_losses returns for them, and "total": their sum (computed by the kernel; back-propagate
+    through it OR through the terms)."""
     lam_d = float(cfg.lambda_dist) if step > 8000 else 0.0
     c = dict(lambda_dssim=float(cfg.lambda_dssim), rgb_wt=float(cfg.rgb_wt), mask_wt=float(cfg.mask_wt), dist_wt=lam_d)
     if isinstance(colors, torch.Tensor):
-        rgb, mask, dist = _Stage3Loss.apply(c, batch, bkgd, colors, allmaps)
+        rgb, mask, dist, total = _Stage3Loss.apply(c, batch, bkgd, colors, allmaps)
     else:
-        rgb, mask, dist = _Stage3Loss.apply(c, batch, bkgd, *colors, *allmaps)
-    return {"rgb": rgb, "mask": mask, "dist_loss": dist}
+        rgb, mask, dist, total = _Stage3Loss.apply(c, batch, bkgd, *colors, *allmaps)
+    return {"rgb": rgb, "mask": mask, "dist_loss": dist, "total": total}

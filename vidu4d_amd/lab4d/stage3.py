@@ -167,6 +167,21 @@ class Stage3Trainer:
             off += p.numel()
         return self._flat
 
+    def _flat_needed(self):
+        """One rank, surfels on the GPU, frozen networks: nothing reads the gradients but the one-launch clip and the
+        one-launch Adam, which take per-tensor pointers -- autograd then hands every parameter its gradient tensor as it
+        is (no accumulation into a pre-bound buffer: 16 read-add-write passes per step) and there is nothing to zero."""
+        return not (self.world == 1 and self._fold_clip_into_adam())
+
+    def begin_gradients(self):
+        """The step's zero_grad: the flat buffer where it is needed (bind_flat_gradients), else plain `grad = None`."""
+        if self._flat_needed():
+            return self.bind_flat_gradients()
+        self._flat = None
+        for p in self.exchanged_params():
+            p.grad = None
+        return None
+
     def allreduce_gradients(self, async_op: bool = False):
         """Sum of the flat gradient buffer over the ranks (the mean is folded into clip_gradients).  With async_op
         the collective is left in flight (RCCL runs it on its own stream) and `wait_gradients` joins it, so that
@@ -193,14 +208,19 @@ class Stage3Trainer:
 
     def clip_gradients(self, max_norm: float = 5.0):
         """clip_grad_norm_ over the exchanged parameters (trainer.py:861-869), one norm over the flat buffer."""
+        if self._fold_clip_into_adam():
+            # norm and coefficient from one launch; the surfel Adam multiplies the gradients by the coefficient on the
+            # way in (csrc/optim.hip)
+            from ..gs.surfel_optim import clip_coef
+            grads = [self._flat] if self._flat is not None else [p.grad for p in self.exchanged_params()]
+            if not any(g is not None for g in grads):
+                return None
+            norm, self._clip_coef = clip_coef(grads, max_norm)
+            return norm
         if self._flat is None:
             return torch.nn.utils.clip_grad_norm_(self.exchanged_params(), max_norm)
         norm = torch.linalg.vector_norm(self._flat)
-        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
-        if self._fold_clip_into_adam():
-            self._clip_coef = coef  # the surfel Adam multiplies the gradients by it on the way in (csrc/optim.hip)
-        else:
-            self._flat.mul_(coef)
+        self._flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
         return norm
 
     def _fold_clip_into_adam(self):
@@ -215,7 +235,7 @@ class Stage3Trainer:
         if coef is not None:
             # every exchanged gradient is a live view of the flat buffer unless a parameter was re-created this step
             # (densify / prune / reset_opacity): only then is the buffer not left zero-filled
-            whole = all(p.grad is not None for p in self.exchanged_params())
+            whole = self._flat is not None and all(p.grad is not None for p in self.exchanged_params())
             self.gs_optimizer.step(grad_scale=coef, zero_grads=whole)
             self._flat_is_zero = whole
         else:
@@ -246,8 +266,15 @@ class Stage3Trainer:
                 colors, allmaps = rendered["raw_stacked"]
             else:
                 colors, allmaps = zip(*rendered["raw"])
+            from .loss_fused import unit_gradient
             losses = stage3_loss(colors, allmaps, getattr(m, "learnable_bkgd", None), batch, step, self.cfg)
-            losses["normal_loss"] = torch.zeros((), device=m._xyz.device)
+            total = losses.pop("total")  # (summed by the kernel; the backward starts from a cached 1.0)
+            z = self.__dict__.get("_zero_loss")
+            if z is None or z.device != m._xyz.device:
+                z = self._zero_loss = torch.zeros((), device=m._xyz.device)
+            losses["normal_loss"] = z
+            total.backward(gradient=unit_gradient(m._xyz.device))
+            return losses
         else:
             outputs = None if need_geometry else ("render", "acc", "rend_dist")
             rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=outputs)
@@ -267,14 +294,14 @@ class Stage3Trainer:
             # one check per step: if a frame outgrew its buffer -- it then rendered only the background --
             # the gradients of this step are dropped and the step is replayed with exact buffers.
             from .. import _C
-            self.bind_flat_gradients()
+            self.begin_gradients()
             with _C.deferred_capacity_check():
                 losses = self._forward_backward(batch, step)
             if not _C.check_deferred():
-                self.bind_flat_gradients()
+                self.begin_gradients()
                 losses = self._forward_backward(batch, step)
         else:
-            self.bind_flat_gradients()
+            self.begin_gradients()
             losses = self._forward_backward(batch, step)
         self.allreduce_gradients(async_op=True)   # in flight while the statistics below are gathered
 
