@@ -15,7 +15,7 @@ def _mix(n_rows, n_cols, seed):
 
 def fake_raster(settings, means3D, opacities, shs, scales, rotations):
     """-> color (3,H,W), radii (N,) int32, allmap (8,H,W): fixed random linear maps of per-surfel features, then a
-    plane-wise nonlinearity (alpha in (0,1) with an exactly-empty corner, positive depths)."""
+    plane-wise nonlinearity (alpha in (0,1), positive depths)."""
     H, W = int(settings.image_height), int(settings.image_width)
     N = means3D.shape[0]
     dev = means3D.device
@@ -25,13 +25,13 @@ def fake_raster(settings, means3D, opacities, shs, scales, rotations):
     fov = torch.as_tensor([float(settings.tanfovx), float(settings.tanfovy)], device=dev)
     pooled = torch.cat([pooled.reshape(-1), fov])                                         # (K*16+2,)
     planes = (_mix(11 * H * W, pooled.numel(), 11).to(dev) @ pooled).reshape(11, H, W) / pooled.numel() ** 0.5
-    color = torch.sigmoid(planes[:3])
+    color = torch.sigmoid(planes[:3]) * 1.0  # (upstream's render_view composites the background IN PLACE into this
+    # tensor, deformable_gaussian.py:190: it must not be an output autograd saved)
     alpha = torch.sigmoid(2.0 * planes[4:5])
-    hole = torch.ones(1, H, W, device=dev)
-    hole[:, : H // 3, : W // 4] = 0.0                                                      # no contributor there
-    alpha = alpha * hole
+    # (no exactly-empty pixels: upstream's d(depth / alpha) is NaN there -- refpy_render.npz pins that behaviour -- and
+    # through this function's pooling one NaN would reach every gradient)
     depth = 2.0 + torch.sigmoid(planes[3:4])
-    allmap = torch.cat([depth * alpha, alpha, planes[5:8] * alpha, (depth * 1.01) * hole,
+    allmap = torch.cat([depth * alpha, alpha, planes[5:8] * alpha, depth * 1.01,
                         0.1 * torch.sigmoid(planes[8:9]), torch.sigmoid(planes[9:10])], dim=0)
     radii = (opacities[:, 0].detach() * 97.0).to(torch.int32) % 4   # some surfels invisible (sigmoid of the same numbers
     # on both sides: bit-identical, unlike anything derived from the warped centres)

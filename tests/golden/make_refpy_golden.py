@@ -523,6 +523,166 @@ def gen_render(out_dir, dsr, cams):
     npz(os.path.join(out_dir, "refpy_render.npz"), **out)
 
 
+def _load_fake_raster():
+    spec = importlib.util.spec_from_file_location("_vidu4d_fake_raster", os.path.join(HERE, "fake_raster.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.fake_raster
+
+
+def gen_loop(out_dir, dsr):
+    """The per-frame render loop itself: DeformableGaussian.query_field (deformable_gaussian.py:1048-1275:
+    canonical surfels -> forward_warp -> one KCamera per frame -> render_view per frame -> permute / cat across frames,
+    `_viewspace_points_batch` / `_visibility_filter_batch` / `_radii_batch`) and render_view (:178-202: xyz / rotation
+    overrides, background_feat handed to render(), learnable-background composite), called unbound on a holder that
+    carries the reference's own warp / camera networks (the `v2` state dicts of refpy_nets.pt) and GaussianModel
+    properties.  The rasterizer is tests/golden/fake_raster.py (a smooth function of every argument it is handed)."""
+    import torch
+    import torch.nn.functional as F
+    from lab4d.nnutils.pose import CameraMLP
+    from lab4d.nnutils.warping import SkinningWarp
+    from lab4d.nnutils.deformable_gaussian import DeformableGaussian
+
+    fake = _load_fake_raster()
+    nets = torch.load(os.path.join(out_dir, "refpy_nets.pt"), weights_only=False)["v2"]
+    frame_info = make_frame_info(nets["offsets"])
+    warp = SkinningWarp(frame_info)
+    warp.load_state_dict(nets["warp"])
+    cam = CameraMLP(nets["rtmat"].numpy().copy(), frame_info=frame_info)
+    cam.load_state_dict(nets["camera_mlp"])
+    warp.eval()
+    cam.eval()
+
+    class Holder:
+        get_xyz = DeformableGaussian.get_xyz
+        get_rotation = DeformableGaussian.get_rotation
+        get_scaling = DeformableGaussian.get_scaling
+        get_opacity = DeformableGaussian.get_opacity
+        get_features = DeformableGaussian.get_features
+        render_view = DeformableGaussian.render_view
+        forward_warp = DeformableGaussian.forward_warp
+        get_gs_Kcamera = DeformableGaussian.get_gs_Kcamera
+        apply_qt_to_gaussian = staticmethod(DeformableGaussian.apply_qt_to_gaussian)
+
+        def compute_gauss_density(self, xyz, samples_dict):  # bone-density visualisation: out of scope, never read
+            return {"gauss_density": torch.ones(xyz.shape[0], 1)}
+
+        def cycle_loss(self, *a, **k):                       # dropped by --rgb_loss_only
+            return {}
+
+    class Recorder(dsr.GaussianRasterizer):
+        calls = []
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+            assert colors_precomp is None and cov3D_precomp is None
+            Recorder.calls.append(dict(settings=self.raster_settings, means3D=means3D.detach().clone(),
+                                       rotations=rotations.detach().clone(), scales=scales.detach().clone(),
+                                       opacities=opacities.detach().clone(), shs=shs.detach().clone(),
+                                       means2D=means2D.detach().clone()))
+            return fake(self.raster_settings, means3D, opacities, shs, scales, rotations)
+
+    import gs.gaussian_renderer as ref_gr
+    import lab4d.nnutils.deformable_gaussian as ref_dg
+    saved = ref_gr.GaussianRasterizer
+    saved_apply = ref_dg.quaternion_apply
+    ref_gr.GaussianRasterizer = Recorder
+
+    def flat_apply(q, p):
+        # query_field rotates a per-surfel axis of shape (M,1,N,3) by (M,N,4) rotations (:1139-1148): the CUDA op sees both
+        # as flat row lists (third_party/quaternion/quaternion.py:49-73 reads B = shape[0] of its reshaped inputs), the
+        # pure-torch forms would broadcast instead.  The result only feeds `concated_feat`, which :1183 discards.
+        if p.shape[:-1] != q.shape[:-1] and p.numel() // 3 == q.numel() // 4:
+            p = p.reshape(q.shape[:-1] + (3,))
+        return saved_apply(q, p)
+    ref_dg.quaternion_apply = flat_apply
+    out = {}
+    try:
+        for tag, learnable_bg in (("bg", True), ("nobg", False)):
+            g = torch.Generator().manual_seed(77)
+            N, M = 120, 3
+            H, W = [20, 20, 20], [28, 28, 28]
+            h = Holder()
+            h.warp = warp
+            h.opts = {"gs_learnable_bg": learnable_bg, "debug": False}
+            h._xyz = ((torch.rand(N, 3, generator=g) * 2 - 1) * 0.12).requires_grad_(True)
+            h._rotation = torch.randn(N, 4, generator=g).requires_grad_(True)
+            h._scaling = (torch.randn(N, 2, generator=g) * 0.3 - 3.0).requires_grad_(True)
+            h._opacity = torch.randn(N, 1, generator=g).requires_grad_(True)
+            h._features_dc = (0.5 * torch.randn(N, 1, 3, generator=g)).requires_grad_(True)
+            h._features_rest = (0.1 * torch.randn(N, 15, 3, generator=g)).requires_grad_(True)
+            h._regist_feat = torch.zeros(N, 16)
+            h.scaling_activation, h.opacity_activation, h.rotation_activation = torch.exp, torch.sigmoid, F.normalize
+            h.active_sh_degree = 2
+            h.pipeline = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, depth_ratio=0.0,
+                                               debug=False)
+            h.background = torch.zeros(3)
+            h.background_feat = torch.zeros(3)
+            if learnable_bg:
+                h.learnable_bkgd = torch.tensor([0.5, 0.3, 0.7], requires_grad=True)
+            frame_id = torch.tensor([3, 17, 20])
+            inst_id = torch.tensor([0, 0, 0])
+            K = torch.tensor([[[40.0, 0, 14.0], [0, 38.0, 10.0], [0, 0, 1]],
+                              [[40.0, 0, 14.0], [0, 38.0, 10.0], [0, 0, 1]],
+                              [[36.0, 0, 13.5], [0, 36.0, 10.25], [0, 0, 1]]])
+            Kinv = torch.inverse(K)
+            with torch.no_grad():
+                t_art, rest_art = warp.articulation.get_vals_and_mean(frame_id)
+                cq, ct = cam.get_vals(frame_id)
+            samples = {"Kinv": Kinv, "field2cam": (cq, ct), "frame_id": frame_id, "inst_id": inst_id,
+                       "near_far": torch.zeros(M, 2), "hxy": torch.zeros(M, 1, 2), "H": H, "W": W,
+                       "t_articulation": t_art, "rest_articulation": rest_art, "is_gen3d": True}
+            Recorder.calls = []
+            feat, deltas, aux = DeformableGaussian.query_field(h, samples)
+            keys = ("rendered", "mask", "rend_dist", "rend_normal", "surf_normal", "surf_depth", "render_depth_median",
+                    "render_depth_expected")
+            Gs = {k: torch.randn(feat[k].shape, generator=g) for k in keys}
+            leaves = [h._xyz, h._rotation, h._scaling, h._opacity, h._features_dc, h._features_rest]
+            names = ["xyz", "rotation", "scaling", "opacity", "features_dc", "features_rest"]
+            if learnable_bg:
+                leaves.append(h.learnable_bkgd)
+                names.append("learnable_bkgd")
+            # (the three maps that are raw rasterizer planes + the background composite: what the GPU test of the stacked
+            # trainer path can rebuild without render()'s post-processing)
+            grads3 = torch.autograd.grad(sum((feat[k] * Gs[k]).sum() for k in ("rendered", "mask", "rend_dist")), leaves,
+                                         retain_graph=True)
+            grads = torch.autograd.grad(sum((feat[k] * Gs[k]).sum() for k in keys), leaves)
+            if tag == "bg":
+                out.update(frame_id=frame_id, inst_id=inst_id, Kinv=Kinv, H=torch.tensor(H), W=torch.tensor(W),
+                           cam_q=cq, cam_t=ct, t_art_r=t_art[0], t_art_d=t_art[1], rest_art_r=rest_art[0],
+                           rest_art_d=rest_art[1])
+                for n, leaf in zip(names, leaves):
+                    out[f"in_{n}"] = leaf
+            for k in keys:
+                out[f"{tag}_{k}"] = feat[k]
+                out[f"{tag}_G_{k}"] = Gs[k]
+            out[f"{tag}_xyz_cam"] = feat["xyz_cam"]
+            for n, gr_, gr3 in zip(names, grads, grads3):
+                out[f"{tag}_g_{n}"] = gr_
+                if tag == "bg":
+                    out[f"bg3_g_{n}"] = gr3
+            assert len(Recorder.calls) == M and len(h._radii_batch) == M and len(h._viewspace_points_batch) == M
+            for i, c in enumerate(Recorder.calls):
+                s = c["settings"]
+                out[f"{tag}_f{i}_means3D"], out[f"{tag}_f{i}_rotations"] = c["means3D"], c["rotations"]
+                out[f"{tag}_f{i}_scales"], out[f"{tag}_f{i}_opacities"], out[f"{tag}_f{i}_shs"] = c["scales"], c["opacities"], c["shs"]
+                out[f"{tag}_f{i}_means2D"] = c["means2D"]
+                out[f"{tag}_f{i}_tanfov"] = torch.stack([torch.as_tensor(s.tanfovx).float().reshape(()),
+                                                        torch.as_tensor(s.tanfovy).float().reshape(())])
+                out[f"{tag}_f{i}_hw"] = torch.tensor([int(s.image_height), int(s.image_width)])
+                out[f"{tag}_f{i}_bg"] = s.bg
+                out[f"{tag}_f{i}_projmatrix"], out[f"{tag}_f{i}_viewmatrix"] = s.projmatrix, s.viewmatrix
+                out[f"{tag}_f{i}_sh_degree"] = torch.tensor(s.sh_degree)
+                out[f"{tag}_f{i}_radii"] = h._radii_batch[i]
+                out[f"{tag}_f{i}_visibility_filter"] = h._visibility_filter_batch[i]
+                out[f"{tag}_f{i}_viewspace_shape"] = torch.tensor(h._viewspace_points_batch[i].shape)
+            assert not hasattr(h, "_override_xyz") and not hasattr(h, "_override_rotation")
+    finally:
+        ref_gr.GaussianRasterizer = saved
+        ref_dg.quaternion_apply = saved_apply
+    npz(os.path.join(out_dir, "refpy_loop.npz"), **out)
+
+
 def gen_densify(out_dir):
     """gs/scene/gaussian_model.py: create_from_pcd :127-151, reset_opacity :222-225, optimizer surgery :270-356,
     densify_and_split / _clone / _prune :384-448, add_densification_stats :450-452; optimizer groups as
@@ -730,7 +890,7 @@ def main():
     dsr = install_environment()
     import torch
     torch.set_num_threads(1)  # bit-reproducible reductions
-    todo = args.only.split(",") if args.only else ["quat", "warp", "camera", "render", "densify", "losses", "vidloader"]
+    todo = args.only.split(",") if args.only else ["quat", "warp", "camera", "render", "loop", "densify", "losses", "vidloader"]
     if "quat" in todo:
         gen_quat(args.out)
     if "warp" in todo:
@@ -738,6 +898,8 @@ def main():
     cams = gen_camera(args.out) if ("camera" in todo or "render" in todo) else None
     if "render" in todo:
         gen_render(args.out, dsr, cams)
+    if "loop" in todo:
+        gen_loop(args.out, dsr)
     if "densify" in todo:
         gen_densify(args.out)
     if "losses" in todo:
