@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 9
+#define VIDU4D_SURFEL_ABI 10
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -119,6 +119,15 @@ typedef struct Vidu4dSurfelForwardArgs {
     const float* frame_campos[8];
     float frame_tan_fovx[8];
     float frame_tan_fovy[8];
+    /* ---- canonical parameters as the optimizer holds them (extension).  Upstream activates and concatenates them in
+     * torch before every rasterizer call (gs/scene/gaussian_model.py:98-118: exp of `_scaling`, sigmoid of `_opacity`,
+     * cat of `_features_dc` / `_features_rest`) and differentiates back through those launches.
+     * sh_dc (P,1,3) + sh_rest (P,15,3), both non-NULL and 16-byte aligned: used instead of `shs` (which must then be
+     * NULL; M must be 16).  raw_params != 0: `scales` holds LOG-scales and `opacities` LOGITS; exp(x) and
+     * 1 / (1 + exp(-x)) are applied by the per-surfel kernels. */
+    const float* sh_dc;
+    const float* sh_rest;
+    int raw_params;
 } Vidu4dSurfelForwardArgs;
 #define VIDU4D_SURFEL_MAX_FRAMES 8
 size_t vidu4d_surfel_image_bytes_frames(int width, int height, int frames);
@@ -176,6 +185,15 @@ typedef struct Vidu4dSurfelBackwardArgs {
     const float* frame_campos[8];
     float frame_tan_fovx[8];
     float frame_tan_fovy[8];
+    /* ---- canonical parameters, as in the forward (same values there and here).  With sh_dc / sh_rest the SH gradient
+     * leaves as dL_dsh_dc (P,1,3) + dL_dsh_rest (P,15,3) (16-byte aligned; dL_dsh is ignored).  raw_params != 0:
+     * dL_dscales is the gradient w.r.t. the log-scales (dL/ds * s) and dL_dopacity w.r.t. the logits
+     * ((dL/do * (1 - o)) * o, torch's sigmoid_backward). */
+    const float* sh_dc;
+    const float* sh_rest;
+    float* dL_dsh_dc;
+    float* dL_dsh_rest;
+    int raw_params;
 } Vidu4dSurfelBackwardArgs;
 
 int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* args, void* stream);

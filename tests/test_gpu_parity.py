@@ -566,6 +566,63 @@ def test_stacked_frames_equal_single_frame_calls(gpu_device, monkeypatch, F, spl
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), what
 
 
+@pytest.mark.parametrize("F,N", [(1, 6000), (2, 6000), (3, 777)])
+def test_canonical_parameters_equal_the_activated_path(gpu_device, F, N):
+    """The canonical parameters straight from the optimizer (`_features_dc` + `_features_rest` instead of their
+    concatenation, log-scales and opacity logits with raw_params=True; gs/scene/gaussian_model.py:47-57, :98-118) give
+    what exp / sigmoid / cat in torch followed by the activated call give: identical integers and images, and the
+    gradients w.r.t. the RAW tensors that autograd derives through the torch activations.  N = 777: a last workgroup
+    with fewer than 256 rows (scalar tails of the two SH runs)."""
+    import diff_surfel_rasterization as dsr
+    from vidu4d_amd.synthetic import frame_motion
+    dev = gpu_device
+    W, H = 176, 120
+    sc = make_scene(N, W, H, seed=33, sigma_px=6.0).to(dev)
+    frames = [frame_motion(sc, 3 * f, 12) for f in range(F)]
+    views = [dsr.GaussianRasterizationSettings(H, W, sc.tanfovx * (1 + 0.1 * f), sc.tanfovy, sc.bg, 1.0, sc.viewmatrix,
+                                               sc.projmatrix, sc.sh_degree, sc.campos, False, False) for f in range(F)]
+    dc, do = make_upstream_grads(W, H)
+    dcs = torch.stack([(dc * (1 + 0.3 * f)).to(dev) for f in range(F)], 1)
+    dos = torch.stack([(do * (1 - 0.2 * f)).to(dev) for f in range(F)], 1)
+    raw = lambda: [t.clone().requires_grad_(True) for t in (  # noqa: E731
+        torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)), sc.scales.log(), sc.shs[:, :1].contiguous(),
+        sc.shs[:, 1:].contiguous())]
+    M3 = torch.stack([fr.means3D for fr in frames])
+    R4 = torch.stack([fr.rotations for fr in frames])
+
+    def run(canonical):
+        o, s, hd, hr = raw()
+        m3, r4 = M3.clone().requires_grad_(True), R4.clone().requires_grad_(True)
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        if canonical:
+            out = dsr.rasterize_frames(m3, m2, hd, o, s, r4, views, sh_rest=hr, raw_params=True)
+        else:
+            out = dsr.rasterize_frames(m3, m2, torch.cat((hd, hr), dim=1), torch.sigmoid(o), torch.exp(s), r4, views)
+        torch.autograd.backward([out[0], out[2]], [dcs, dos])
+        return out, (o.grad, s.grad, hd.grad, hr.grad, m3.grad, r4.grad, m2.grad)
+
+    (c1, rd1, a1), g1 = run(False)
+    (c2, rd2, a2), g2 = run(True)
+    assert torch.equal(rd1, rd2), "radii"
+    assert torch.equal(c1, c2) and torch.equal(a1, a2), "images"
+    for a, b, what in zip(g2, g1, ("opacity logits", "log-scales", "features_dc", "features_rest", "means3D", "rotations",
+                                    "means2D")):
+        assert a.shape == b.shape, what
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), (what, float((a - b).abs().max()))
+
+
+def test_canonical_parameters_are_validated(gpu_device):
+    import diff_surfel_rasterization as dsr
+    dev = gpu_device
+    sc = make_scene(100, 64, 48, seed=1).to(dev)
+    rs = dsr.GaussianRasterizationSettings(48, 64, sc.tanfovx, sc.tanfovy, sc.bg, 1.0, sc.viewmatrix, sc.projmatrix, 3,
+                                           sc.campos, False, False)
+    m3, r4 = sc.means3D[None].contiguous(), sc.rotations[None].contiguous()
+    with pytest.raises(RuntimeError, match="canonical SH pair"):
+        dsr.rasterize_frames(m3, torch.zeros_like(m3), sc.shs[:, :2].contiguous(), sc.opacities, sc.scales, r4, [rs],
+                             sh_rest=sc.shs[:, 2:].contiguous())
+
+
 def test_stacked_frames_without_surfels(gpu_device):
     """P == 0 through the stacked entry point: background only, as rasterize_points.cu:105 for one frame."""
     import diff_surfel_rasterization as dsr

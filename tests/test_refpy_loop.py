@@ -123,9 +123,15 @@ def test_trainer_path_hands_the_rasterizer_what_the_reference_loop_does(gpu_devi
     fake = _fake_raster()
     seen = {}
 
-    def rasterize_frames(means3D, means2D, shs, opacities, scales, rotations, settings):
+    def rasterize_frames(means3D, means2D, shs, opacities, scales, rotations, settings, sh_rest=None, raw_params=False):
+        # the trainer hands over the canonical parameters (the kernels activate them: test_gpu_parity.py::
+        # test_canonical_parameters_equal_the_activated_path); here they are activated as upstream does it
+        if sh_rest is not None:
+            shs = torch.cat((shs, sh_rest), dim=1)
+        if raw_params:
+            opacities, scales = torch.sigmoid(opacities), torch.exp(scales)
         seen.update(means3D=means3D, means2D=means2D, shs=shs, opacities=opacities, scales=scales, rotations=rotations,
-                    settings=settings)
+                    settings=settings, canonical=(sh_rest is not None, bool(raw_params)))
         outs = [fake(s, means3D[i], opacities, shs, scales, rotations[i]) for i, s in enumerate(settings)]
         return (torch.stack([o[0] for o in outs], 1), torch.stack([o[1] for o in outs], 0),
                 torch.stack([o[2] for o in outs], 1))
@@ -160,6 +166,7 @@ def test_trainer_path_hands_the_rasterizer_what_the_reference_loop_does(gpu_devi
     close(seen["opacities"], r["bg_f0_opacities"], rtol=1e-6, atol=1e-7)
     close(seen["shs"], r["bg_f0_shs"], rtol=0, atol=0)
     assert seen["means2D"].shape == seen["means3D"].shape and seen["means2D"].requires_grad
+    assert seen["canonical"] == (True, True)
     # the raw planes are the reference's maps before its learnable-background composite / permute / cat: rebuild the two
     # maps that need nothing else (mask = alpha plane, rend_dist = plane 6) and the composite
     close(allmap[1].unsqueeze(-1), r["bg_mask"], what="mask", rtol=1e-4, atol=1e-5)

@@ -164,8 +164,12 @@ def _set_frame_cams(args, frame_cams, keep):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, frame_cams=None):
+                        prefiltered, debug, frame_cams=None, sh_rest=None, raw_params=False):
     """-> (num_rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer)
+
+    sh_rest / raw_params (extension: the canonical parameters as the optimizer holds them, no activation / concatenation
+    launches in between): with sh_rest (P,15,3), `sh` is the (P,1,3) DC tensor; raw_params: `scales` are log-scales and
+    `opacity` logits (exp / sigmoid applied by the kernels, gs/scene/gaussian_model.py:47-57, :98-118).
 
     frame_cams (extension): a list of F <= 8 (viewmatrix, campos, tan_fovx, tan_fovy) -- F frames that
     share opacity / scales / sh are rasterized by one launch set: means3D (F,P,3), rotations (F,P,4) -> out_color
@@ -203,6 +207,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if sh.numel():
         sh = _f32c(sh, "sh")
         M = sh.shape[1]
+    if sh_rest is not None:
+        sh_rest = _f32c(sh_rest, "sh_rest")
+        if sh.shape[1:] != (1, 3) or sh_rest.shape[1:] != (15, 3) or sh_rest.shape[0] != sh.shape[0]:
+            raise RuntimeError("canonical SH pair: sh (num_points, 1, 3) and sh_rest (num_points, 15, 3) required")
+        M = 16
     if colors.numel():
         colors = _f32c(colors, "colors")
 
@@ -222,6 +231,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.scale_modifier = float(scale_modifier)
     a.prefiltered, a.debug = int(bool(prefiltered)), int(bool(debug))
     a.background, a.means3D, a.shs, a.colors_precomp = _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors)
+    if sh_rest is not None:
+        a.shs, a.sh_dc, a.sh_rest = None, _ptr(sh), _ptr(sh_rest)
+    a.raw_params = int(bool(raw_params))
     a.opacities, a.scales, a.rotations = _ptr(opacity), _ptr(scales), _ptr(rotations)
     a.transMat_precomp = _ptr(transMat_precomp)
     a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
@@ -311,8 +323,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 binning_capacity=None, segment_split=None, frame_cams=None):
+                                 binning_capacity=None, segment_split=None, frame_cams=None, sh_rest=None,
+                                 raw_params=False):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations)
+
+    sh_rest / raw_params as in rasterize_gaussians: dL_dsh is then the pair (dL_dsh_dc (P,1,3), dL_dsh_rest (P,15,3)),
+    dL_dscales / dL_dopacity are w.r.t. the log-scales / logits.
 
     frame_cams: as in rasterize_gaussians (means3D (F,P,3), rotations (F,P,4), radii (F,P), dL_dout_color (3,F,H,W),
     dL_dout_others (8,F,H,W)); per-frame gradients come back (F,P,.), those of opacity / scales / sh summed over the
@@ -330,6 +346,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = means3D.shape[0] // F  # (surfels per frame)
     H, W = dL_dout_color.shape[-2], dL_dout_color.shape[-1]
     M = sh.shape[1] if sh.numel() else 0
+    if sh_rest is not None:
+        M = 16
     opt = dict(dtype=torch.float32, device=dev)
     lead = (P,) if frame_cams is None else (F, P)
     dL_dmeans3D = torch.empty(lead + (3,), **opt)
@@ -337,7 +355,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dcolors = torch.empty(lead + (3,), **opt)
     dL_dopacity = torch.empty((P, 1), **opt)
     dL_dtransMat = torch.empty(lead + (9,), **opt)
-    dL_dsh = torch.empty((P, M, 3), **opt)
+    if sh_rest is not None:
+        dL_dsh = (torch.empty((P, 1, 3), **opt), torch.empty((P, 15, 3), **opt))
+    else:
+        dL_dsh = torch.empty((P, M, 3), **opt)
     dL_dscales = torch.empty((P, 2), **opt)
     dL_drotations = torch.empty(lead + (4,), **opt)
     if P == 0:
@@ -358,6 +379,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     campos = _f32c(campos, "campos")
     if sh.numel():
         sh = _f32c(sh, "sh")
+    if sh_rest is not None:
+        sh_rest = _f32c(sh_rest, "sh_rest")
     if colors.numel():
         colors = _f32c(colors, "colors")
 
@@ -380,7 +403,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     b.segment_split = int(segment_split)
     b.workspace, b.workspace_bytes = ws.data_ptr(), ws.numel()
     b.dL_dmeans2D, b.dL_dcolors, b.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dcolors.data_ptr(), dL_dopacity.data_ptr()
-    b.dL_dmeans3D, b.dL_dtransMat, b.dL_dsh = dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh)
+    b.dL_dmeans3D, b.dL_dtransMat = dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr()
+    if sh_rest is not None:
+        b.shs, b.sh_dc, b.sh_rest = None, _ptr(sh), _ptr(sh_rest)
+        b.dL_dsh, b.dL_dsh_dc, b.dL_dsh_rest = None, dL_dsh[0].data_ptr(), dL_dsh[1].data_ptr()
+    else:
+        b.dL_dsh = _ptr(dL_dsh)
+    b.raw_params = int(bool(raw_params))
     b.dL_dscales, b.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
     _lib.check(lib.vidu4d_surfel_backward(C.byref(b), _stream(dev)), "surfel backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations

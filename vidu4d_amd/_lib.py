@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ForwardArgs(C.Structure):
@@ -28,6 +28,7 @@ class ForwardArgs(C.Structure):
         ("image_bytes", C.c_size_t), ("segment_split", C.c_int), ("depth_used", C.c_void_p),
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
+        ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("raw_params", C.c_int),
     ]
 
 
@@ -92,6 +93,8 @@ class BackwardArgs(C.Structure):
         ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("segment_split", C.c_int),
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
+        ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("dL_dsh_dc", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
+        ("raw_params", C.c_int),
     ]
 
 

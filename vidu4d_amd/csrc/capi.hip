@@ -170,6 +170,19 @@ static int check_frames(const Args* a)
     return VIDU4D_OK;
 }
 
+// The canonical SH pair (sh_dc (P,1,3) + sh_rest (P,15,3)) replaces `shs`; it only exists on the LDS-staged kernels.
+template <typename Args>
+static int check_canonical_sh(const Args* a)
+{
+    if (!a->sh_dc && !a->sh_rest) return VIDU4D_OK;
+    if (!a->sh_dc || !a->sh_rest) return fail(VIDU4D_E_INVALID, "sh_dc and sh_rest come together");
+    if (a->shs) return fail(VIDU4D_E_INVALID, "sh_dc / sh_rest replace shs: pass shs = NULL");
+    if (a->M != 16) return fail(VIDU4D_E_INVALID, "sh_dc / sh_rest need M = 16 (1 + 15 coefficients), got %d", a->M);
+    if (((uintptr_t)a->sh_dc & 15) || ((uintptr_t)a->sh_rest & 15))
+        return fail(VIDU4D_E_INVALID, "sh_dc / sh_rest must be 16-byte aligned");
+    return VIDU4D_OK;
+}
+
 static int check_forward(const Vidu4dSurfelForwardArgs* a)
 {
     if (!a) return fail(VIDU4D_E_INVALID, "args is NULL");
@@ -178,9 +191,11 @@ static int check_forward(const Vidu4dSurfelForwardArgs* a)
         return fail(VIDU4D_E_UNSUPPORTED,
                     "cov3D_precomp/transMat_precomp is not supported: the reference path leaves the normal "
                     "uninitialised (forward.cu:214-224) and its backward dereferences scales/rotations anyway");
-    if ((a->shs == nullptr) == (a->colors_precomp == nullptr) && a->P > 0)
+    if (int rc = check_canonical_sh(a)) return rc;
+    const bool has_sh = a->shs != nullptr || a->sh_dc != nullptr;
+    if (has_sh == (a->colors_precomp != nullptr) && a->P > 0)
         return fail(VIDU4D_E_INVALID, "provide exactly one of shs / colors_precomp");
-    if (a->shs && (a->M <= 0 || a->M > 16 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M))
+    if (has_sh && (a->M <= 0 || a->M > 16 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M))
         return fail(VIDU4D_E_INVALID, "bad SH configuration D=%d M=%d", a->D, a->M);
     const int F = frames_of(a);
     if (int rc = check_frames(a)) return rc;
@@ -239,6 +254,9 @@ extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void
     pa.opacities = a->opacities;
     pa.shs = a->shs;
     pa.colors_precomp = a->colors_precomp;
+    pa.sh_dc = a->sh_dc;
+    pa.sh_rest = a->sh_rest;
+    pa.raw_params = a->raw_params;
     pa.radii = a->radii;
     pa.geom = g;
     pa.tile_count = img.tile_count;
@@ -332,6 +350,9 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     if (!a->dL_dmeans2D || !a->dL_dcolors || !a->dL_dopacity || !a->dL_dmeans3D || !a->dL_dtransMat ||
         !a->dL_dscales || !a->dL_drotations || (a->shs && !a->dL_dsh))
         return fail(VIDU4D_E_INVALID, "an output pointer is NULL");
+    if (int rc = check_canonical_sh(a)) return rc;
+    if (a->sh_dc && (!a->dL_dsh_dc || !a->dL_dsh_rest || ((uintptr_t)a->dL_dsh_dc & 15) || ((uintptr_t)a->dL_dsh_rest & 15)))
+        return fail(VIDU4D_E_INVALID, "sh_dc / sh_rest need 16-byte aligned dL_dsh_dc / dL_dsh_rest");
     if (a->workspace_bytes < vidu4d_surfel_backward_workspace_bytes(P)) return fail(VIDU4D_E_BUFFER, "workspace too small");
     if (a->binning_capacity > 0 && !a->binning_buffer) return fail(VIDU4D_E_INVALID, "binning_buffer is NULL");
 
@@ -366,12 +387,17 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     ba.dL_dsh = a->dL_dsh;
     ba.dL_dscales = a->dL_dscales;
     ba.dL_drotations = a->dL_drotations;
+    ba.sh_dc = a->sh_dc;
+    ba.sh_rest = a->sh_rest;
+    ba.dL_dsh_dc = a->sh_dc ? a->dL_dsh_dc : nullptr;
+    ba.dL_dsh_rest = a->sh_dc ? a->dL_dsh_rest : nullptr;
+    ba.raw_params = a->raw_params;
 
     {
         StageTimer t(ST_BWD_ZERO, stream);
         zero_fill(ba.acc, (size_t)P * ACC_FLOATS * sizeof(float), stream);
-        const bool sums_in_kernel = a->shs && a->dL_dsh && a->M == 16 && ((uintptr_t)a->shs & 15) == 0 &&
-                                    ((uintptr_t)a->dL_dsh & 15) == 0;  // (preprocess_bwd_stacked_kernel's condition)
+        const bool sums_in_kernel = a->M == 16 && (a->sh_dc || (a->shs && a->dL_dsh && ((uintptr_t)a->shs & 15) == 0 &&
+                                                               ((uintptr_t)a->dL_dsh & 15) == 0));  // (preprocess_bwd_stacked_kernel's condition)
         if (F > 1 && !sums_in_kernel) {  // the frames ADD their gradients of the shared parameters (preprocess_bwd_kernel)
             zero_fill_f32(a->dL_dopacity, (size_t)a->P, stream);
             zero_fill_f32(a->dL_dscales, (size_t)a->P * 2, stream);

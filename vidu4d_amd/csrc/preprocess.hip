@@ -24,12 +24,81 @@ __device__ __forceinline__ FrameIndex frame_index(const CameraParams& cam, int i
     return FrameIndex{f, idx - f * cam.frame_surfels};
 }
 
+// Activations of the canonical parameters (raw_params; gs/scene/gaussian_model.py:47-57: exp, sigmoid), written as
+// torch's elementwise kernels evaluate them -- exp(x) and 1 / (1 + exp(-x)) in fp32 -- so that the raw path gives the
+// values torch.exp / torch.sigmoid hand to the activated path.
+__device__ __forceinline__ float act_scale(float raw) { return expf(raw); }
+__device__ __forceinline__ float act_opacity(float raw) { return 1.0f / (1.0f + expf(-raw)); }
+
+// The [256][49] LDS tile of SH rows (row stride 49 words: the per-thread walk over a row is conflict free).
+// Sources: one (P,16,3) tensor -- the 256 rows of a workgroup are one contiguous 48 KiB run -- or the canonical pair
+// (P,1,3) + (P,15,3): two contiguous runs (3 KiB into columns 0-2, 45 KiB into columns 3-47).  All copies are
+// coalesced 16-byte accesses; the runs start 16-byte aligned because block_first is a multiple of 256.
+constexpr int SH_ROW = 48, SH_STRIDE = 49, SH_DC = 3, SH_REST = 45;
+
+template <int WIDTH, int COL0>
+__device__ __forceinline__ void tile_load_run(float* s_sh, const float* __restrict__ src, int rows)
+{
+    const int n = rows * WIDTH, n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(src);
+    for (int i = threadIdx.x; i < n4; i += PRE_BLOCK) {
+        const float4 v = g4[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = 4 * i + j;
+            s_sh[(k / WIDTH) * SH_STRIDE + COL0 + k % WIDTH] = e[j];
+        }
+    }
+    for (int k = 4 * n4 + threadIdx.x; k < n; k += PRE_BLOCK) s_sh[(k / WIDTH) * SH_STRIDE + COL0 + k % WIDTH] = src[k];
+}
+
+template <int WIDTH, int COL0>
+__device__ __forceinline__ void tile_store_run(const float* s_sh, float* __restrict__ dst, int rows)
+{
+    const int n = rows * WIDTH, n4 = n >> 2;
+    float4* o4 = reinterpret_cast<float4*>(dst);
+    for (int i = threadIdx.x; i < n4; i += PRE_BLOCK) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = 4 * i + j;
+            e[j] = s_sh[(k / WIDTH) * SH_STRIDE + COL0 + k % WIDTH];
+        }
+        o4[i] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    for (int k = 4 * n4 + threadIdx.x; k < n; k += PRE_BLOCK) dst[k] = s_sh[(k / WIDTH) * SH_STRIDE + COL0 + k % WIDTH];
+}
+
+__device__ __forceinline__ void sh_tile_load(float* s_sh, const float* shs, const float* sh_dc, const float* sh_rest,
+                                             int block_first, int rows)
+{
+    if (sh_dc) {
+        tile_load_run<SH_DC, 0>(s_sh, sh_dc + (size_t)block_first * SH_DC, rows);
+        tile_load_run<SH_REST, SH_DC>(s_sh, sh_rest + (size_t)block_first * SH_REST, rows);
+    } else {
+        tile_load_run<SH_ROW, 0>(s_sh, shs + (size_t)block_first * SH_ROW, rows);
+    }
+}
+
+__device__ __forceinline__ void sh_tile_store(const float* s_sh, float* dL_dsh, float* dL_dsh_dc, float* dL_dsh_rest,
+                                              int block_first, int rows)
+{
+    if (dL_dsh_dc) {
+        tile_store_run<SH_DC, 0>(s_sh, dL_dsh_dc + (size_t)block_first * SH_DC, rows);
+        tile_store_run<SH_REST, SH_DC>(s_sh, dL_dsh_rest + (size_t)block_first * SH_REST, rows);
+    } else {
+        tile_store_run<SH_ROW, 0>(s_sh, dL_dsh + (size_t)block_first * SH_ROW, rows);
+    }
+}
+
 // Projection of surfel idx; writes record / radius / tile count and returns the tile rect.
 __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const Camera& cam, int idx, int shared,
                                                    Projected& o)
 {
     const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    const float2 sc = reinterpret_cast<const float2*>(a.scales)[shared];
+    float2 sc = reinterpret_cast<const float2*>(a.scales)[shared];
+    if (a.raw_params) sc = make_float2(act_scale(sc.x), act_scale(sc.y));
     const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
     const float scale[2] = {sc.x, sc.y};
     const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -42,7 +111,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         float4* rec = reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
         rec[0] = make_float4(o.T[0], o.T[1], o.T[2], o.T[3]);
         rec[1] = make_float4(o.T[4], o.T[5], o.T[6], o.T[7]);
-        const float opacity = a.opacities[shared];
+        const float opacity = a.raw_params ? act_opacity(a.opacities[shared]) : a.opacities[shared];
         rec[2] = make_float4(o.T[8], o.center[0], o.center[1], opacity);
         rec[3] = make_float4(o.normal[0], o.normal[1], o.normal[2], o.depth);
         float box[4];
@@ -107,8 +176,6 @@ __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(Pre
 // 48 KiB run -- are copied with coalesced 16-byte loads into an LDS tile with a 49-word row stride (odd: the
 // per-thread walk is conflict free), as the per-surfel backward does.  SH_LDS needs 16 coefficients and a
 // 16-byte aligned tensor; otherwise (and for colors_precomp) rows are read directly.
-constexpr int SH_ROW = 48, SH_STRIDE = 49;
-
 template <bool SH_LDS>
 __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs a)
 {
@@ -123,16 +190,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs 
     const int idx = frame * N + shared;
     const int rows = (N - block_first) < PRE_BLOCK ? (N - block_first) : PRE_BLOCK;
     if (SH_LDS) {
-        const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
-        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
-            const float4 v = g4[i];
-            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
-            float* d = s_sh + r * SH_STRIDE + c;
-            d[0] = v.x;
-            d[1] = v.y;
-            d[2] = v.z;
-            d[3] = v.w;
-        }
+        sh_tile_load(s_sh, a.shs, a.sh_dc, a.sh_rest, block_first, rows);
         __syncthreads();
     }
     if (shared >= N) return;
@@ -157,8 +215,9 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return;
     const int num_tiles = total_tiles(a.cam);
-    const bool sh_lds = a.colors_precomp == nullptr && a.shs != nullptr && a.cam.sh_coeffs == 16 &&
-                        (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0;
+    // (the canonical pair sh_dc / sh_rest only exists on the LDS path; capi checks its alignment)
+    const bool sh_lds = a.colors_precomp == nullptr && a.cam.sh_coeffs == 16 &&
+                        (a.sh_dc != nullptr || (a.shs != nullptr && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0));
     const int color_blocks = a.cam.frames > 1 ? a.cam.frames * pre_blocks(a.cam.frame_surfels) : pre_blocks(a.P);
     if (sh_lds)
         hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(color_blocks), dim3(PRE_BLOCK),
@@ -201,18 +260,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
     const int M = cam.sh_coeffs;
     const int rows = (N - block_first) < PRE_BLOCK ? (N - block_first) : PRE_BLOCK;
     if (SH_LDS) {
-        const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
-        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
-            const float4 v = g4[i];
-            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
-            float* d = s_sh + r * SH_STRIDE + c;
-            d[0] = v.x;
-            d[1] = v.y;
-            d[2] = v.z;
-            d[3] = v.w;
-        }
+        sh_tile_load(s_sh, a.shs, a.sh_dc, a.sh_rest, block_first, rows);
         __syncthreads();
     }
+    const bool has_sh = a.shs != nullptr || a.sh_dc != nullptr;
     const bool live = shared < N;
     const bool visible = live && a.radii[idx] > 0;
     float* sh_row = s_sh + threadIdx.x * SH_STRIDE;  // SH_LDS: this thread's private row (read, then overwritten)
@@ -250,25 +301,33 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
         }
         float T[9];
         uint32_t clamp_mask;
+        float opacity_act;  // (the activated opacity the forward stored in the record)
         {
             const float4* r = reinterpret_cast<const float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
             const float4 q0 = r[0], q1 = r[1], q2 = r[2], q4 = r[4];
             T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q0.w;
             T[4] = q1.x; T[5] = q1.y; T[6] = q1.z; T[7] = q1.w;
             T[8] = q2.x;
+            opacity_act = q2.w;
             clamp_mask = __float_as_uint(q4.w);
         }
         const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-        const float2 sc = reinterpret_cast<const float2*>(a.scales)[shared];
+        float2 sc = reinterpret_cast<const float2*>(a.scales)[shared];
+        if (a.raw_params) sc = make_float2(act_scale(sc.x), act_scale(sc.y));
         const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
         const float scale[2] = {sc.x, sc.y};
         const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
         SurfelGrads o;
         surfel_backward(cam, p_world, quat, scale, T, acc, o);
+        if (a.raw_params) {  // chain through exp / sigmoid as torch's backward formulas do (grad * result; (grad * (1 - y)) * y)
+            o.dscale[0] *= scale[0];
+            o.dscale[1] *= scale[1];
+            acc[A_OPAC] = (acc[A_OPAC] * (1.0f - opacity_act)) * opacity_act;
+        }
 
         float dmean[3] = {o.dmean3D[0], o.dmean3D[1], o.dmean3D[2]};
         const float dcol[3] = {acc[A_RGB], acc[A_RGB + 1], acc[A_RGB + 2]};
-        if (a.shs != nullptr) {
+        if (has_sh) {
             if (SH_LDS) {
                 // in place: coefficient k is read before gradient k is stored over it
                 sh_backward(cam.sh_degree, M, p_world, cam.campos, sh_row, clamp_mask, dcol, sh_row, dmean);
@@ -302,16 +361,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(BackwardArgs 
         }
     }
     if (SH_LDS) {
-        if (visible && a.shs == nullptr)
+        if (visible && !has_sh)
             for (int k = 0; k < SH_ROW; k++) sh_row[k] = 0.f;
         __syncthreads();
         if (!stacked) {
-            float4* o4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)block_first * SH_ROW);
-            for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
-                const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
-                const float* d = s_sh + r * SH_STRIDE + c;
-                o4[i] = make_float4(d[0], d[1], d[2], d[3]);
-            }
+            sh_tile_store(s_sh, a.dL_dsh, a.dL_dsh_dc, a.dL_dsh_rest, block_first, rows);
         } else {
             float* out = a.dL_dsh + (size_t)block_first * SH_ROW;
             for (int i = threadIdx.x; i < rows * SH_ROW; i += PRE_BLOCK) {
@@ -332,27 +386,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_stacked_kernel(Backw
     const int block_first = blockIdx.x * PRE_BLOCK;
     const int shared = block_first + threadIdx.x;
     const int rows = (N - block_first) < PRE_BLOCK ? (N - block_first) : PRE_BLOCK;
-    {
-        const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)block_first * SH_ROW);
-        for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
-            const float4 v = g4[i];
-            const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
-            float* d = s_sh + r * SH_STRIDE + c;
-            d[0] = v.x;
-            d[1] = v.y;
-            d[2] = v.z;
-            d[3] = v.w;
-        }
-        __syncthreads();
-    }
+    sh_tile_load(s_sh, a.shs, a.sh_dc, a.sh_rest, block_first, rows);
+    __syncthreads();
     const bool live = shared < N;
     float* sh_row = s_sh + threadIdx.x * SH_STRIDE;
     float g_sh[SH_ROW];
 #pragma unroll
     for (int k = 0; k < SH_ROW; k++) g_sh[k] = 0.f;
     float g_opacity = 0.f, g_scale0 = 0.f, g_scale1 = 0.f;
-    const float2 sc = live ? reinterpret_cast<const float2*>(a.scales)[shared] : make_float2(0.f, 0.f);
+    float2 sc = live ? reinterpret_cast<const float2*>(a.scales)[shared] : make_float2(0.f, 0.f);
+    if (a.raw_params) sc = make_float2(act_scale(sc.x), act_scale(sc.y));
     const float scale[2] = {sc.x, sc.y};
+    float opacity_act = 0.f;  // (the activated opacity, from the record of any frame that sees the surfel)
 #pragma unroll 1
     for (int f = 0; f < F && live; f++) {
         const int idx = f * N + shared;
@@ -387,6 +432,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_stacked_kernel(Backw
             T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q0.w;
             T[4] = q1.x; T[5] = q1.y; T[6] = q1.z; T[7] = q1.w;
             T[8] = q2.x;
+            opacity_act = q2.w;
             clamp_mask = __float_as_uint(q4.w);
         }
         const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -412,6 +458,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_stacked_kernel(Backw
         for (int k = 0; k < 4; k++) a.dL_drotations[4 * idx + k] = o.drot[k];
     }
     if (live) {
+        if (a.raw_params) {  // the frames' sum through exp / sigmoid (torch: grad * result; (grad * (1 - y)) * y)
+            g_scale0 *= scale[0];
+            g_scale1 *= scale[1];
+            g_opacity = (g_opacity * (1.0f - opacity_act)) * opacity_act;
+        }
         a.dL_dopacity[shared] = g_opacity;
         a.dL_dscales[2 * shared] = g_scale0;
         a.dL_dscales[2 * shared + 1] = g_scale1;
@@ -420,20 +471,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_stacked_kernel(Backw
 #pragma unroll
     for (int k = 0; k < SH_ROW; k++) sh_row[k] = g_sh[k];
     __syncthreads();
-    float4* o4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)block_first * SH_ROW);
-    for (int i = threadIdx.x; i < rows * (SH_ROW / 4); i += PRE_BLOCK) {
-        const int r = (4 * i) / SH_ROW, c = (4 * i) % SH_ROW;
-        const float* d = s_sh + r * SH_STRIDE + c;
-        o4[i] = make_float4(d[0], d[1], d[2], d[3]);
-    }
+    sh_tile_store(s_sh, a.dL_dsh, a.dL_dsh_dc, a.dL_dsh_rest, block_first, rows);
 }
 
 void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream)
 {
     if (a.P <= 0) return;
-    const bool sh_lds = a.shs != nullptr && a.dL_dsh != nullptr && a.cam.sh_coeffs == 16 &&
-                        (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0 &&
-                        (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0;
+    const bool sh_lds = a.cam.sh_coeffs == 16 &&
+                        (a.sh_dc != nullptr ||  // (canonical pair: always this path; capi checked the alignment)
+                         (a.shs != nullptr && a.dL_dsh != nullptr && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0));
     if (a.cam.frames > 1 && sh_lds) {
         hipLaunchKernelGGL(preprocess_bwd_stacked_kernel, dim3(pre_blocks(a.cam.frame_surfels)), dim3(PRE_BLOCK),
                            (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);

@@ -233,6 +233,9 @@ struct PreprocessArgs {
     const float* opacities;
     const float* shs;
     const float* colors_precomp;
+    const float* sh_dc;    // canonical SH rows in two tensors (P,1,3) + (P,15,3) instead of `shs` (both or neither)
+    const float* sh_rest;
+    int raw_params;        // scales = log-scales, opacities = logits: activated by the kernels
     int32_t* radii;
     GeomState geom;
     uint32_t* tile_count;    // atomic path: [tiles][TILE_SLICES], zeroed before the launch
@@ -284,6 +287,11 @@ struct BackwardArgs {
     float* dL_dsh;
     float* dL_dscales;
     float* dL_drotations;
+    const float* sh_dc;   // as in PreprocessArgs; then the SH gradient leaves through dL_dsh_dc / dL_dsh_rest
+    const float* sh_rest;
+    float* dL_dsh_dc;
+    float* dL_dsh_rest;
+    int raw_params;       // scales are log-scales; dL_dscales / dL_dopacity are w.r.t. log-scales / logits
 };
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream);
 void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream);

@@ -104,10 +104,11 @@ class _RasterizeGaussians(torch.autograd.Function):
 class _RasterizeFrames(torch.autograd.Function):
     """Extension: the F frames of a step in ONE launch set.  Upstream renders them one after the other
     (lab4d/nnutils/deformable_gaussian.py:1175-1228); here frame f owns rows [f] of means3D (F,N,3) / rotations (F,N,4)
-    and tile grid f of a stacked grid, opacity / scales / sh are shared.  Per-frame results are those of F single calls."""
+    and tile grid f of a stacked grid, opacity / scales / sh are shared.  Per-frame results are those of F single calls.
+    sh_rest / raw_params: the canonical parameters straight from the optimizer (see rasterize_frames)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list):
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, sh_rest, raw_params):
         rs0 = settings_list[0]
         cams = [(rs.viewmatrix, rs.campos, rs.tanfovx, rs.tanfovy) for rs in settings_list]
         for rs in settings_list[1:]:
@@ -117,34 +118,45 @@ class _RasterizeFrames(torch.autograd.Function):
         out = _C.rasterize_gaussians(rs0.bg, means3D, empty, opacities, scales, rotations, rs0.scale_modifier, empty,
                                      rs0.viewmatrix, rs0.projmatrix, rs0.tanfovx, rs0.tanfovy, rs0.image_height,
                                      rs0.image_width, sh, rs0.sh_degree, rs0.campos, rs0.prefiltered, rs0.debug,
-                                     frame_cams=cams)
+                                     frame_cams=cams, sh_rest=sh_rest, raw_params=raw_params)
         num_rendered, color, others, radii, geom_buf, binning_buf, img_buf = out
         ctx.settings, ctx.cams, ctx.num_rendered = rs0, cams, num_rendered
         ctx.binning_capacity = getattr(binning_buf, "_vidu4d_capacity", max(num_rendered, 1))
         ctx.segment_split = getattr(binning_buf, "_vidu4d_split", 0)
-        ctx.save_for_backward(means3D, scales, rotations, radii, sh, geom_buf, binning_buf, img_buf)
+        ctx.split_sh, ctx.raw_params = sh_rest is not None, bool(raw_params)
+        ctx.save_for_backward(means3D, scales, rotations, radii, sh, geom_buf, binning_buf, img_buf,
+                              sh_rest if sh_rest is not None else empty)
         ctx.mark_non_differentiable(radii)
         return color, radii, others
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_others):
         rs = ctx.settings
-        means3D, scales, rotations, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors
+        means3D, scales, rotations, radii, sh, geom_buf, binning_buf, img_buf, sh_rest = ctx.saved_tensors
         empty = torch.empty(0, device=means3D.device)
         g = _C.rasterize_gaussians_backward(rs.bg, means3D, radii, empty, scales, rotations, rs.scale_modifier, empty,
                                             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_others,
                                             sh, rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf,
                                             rs.debug, binning_capacity=ctx.binning_capacity,
-                                            segment_split=ctx.segment_split, frame_cams=ctx.cams)
+                                            segment_split=ctx.segment_split, frame_cams=ctx.cams,
+                                            sh_rest=sh_rest if ctx.split_sh else None, raw_params=ctx.raw_params)
         g_means2D, _g_colors, g_opacities, g_means3D, _g_T, g_sh, g_scales, g_rotations = g
-        return g_means3D, g_means2D, g_sh, g_opacities, g_scales, g_rotations, None
+        g_sh, g_sh_rest = g_sh if ctx.split_sh else (g_sh, None)
+        return g_means3D, g_means2D, g_sh, g_opacities, g_scales, g_rotations, None, g_sh_rest, None
 
 
-def rasterize_frames(means3D, means2D, sh, opacities, scales, rotations, settings_list):
+def rasterize_frames(means3D, means2D, sh, opacities, scales, rotations, settings_list, sh_rest=None, raw_params=False):
     """means3D (F,N,3), means2D (F,N,3) [receives the screen-space statistic], rotations (F,N,4); sh (N,M,3), opacities
     (N,1), scales (N,2) shared; settings_list: F GaussianRasterizationSettings (same size / SH degree / background).
-    -> color (3,F,H,W), radii (F,N), allmap (8,F,H,W): frame f is color[:, f], allmap[:, f]."""
-    return _RasterizeFrames.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list))
+    -> color (3,F,H,W), radii (F,N), allmap (8,F,H,W): frame f is color[:, f], allmap[:, f].
+
+    The canonical parameters can be handed over as the optimizer holds them (gs/scene/gaussian_model.py:47-57, :98-118):
+    `sh` = `_features_dc` (N,1,3) with `sh_rest` = `_features_rest` (N,15,3) instead of their concatenation, and with
+    raw_params=True `scales` = `_scaling` (log-scales), `opacities` = `_opacity` (logits); the kernels activate them and
+    the backward returns the gradients w.r.t. the raw tensors -- same values as exp / sigmoid / cat in torch, without
+    their launches and their backward's."""
+    return _RasterizeFrames.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), sh_rest,
+                                  raw_params)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

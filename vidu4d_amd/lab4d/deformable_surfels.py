@@ -345,8 +345,14 @@ class DeformableSurfels(GaussianModel):
         if buf is None or buf.shape != xyz_cam.shape or buf.device != xyz_cam.device:
             buf = self.__dict__["_screen_buf"] = torch.zeros_like(xyz_cam)
         screen = buf.detach().requires_grad_(True)
-        color, radii, allmap = rasterize_frames(xyz_cam, screen, self.get_features, self.get_opacity, self.get_scaling,
-                                                rotations, settings)
+        if self.opts.get("canonical_params", True) and self._features_rest.shape[1] == 15:
+            # the parameters as the optimizer holds them: the kernels apply exp / sigmoid and read the two SH tensors in
+            # place -- no activation / concatenation launches here, none of their backward launches either
+            color, radii, allmap = rasterize_frames(xyz_cam, screen, self._features_dc, self._opacity, self._scaling,
+                                                    rotations, settings, sh_rest=self._features_rest, raw_params=True)
+        else:
+            color, radii, allmap = rasterize_frames(xyz_cam, screen, self.get_features, self.get_opacity,
+                                                    self.get_scaling, rotations, settings)
         M = xyz_cam.shape[0]
         self._viewspace_points_batch = [self._FrameGrad(screen, i) for i in range(M)]
         self._visibility_filter_batch = self._Visible(radii)
