@@ -7,7 +7,9 @@ N, H, W, frames = int(__import__("os").environ.get("FIT_N", "200000")), 512, 512
 RADIUS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0  # object radius; camera at distance 3, tan(fov/2)=0.5
 rng = np.random.default_rng(0)
 import os
-m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0, frame_streams=os.environ.get("FIT_STREAMS", "1") == "1"), num_frames=frames, device=dev)
+opts = dict(fg_motion="gs-bob", densify_until_iter=0, frame_streams=os.environ.get("FIT_STREAMS", "1") == "1")
+opts.update(__import__("json").loads(os.environ.get("FIT_OPTS", "{}")))  # e.g. FIT_OPTS='{"canonical_params": false}' for an A/B
+m = DeformableSurfels(opts, num_frames=frames, device=dev)
 pts = rng.normal(size=(N, 3)).astype(np.float32); pts = RADIUS * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32), )
 with torch.no_grad(): m._scaling.add_(0.0)
@@ -19,7 +21,7 @@ for b in batches: b["Kinv"] = batches[0]["Kinv"]  # one intrinsics tensor for th
 for i in range(6): tr.train_step(batches[i % 4])
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-t0 = time.perf_counter(); K = 10
+t0 = time.perf_counter(); K = int(os.environ.get("FIT_K", "10"))
 for i in range(K): tr.train_step(batches[i % 4])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 print(f"FIT_STEP 200k/512^2 radius {RADIUS}, 2 frames/step: {dt*1e3:.2f} ms/step = {2/dt:.1f} images/s")

@@ -220,9 +220,20 @@ class DeformableSurfels(GaussianModel):
                        "rest1": rest1, "bone_frames": sm.bone_frames(rest1), "bone_A": A.contiguous(),
                        "bone_c": c0.contiguous(),
                        "frame_bias": sm.frame_bias(None, None, 1, ids.device) if sm.has_delta else None,
+                       # ... and with every instance code: the mean time code behind it is an MLP over ALL frames
+                       "frame_bias_inst": self._frame_bias_per_instance(sm, ids.device),
                        "cam_q": cq.contiguous(), "cam_t": ct.contiguous()}
             self.__dict__["_warp_table"] = tab
         return tab
+
+    @staticmethod
+    def _frame_bias_per_instance(sm, device):
+        if not sm.has_delta:
+            return None
+        emb = getattr(sm.delta_field, "inst_embedding", None)
+        if emb is None or emb.out_channels == 0:
+            return None
+        return sm.frame_bias(None, torch.arange(emb.mapping.weight.shape[0], device=device), 1, device).contiguous()
 
     def forward_warp_fused(self, frame_id, inst_id=None, samples_dict=None):
         """forward_warp for frozen bones: the skinning weights of the forward warp depend on neither the
@@ -257,7 +268,11 @@ class DeformableSurfels(GaussianModel):
         else:
             A, c0, bias = tab["bone_A"], tab["bone_c"], tab["frame_bias"]   # (bias: mean instance code)
             if sm.has_delta and iid is not None:
-                bias = sm.frame_bias(None, iid, 1, self._xyz.device)
+                per_inst = tab["frame_bias_inst"]   # (instances, W): a row look-up instead of the time-code MLP per step
+                if per_inst is None or not self.opts.get("cached_frame_bias", True):
+                    bias = sm.frame_bias(None, iid, 1, self._xyz.device)
+                else:  # (a single-instance model answers every id with its one code: nets.InstanceCode)
+                    bias = per_inst if per_inst.shape[0] == 1 else per_inst[iid]
         if M <= 8 and self.opts.get("fused_skin", True) and (not sm.has_delta or sm.num_freq_xyz == 0):
             # bone coordinates and the delta MLP as feature-major GEMMs (4 library calls), everything else -- distances,
             # relu * 0.1, softmax, blend, apply, camera, for all frames -- in one HIP kernel per direction
