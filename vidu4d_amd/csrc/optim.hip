@@ -95,6 +95,27 @@ __global__ __launch_bounds__(256) void clip_kernel(ClipLaunch a)
         const float* __restrict__ g = a.g[k];
         const int64_t n = a.numel[k];
         int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+            // 16-byte loads, four of them in flight per thread (47 MB of gradients: 37 us with dword loads)
+            const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+            const int64_t n4 = n >> 2;
+            for (; e + 3 * stride < n4; e += 4 * stride) {
+                const float4 v0 = g4[e], v1 = g4[e + stride], v2 = g4[e + 2 * stride], v3 = g4[e + 3 * stride];
+                s0 = fmaf(v0.w, v0.w, fmaf(v0.z, v0.z, fmaf(v0.y, v0.y, fmaf(v0.x, v0.x, s0))));
+                s1 = fmaf(v1.w, v1.w, fmaf(v1.z, v1.z, fmaf(v1.y, v1.y, fmaf(v1.x, v1.x, s1))));
+                s2 = fmaf(v2.w, v2.w, fmaf(v2.z, v2.z, fmaf(v2.y, v2.y, fmaf(v2.x, v2.x, s2))));
+                s3 = fmaf(v3.w, v3.w, fmaf(v3.z, v3.z, fmaf(v3.y, v3.y, fmaf(v3.x, v3.x, s3))));
+            }
+            for (; e < n4; e += stride) {
+                const float4 v = g4[e];
+                s0 = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, fmaf(v.x, v.x, s0))));
+            }
+            if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // (the last n mod 4 elements)
+                const float v = g[4 * n4 + threadIdx.x];
+                s1 = fmaf(v, v, s1);
+            }
+            continue;
+        }
         for (; e + 3 * stride < n; e += 4 * stride) {
             const float v0 = g[e], v1 = g[e + stride], v2 = g[e + 2 * stride], v3 = g[e + 3 * stride];
             s0 = fmaf(v0, v0, s0);
