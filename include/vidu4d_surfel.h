@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 10
+#define VIDU4D_SURFEL_ABI 11
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -128,7 +128,15 @@ typedef struct Vidu4dSurfelForwardArgs {
     const float* sh_dc;
     const float* sh_rest;
     int raw_params;
+    /* ---- auxiliary planes the caller will read (extension).  Bit i = plane i of out_others; 0 means all (0xFF).
+     * When only the alpha plane is named (aux_planes == VIDU4D_AUX_ALPHA: colour + silhouette losses, the Stage-3 loop
+     * until its regularisers switch on, lab4d/engine/model.py:895-1012 with lambda_dist = lambda_normal = 0) the blend
+     * carries colour, transmittance and the contributor count only: out_color and plane 1 are what the full blend
+     * gives, bit for bit; the other planes come out as zeros, and the state kept for the backward holds no distortion
+     * moments and no median contributor.  Any other value: everything is computed. */
+    int aux_planes;
 } Vidu4dSurfelForwardArgs;
+#define VIDU4D_AUX_ALPHA 0x02
 #define VIDU4D_SURFEL_MAX_FRAMES 8
 size_t vidu4d_surfel_image_bytes_frames(int width, int height, int frames);
 
@@ -194,6 +202,11 @@ typedef struct Vidu4dSurfelBackwardArgs {
     float* dL_dsh_dc;
     float* dL_dsh_rest;
     int raw_params;
+    /* ---- planes of dL_dout_others that may be non-zero (0 = all).  VIDU4D_AUX_ALPHA: only dL_dout_color and plane 1 are
+     * read -- the other planes are TAKEN as zero, whatever they hold -- and the depth / normal / median / distortion
+     * chains they would multiply are skipped.  Must name every plane the forward's aux_planes did not compute: after a
+     * forward with VIDU4D_AUX_ALPHA the backward must be given VIDU4D_AUX_ALPHA too. */
+    int aux_planes;
 } Vidu4dSurfelBackwardArgs;
 
 int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* args, void* stream);

@@ -623,6 +623,50 @@ def test_canonical_parameters_are_validated(gpu_device):
                              sh_rest=sc.shs[:, 2:].contiguous())
 
 
+@pytest.mark.parametrize("F,split", [(1, "0"), (2, "0"), (2, "1")])
+def test_alpha_only_blend_equals_the_full_blend(gpu_device, monkeypatch, F, split):
+    """aux_planes = AUX_ALPHA (colour + silhouette losses: only the alpha plane of allmap is read): colour, alpha plane,
+    radii are those of the full blend bit for bit, the other planes are zeros, and the backward -- which TAKES the other
+    gradient planes as zero: they hold NaNs here -- gives what the full backward gives for zero-filled planes."""
+    import diff_surfel_rasterization as dsr
+    from vidu4d_amd import _C
+    from vidu4d_amd.synthetic import frame_motion
+    monkeypatch.setattr(_C, "_SPLIT", split)
+    dev = gpu_device
+    W, H, N = 176, 120, 6000
+    sc = make_scene(N, W, H, seed=5, sigma_px=(14.0 if split == "1" else 6.0)).to(dev)
+    frames = [frame_motion(sc, 3 * f, 12) for f in range(F)]
+    views = [dsr.GaussianRasterizationSettings(H, W, sc.tanfovx, sc.tanfovy * (1 + 0.1 * f), sc.bg + 0.3, 1.0, sc.viewmatrix,
+                                               sc.projmatrix, sc.sh_degree, sc.campos, False, False) for f in range(F)]
+    dc, do = make_upstream_grads(W, H)
+    dcs = torch.stack([(dc * (1 + 0.3 * f)).to(dev) for f in range(F)], 1)
+    dos = torch.stack([(do * (1 - 0.2 * f)).to(dev) for f in range(F)], 1)
+    dos_zero = torch.zeros_like(dos)
+    dos_zero[1] = dos[1]
+    dos_nan = torch.full_like(dos, float("nan"))
+    dos_nan[1] = dos[1]
+    M3 = torch.stack([fr.means3D for fr in frames])
+    R4 = torch.stack([fr.rotations for fr in frames])
+
+    def run(aux, g_others):
+        leaves = [t.clone().requires_grad_(True) for t in (M3, torch.zeros_like(M3), sc.shs, sc.opacities, sc.scales, R4)]
+        out = dsr.rasterize_frames(*leaves, views, aux_planes=aux)
+        torch.autograd.backward([out[0], out[2]], [dcs, g_others])
+        return out, [t.grad for t in leaves]
+
+    (c1, rd1, a1), g1 = run(0, dos_zero)
+    (c2, rd2, a2), g2 = run(dsr.AUX_ALPHA, dos_nan)
+    assert torch.equal(rd1, rd2)
+    assert torch.equal(c1, c2), "colour"
+    assert torch.equal(a1[1], a2[1]), "alpha plane"
+    for p in (0, 2, 3, 4, 5, 6, 7):
+        assert float(a2[p].detach().abs().max()) == 0.0, p
+    assert float(a1[0].detach().abs().max()) > 0.0
+    for a, b, what in zip(g2, g1, ("means3D", "means2D", "sh", "opacity", "scales", "rotations")):
+        assert torch.isfinite(a).all(), what
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), (what, float((a - b).abs().max()))
+
+
 def test_stacked_frames_without_surfels(gpu_device):
     """P == 0 through the stacked entry point: background only, as rasterize_points.cu:105 for one frame."""
     import diff_surfel_rasterization as dsr

@@ -123,7 +123,8 @@ def test_trainer_path_hands_the_rasterizer_what_the_reference_loop_does(gpu_devi
     fake = _fake_raster()
     seen = {}
 
-    def rasterize_frames(means3D, means2D, shs, opacities, scales, rotations, settings, sh_rest=None, raw_params=False):
+    def rasterize_frames(means3D, means2D, shs, opacities, scales, rotations, settings, sh_rest=None, raw_params=False,
+                         aux_planes=0):
         # the trainer hands over the canonical parameters (the kernels activate them: test_gpu_parity.py::
         # test_canonical_parameters_equal_the_activated_path); here they are activated as upstream does it
         if sh_rest is not None:

@@ -164,12 +164,14 @@ def _set_frame_cams(args, frame_cams, keep):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, frame_cams=None, sh_rest=None, raw_params=False):
+                        prefiltered, debug, frame_cams=None, sh_rest=None, raw_params=False, aux_planes=0):
     """-> (num_rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer)
 
     sh_rest / raw_params (extension: the canonical parameters as the optimizer holds them, no activation / concatenation
     launches in between): with sh_rest (P,15,3), `sh` is the (P,1,3) DC tensor; raw_params: `scales` are log-scales and
     `opacity` logits (exp / sigmoid applied by the kernels, gs/scene/gaussian_model.py:47-57, :98-118).
+    aux_planes (extension): bit mask of the out_others planes the caller reads, 0 = all; _lib.AUX_ALPHA (plane 1 only)
+    selects the colour + alpha blend (the other planes come out as zeros; hand the same mask to the backward).
 
     frame_cams (extension): a list of F <= 8 (viewmatrix, campos, tan_fovx, tan_fovy) -- F frames that
     share opacity / scales / sh are rasterized by one launch set: means3D (F,P,3), rotations (F,P,4) -> out_color
@@ -233,7 +235,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.background, a.means3D, a.shs, a.colors_precomp = _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors)
     if sh_rest is not None:
         a.shs, a.sh_dc, a.sh_rest = None, _ptr(sh), _ptr(sh_rest)
-    a.raw_params = int(bool(raw_params))
+    a.raw_params, a.aux_planes = int(bool(raw_params)), int(aux_planes)
     a.opacities, a.scales, a.rotations = _ptr(opacity), _ptr(scales), _ptr(rotations)
     a.transMat_precomp = _ptr(transMat_precomp)
     a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
@@ -324,7 +326,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
                                  binning_capacity=None, segment_split=None, frame_cams=None, sh_rest=None,
-                                 raw_params=False):
+                                 raw_params=False, aux_planes=0):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations)
 
     sh_rest / raw_params as in rasterize_gaussians: dL_dsh is then the pair (dL_dsh_dc (P,1,3), dL_dsh_rest (P,15,3)),
@@ -409,7 +411,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         b.dL_dsh, b.dL_dsh_dc, b.dL_dsh_rest = None, dL_dsh[0].data_ptr(), dL_dsh[1].data_ptr()
     else:
         b.dL_dsh = _ptr(dL_dsh)
-    b.raw_params = int(bool(raw_params))
+    b.raw_params, b.aux_planes = int(bool(raw_params)), int(aux_planes)
     b.dL_dscales, b.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
     _lib.check(lib.vidu4d_surfel_backward(C.byref(b), _stream(dev)), "surfel backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ForwardArgs(C.Structure):
@@ -28,7 +28,7 @@ class ForwardArgs(C.Structure):
         ("image_bytes", C.c_size_t), ("segment_split", C.c_int), ("depth_used", C.c_void_p),
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
-        ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("raw_params", C.c_int),
+        ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("raw_params", C.c_int), ("aux_planes", C.c_int),
     ]
 
 
@@ -71,6 +71,7 @@ class Stage3LossGrads(C.Structure):
 
 
 SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
+AUX_ALPHA = 0x02  # VIDU4D_AUX_ALPHA
 ADAM_MAX_TENSORS = 8
 CLIP_MAX_TENSORS = 16
 CLIP_WORKSPACE_FLOATS = 1056
@@ -94,7 +95,7 @@ class BackwardArgs(C.Structure):
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
         ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("dL_dsh_dc", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
-        ("raw_params", C.c_int),
+        ("raw_params", C.c_int), ("aux_planes", C.c_int),
     ]
 
 

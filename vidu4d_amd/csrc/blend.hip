@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
     seg_data[((size_t)wk.slot * SEG_FLOATS + SG_TSEG) * 256 + threadIdx.x] = T;
 }
 
-// The blend (pass 2 of the segment-parallel forward when SPLIT).
-template <bool SPLIT>
+// The blend (pass 2 of the segment-parallel forward when SPLIT).  LITE: colour + alpha plane only (surfel_math.h,
+// fwd_accumulate<true>); the other auxiliary planes, the distortion moments and the median contributor come out as zeros.
+template <bool SPLIT, bool LITE>
 __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        int64_t capacity, int max_seg, const float* __restrict__ rec,
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
                     if (okA) {
                         const float4 q3 = s_rec[ja * 5 + 3], q4 = s_rec[ja * 5 + 4];
                         const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = true;
+                        if (!fwd_accumulate<LITE>(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = true;
                     }
                 }
                 okB = okB && !done;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
                     if (okB) {
                         const float4 q3 = s_rec[jb * 5 + 3], q4 = s_rec[jb * 5 + 4];
                         const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = true;
+                        if (!fwd_accumulate<LITE>(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = true;
                     }
                 }
             }
@@ -437,14 +438,14 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
 
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
-                      float* out_others, uint32_t* depth_used, hipStream_t stream)
+                      float* out_others, uint32_t* depth_used, bool lite, hipStream_t stream)
 {
     const int tiles = total_tiles(cam), grid_y = cam.grid_y * cam.frames;  // (stacked frames: a taller tile grid)
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
-        hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                           grid_y, g.hdr, img, point_list, capacity, 0, g.rec, background, b.seg_data, out_color,
-                           out_others, depth_used);
+        auto kernel = lite ? &blend_fwd_kernel<false, true> : &blend_fwd_kernel<false, false>;
+        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
+                           point_list, capacity, 0, g.rec, background, b.seg_data, out_color, out_others, depth_used);
         return;
     }
     // upper bounds; the device knows the exact counts.  The combine runs over ALL schedule positions: the
@@ -454,9 +455,9 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     const int split_tiles = tiles;
     hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y,
                        g.hdr, img, point_list, capacity, max_seg, g.rec, b.seg_data);
-    hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                       grid_y, g.hdr, img, point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color,
-                       out_others, depth_used);
+    auto kernel = lite ? &blend_fwd_kernel<true, true> : &blend_fwd_kernel<true, false>;
+    hipLaunchKernelGGL(kernel, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
+                       point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used);
     hipLaunchKernelGGL(blend_combine_kernel, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
                        grid_y, g.hdr, img, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used);
 }
@@ -545,7 +546,9 @@ __device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
 // SPLIT: the tiles the forward blended segment-parallel are walked segment-parallel here too.  The
 // back-to-front recurrences of a segment start from what the segments behind it add up to (stored by
 // blend_combine_kernel); everything else is the single-workgroup loop restricted to the segment.
-template <bool SPLIT>
+// LITE: only dL/dcolour and dL/d(alpha plane) are read (the caller promised zeros elsewhere, aux_planes); the forward
+// that filled the state may itself have run LITE (no distortion moments, no median contributor: never read here).
+template <bool SPLIT, bool LITE>
 __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        const float* __restrict__ rec, const float* __restrict__ bg,
@@ -585,17 +588,19 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     for (int c = 0; c < 3; c++) s.dL_dpixel[c] = s.dL_dnormal2D[c] = 0.f;
     if (inside) {
         s.T_final = final_T[pid];
-        s.final_D = final_T[pid + HW];
-        s.final_D2 = final_T[pid + 2 * HW];
         s.last_contributor = n_contrib[pid];
-        s.median_contributor = n_contrib[pid + HW];
         for (int c = 0; c < 3; c++) s.dL_dpixel[c] = dL_dcolor[c * HW + pid];
-        s.dL_ddepth = dL_dothers[pid];
         s.dL_daccum = dL_dothers[pid + HW];
-        for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = dL_dothers[pid + (2 + c) * HW];
-        s.dL_dmedian_depth = dL_dothers[pid + 5 * HW];
-        s.dL_dreg = dL_dothers[pid + 6 * HW];
-        s.dL_dmax_dweight = dL_dothers[pid + 7 * HW];
+        if (!LITE) {
+            s.final_D = final_T[pid + HW];
+            s.final_D2 = final_T[pid + 2 * HW];
+            s.median_contributor = n_contrib[pid + HW];
+            s.dL_ddepth = dL_dothers[pid];
+            for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = dL_dothers[pid + (2 + c) * HW];
+            s.dL_dmedian_depth = dL_dothers[pid + 5 * HW];
+            s.dL_dreg = dL_dothers[pid + 6 * HW];
+            s.dL_dmax_dweight = dL_dothers[pid + 7 * HW];
+        }
     }
     s.T = s.T_final;
     s.final_A = 1.0f - s.T_final;
@@ -609,15 +614,15 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
             // the walk enters from the segments behind: start from what they add up to
             const float inv = 1.0f / T_end;
             const float behind = T_end - s.T_final;  // sum of their blend weights
-            for (int ch = 0; ch < 3; ch++) {
-                s.accum_rec[ch] = d[(SG_C + ch) * 256] * inv;
-                s.accum_normal_rec[ch] = d[(SG_N + ch) * 256] * inv;
-            }
-            s.accum_depth_rec = d[SG_D * 256] * inv;
+            for (int ch = 0; ch < 3; ch++) s.accum_rec[ch] = d[(SG_C + ch) * 256] * inv;
             s.accum_alpha_rec = behind * inv;
-            s.last_dL_dT = inv * (s.dL_dmax_dweight * d[SG_MED_W * 256] +
-                                  s.dL_dreg * (s.final_D2 * behind + s.final_A * d[SG_M2 * 256] -
-                                               2.0f * s.final_D * d[SG_M1 * 256]));
+            if (!LITE) {
+                for (int ch = 0; ch < 3; ch++) s.accum_normal_rec[ch] = d[(SG_N + ch) * 256] * inv;
+                s.accum_depth_rec = d[SG_D * 256] * inv;
+                s.last_dL_dT = inv * (s.dL_dmax_dweight * d[SG_MED_W * 256] +
+                                      s.dL_dreg * (s.final_D2 * behind + s.final_A * d[SG_M2 * 256] -
+                                                   2.0f * s.final_D * d[SG_M1 * 256]));
+            }
             s.T = T_end;
             s.last_contributor = seg_end;
         }
@@ -685,11 +690,11 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
                 if (ok) {
                     const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                     const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                    pg = bwd_pair_core(s, e, nrm, rgb, contributor + 1 == s.median_contributor);
+                    pg = bwd_pair_core<LITE>(s, e, nrm, rgb, contributor + 1 == s.median_contributor);
                 }
                 e.sanitise(ok);
                 float g[ACC_FLOATS];
-                bwd_pair_geometry(s, e, pg, Tw, q2.w, pixx, pixy, g);
+                bwd_pair_geometry<LITE>(s, e, pg, Tw, q2.w, pixx, pixy, g);
                 float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
                                g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
                 const float r16 = wave_reduce_scatter16(v, lane);
@@ -716,14 +721,16 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
 {
     const int tiles = total_tiles(a.cam), grid_y = a.cam.grid_y * a.cam.frames;
-    if (a.split && a.seg_data)
-        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), 0, stream,
-                           a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec,
-                           a.background, a.seg_data, a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc);
-    else
-        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x,
-                           grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0,
-                           a.dL_dcolor, a.dL_dothers, a.acc);
+    if (a.split && a.seg_data) {
+        auto kernel = a.lite ? &blend_bwd_kernel<true, true> : &blend_bwd_kernel<true, false>;
+        hipLaunchKernelGGL(kernel, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), 0, stream, a.cam.W, a.cam.H,
+                           a.cam.grid_x, grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data,
+                           a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc);
+    } else {
+        auto kernel = a.lite ? &blend_bwd_kernel<false, true> : &blend_bwd_kernel<false, false>;
+        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.geom.hdr,
+                           a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0, a.dL_dcolor, a.dL_dothers, a.acc);
+    }
 }
 
 }  // namespace surfel

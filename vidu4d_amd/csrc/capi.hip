@@ -328,7 +328,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
         // segment_split: 0 off, 1 on, k > 1: on, at most k segments per tile (Header::truncated reports a miss)
         const int max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
         launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, max_seg, a->background, a->out_color, a->out_others,
-                         a->depth_used, stream);
+                         a->depth_used, a->aux_planes == VIDU4D_AUX_ALPHA, stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
     return VIDU4D_OK;
@@ -392,6 +392,7 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     ba.dL_dsh_dc = a->sh_dc ? a->dL_dsh_dc : nullptr;
     ba.dL_dsh_rest = a->sh_dc ? a->dL_dsh_rest : nullptr;
     ba.raw_params = a->raw_params;
+    ba.lite = a->aux_planes == VIDU4D_AUX_ALPHA;
 
     {
         StageTimer t(ST_BWD_ZERO, stream);

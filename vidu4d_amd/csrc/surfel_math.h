@@ -552,6 +552,11 @@ struct FwdPixel {
 
 // One accepted sample (forward.cu:400-438).  Returns false (and leaves the state untouched) when
 // the pixel saturates on this sample.
+//
+// LITE (aux_planes names only the alpha plane: colour + silhouette losses, Stage-3 before the regularisers switch on):
+// depth, normal, median and distortion accumulations are not carried; their planes come out as zeros.  Colour,
+// transmittance and the contributor count are the same operations on the same operands as in the full version.
+template <bool LITE = false>
 SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal[3], const float rgb[3],
                               uint32_t contributor)
 {
@@ -559,19 +564,21 @@ SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal
     const float test_T = s.T * (1.0f - e.alpha);  // THRESHOLD-EXACT (same two roundings as the oracle)
     if (test_T < T_EPS) return false;
     const float w = e.alpha * s.T;
-    const float A = 1.0f - s.T;
-    const float m = map_depth(e.depth);
-    const float error = fmaf(m * m, A, fmaf(-2.0f * m, s.dist1, s.dist2));
-    s.distortion = fmaf(error, w, s.distortion);
-    if (s.T > 0.5f) {
-        s.median_depth = e.depth;
-        s.median_weight = w;
-        s.median_contributor = contributor;
+    if (!LITE) {
+        const float A = 1.0f - s.T;
+        const float m = map_depth(e.depth);
+        const float error = fmaf(m * m, A, fmaf(-2.0f * m, s.dist1, s.dist2));
+        s.distortion = fmaf(error, w, s.distortion);
+        if (s.T > 0.5f) {
+            s.median_depth = e.depth;
+            s.median_weight = w;
+            s.median_contributor = contributor;
+        }
+        for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(normal[ch], w, s.N[ch]);
+        s.D = fmaf(e.depth, w, s.D);
+        s.dist1 = fmaf(m, w, s.dist1);
+        s.dist2 = fmaf(m * m, w, s.dist2);
     }
-    for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(normal[ch], w, s.N[ch]);
-    s.D = fmaf(e.depth, w, s.D);
-    s.dist1 = fmaf(m, w, s.dist1);
-    s.dist2 = fmaf(m * m, w, s.dist2);
     for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(rgb[ch], w, s.C[ch]);
     s.T = test_T;
     s.last_contributor = contributor;
@@ -602,6 +609,9 @@ struct PairGrad {
     float w, dL_dalpha, dL_dz;
 };
 
+// LITE: only dL/dcolour and dL/dalpha-plane are live (every other upstream gradient plane is zero by the caller's
+// promise, aux_planes): the depth / normal / median / distortion chains, which would multiply by those zeros, are left out.
+template <bool LITE = false>
 SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float normal[3], const float rgb[3],
                                  bool is_median)
 {
@@ -612,6 +622,18 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
     const float w = alpha * s.T;
     float dL_dalpha = 0.0f;
     for (int ch = 0; ch < 3; ch++) dL_dalpha += (rgb[ch] - s.accum_rec[ch]) * s.dL_dpixel[ch];
+    if (LITE) {
+        dL_dalpha += (1.0f - s.accum_alpha_rec) * s.dL_daccum;
+        dL_dalpha *= s.T;
+        dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot_dpixel;
+        for (int ch = 0; ch < 3; ch++) s.accum_rec[ch] = alpha * rgb[ch] + one_m_alpha * s.accum_rec[ch];
+        s.accum_alpha_rec = alpha + one_m_alpha * s.accum_alpha_rec;
+        PairGrad r;
+        r.w = w;
+        r.dL_dalpha = dL_dalpha;
+        r.dL_dz = 0.f;
+        return r;
+    }
     float dL_dz = 0.0f, dL_dweight = 0.0f;
     // m_d = far (d - near) / ((far - near) d) and its derivative far near / ((far - near) d^2) from ONE reciprocal
     const float inv_d = fast_rcp((FAR_PLANE - NEAR_PLANE) * c_d);
@@ -653,18 +675,43 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
 // contribute passes pg = 0 and `e` with finite sx, sy, ipz, G (PairEval::sanitise) and gets exact zeros without
 // a branch.  The six dL/dTu, dL/dTv sums are accumulated with the OPPOSITE sign (+dk, +dl: the negations are
 // seven VALU instructions per pair); surfel_backward flips them back (exact).
+template <bool LITE = false>
 SURFEL_HD void bwd_pair_geometry(const BwdPixel& s, const PairEval& e, const PairGrad& pg, const float Tw[3],
                                  float opacity, float pixx, float pixy, float g[ACC_FLOATS])
 {
-    const float G = e.G, dL_dz = pg.dL_dz;
+    const float G = e.G, dL_dz = LITE ? 0.f : pg.dL_dz;
     for (int ch = 0; ch < 3; ch++) {
         g[A_RGB + ch] = pg.w * s.dL_dpixel[ch];
-        g[A_NRM + ch] = pg.w * s.dL_dnormal2D[ch];
+        g[A_NRM + ch] = LITE ? 0.f : pg.w * s.dL_dnormal2D[ch];
     }
     const float dL_dG = opacity * pg.dL_dalpha;  // straight-through the 0.99 clamp (backward.cu:400)
     g[A_OPAC] = G * pg.dL_dalpha;
     g[15] = 0.f;
     g[19] = 0.f;
+    if (LITE) {  // (dL_dz == 0: the same expressions without the terms it multiplies)
+        if (e.rho3d <= e.rho2d) {
+            const float dL_dsx = dL_dG * -G * e.sx, dL_dsy = dL_dG * -G * e.sy;
+            const float dpx = dL_dsx * e.ipz, dpy = dL_dsy * e.ipz, dpz = -(dpx * e.sx + dpy * e.sy);
+            const float dkx = e.ly * dpz - e.lz * dpy, dky = e.lz * dpx - e.lx * dpz, dkz = e.lx * dpy - e.ly * dpx;
+            const float dlx = dpy * e.kz - dpz * e.ky, dly = dpz * e.kx - dpx * e.kz, dlz = dpx * e.ky - dpy * e.kx;
+            g[A_T + 0] = dkx;
+            g[A_T + 1] = dky;
+            g[A_T + 2] = dkz;
+            g[A_T + 3] = dlx;
+            g[A_T + 4] = dly;
+            g[A_T + 5] = dlz;
+            g[A_T + 6] = pixx * dkx + pixy * dlx;
+            g[A_T + 7] = pixx * dky + pixy * dly;
+            g[A_T + 8] = pixx * dkz + pixy * dlz;
+            g[A_M2D + 0] = 0.f;
+            g[A_M2D + 1] = 0.f;
+        } else {
+            for (int k = 0; k < 9; k++) g[A_T + k] = 0.f;
+            g[A_M2D + 0] = dL_dG * (-G * 2.0f * e.dx);
+            g[A_M2D + 1] = dL_dG * (-G * 2.0f * e.dy);
+        }
+        return;
+    }
     if (e.rho3d <= e.rho2d) {
         const float dL_dsx = dL_dG * -G * e.sx + dL_dz * Tw[0];
         const float dL_dsy = dL_dG * -G * e.sy + dL_dz * Tw[1];

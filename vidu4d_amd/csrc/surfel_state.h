@@ -257,7 +257,7 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
 // previous frames went saves the rest of pass 1); Header::truncated is set if that was not enough
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
-                      float* out_others, uint32_t* depth_used, hipStream_t stream);
+                      float* out_others, uint32_t* depth_used, bool lite, hipStream_t stream);
 
 struct BackwardArgs {
     CameraParams cam;
@@ -292,6 +292,7 @@ struct BackwardArgs {
     float* dL_dsh_dc;
     float* dL_dsh_rest;
     int raw_params;       // scales are log-scales; dL_dscales / dL_dopacity are w.r.t. log-scales / logits
+    bool lite;            // only dL_dcolor and plane 1 of dL_dothers are live (aux_planes == alpha only)
 };
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream);
 void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream);

@@ -108,7 +108,7 @@ class _RasterizeFrames(torch.autograd.Function):
     sh_rest / raw_params: the canonical parameters straight from the optimizer (see rasterize_frames)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, sh_rest, raw_params):
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, sh_rest, raw_params, aux_planes):
         rs0 = settings_list[0]
         cams = [(rs.viewmatrix, rs.campos, rs.tanfovx, rs.tanfovy) for rs in settings_list]
         for rs in settings_list[1:]:
@@ -118,12 +118,12 @@ class _RasterizeFrames(torch.autograd.Function):
         out = _C.rasterize_gaussians(rs0.bg, means3D, empty, opacities, scales, rotations, rs0.scale_modifier, empty,
                                      rs0.viewmatrix, rs0.projmatrix, rs0.tanfovx, rs0.tanfovy, rs0.image_height,
                                      rs0.image_width, sh, rs0.sh_degree, rs0.campos, rs0.prefiltered, rs0.debug,
-                                     frame_cams=cams, sh_rest=sh_rest, raw_params=raw_params)
+                                     frame_cams=cams, sh_rest=sh_rest, raw_params=raw_params, aux_planes=aux_planes)
         num_rendered, color, others, radii, geom_buf, binning_buf, img_buf = out
         ctx.settings, ctx.cams, ctx.num_rendered = rs0, cams, num_rendered
         ctx.binning_capacity = getattr(binning_buf, "_vidu4d_capacity", max(num_rendered, 1))
         ctx.segment_split = getattr(binning_buf, "_vidu4d_split", 0)
-        ctx.split_sh, ctx.raw_params = sh_rest is not None, bool(raw_params)
+        ctx.split_sh, ctx.raw_params, ctx.aux_planes = sh_rest is not None, bool(raw_params), int(aux_planes)
         ctx.save_for_backward(means3D, scales, rotations, radii, sh, geom_buf, binning_buf, img_buf,
                               sh_rest if sh_rest is not None else empty)
         ctx.mark_non_differentiable(radii)
@@ -139,13 +139,15 @@ class _RasterizeFrames(torch.autograd.Function):
                                             sh, rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf,
                                             rs.debug, binning_capacity=ctx.binning_capacity,
                                             segment_split=ctx.segment_split, frame_cams=ctx.cams,
-                                            sh_rest=sh_rest if ctx.split_sh else None, raw_params=ctx.raw_params)
+                                            sh_rest=sh_rest if ctx.split_sh else None, raw_params=ctx.raw_params,
+                                            aux_planes=ctx.aux_planes)
         g_means2D, _g_colors, g_opacities, g_means3D, _g_T, g_sh, g_scales, g_rotations = g
         g_sh, g_sh_rest = g_sh if ctx.split_sh else (g_sh, None)
-        return g_means3D, g_means2D, g_sh, g_opacities, g_scales, g_rotations, None, g_sh_rest, None
+        return g_means3D, g_means2D, g_sh, g_opacities, g_scales, g_rotations, None, g_sh_rest, None, None
 
 
-def rasterize_frames(means3D, means2D, sh, opacities, scales, rotations, settings_list, sh_rest=None, raw_params=False):
+def rasterize_frames(means3D, means2D, sh, opacities, scales, rotations, settings_list, sh_rest=None, raw_params=False,
+                     aux_planes=0):
     """means3D (F,N,3), means2D (F,N,3) [receives the screen-space statistic], rotations (F,N,4); sh (N,M,3), opacities
     (N,1), scales (N,2) shared; settings_list: F GaussianRasterizationSettings (same size / SH degree / background).
     -> color (3,F,H,W), radii (F,N), allmap (8,F,H,W): frame f is color[:, f], allmap[:, f].
@@ -154,9 +156,16 @@ def rasterize_frames(means3D, means2D, sh, opacities, scales, rotations, setting
     `sh` = `_features_dc` (N,1,3) with `sh_rest` = `_features_rest` (N,15,3) instead of their concatenation, and with
     raw_params=True `scales` = `_scaling` (log-scales), `opacities` = `_opacity` (logits); the kernels activate them and
     the backward returns the gradients w.r.t. the raw tensors -- same values as exp / sigmoid / cat in torch, without
-    their launches and their backward's."""
+    their launches and their backward's.
+
+    aux_planes: bit mask of the allmap planes the caller reads (0 = all).  `AUX_ALPHA` (plane 1 only; colour + silhouette
+    losses) selects the colour + alpha blend: color and allmap[1] are bit-identical to the full call's, the other planes
+    are zeros, and the backward TAKES the gradients of those planes as zero."""
     return _RasterizeFrames.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), sh_rest,
-                                  raw_params)
+                                  raw_params, aux_planes)
+
+
+AUX_ALPHA = 0x02  # (VIDU4D_AUX_ALPHA)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -338,7 +338,7 @@ class DeformableSurfels(GaussianModel):
                 self._made[i] = self._radii[i] > 0
             return self._made[i]
 
-    def _render_frames_stacked(self, cams, xyz_cam, rot_cam, rot_is_unit):
+    def _render_frames_stacked(self, cams, xyz_cam, rot_cam, rot_is_unit, aux_planes=0):
         """All frames of the step through ONE launch set (diff_surfel_rasterization.rasterize_frames: stacked tile
         grids).  -> {"raw_stacked": (color (3,M,H,W), allmap (8,M,H,W))}; frame i is [:, i]."""
         from ..diff_surfel_rasterization import GaussianRasterizationSettings, rasterize_frames
@@ -364,10 +364,11 @@ class DeformableSurfels(GaussianModel):
             # the parameters as the optimizer holds them: the kernels apply exp / sigmoid and read the two SH tensors in
             # place -- no activation / concatenation launches here, none of their backward launches either
             color, radii, allmap = rasterize_frames(xyz_cam, screen, self._features_dc, self._opacity, self._scaling,
-                                                    rotations, settings, sh_rest=self._features_rest, raw_params=True)
+                                                    rotations, settings, sh_rest=self._features_rest, raw_params=True,
+                                                    aux_planes=aux_planes)
         else:
             color, radii, allmap = rasterize_frames(xyz_cam, screen, self.get_features, self.get_opacity,
-                                                    self.get_scaling, rotations, settings)
+                                                    self.get_scaling, rotations, settings, aux_planes=aux_planes)
         M = xyz_cam.shape[0]
         self._viewspace_points_batch = [self._FrameGrad(screen, i) for i in range(M)]
         self._visibility_filter_batch = self._Visible(radii)
@@ -393,9 +394,11 @@ class DeformableSurfels(GaussianModel):
             pool.append(torch.cuda.Stream(device=self._xyz.device))
         return pool
 
-    def render_frames(self, frame_id, Kinv, H, W, inst_id=None, samples_dict=None, outputs=None):
+    def render_frames(self, frame_id, Kinv, H, W, inst_id=None, samples_dict=None, outputs=None, aux_planes=0):
         """The per-frame render loop of query_field (:1175-1233): returns a dict of (M,H,W,C) maps and
-        keeps the per-frame screen-space tensors the densification statistics need."""
+        keeps the per-frame screen-space tensors the densification statistics need.
+        aux_planes (stacked raw output only): bit mask of the allmap planes the caller reads, 0 = all
+        (diff_surfel_rasterization.rasterize_frames)."""
         M = frame_id.shape[0]
         if self.fused_warp_ok(inst_id):
             xyz_cam, rot_cam = self.forward_warp_fused(frame_id, inst_id, samples_dict)  # (M,N,3), (M,N,4)
@@ -409,7 +412,7 @@ class DeformableSurfels(GaussianModel):
         cams = self.get_gs_Kcamera(Kinv, H, W)
         if (outputs is not None and tuple(outputs) == ("raw",) and xyz_cam.is_cuda and self.opts.get("stacked_frames", True)
                 and 1 <= M <= 8 and len({(int(h), int(w)) for h, w in zip(H, W)}) == 1):
-            return self._render_frames_stacked(cams, xyz_cam, rot_cam, rot_is_unit)
+            return self._render_frames_stacked(cams, xyz_cam, rot_cam, rot_is_unit, aux_planes)
         stacked, per_frame = {}, {"viewspace_points": [], "visibility_filter": [], "radii": []}
         # outputs containing "raw": the per-frame colour / auxiliary planes are handed out as they leave the rasterizer
         # (out["raw"] = [(color (3,H,W), allmap (8,H,W))], no learnable-background composite, no permute / stack)

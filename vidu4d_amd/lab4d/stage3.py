@@ -261,7 +261,13 @@ class Stage3Trainer:
         if m._xyz.is_cuda and not need_geometry and M <= 8 and m.opts.get("fused_loss", True):
             # colour / silhouette / distortion terms and their gradient planes in five launches (csrc/loss.hip)
             from .loss_fused import stage3_loss
-            rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=("raw",))
+            # colour and silhouette terms read the colour and the alpha plane; the distortion term (plane 6) only counts
+            # once lambda_dist does: until then the blend kernels carry nothing else (aux_planes, csrc/blend.hip LITE)
+            from ..diff_surfel_rasterization import AUX_ALPHA
+            lam_d = float(self.cfg.lambda_dist) if step > 8000 else 0.0
+            aux = AUX_ALPHA if (lam_d == 0.0 and m.opts.get("alpha_only_blend", True)) else 0
+            rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=("raw",),
+                                       aux_planes=aux)
             if "raw_stacked" in rendered:   # the frames came out of one stacked launch set: (3,M,H,W), (8,M,H,W)
                 colors, allmaps = rendered["raw_stacked"]
             else:
