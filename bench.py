@@ -129,7 +129,9 @@ def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int):
     dt = (time.perf_counter() - t0) / steps
     return {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps,
             "config": f"{n_surfels} surfels in a unit ball 3 units from the camera, {W}x{H}, 25 bones, 120 frames, "
-                      "warp / camera networks frozen (--gs_optim_warp=False), densify off"}
+                      "warp / camera networks frozen (--gs_optim_warp=False), densify off; losses as the reference's "
+                      "--rgb_loss_only run before step 8000 (colour + silhouette, lambda_dist = 0), so the blend kernels run "
+                      "their colour + alpha-plane instances (aux_planes); the op-level `value` above drives all 8 planes"}
 
 
 def torch_cpu_baseline(scene, n_images: int, threads: int):
