@@ -22,7 +22,10 @@ constexpr int TILE_SLICES = 16;     // (atomic path) sub-counters per tile: spre
 // workgroups that count / place their pairs with LDS atomics only; the per-(group, tile) counts are
 // prefix-summed in between.  Needs one LDS word per tile.
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_GROUPS = 256;
+#ifndef SURFEL_BIN_MAX_GROUPS
+#define SURFEL_BIN_MAX_GROUPS 256
+#endif
+constexpr int BIN_MAX_GROUPS = SURFEL_BIN_MAX_GROUPS;
 constexpr int BIN_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int TILE_SORT_CAP = 3584;  // list entries a tile can sort entirely inside LDS (2 x 28 KiB ping-pong)
 
