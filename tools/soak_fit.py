@@ -1,0 +1,84 @@
+"""Soak run of the Stage-3 loop (teacher -> student, 16 frames, 192^2): densify / prune every 100 steps from step 200,
+opacity reset at 600, SH degree step at 1000, frozen warp / camera networks (the fused HIP warp), once on the trainer's
+default path (canonical parameters, alpha-only blend, stacked frames, fused loss) and once with those extensions off.
+Prints surfel counts, the loss trajectory of both runs and the final image error against the teacher; every loss and
+parameter must stay finite.  Usage (GPU box): python tools/soak_fit.py [steps]"""
+import os, sys, time
+import numpy as np
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+from vidu4d_amd.lab4d.stage3 import Stage3Trainer, make_intrinsics_inv
+
+dev = torch.device("cuda:0")
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1300
+H = W = 192
+FRAMES = 16
+
+
+def model(n, seed, **opts):
+    rng = np.random.default_rng(seed)
+    o = dict(fg_motion="gs-bob", sh_degree=3)
+    o.update(opts)
+    torch.manual_seed(seed)
+    m = DeformableSurfels(o, num_frames=FRAMES, device=dev)
+    pts = rng.normal(size=(n, 3)).astype(np.float32)
+    pts = 0.3 * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.7, 1.0, size=(n, 1)).astype(np.float32)
+    m.init_from_points(pts, rng.uniform(size=(n, 3)).astype(np.float32))
+    return m
+
+
+teacher = model(20000, 1, gs_learnable_bg=False)
+with torch.no_grad():
+    teacher._opacity.fill_(2.0)
+    teacher._features_dc.normal_(0.0, 1.0)
+    teacher._features_rest.normal_(0.0, 0.1)
+fid = torch.arange(FRAMES, device=dev)
+Kinv = make_intrinsics_inv(FRAMES, H, W, device=dev)
+with torch.no_grad():
+    tgt = teacher.render_frames(fid, Kinv, [H] * FRAMES, [W] * FRAMES)
+nets = {k: v for k, v in teacher.state_dict().items() if k.startswith(("warp.", "camera_mlp."))}
+
+
+def run(tag, **opts):
+    s = model(8000, 2, densify_from_iter=200, densification_interval=100, densify_until_iter=1200, opacity_reset_interval=600,
+              densify_grad_threshold=5e-6, **opts)
+    s.load_state_dict(nets, strict=False)
+    for mod in (s.warp, s.camera_mlp):
+        for p in mod.parameters():
+            p.requires_grad_(False)
+    tr = Stage3Trainer(s)
+    hist, counts = [], []
+    t0 = time.perf_counter()
+    for step in range(STEPS):
+        ids = [(2 * step) % FRAMES, (2 * step + 1) % FRAMES]
+        batch = {"frameid": torch.tensor(ids, device=dev), "Kinv": make_intrinsics_inv(2, H, W, device="cpu"),
+                 "H": [H, H], "W": [W, W], "rgb": tgt["rendered"][ids], "mask": tgt["mask"][ids].detach(),
+                 "vis2d": torch.ones(2, H, W, 1, device=dev)}
+        losses = tr.train_step(batch)
+        if step % 25 == 0 or step == STEPS - 1:
+            v = float(sum(losses.values()))
+            assert np.isfinite(v), (tag, step, losses)
+            hist.append(round(v, 5))
+            counts.append(int(s._xyz.shape[0]))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for n, p in s.named_parameters():
+        assert torch.isfinite(p).all(), (tag, n)
+    with torch.no_grad():
+        out = s.render_frames(fid, Kinv, [H] * FRAMES, [W] * FRAMES)
+    err = float((out["rendered"] - tgt["rendered"]).abs().mean())
+    merr = float((out["mask"] - tgt["mask"]).abs().mean())
+    print(f"[{tag}] {STEPS} steps in {dt:.1f} s ({1e3 * dt / STEPS:.2f} ms/step); surfels {counts[0]} -> {counts[-1]} "
+          f"(max {max(counts)}); SH degree {s.active_sh_degree}; loss {hist[0]} -> {hist[-1]}; "
+          f"mean |image error| {err:.4f}, mean |mask error| {merr:.4f}")
+    print(f"[{tag}] loss every 25 steps:", hist)
+    return hist, err
+
+
+h1, e1 = run("default path")
+h2, e2 = run("extensions off", canonical_params=False, alpha_only_blend=False, stacked_frames=False, fused_loss=False)
+assert h1[-1] < 0.5 * h1[0] and h2[-1] < 0.5 * h2[0], "the fit did not converge"
+assert abs(e1 - e2) < 0.25 * max(e1, e2) + 0.01, (e1, e2)
+print("SOAK OK")
