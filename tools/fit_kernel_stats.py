@@ -3,7 +3,7 @@ Usage: python tools/fit_kernel_stats.py <..._kernel_stats.csv> <steps traced> > 
 import csv, sys
 
 path, steps = sys.argv[1], float(sys.argv[2])
-rows = list(csv.DictReader(open(path)))
+rows = [r for r in csv.DictReader(open(path)) if float(r["Calls"]) / steps >= 0.1]  # (one-off initialisation kernels dropped)
 total = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e3
 print(f"# rocprofv3 --kernel-trace --stats of tools/fit_profile.py (full Stage-3 step: 2 frames, 200k surfels, 512^2, dense ball),"
       f" per optimizer step over {int(steps)} steps (6 of them warm-up); serialised kernel time {total:.0f} us per step")

@@ -75,28 +75,33 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
 }
 
 // ------------------------------------------------------------------------------------------------ gradient clip
-constexpr int CLIP_BLOCKS = 1024;
+constexpr int CLIP_BLOCKS = 512, CLIP_THREADS = 512;
+constexpr int CLIP_L1 = 16;          // first-level arrival counters (CLIP_BLOCKS / CLIP_L1 blocks each), one cache line apart
+constexpr int CLIP_PARTIALS = 32 + CLIP_L1 * 16;  // workspace offset of the block partials
 struct ClipLaunch {
     const float* g[VIDU4D_CLIP_MAX_TENSORS];
     int64_t numel[VIDU4D_CLIP_MAX_TENSORS];
     int n;
     float max_norm;
-    float* workspace;  // [0] arrival counter (as unsigned), [32 .. 32 + CLIP_BLOCKS) block partials
+    float* workspace;  // [0] final arrival counter, [32 + 16 i] first-level counters (as unsigned), then the block partials
     float* out;
 };
 
 // Every block strides over every tensor; the block that arrives last adds the CLIP_BLOCKS partials in index order (in
-// double), so the result does not depend on the arrival order.
-__global__ __launch_bounds__(256) void clip_kernel(ClipLaunch a)
+// double), so the result does not depend on the arrival order.  Arrival is counted in two levels: device-scope atomics
+// on ONE address are served one after the other at the memory side (~35 ns each on the MI355X: with 1024 blocks on one
+// counter this kernel took 37-44 us whatever the width of its loads), so blocks first meet in CLIP_L1 groups on separate
+// cache lines and only the last of each group goes on to the final counter: 32 + 16 serialised atomics instead of 1024.
+__global__ __launch_bounds__(CLIP_THREADS) void clip_kernel(ClipLaunch a)
 {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const int64_t stride = (int64_t)CLIP_BLOCKS * 256;
+    const int64_t stride = (int64_t)CLIP_BLOCKS * CLIP_THREADS;
     for (int k = 0; k < a.n; k++) {
         const float* __restrict__ g = a.g[k];
         const int64_t n = a.numel[k];
-        int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        int64_t e = (int64_t)blockIdx.x * CLIP_THREADS + threadIdx.x;
         if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
-            // 16-byte loads, four of them in flight per thread (47 MB of gradients: 37 us with dword loads)
+            // 16-byte loads, four of them in flight per thread
             const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
             const int64_t n4 = n >> 2;
             for (; e + 3 * stride < n4; e += 4 * stride) {
@@ -128,32 +133,41 @@ __global__ __launch_bounds__(256) void clip_kernel(ClipLaunch a)
     float s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-    __shared__ float s_part[4];
+    __shared__ float s_part[CLIP_THREADS / 64];
     __shared__ bool s_last;
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
     __syncthreads();
     unsigned* counter = reinterpret_cast<unsigned*>(a.workspace);
-    float* partial = a.workspace + 32;
+    float* partial = a.workspace + CLIP_PARTIALS;
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        float t = 0.f;
+        for (int w = 0; w < CLIP_THREADS / 64; w++) t += s_part[w];
+        partial[blockIdx.x] = t;
         __threadfence();
-        s_last = atomicAdd(counter, 1u) == (unsigned)(CLIP_BLOCKS - 1);
+        bool last = atomicAdd(counter + 32 + 16 * (blockIdx.x % CLIP_L1), 1u) == (unsigned)(CLIP_BLOCKS / CLIP_L1 - 1);
+        if (last) {
+            __threadfence();
+            last = atomicAdd(counter, 1u) == (unsigned)(CLIP_L1 - 1);
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();
     double t = 0.0;
-    for (int i = threadIdx.x; i < CLIP_BLOCKS; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __shared__ double s_t[256];
+    for (int i = threadIdx.x; i < CLIP_BLOCKS; i += CLIP_THREADS)
+        t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ double s_t[CLIP_THREADS];
     s_t[threadIdx.x] = t;
     __syncthreads();
+    if (threadIdx.x < 32 + CLIP_L1 * 16 && (threadIdx.x == 0 || (threadIdx.x >= 32 && (threadIdx.x & 15) == 0)))
+        counter[threadIdx.x] = 0u;  // (the counters are ready for the next launch)
     if (threadIdx.x == 0) {
         double tot = 0.0;
-        for (int i = 0; i < 256; i++) tot += s_t[i];
+        for (int i = 0; i < CLIP_THREADS; i++) tot += s_t[i];
         const float norm = (float)sqrt(tot);
         a.out[0] = norm;
         a.out[1] = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
-        *counter = 0u;
     }
 }
 
@@ -313,7 +327,7 @@ extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double b
 extern "C" int vidu4d_grad_clip_coef(int n, const float* const* grads, const int64_t* numel, float max_norm,
                                      float* workspace, float* out, void* stream)
 {
-    static_assert(VIDU4D_CLIP_WORKSPACE_FLOATS >= 32 + CLIP_BLOCKS, "clip workspace");
+    static_assert(VIDU4D_CLIP_WORKSPACE_FLOATS >= CLIP_PARTIALS + CLIP_BLOCKS, "clip workspace");
     if (n < 0 || n > VIDU4D_CLIP_MAX_TENSORS || (n && (!grads || !numel)) || !workspace || !out) return VIDU4D_E_INVALID;
     ClipLaunch a;
     a.n = 0;
@@ -328,7 +342,7 @@ extern "C" int vidu4d_grad_clip_coef(int n, const float* const* grads, const int
     a.workspace = workspace;
     a.out = out;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(clip_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(clip_kernel, dim3(CLIP_BLOCKS), dim3(CLIP_THREADS), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
