@@ -134,6 +134,28 @@ def test_sort_ties_keep_surfel_order(gpu_device):
     _check_forward(sc, st, out)
 
 
+@pytest.mark.parametrize("n_clones,concentrated", [(12, False), (40, False), (12, True)])
+def test_sort_few_ties_are_put_in_id_order(gpu_device, n_clones, concentrated):
+    """A handful of exact depth ties (the tile sort's in-place fix-up: runs of equal depths are ordered by id after the
+    depth-only passes; many ties take the full LSD sequence, test_sort_ties_keep_surfel_order): clones appended far
+    from their originals, some of them twice, must come out in ascending id order.  concentrated: lists longer than the
+    LDS capacity (the global-memory sort)."""
+    if concentrated:
+        sc = make_scene(9000, 48, 48, seed=43, sigma_px=5.0)
+        sc.means3D[:, :2] *= 0.15   # everything into a few tiles: lists of several thousand entries
+    else:
+        sc = make_scene(2500, 96, 80, seed=42, sigma_px=5.0)
+    g = torch.Generator().manual_seed(3)
+    pick = torch.randperm(sc.means3D.shape[0], generator=g)[:n_clones]
+    pick = torch.cat([pick, pick[:3]])  # three of them a second time: runs of three
+    for name in ("means3D", "scales", "rotations", "opacities", "shs"):
+        t = getattr(sc, name)
+        setattr(sc, name, torch.cat([t, t[pick]], 0).contiguous())
+    st = oracle_forward(sc)
+    d, shs, cols, out = _native_forward(sc, gpu_device)
+    _check_forward(sc, st, out)
+
+
 def test_empty_culled_and_offscreen(gpu_device):
     from vidu4d_amd import _C
     dev = gpu_device

@@ -418,8 +418,8 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
     const int w_hi = (w_lo + chunk < n) ? w_lo + chunk : n;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-    for (int pass = 0; pass < id_bytes + 4; pass++) {
-        const int shift = 8 * (pass < id_bytes ? pass : 4 + pass - id_bytes);
+    // One stable counting pass on the byte at `shift` (skipped when the whole list shares that byte).
+    auto radix_pass = [&](int shift) {
         for (int i = threadIdx.x; i < WAVES * 256; i += THREADS) (&s_cnt[0][0])[i] = 0;
         __syncthreads();  // also orders the previous pass's scatter (or the initial load) before the reads
         for (int i = w_lo + lane; i < w_hi; i += 64) atomicAdd(&s_cnt[wave][(uint32_t)(A[i] >> shift) & 255u], 1u);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
         uint32_t tot = 0;
         if (threadIdx.x < 256)
             for (int w = 0; w < WAVES; w++) tot += s_cnt[w][d];
-        if (__syncthreads_or(tot == (uint32_t)n)) continue;  // whole segment shares this digit: nothing to move
+        if (__syncthreads_or(tot == (uint32_t)n)) return;  // whole segment shares this digit: nothing to move
         uint32_t total;
         const uint32_t dbase = block_exclusive_scan(tot, s_scan, total);  // (waves >= 4 contribute zeros)
         if (threadIdx.x < 256) {
@@ -463,6 +463,46 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
         A = B;
         B = t;
         __syncthreads();  // every wave is done with its cursors before the next pass clears them
+    };
+
+    // The order to reproduce is the reference's: stable sort by depth of entries emitted in id order, i.e. (depth, id)
+    // ascending.  Sorting on all of (id bytes, depth bytes) costs 6-7 passes; ties in depth are what the id bytes
+    // are for, and exact fp32 depth ties between two surfels of one tile hardly ever happen.  So: the depth bytes
+    // only (3 effective passes: the exponent byte is constant), then a look for adjacent equal depths.  None (the
+    // usual case): done.  A few: every run of equal depths is put in id order by the thread that finds its start
+    // (runs are disjoint).  Many (degenerate scenes, e.g. all surfels on one plane): the full LSD sequence is run
+    // on the list as it stands -- an LSD sort does not care about the order it starts from.
+    constexpr uint32_t TIE_SERIAL_MAX = 48;
+    __shared__ uint32_t s_ties;
+    for (int pass = 0; pass < 4; pass++) radix_pass(32 + 8 * pass);
+    if (threadIdx.x == 0) s_ties = 0;
+    __syncthreads();
+    {
+        uint32_t local = 0;
+        for (int i = threadIdx.x + 1; i < n; i += THREADS) local += (uint32_t)(A[i] >> 32) == (uint32_t)(A[i - 1] >> 32);
+        if (local) atomicAdd(&s_ties, local);
+    }
+    __syncthreads();
+    const uint32_t ties = s_ties;
+    if (ties > TIE_SERIAL_MAX) {
+        for (int pass = 0; pass < id_bytes + 4; pass++) radix_pass(8 * (pass < id_bytes ? pass : 4 + pass - id_bytes));
+    } else if (ties) {
+        for (int i = threadIdx.x; i + 1 < n; i += THREADS) {
+            const uint32_t d = (uint32_t)(A[i] >> 32);
+            if ((uint32_t)(A[i + 1] >> 32) != d || (i > 0 && (uint32_t)(A[i - 1] >> 32) == d)) continue;  // not a run start
+            int j = i + 1;
+            while (j + 1 < n && (uint32_t)(A[j + 1] >> 32) == d) j++;
+            for (int a = i + 1; a <= j; a++) {  // insertion sort of A[i..j] (equal depths: the keys order by id)
+                const uint64_t key = A[a];
+                int b = a - 1;
+                while (b >= i && A[b] > key) {
+                    A[b + 1] = A[b];
+                    b--;
+                }
+                A[b + 1] = key;
+            }
+        }
+        __syncthreads();
     }
     for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t key = A[i];
