@@ -68,15 +68,16 @@ __device__ __forceinline__ void stage_frame(const float* se3_qr, const float* se
         s_q[i] = se3_qr[(size_t)m * B * 4 + i];
         s_q[MAX_BONES * 4 + i] = se3_qd[(size_t)m * B * 4 + i];
     }
+    for (int a = threadIdx.x; a < B; a += blockDim.x) s_sign[a] = 0ull;
     __syncthreads();
-    for (int a = threadIdx.x; a < B; a += blockDim.x) {
-        unsigned long long bits = 0;
-        for (int b = 0; b < B; b++) {
-            float d = 0.f;
-            for (int k = 0; k < 4; k++) d += s_q[a * 4 + k] * s_q[b * 4 + k];
-            if (d > 0.f) bits |= 1ull << b;
-        }
-        s_sign[a] = bits;  // bit b set: bone b is in bone a's hemisphere (geom_utils.py:70-72)
+    // bit b of s_sign[a]: bone b is in bone a's hemisphere (geom_utils.py:70-72).  One thread per (a, b) pair: with one
+    // thread per ROW (B of the 256 threads walking B * 4 products each) this prologue was the longest dependent chain of
+    // the kernel -- every workgroup paid ~B^2 * 8 LDS reads on 25 lanes before its surfels could start.
+    for (int i = threadIdx.x; i < B * B; i += blockDim.x) {
+        const int a = i / B, b = i - a * B;
+        float d = 0.f;
+        for (int k = 0; k < 4; k++) d += s_q[a * 4 + k] * s_q[b * 4 + k];
+        if (d > 0.f) atomicOr(&s_sign[a], 1ull << b);
     }
     __syncthreads();
 }
