@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 11
+#define VIDU4D_SURFEL_ABI 12
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -274,14 +274,19 @@ int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_q
  * M <= 8 frames.  The backward writes g_xbT (3B, N), g_rawT (B, N) (NULL iff rawT is) and the gradients w.r.t. the
  * canonical centres (N, 3) and orientations (N, 4) already summed over the frames.  unit_rot != 0: the orientations
  * leave the kernel normalised (v / max(|v|, 1e-12): the rotation_activation that gs.gaussian_renderer.render applies to
- * them, gs/scene/gaussian_model.py:57 / gs/gaussian_renderer/__init__.py:73) and the backward goes through it. */
+ * them, gs/scene/gaussian_model.py:57 / gs/gaussian_renderer/__init__.py:73) and the backward goes through it.
+ * bone_A (3B, 3) / bone_c (3B) with xbT == NULL: the bone coordinates are evaluated inside the kernels, x_bone = A xyz + c
+ * (the rest pose's bone map, as vidu4d_skin_field_* takes it), and the backward adds A^T (d/d x_bone) to g_xyz instead of
+ * writing g_xbT (which may be NULL): three quarters of the kernels' traffic.  Otherwise pass bone_A = bone_c = NULL. */
 int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                             const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
-                            const float* cam_t, float* out_xyz, float* out_rot, int unit_rot, void* stream);
+                            const float* cam_t, float* out_xyz, float* out_rot, int unit_rot, const float* bone_A,
+                            const float* bone_c, void* stream);
 int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                              const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                              const float* cam_t, const float* g_out_xyz, const float* g_out_rot, float* g_xbT,
-                             float* g_rawT, float* g_xyz, float* g_rot, int unit_rot, void* stream);
+                             float* g_rawT, float* g_xyz, float* g_rot, int unit_rot, const float* bone_A,
+                             const float* bone_c, void* stream);
 
 /* ---- the per-surfel part of the bob skinning field, once per optimizer step: Gaussian-bone coordinates of the rest
  *      pose and the delta-skin MLP on them (replaces gauss_mlp_skinning's bone transform and SkinningField.delta_field,

@@ -187,3 +187,32 @@ def test_lbs_skin_unit_rotation_equals_normalize_after(gpu_device):
     for a, b in zip(res[True], res[False]):
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-6 * float(b.abs().max()))
     assert torch.allclose(res[True][1].norm(dim=-1), torch.ones(M, N, device=dev), atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,B,with_raw", [(2, 3000, 25, True), (3, 513, 25, False), (1, 100, 40, True)])
+def test_lbs_skin_with_the_bone_map_equals_precomputed_coordinates(gpu_device, M, N, B, with_raw):
+    """lbs_skin_apply(None, ..., bone_map=(A, c)) -- x_bone = A xyz + c evaluated inside the kernels, A^T d x_bone folded
+    into the centre's gradient -- == the same call on xbT = addmm(c, A, xyz^T) made by torch (values, and the gradients
+    w.r.t. xyz incl. the path through the coordinates, rot, rawT)."""
+    from vidu4d_amd.lab4d.lbs_fused import lbs_skin_apply
+    dev = gpu_device
+    qr, qd, logits, xyz, rot, cq, ct = _inputs(dev, M, N, B, seed=11)
+    g = torch.Generator().manual_seed(7)
+    A = (1.5 * torch.randn(3 * B, 3, generator=g)).to(dev)
+    c = (0.3 * torch.randn(3 * B, generator=g)).to(dev)
+    raw0 = torch.randn(B, N, generator=g).to(dev) if with_raw else None
+    gx, gr = torch.randn(M, N, 3, generator=g).to(dev), torch.randn(M, N, 4, generator=g).to(dev)
+    res = {}
+    for fused in (True, False):
+        x, r = xyz.clone().requires_grad_(True), rot.clone().requires_grad_(True)
+        raw = None if raw0 is None else raw0.clone().requires_grad_(True)
+        if fused:
+            ox, orot = lbs_skin_apply(None, raw, (qr, qd), x, r, cq, ct, unit_rot=True, bone_map=(A, c))
+        else:
+            ox, orot = lbs_skin_apply(torch.addmm(c[:, None], A, x.t()), raw, (qr, qd), x, r, cq, ct, unit_rot=True)
+        ((ox * gx).sum() + (orot * gr).sum()).backward()
+        res[fused] = [t.detach() for t in (ox, orot, x.grad, r.grad)] + ([] if raw is None else [raw.grad])
+    for a, b, what in zip(res[True], res[False], ("xyz_cam", "rot_cam", "g_xyz", "g_rot", "g_raw")):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max())), (what, float((a - b).abs().max()))
+    with pytest.raises(RuntimeError, match="bone coordinates xbT OR the bone map"):
+        lbs_skin_apply(None, None, (qr, qd), xyz, rot, cq, ct)

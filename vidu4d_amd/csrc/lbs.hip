@@ -196,7 +196,11 @@ constexpr int MAX_FRAMES = 8;
 
 // BCAP: compile-time bound of the bone loops (32 for the bob field's 25 bones: fully unrolled, the per-bone weights and
 // weight gradients stay in registers; the 64-bone instance indexes them dynamically, i.e. through scratch memory).
-template <bool BACKWARD, int BCAP>
+// XB_FROM_XYZ: the Gaussian-bone coordinates are not read from xbT but evaluated here, x_bone = A xyz + c with the
+// (3B, 3) bone map of the rest pose staged in LDS (225 FMAs per surfel), and the backward folds A^T (d/d x_bone) into the
+// centre's gradient instead of writing g_xbT: both kernels are bound by their traffic -- 100 feature-major floats per
+// surfel read (twice in the backward) and written -- of which the coordinates are three quarters.
+template <bool BACKWARD, int BCAP, bool XB_FROM_XYZ>
 __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
                                                        const float* __restrict__ rawT,
                                                        const float* __restrict__ se3_qr,
@@ -209,22 +213,34 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
                                                        const float* __restrict__ g_out_rot,
                                                        float* __restrict__ g_xbT, float* __restrict__ g_rawT,
                                                        float* __restrict__ g_xyz, float* __restrict__ g_rot,
-                                                       int unit_rot)
+                                                       int unit_rot, const float* __restrict__ bone_A,
+                                                       const float* __restrict__ bone_c)
 {
     __shared__ float s_q[MAX_FRAMES][2 * MAX_BONES * 4];
     __shared__ unsigned long long s_sign[MAX_FRAMES][MAX_BONES];
+    __shared__ float4 s_map[XB_FROM_XYZ ? 3 * BCAP : 1];  // row k of the bone map: (A[k][0..2], c[k])
+    if (XB_FROM_XYZ)
+        for (int k = threadIdx.x; k < 3 * B; k += 256)
+            s_map[k] = make_float4(bone_A[3 * k], bone_A[3 * k + 1], bone_A[3 * k + 2], bone_c[k]);
     for (int m = 0; m < M; m++) stage_frame(se3_qr, se3_qd, m, B, s_q[m], s_sign[m]);
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
 
+    const float cx_ = xyz[3 * n], cy_ = xyz[3 * n + 1], cz_ = xyz[3 * n + 2];
+    auto bone_coord = [&](int k) {
+        if (XB_FROM_XYZ) {
+            const float4 r = s_map[k];
+            return fmaf(r.x, cx_, fmaf(r.y, cy_, fmaf(r.z, cz_, r.w)));
+        }
+        return xbT[(size_t)k * N + n];
+    };
     float w[BCAP];
     int anchor = 0;
     float best = -3.0e38f;
 #pragma unroll
     for (int b = 0; b < BCAP; b++) {
         if (b >= B) break;
-        const float x0 = xbT[(size_t)(3 * b) * N + n], x1 = xbT[(size_t)(3 * b + 1) * N + n],
-                    x2 = xbT[(size_t)(3 * b + 2) * N + n];
+        const float x0 = bone_coord(3 * b), x1 = bone_coord(3 * b + 1), x2 = bone_coord(3 * b + 2);
         const float raw = rawT ? rawT[(size_t)b * N + n] : 0.f;
         w[b] = -((x0 * x0 + x1 * x1 + x2 * x2) + 0.1f * fmaxf(raw, 0.f));
         if (w[b] > best) {  // first maximum, like torch.argmax (the softmax keeps the order)
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
     _Pragma("unroll") for (int b = 0; b < BCAP; b++)
         if (b < B) w[b] *= isum;
 
-    const Q p = qvec(xyz[3 * n], xyz[3 * n + 1], xyz[3 * n + 2]);
+    const Q p = qvec(cx_, cy_, cz_);
     const Q r = ldq(rot + 4 * n);
     float gw[BCAP];
     Q acc_p = {0, 0, 0, 0}, acc_r = {0, 0, 0, 0};
@@ -322,11 +338,18 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
     for (int b = 0; b < BCAP; b++) {
         if (b >= B) break;
         const float g_logit = w[b] * (gw[b] - dot);
-        const float x0 = xbT[(size_t)(3 * b) * N + n], x1 = xbT[(size_t)(3 * b + 1) * N + n],
-                    x2 = xbT[(size_t)(3 * b + 2) * N + n];
-        g_xbT[(size_t)(3 * b) * N + n] = -2.0f * x0 * g_logit;
-        g_xbT[(size_t)(3 * b + 1) * N + n] = -2.0f * x1 * g_logit;
-        g_xbT[(size_t)(3 * b + 2) * N + n] = -2.0f * x2 * g_logit;
+        const float x0 = bone_coord(3 * b), x1 = bone_coord(3 * b + 1), x2 = bone_coord(3 * b + 2);
+        const float g0 = -2.0f * x0 * g_logit, g1 = -2.0f * x1 * g_logit, g2 = -2.0f * x2 * g_logit;
+        if (XB_FROM_XYZ) {  // d xyz += A^T d x_bone
+            const float4 r0 = s_map[3 * b], r1 = s_map[3 * b + 1], r2 = s_map[3 * b + 2];
+            acc_p.x += r0.x * g0 + r1.x * g1 + r2.x * g2;
+            acc_p.y += r0.y * g0 + r1.y * g1 + r2.y * g2;
+            acc_p.z += r0.z * g0 + r1.z * g1 + r2.z * g2;
+        } else {
+            g_xbT[(size_t)(3 * b) * N + n] = g0;
+            g_xbT[(size_t)(3 * b + 1) * N + n] = g1;
+            g_xbT[(size_t)(3 * b + 2) * N + n] = g2;
+        }
         if (g_rawT) g_rawT[(size_t)b * N + n] = (rawT[(size_t)b * N + n] > 0.f) ? -0.1f * g_logit : 0.f;
     }
     g_xyz[3 * n] = acc_p.x;
@@ -336,6 +359,19 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
     g_rot[4 * n + 1] = acc_r.x;
     g_rot[4 * n + 2] = acc_r.y;
     g_rot[4 * n + 3] = acc_r.z;
+}
+
+template <bool BACKWARD, typename... Args>
+void launch_lbs_skin(int M, int N, int B, bool from_xyz, hipStream_t stream, Args... args)
+{
+    const dim3 grid((N + 255) / 256), block(256);
+    if (B <= 32) {
+        if (from_xyz) hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, true>), grid, block, 0, stream, M, N, B, args...);
+        else hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, false>), grid, block, 0, stream, M, N, B, args...);
+    } else {
+        if (from_xyz) hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, MAX_BONES, true>), grid, block, 0, stream, M, N, B, args...);
+        else hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, MAX_BONES, false>), grid, block, 0, stream, M, N, B, args...);
+    }
 }
 
 int check(int M, int N, int B)
@@ -377,20 +413,17 @@ extern "C" int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const f
 
 extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                                        const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
-                                       const float* cam_t, float* out_xyz, float* out_rot, int unit_rot, void* stream)
+                                       const float* cam_t, float* out_xyz, float* out_rot, int unit_rot,
+                                       const float* bone_A, const float* bone_c, void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
-    if (!xbT || !se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !out_xyz || !out_rot) return VIDU4D_E_INVALID;
+    if ((bone_A == nullptr) != (bone_c == nullptr) || (bone_A != nullptr) == (xbT != nullptr)) return VIDU4D_E_INVALID;
+    if (!se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !out_xyz || !out_rot) return VIDU4D_E_INVALID;
     (void)hipGetLastError();
-    if (B <= 32)
-        hipLaunchKernelGGL((lbs_skin_kernel<false, 32>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B,
-                           xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, unit_rot);
-    else
-        hipLaunchKernelGGL((lbs_skin_kernel<false, MAX_BONES>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M,
-                           N, B, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, out_xyz, out_rot, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, nullptr, unit_rot);
+    launch_lbs_skin<false>(M, N, B, bone_A != nullptr, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t,
+                           out_xyz, out_rot, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, unit_rot, bone_A, bone_c);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
@@ -398,21 +431,18 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
                                         const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                                         const float* cam_t, const float* g_out_xyz, const float* g_out_rot,
                                         float* g_xbT /*(3B,N)*/, float* g_rawT /*(B,N) or NULL*/, float* g_xyz /*(N,3)*/,
-                                        float* g_rot /*(N,4)*/, int unit_rot, void* stream)
+                                        float* g_rot /*(N,4)*/, int unit_rot, const float* bone_A, const float* bone_c,
+                                        void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
-    if (!xbT || !se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !g_out_xyz || !g_out_rot || !g_xbT || !g_xyz ||
+    if ((bone_A == nullptr) != (bone_c == nullptr) || (bone_A != nullptr) == (xbT != nullptr)) return VIDU4D_E_INVALID;
+    if (!se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !g_out_xyz || !g_out_rot || (xbT && !g_xbT) || !g_xyz ||
         !g_rot || (rawT && !g_rawT))
         return VIDU4D_E_INVALID;
     (void)hipGetLastError();
-    if (B <= 32)
-        hipLaunchKernelGGL((lbs_skin_kernel<true, 32>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N, B,
-                           xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot, g_xbT,
-                           g_rawT, g_xyz, g_rot, unit_rot);
-    else
-        hipLaunchKernelGGL((lbs_skin_kernel<true, MAX_BONES>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, N,
-                           B, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, nullptr, nullptr, g_out_xyz, g_out_rot,
-                           g_xbT, g_rawT, g_xyz, g_rot, unit_rot);
+    launch_lbs_skin<true>(M, N, B, bone_A != nullptr, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t,
+                          (float*)nullptr, (float*)nullptr, g_out_xyz, g_out_rot, g_xbT, g_rawT, g_xyz, g_rot, unit_rot, bone_A,
+                          bone_c);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }

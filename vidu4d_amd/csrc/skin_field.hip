@@ -343,7 +343,7 @@ int check_args(const Vidu4dSkinFieldArgs* a, bool backward)
     if (a->N == 0) return VIDU4D_OK;
     if (!a->xyz || !a->bone_A || !a->bone_c || !a->w_in || !a->b_in || !a->w_out || !a->b_out) return VIDU4D_E_INVALID;
     if (a->D > 1 && (!a->w_hid || !a->b_hid)) return VIDU4D_E_INVALID;
-    if (!backward) return (a->xbT && a->rawT) ? VIDU4D_OK : VIDU4D_E_INVALID;
+    if (!backward) return a->rawT ? VIDU4D_OK : VIDU4D_E_INVALID;  // (xbT may be NULL: a caller that evaluates the bone map itself)
     return (a->g_rawT && a->g_xyz) ? VIDU4D_OK : VIDU4D_E_INVALID;
 }
 

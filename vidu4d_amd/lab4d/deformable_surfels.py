@@ -285,14 +285,19 @@ class DeformableSurfels(GaussianModel):
                     sf_tab = tab.get("skin_field")
                     if sf_tab is None:
                         sf_tab = tab["skin_field"] = prepare_skin_field(sm, A, c0)
-                xbT, rawT = skin_field(self._xyz, bias[0].detach(), sf_tab)
+                # (the bone coordinates themselves are re-evaluated by the skinning kernel from the same (3B, 3) map: the
+                # (3B, N) array and its gradient never cross HBM)
+                bone_map = (sf_tab["bone_A"], sf_tab["bone_c"]) if self.opts.get("fused_bone_map", True) else None
+                xbT, rawT = skin_field(self._xyz, bias[0].detach(), sf_tab, want_xb=bone_map is None)
             else:
+                bone_map = None
                 xbT = torch.addmm(c0[:, None], A, self._xyz.t())
                 rawT = sm.delta_raw_T(xbT, bias[0]) if sm.has_delta else None
             # (the renderer's rotation activation -- F.normalize per frame, 6 launches forward and backward -- is
             # applied inside the kernel: render_frames hands these orientations on as already activated)
             unit = bool(self.opts.get("fused_rot_activation", True))
-            xyz_cam, rot_cam = lbs_skin_apply(xbT, rawT, se3, self._xyz, self._rotation, cq, ct, unit_rot=unit)
+            xyz_cam, rot_cam = lbs_skin_apply(xbT, rawT, se3, self._xyz, self._rotation, cq, ct, unit_rot=unit,
+                                              bone_map=bone_map)
             self.__dict__["_warp_rot_is_unit"] = unit
             skin = delta = None
         else:

@@ -63,61 +63,78 @@ def lbs_apply(skin_prob, se3, xyz, rot, cam_q, cam_t):
 
 
 class _LbsSkinApply(Function):
-    """xbT (3B,N) bone coordinates, rawT (B,N) raw delta-MLP output or None -> softmax skinning weights -> blend ->
-    apply -> camera, for all frames, one kernel per direction (csrc/lbs.hip lbs_skin_kernel)."""
+    """xbT (3B,N) bone coordinates -- or None with the bone map (bone_A (3B,3), bone_c (3B)) of the rest pose: the kernels
+    then evaluate x_bone = A xyz + c themselves --, rawT (B,N) raw delta-MLP output or None -> softmax skinning weights
+    -> blend -> apply -> camera, for all frames, one kernel per direction (csrc/lbs.hip lbs_skin_kernel)."""
 
     @staticmethod
-    def forward(ctx, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, unit_rot=False):
+    def forward(ctx, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, unit_rot=False, bone_A=None, bone_c=None):
         if not xyz.is_cuda:
             raise RuntimeError("lbs_skin_apply: HIP tensors required")
-        for t, name in ((se3_qr, "se3"), (se3_qd, "se3"), (cam_q, "field2cam"), (cam_t, "field2cam")):
+        consts = [(se3_qr, "se3"), (se3_qd, "se3"), (cam_q, "field2cam"), (cam_t, "field2cam")]
+        if bone_A is not None:
+            consts += [(bone_A, "bone map"), (bone_c, "bone map")]
+        for t, name in consts:
             if t.requires_grad:
                 raise RuntimeError(f"lbs_skin_apply: {name} requires grad; the fused path treats it as constant")
         M, B = se3_qr.shape[:2]
         N = xyz.shape[0]
-        if xbT.shape != (3 * B, N) or (rawT is not None and rawT.shape != (B, N)):
-            raise RuntimeError(f"lbs_skin_apply: xbT {tuple(xbT.shape)} / rawT must be (3B, N) / (B, N) with B={B}, N={N}")
-        args = [_c(xbT), None if rawT is None else _c(rawT), _c(se3_qr), _c(se3_qd), _c(xyz), _c(rot), _c(cam_q), _c(cam_t)]
+        if (xbT is None) == (bone_A is None):
+            raise RuntimeError("lbs_skin_apply: pass the bone coordinates xbT OR the bone map (bone_A, bone_c)")
+        if xbT is not None and xbT.shape != (3 * B, N) or (rawT is not None and rawT.shape != (B, N)):
+            raise RuntimeError(f"lbs_skin_apply: xbT / rawT must be (3B, N) / (B, N) with B={B}, N={N}")
+        if bone_A is not None and (bone_A.shape != (3 * B, 3) or bone_c.shape != (3 * B,)):
+            raise RuntimeError(f"lbs_skin_apply: bone map must be (3B, 3) / (3B,) with B={B}")
+        args = [None if xbT is None else _c(xbT), None if rawT is None else _c(rawT), _c(se3_qr), _c(se3_qd), _c(xyz),
+                _c(rot), _c(cam_q), _c(cam_t)]
+        bmap = [None, None] if bone_A is None else [_c(bone_A), _c(bone_c)]
         out_xyz = torch.empty(M, N, 3, dtype=torch.float32, device=xyz.device)
         out_rot = torch.empty(M, N, 4, dtype=torch.float32, device=xyz.device)
         lib = _lib.load()
         ptr = [None if a is None else a.data_ptr() for a in args]
-        _lib.check(lib.vidu4d_lbs_skin_forward(M, N, B, *ptr, out_xyz.data_ptr(), out_rot.data_ptr(), int(unit_rot),
+        bptr = [None if a is None else a.data_ptr() for a in bmap]
+        _lib.check(lib.vidu4d_lbs_skin_forward(M, N, B, *ptr, out_xyz.data_ptr(), out_rot.data_ptr(), int(unit_rot), *bptr,
                                                torch.cuda.current_stream(xyz.device).cuda_stream), "lbs skin forward")
-        ctx.has_raw = rawT is not None
+        ctx.present = [a is not None for a in args + bmap]
         ctx.unit_rot = bool(unit_rot)
-        ctx.save_for_backward(*[a for a in args if a is not None])
+        ctx.save_for_backward(*[a for a in args + bmap if a is not None])
         ctx.dims = (M, N, B)
         return out_xyz, out_rot
 
     @staticmethod
     def backward(ctx, g_xyz_out, g_rot_out):
         M, N, B = ctx.dims
-        saved = list(ctx.saved_tensors)
-        if not ctx.has_raw:
-            saved.insert(1, None)
-        dev = saved[0].device
+        it = iter(ctx.saved_tensors)
+        full = [next(it) if have else None for have in ctx.present]
+        saved, bmap = full[:8], full[8:]
+        has_xb, has_raw = saved[0] is not None, saved[1] is not None
+        dev = saved[4].device
         g_xyz_out = torch.zeros(M, N, 3, device=dev) if g_xyz_out is None else _c(g_xyz_out)
         g_rot_out = torch.zeros(M, N, 4, device=dev) if g_rot_out is None else _c(g_rot_out)
-        g_xbT = torch.empty(3 * B, N, dtype=torch.float32, device=dev)
-        g_rawT = torch.empty(B, N, dtype=torch.float32, device=dev) if ctx.has_raw else None
+        g_xbT = torch.empty(3 * B, N, dtype=torch.float32, device=dev) if has_xb else None
+        g_rawT = torch.empty(B, N, dtype=torch.float32, device=dev) if has_raw else None
         g_xyz = torch.empty(N, 3, dtype=torch.float32, device=dev)
         g_rot = torch.empty(N, 4, dtype=torch.float32, device=dev)
         lib = _lib.load()
         ptr = [None if a is None else a.data_ptr() for a in saved]
-        _lib.check(lib.vidu4d_lbs_skin_backward(M, N, B, *ptr, g_xyz_out.data_ptr(), g_rot_out.data_ptr(), g_xbT.data_ptr(),
+        bptr = [None if a is None else a.data_ptr() for a in bmap]
+        _lib.check(lib.vidu4d_lbs_skin_backward(M, N, B, *ptr, g_xyz_out.data_ptr(), g_rot_out.data_ptr(),
+                                                None if g_xbT is None else g_xbT.data_ptr(),
                                                 None if g_rawT is None else g_rawT.data_ptr(), g_xyz.data_ptr(),
-                                                g_rot.data_ptr(), int(ctx.unit_rot),
+                                                g_rot.data_ptr(), int(ctx.unit_rot), *bptr,
                                                 torch.cuda.current_stream(dev).cuda_stream),
                    "lbs skin backward")
-        return g_xbT, g_rawT, None, None, g_xyz, g_rot, None, None, None
+        return g_xbT, g_rawT, None, None, g_xyz, g_rot, None, None, None, None, None
 
 
-def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False):
+def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False, bone_map=None):
     """xbT (3B,N) Gaussian-bone coordinates; rawT (B,N) raw output of the delta-skin MLP or None; se3 = (qr, qd)
     each (M,B,4), M <= 8; xyz (N,3); rot (N,4); cam_q (M,4), cam_t (M,3).  -> xyz_cam (M,N,3), rot_cam (M,N,4);
-    unit_rot: rot_cam comes out normalised (F.normalize, the renderer's rotation activation, fused in)."""
-    return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot)
+    unit_rot: rot_cam comes out normalised (F.normalize, the renderer's rotation activation, fused in).
+    bone_map = (A (3B,3), c (3B)) with xbT = None (frozen bones): the kernels evaluate x_bone = A xyz + c themselves and
+    the gradient w.r.t. xyz includes that path -- the (3B,N) coordinates and their gradient never cross HBM."""
+    bone_A, bone_c = (None, None) if bone_map is None else bone_map
+    return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot, bone_A, bone_c)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -176,7 +193,7 @@ def _skin_field_args(tab, N, xyz, b_in, **ptrs):
 
 class _SkinField(Function):
     @staticmethod
-    def forward(ctx, xyz, b_in, tab):
+    def forward(ctx, xyz, b_in, tab, want_xb=True):
         if not xyz.is_cuda:
             raise RuntimeError("skin_field: HIP tensors required")
         if b_in.requires_grad:
@@ -184,7 +201,7 @@ class _SkinField(Function):
                                "treats the skinning network as constant")
         N = xyz.shape[0]
         x, b = _c(xyz), _c(b_in).reshape(-1)
-        xbT = torch.empty(3 * tab["B"], N, dtype=torch.float32, device=xyz.device)
+        xbT = torch.empty(3 * tab["B"], N, dtype=torch.float32, device=xyz.device) if want_xb else None
         rawT = torch.empty(tab["B"], N, dtype=torch.float32, device=xyz.device)
         # which hidden units are active, per layer / 32-surfel tile / lane: spares the backward its recomputation
         masks = torch.empty(tab["D"] * 64 * ((N + 31) // 32), dtype=torch.int32, device=xyz.device)
@@ -205,10 +222,11 @@ class _SkinField(Function):
         a = _skin_field_args(tab, N, x, b, g_xbT=g_xbT, g_rawT=g_rawT, g_xyz=g_xyz, relu_masks=masks)
         _lib.check(_lib.load().vidu4d_skin_field_backward(a, torch.cuda.current_stream(x.device).cuda_stream),
                    "skin field backward")
-        return g_xyz, None, None
+        return g_xyz, None, None, None
 
 
-def skin_field(xyz, b_in, tab):
+def skin_field(xyz, b_in, tab, want_xb=True):
     """xyz (N,3) canonical centres; b_in (W,) first-layer bias of the step (SkinningField.frame_bias); tab from
-    prepare_skin_field.  -> xbT (3B,N) Gaussian-bone coordinates, rawT (B,N) raw delta-skin output."""
-    return _SkinField.apply(xyz, b_in, tab)
+    prepare_skin_field.  -> xbT (3B,N) Gaussian-bone coordinates (None when want_xb is False: lbs_skin_apply with
+    bone_map evaluates them itself), rawT (B,N) raw delta-skin output."""
+    return _SkinField.apply(xyz, b_in, tab, want_xb)
