@@ -323,19 +323,19 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
     if (SPLIT && wk.seg >= 0) {
         // partial results of this segment; blend_combine_kernel adds the segments up in list order
         float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
-        for (int ch = 0; ch < 3; ch++) {
-            d[(SG_C + ch) * 256] = s.C[ch];
-            d[(SG_N + ch) * 256] = s.N[ch];
-        }
-        d[SG_D * 256] = s.D;
+        for (int ch = 0; ch < 3; ch++) d[(SG_C + ch) * 256] = s.C[ch];
         d[SG_TEND * 256] = dead ? -1.0f : s.T;
-        d[SG_M1 * 256] = s.dist1;
-        d[SG_M2 * 256] = s.dist2;
-        d[SG_DIST * 256] = s.distortion;
-        d[SG_MED_D * 256] = s.median_depth;
-        d[SG_MED_W * 256] = s.median_weight;
-        d[SG_MED_C * 256] = __uint_as_float(s.median_contributor);
         d[SG_LAST * 256] = __uint_as_float(s.last_contributor);
+        if (!LITE) {  // (LITE: nobody reads the other fields -- blend_combine_kernel<true>, blend_bwd_kernel<true, true>)
+            for (int ch = 0; ch < 3; ch++) d[(SG_N + ch) * 256] = s.N[ch];
+            d[SG_D * 256] = s.D;
+            d[SG_M1 * 256] = s.dist1;
+            d[SG_M2 * 256] = s.dist2;
+            d[SG_DIST * 256] = s.distortion;
+            d[SG_MED_D * 256] = s.median_depth;
+            d[SG_MED_W * 256] = s.median_weight;
+            d[SG_MED_C * 256] = __uint_as_float(s.median_contributor);
+        }
         return;
     }
     if (inside)
@@ -350,6 +350,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
 // where _p is the state at the segment start and a_i, m1_i, m2_i run inside the segment.  Pass 2 used
 // the global accumulated alpha (1 - T) and segment-local moments, which leaves
 //   M2_p * (sum w_i) - 2 M1_p * (sum w_i m_i)      with sum w_i = T_start - T_end.
+// LITE (colour + alpha plane only): the segments hold colour, end transmittance and last contributor, nothing else.
+template <bool LITE>
 __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                            ImageState img, int64_t capacity, int max_seg,
                                                            const float* __restrict__ bg,
@@ -380,18 +382,18 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
         const float T_end = d[SG_TEND * 256];
         T_raw = T_raw * d[SG_TSEG * 256];
         if (T_end < 0.f) continue;  // saturated before this segment
+        for (int ch = 0; ch < 3; ch++) s.C[ch] += d[(SG_C + ch) * 256];
+        s.T = T_end;
+        const uint32_t last = __float_as_uint(d[SG_LAST * 256]);
+        if (last) s.last_contributor = last;
+        if (LITE) continue;
         const float m1 = d[SG_M1 * 256], m2 = d[SG_M2 * 256];
         s.distortion += d[SG_DIST * 256] + (s.dist2 * (T_start - T_end) - 2.0f * s.dist1 * m1);
-        for (int ch = 0; ch < 3; ch++) {
-            s.C[ch] += d[(SG_C + ch) * 256];
-            s.N[ch] += d[(SG_N + ch) * 256];
-        }
+        for (int ch = 0; ch < 3; ch++) s.N[ch] += d[(SG_N + ch) * 256];
         s.D += d[SG_D * 256];
         s.dist1 += m1;
         s.dist2 += m2;
-        s.T = T_end;
-        const uint32_t last = __float_as_uint(d[SG_LAST * 256]), med = __float_as_uint(d[SG_MED_C * 256]);
-        if (last) s.last_contributor = last;
+        const uint32_t med = __float_as_uint(d[SG_MED_C * 256]);
         if (med) {
             s.median_contributor = med;
             s.median_depth = d[SG_MED_D * 256];
@@ -413,6 +415,14 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     for (int q = nseg - 1; q >= 0; q--) {
         float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
         if (d[SG_TEND * 256] < 0.f) continue;
+        if (LITE) {
+            const float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
+            d[(SG_C + 0) * 256] = sufC[0];
+            d[(SG_C + 1) * 256] = sufC[1];
+            d[(SG_C + 2) * 256] = sufC[2];
+            sufC[0] += c0, sufC[1] += c1, sufC[2] += c2;
+            continue;
+        }
         const float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
         const float n0 = d[(SG_N + 0) * 256], n1 = d[(SG_N + 1) * 256], n2 = d[(SG_N + 2) * 256];
         const float dd = d[SG_D * 256], m1 = d[SG_M1 * 256], m2 = d[SG_M2 * 256];
@@ -458,8 +468,9 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     auto kernel = lite ? &blend_fwd_kernel<true, true> : &blend_fwd_kernel<true, false>;
     hipLaunchKernelGGL(kernel, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
                        point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used);
-    hipLaunchKernelGGL(blend_combine_kernel, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x,
-                       grid_y, g.hdr, img, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used);
+    auto combine = lite ? &blend_combine_kernel<true> : &blend_combine_kernel<false>;
+    hipLaunchKernelGGL(combine, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
+                       capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used);
 }
 
 // ---------------------------------------------------------------------------------------------
