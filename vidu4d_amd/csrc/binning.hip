@@ -466,44 +466,41 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
     };
 
     // The order to reproduce is the reference's: stable sort by depth of entries emitted in id order, i.e. (depth, id)
-    // ascending.  Sorting on all of (id bytes, depth bytes) costs 6-7 passes; ties in depth are what the id bytes
-    // are for, and exact fp32 depth ties between two surfels of one tile hardly ever happen.  So: the depth bytes
-    // only (3 effective passes: the exponent byte is constant), then a look for adjacent equal depths.  None (the
-    // usual case): done.  A few: every run of equal depths is put in id order by the thread that finds its start
-    // (runs are disjoint).  Many (degenerate scenes, e.g. all surfels on one plane): the full LSD sequence is run
-    // on the list as it stands -- an LSD sort does not care about the order it starts from.
-    constexpr uint32_t TIE_SERIAL_MAX = 48;
-    __shared__ uint32_t s_ties;
+    // ascending.  Sorting on all of (id bytes, depth bytes) costs 6-7 passes, and the id bytes are only there for exact
+    // fp32 depth ties between surfels of one tile: rare in short lists, a few dozen pairs per list in 25 k-entry ones
+    // (birthday statistics over ~2^21 depth values), whole clouds when densification has just cloned surfels.  So: the
+    // depth bytes only (3 effective passes: the exponent byte is constant and skipped), then every run of equal depths
+    // is put in id order in place by the thread that finds its start -- runs are disjoint, and permuting ids inside a
+    // run changes no depth word, so the other threads' run-start tests are unaffected.  Only a run longer than
+    // TIE_RUN_MAX (degenerate scenes: a plane of surfels at one depth) sends the list, as it stands, through the full
+    // LSD sequence, which does not care about the order it starts from.
+    constexpr int TIE_RUN_MAX = 32;
+    __shared__ uint32_t s_long_run;
     for (int pass = 0; pass < 4; pass++) radix_pass(32 + 8 * pass);
-    if (threadIdx.x == 0) s_ties = 0;
+    if (threadIdx.x == 0) s_long_run = 0;
     __syncthreads();
-    {
-        uint32_t local = 0;
-        for (int i = threadIdx.x + 1; i < n; i += THREADS) local += (uint32_t)(A[i] >> 32) == (uint32_t)(A[i - 1] >> 32);
-        if (local) atomicAdd(&s_ties, local);
-    }
-    __syncthreads();
-    const uint32_t ties = s_ties;
-    if (ties > TIE_SERIAL_MAX) {
-        for (int pass = 0; pass < id_bytes + 4; pass++) radix_pass(8 * (pass < id_bytes ? pass : 4 + pass - id_bytes));
-    } else if (ties) {
-        for (int i = threadIdx.x; i + 1 < n; i += THREADS) {
-            const uint32_t d = (uint32_t)(A[i] >> 32);
-            if ((uint32_t)(A[i + 1] >> 32) != d || (i > 0 && (uint32_t)(A[i - 1] >> 32) == d)) continue;  // not a run start
-            int j = i + 1;
-            while (j + 1 < n && (uint32_t)(A[j + 1] >> 32) == d) j++;
-            for (int a = i + 1; a <= j; a++) {  // insertion sort of A[i..j] (equal depths: the keys order by id)
-                const uint64_t key = A[a];
-                int b = a - 1;
-                while (b >= i && A[b] > key) {
-                    A[b + 1] = A[b];
-                    b--;
-                }
-                A[b + 1] = key;
-            }
+    for (int i = threadIdx.x; i + 1 < n; i += THREADS) {
+        const uint32_t d = (uint32_t)(A[i] >> 32);
+        if ((uint32_t)(A[i + 1] >> 32) != d || (i > 0 && (uint32_t)(A[i - 1] >> 32) == d)) continue;  // not a run start
+        int j = i + 1;
+        while (j + 1 < n && j - i < TIE_RUN_MAX && (uint32_t)(A[j + 1] >> 32) == d) j++;
+        if (j - i >= TIE_RUN_MAX) {
+            s_long_run = 1;
+            continue;
         }
-        __syncthreads();
+        for (int a = i + 1; a <= j; a++) {  // insertion sort of A[i..j] (equal depths: the keys order by id)
+            const uint64_t key = A[a];
+            int b = a - 1;
+            while (b >= i && A[b] > key) {
+                A[b + 1] = A[b];
+                b--;
+            }
+            A[b + 1] = key;
+        }
     }
+    __syncthreads();
+    if (s_long_run)
+        for (int pass = 0; pass < id_bytes + 4; pass++) radix_pass(8 * (pass < id_bytes ? pass : 4 + pass - id_bytes));
     for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t key = A[i];
         point_list[start + i] = (uint32_t)key;
