@@ -7,9 +7,9 @@
 // MI355X design (DESIGN.md "blend kernels"):
 //   * one 256-thread workgroup (4 wave64) per 16x16 tile; each wave owns an 8x8 pixel quadrant
 //     (compact footprint, 32-byte row segments on output);
-//   * workgroup -> tile mapping is XCD-aware: workgroup b is dispatched to XCD b % 8, so XCD x gets
-//     the contiguous band of tiles [x*per, (x+1)*per); neighbouring tiles, which share most of
-//     their surfels, then hit the same 4 MiB L2;
+//   * workgroup b takes tile tile_order[b]: longest list first (binning.hip builds the schedule); workgroups are
+//     dispatched in index order and round-robin over the 8 XCDs, so the long tiles start first, spread over the
+//     XCDs, and the short ones fill in behind them;
 //   * the tile's depth-sorted surfel list is staged 256 (forward) / 128 (backward) entries at a
 //     time into LDS as 80-byte records (five ds_write_b128 per lane, conflict-free at a 20-dword
 //     stride) and read back with wave-uniform (broadcast) ds_read_b128;
@@ -18,14 +18,17 @@
 //     wave then iterates only over the set bits with scalar bit tricks (s_ff1 / s_and): list entries
 //     that cannot reach a wave's 64 pixels are never evaluated.  The pair evaluation itself is
 //     branch-free; the only branches in the loop are wave-uniform;
-//   * backward: all 64 lanes of a wave work on the same list entry, so the 18 gradient components
-//     are first reduced across the wave with a reduce-scatter (gfx950 lane swaps across the 16-lane rows,
-//     DPP inside a row), then combined across the 4 waves with LDS float atomics, and only one global
-//     atomic per (entry, component) is issued per 128-entry batch.  The reference issues up to 16 global
-//     atomics per (pixel, entry).  Measured alternatives to the register reduce-scatter (round 2,
-//     DESIGN.md §4.3): an LDS transposition, exact-f32 MFMA contraction of the pixel axis
-//     (tools/experiments/blend_bwd_mfma_contraction.hip.txt) and per-lane LDS atomics for sparse entries
-//     -- none was faster.
+//   * backward: all 64 lanes of a wave work on the same list entry, so the 16 main gradient components are first
+//     reduced across the wave with a reduce-scatter (gfx950 lane swaps across the 16-lane rows, DPP inside a row),
+//     then combined across the 4 waves with LDS float atomics (16 distinct addresses), and one global atomic per
+//     (entry, component) leaves the workgroup per 128-entry batch, lane-contiguous over the batch's 80-byte records.
+//     The reference issues up to 16 global atomics per (pixel, entry).  Measured alternatives to the register
+//     reduce-scatter (round 2): an LDS transposition, exact-f32 MFMA contraction of the pixel axis
+//     (tools/experiments/blend_bwd_mfma_contraction.hip.txt), per-lane LDS atomics for sparse entries, pair
+//     compaction, a 4x4-block row walk -- none was faster;
+//   * long lists are blended segment-parallel (SPLIT instances: transmittance pre-pass, per-segment blend, in-order
+//     combine); callers that read only colour + alpha plane get the LITE instances (aux_planes), which carry
+//     nothing else.
 #include <algorithm>
 
 #include "surfel_state.h"
