@@ -138,3 +138,18 @@ def test_camera_mlp_init_from_prior():
     assert loss < 2e-5
     q, t = cam.get_vals()
     assert torch.allclose(qt.quaternion_translation_to_se3(q, t), rt, atol=0.05)
+
+
+def test_frozen_table_bias_per_instance_is_the_per_step_evaluation(ref):
+    """DeformableSurfels tabulates the delta-skin MLP's first-layer bias per instance code while the networks are
+    frozen (the mean time code behind it is an MLP over all frames): row i == SkinningField.frame_bias(None, [i])."""
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    nets, a, warp, cam = ref
+    warp.load_state_dict(nets["warp"], strict=True)
+    sm = warp.skinning_model
+    with torch.no_grad():
+        tab = DeformableSurfels._frame_bias_per_instance(sm, "cpu")
+        n_inst = sm.delta_field.inst_embedding.mapping.weight.shape[0]
+        assert tab.shape[0] == n_inst and n_inst == len(nets["offsets"]) - 1
+        for i in range(n_inst):
+            close(tab[i:i + 1], sm.frame_bias(None, torch.tensor([i]), 1, "cpu"), rtol=1e-6, atol=1e-7)
