@@ -689,6 +689,44 @@ def test_alpha_only_blend_equals_the_full_blend(gpu_device, monkeypatch, F, spli
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), (what, float((a - b).abs().max()))
 
 
+def test_trainer_extensions_at_the_headline_size(gpu_device):
+    """200 k surfels, 512 x 512, two stacked frames: canonical parameters + alpha-only blend (what Stage3Trainer runs)
+    against the activated full call -- identical radii, colour and alpha plane; gradients w.r.t. the raw parameters those
+    autograd derives through exp / sigmoid / cat from the full backward with zero-filled dead planes."""
+    import diff_surfel_rasterization as dsr
+    from vidu4d_amd.synthetic import frame_motion
+    dev = gpu_device
+    W = H = 512
+    sc = make_scene(200_000, W, H).to(dev)
+    frames = [frame_motion(sc, f, 120) for f in (3, 77)]
+    views = [dsr.GaussianRasterizationSettings(H, W, sc.tanfovx, sc.tanfovy, sc.bg, 1.0, sc.viewmatrix, sc.projmatrix,
+                                               sc.sh_degree, sc.campos, False, False)] * 2
+    dc, do = make_upstream_grads(W, H)
+    dcs = torch.stack([dc.to(dev), (0.5 * dc).to(dev)], 1)
+    dos = torch.zeros(8, 2, H, W, device=dev)
+    dos[1, 0], dos[1, 1] = do[1].to(dev), (2.0 * do[1]).to(dev)
+    M3, R4 = torch.stack([f.means3D for f in frames]), torch.stack([f.rotations for f in frames])
+    raw = lambda: [t.clone().requires_grad_(True) for t in (  # noqa: E731
+        torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)), sc.scales.log(), sc.shs[:, :1].contiguous(),
+        sc.shs[:, 1:].contiguous(), M3, R4)]
+    o, s, hd, hr, m3, r4 = raw()
+    full = dsr.rasterize_frames(m3, torch.zeros_like(m3, requires_grad=True), torch.cat((hd, hr), 1), torch.sigmoid(o),
+                                torch.exp(s), r4, views)
+    torch.autograd.backward([full[0], full[2]], [dcs, dos])
+    g_full = [t.grad for t in (o, s, hd, hr, m3, r4)]
+    o, s, hd, hr, m3, r4 = raw()
+    lite = dsr.rasterize_frames(m3, torch.zeros_like(m3, requires_grad=True), hd, o, s, r4, views, sh_rest=hr,
+                                raw_params=True, aux_planes=dsr.AUX_ALPHA)
+    torch.autograd.backward([lite[0], lite[2]], [dcs, torch.full_like(dos, float("nan")).index_copy_(
+        0, torch.tensor([1], device=dev), dos[1:2])])
+    assert torch.equal(full[1], lite[1]) and torch.equal(full[0], lite[0]) and torch.equal(full[2][1], lite[2][1])
+    assert float(lite[2][[0, 2, 3, 4, 5, 6, 7]].detach().abs().max()) == 0.0
+    for a, b, what in zip([t.grad for t in (o, s, hd, hr, m3, r4)], g_full,
+                          ("opacity logits", "log-scales", "features_dc", "features_rest", "means3D", "rotations")):
+        assert torch.isfinite(a).all(), what
+        assert torch.allclose(a, b, rtol=5e-4, atol=5e-6 * float(b.abs().max())), (what, float((a - b).abs().max()))
+
+
 def test_stacked_frames_without_surfels(gpu_device):
     """P == 0 through the stacked entry point: background only, as rasterize_points.cu:105 for one frame."""
     import diff_surfel_rasterization as dsr
