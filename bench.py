@@ -391,14 +391,16 @@ def main():
         sync()
         _lib.profile_enable(False)
         mode["streams"] = bool(args.frame_streams)
-    for _ in range(args.warmup):
-        step()
-    sync()
     # (the cyclic collector is kept out of the timed regions: a generation-2 pass over torch's Python objects takes
-    # milliseconds, as long as several steps)
+    # milliseconds, as long as several steps.  Collected BEFORE the warm-up: between the warm-up and the timed region
+    # there is then nothing but the barrier + synchronize the contract prescribes -- with the collection in between the
+    # GPU sat idle for its duration and the first timed region measured 2.5 % below the repeats that follow it.)
     import gc
     gc.collect()
     gc.disable()
+    for _ in range(args.warmup):
+        step()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
