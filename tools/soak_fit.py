@@ -49,6 +49,7 @@ def run(tag, **opts):
         for p in mod.parameters():
             p.requires_grad_(False)
     tr = Stage3Trainer(s)
+    tr.current_steps = int(os.environ.get("SOAK_STEP0", "0"))  # > 8000: the normal-consistency regulariser is on
     hist, counts = [], []
     t0 = time.perf_counter()
     for step in range(STEPS):
