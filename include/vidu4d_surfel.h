@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 12
+#define VIDU4D_SURFEL_ABI 13
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -135,6 +135,15 @@ typedef struct Vidu4dSurfelForwardArgs {
      * gives, bit for bit; the other planes come out as zeros, and the state kept for the backward holds no distortion
      * moments and no median contributor.  Any other value: everything is computed. */
     int aux_planes;
+    /* ---- speculation for the segment-parallel blend (extension; only with segment_split != 0 and aux_planes ==
+     * VIDU4D_AUX_ALPHA, ignored otherwise).  != 0: the caller expects that NO pixel of the frame saturates (transmittance
+     * stays above 1e-4: Stage-3 frames early in a fit).  The transmittance pre-pass of the segment-parallel blend is then
+     * skipped: every segment is blended from T = 1 and scaled by the product of its predecessors in the combine pass
+     * (colour is linear in the start transmittance; without saturation no threshold depends on it).  If some pixel does
+     * come within 0.1 % of the threshold, word 6 of the geometry buffer (`truncated`) is set -- the frame's outputs are then
+     * not those of the exact blend: blend it again with assume_unsaturated = 0.  Word 8 of the geometry buffer holds the
+     * bits of the frame's smallest final transmittance (whatever the mode): what a caller bases the expectation on. */
+    int assume_unsaturated;
 } Vidu4dSurfelForwardArgs;
 #define VIDU4D_AUX_ALPHA 0x02
 #define VIDU4D_SURFEL_MAX_FRAMES 8

@@ -727,6 +727,73 @@ def test_trainer_extensions_at_the_headline_size(gpu_device):
         assert torch.allclose(a, b, rtol=5e-4, atol=5e-6 * float(b.abs().max())), (what, float((a - b).abs().max()))
 
 
+def _concentrated_scene(dev, opacity):
+    sc = make_scene(12000, 64, 48, seed=44, sigma_px=5.0)
+    sc.means3D[:, :2] *= 0.2     # everything into a few tiles: lists of several thousand entries (split into segments)
+    sc.opacities[:] = opacity
+    return sc.to(dev)
+
+
+def _alpha_only_call(sc, dev, dc, d_alpha):
+    from vidu4d_amd import _C, _lib
+    empty = torch.empty(0, device=dev)
+    out = _C.rasterize_gaussians(sc.bg, sc.means3D, empty, sc.opacities, sc.scales, sc.rotations, 1.0, empty, sc.viewmatrix,
+                                 sc.projmatrix, sc.tanfovx, sc.tanfovy, sc.height, sc.width, sc.shs, 3, sc.campos, False, False,
+                                 aux_planes=_lib.AUX_ALPHA)
+    R, color, others, radii, geom, binning, img = out
+    do = torch.zeros(8, sc.height, sc.width, device=dev)
+    do[1] = d_alpha
+    g = _C.rasterize_gaussians_backward(sc.bg, sc.means3D, radii, empty, sc.scales, sc.rotations, 1.0, empty, sc.viewmatrix,
+                                        sc.projmatrix, sc.tanfovx, sc.tanfovy, dc, do, sc.shs, 3, sc.campos, geom, R, binning,
+                                        img, False, aux_planes=_lib.AUX_ALPHA)
+    header = geom[:64].view(torch.int32).cpu()
+    ncon = _C.read_state("n_contrib", None, geom, binning, img, sc.num_surfels, sc.width, sc.height, torch.int32,
+                         2 * sc.width * sc.height)
+    return color, others, radii, ncon, [t for t in g if t.numel()], header
+
+
+def test_speculated_segment_blend_equals_the_exact_one_when_nothing_saturates(gpu_device, monkeypatch):
+    """assume_unsaturated (segment-parallel alpha-only blend without its transmittance pre-pass: segments blended from
+    T = 1, scaled in the combine): on a frame in which no pixel saturates the images and gradients are those of the exact
+    blend up to fp32 re-association, contributor counts identical, `truncated` stays 0 and the header reports the
+    frame's smallest transmittance."""
+    from vidu4d_amd import _C
+    dev = gpu_device
+    sc = _concentrated_scene(dev, 0.004)
+    dc, do = make_upstream_grads(sc.width, sc.height)
+    dc, d_alpha = dc.to(dev), do[1].to(dev)
+    monkeypatch.setattr(_C, "_SPLIT", "1")
+    exact = _alpha_only_call(sc, dev, dc, d_alpha)
+    monkeypatch.setattr(_C, "_spec_force", True)
+    spec = _alpha_only_call(sc, dev, dc, d_alpha)
+    ranges = exact[3]
+    assert int(exact[5][3]) > 0, "the scene must have split tiles"          # Header::num_segments
+    assert int(exact[5][6]) == 0 and int(spec[5][6]) == 0                    # Header::truncated
+    min_T = exact[5][8:9].view(torch.float32).item()
+    assert 4e-4 < min_T < 0.9 and abs(spec[5][8:9].view(torch.float32).item() - min_T) < 1e-5 * min_T + 1e-7
+    assert abs(min_T - float(1.0 - exact[1][1].max())) < 1e-6
+    assert torch.equal(exact[2], spec[2]) and torch.equal(exact[3], spec[3])  # radii, contributor counts
+    for a, b, what in ((spec[0], exact[0], "colour"), (spec[1][1], exact[1][1], "alpha plane")):
+        assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(b.abs().max())), (what, float((a - b).abs().max()))
+    for i, (a, b) in enumerate(zip(spec[4], exact[4])):
+        assert torch.allclose(a, b, rtol=2e-4, atol=5e-6 * float(b.abs().max())), (i, float((a - b).abs().max()))
+
+
+def test_speculated_segment_blend_reports_saturation(gpu_device, monkeypatch):
+    """The same call on a frame whose pixels DO saturate: `truncated` is raised (the caller blends the frame again without
+    the assumption -- _C.check_deferred() reports it like a missed segment limit)."""
+    from vidu4d_amd import _C
+    dev = gpu_device
+    sc = _concentrated_scene(dev, 0.6)
+    dc, do = make_upstream_grads(sc.width, sc.height)
+    monkeypatch.setattr(_C, "_SPLIT", "1")
+    exact = _alpha_only_call(sc, dev, dc.to(dev), do[1].to(dev))
+    assert int(exact[5][6]) == 0 and exact[5][8:9].view(torch.float32).item() < 1.001e-4
+    monkeypatch.setattr(_C, "_spec_force", True)
+    spec = _alpha_only_call(sc, dev, dc.to(dev), do[1].to(dev))
+    assert int(spec[5][6]) == 1
+
+
 def test_stacked_frames_without_surfels(gpu_device):
     """P == 0 through the stacked entry point: background only, as rasterize_points.cu:105 for one frame."""
     import diff_surfel_rasterization as dsr

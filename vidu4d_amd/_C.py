@@ -43,6 +43,16 @@ _depth_hint: dict = {}
 # transmittance pass then skips the tail of long lists that saturate early.  A frame that needed more
 # sets Header::truncated, check_deferred() reports it like an overflow, and the next calls run unlimited.
 _unlimited: dict = {}
+# Speculation for the segment-parallel alpha-only blend (Vidu4dSurfelForwardArgs::assume_unsaturated): deferred callers
+# whose previous frames of the shape kept every pixel's transmittance well above the saturation threshold skip the
+# transmittance pre-pass; a frame in which a pixel comes near it after all sets Header::truncated like a missed
+# segment limit (the step is replayed exactly) and speculation rests for SPEC_REST calls.
+_SPEC = os.environ.get("VIDU4D_SURFEL_SPEC", "1") == "1"
+SPEC_MIN_T = 4e-4    # smallest final transmittance of the previous frames above which a frame is speculated on
+SPEC_REST = 20
+_min_T_hint: dict = {}
+_no_spec: dict = {}
+_spec_force = False   # (tests: speculate whatever the hints say)
 _pinned: dict = {}
 
 
@@ -105,6 +115,14 @@ class graph_capture_mode:
         return False
 
 
+def _note_min_T(slot, key):
+    """Header word 8: bits of the frame's smallest final transmittance -> a slowly recovering minimum per shape."""
+    import struct
+    t = struct.unpack("f", struct.pack("I", int(slot[8]) & 0xFFFFFFFF))[0]
+    prev = _min_T_hint.get(key)
+    _min_T_hint[key] = t if prev is None else min(t, 0.5 * (prev + t))
+
+
 def check_slots(frames) -> bool:
     ok = True
     for slot, stat, cap, key in frames:
@@ -112,8 +130,10 @@ def check_slots(frames) -> bool:
         _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
         if stat is not None:
             _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
+        _note_min_T(slot, key)
         if int(slot[6]):
             _unlimited[key] = 4
+            _no_spec[key] = SPEC_REST
             ok = False
         ok = ok and n <= cap
     return ok
@@ -132,8 +152,10 @@ def check_deferred() -> bool:
         _capacity_hint[key] = max(int(n * 1.25) + 4096, int(0.98 * _capacity_hint.get(key, 0)))
         if stat is not None:
             _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
-        if int(slot[6]):  # the segment limit cut a tile short: this frame is incomplete, the next ones run unlimited
-            _unlimited[key] = 4
+        _note_min_T(slot, key)
+        if int(slot[6]):  # the segment limit cut a tile short (or a speculated frame saturated): this frame is incomplete,
+            _unlimited[key] = 4   # the next ones run unlimited and unspeculated
+            _no_spec[key] = SPEC_REST
             ok = False
         ok = ok and n <= cap
     _pending.clear()
@@ -148,7 +170,7 @@ def _pinned_slot(device):
     k = sum(1 for p in _pending if p[4][2] == str(device) and p[5] == sid) if _deferred else 0
     key = (str(device), sid, k)
     if key not in _pinned:
-        _pinned[key] = torch.zeros(8, dtype=torch.int32).pin_memory()  # Header words 0..7 (surfel_state.h)
+        _pinned[key] = torch.zeros(16, dtype=torch.int32).pin_memory()  # Header words 0..15 (surfel_state.h)
     return _pinned[key]
 
 
@@ -263,6 +285,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         a.depth_used = stat[0].data_ptr()
     else:
         a.segment_split = int(_SPLIT == "1")
+    if a.segment_split and int(aux_planes) == _lib.AUX_ALPHA and not debug:
+        if _spec_force:
+            a.assume_unsaturated, a.segment_split = 1, 1
+        elif _SPEC and _deferred:
+            if _no_spec.get(key, 0) > 0:
+                _no_spec[key] -= 1
+            elif _min_T_hint.get(key, 0.0) > SPEC_MIN_T:
+                a.assume_unsaturated, a.segment_split = 1, 1  # (every segment counts when nothing saturates: no limit)
 
     if P == 0:  # rasterize_points.cu:105: nothing is launched, outputs are zeros
         out_color.zero_()
@@ -292,7 +322,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             # that it also carries the `truncated` flag of a segment-limited split
             _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
                        "surfel forward (run)")
-            slot.copy_(geom[:32].view(torch.int32), non_blocking=True)
+            slot.copy_(geom[:64].view(torch.int32), non_blocking=True)
             ev = None
             if not _graph_mode:
                 ev = torch.cuda.Event()
@@ -301,7 +331,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             binning._vidu4d_capacity = cap
             binning._vidu4d_split = int(a.segment_split)
             return cap, out_color, out_others, radii, geom, binning, img
-        slot.copy_(geom[:32].view(torch.int32), non_blocking=True)
+        slot.copy_(geom[:64].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),

@@ -166,6 +166,18 @@ __device__ __forceinline__ void report_depth(uint32_t* depth_used, uint32_t last
     if ((threadIdx.x & 63) == 0 && v > *depth_used) atomicMax(depth_used, v);
 }
 
+// Smallest final transmittance of the frame (bits of a non-negative float order like unsigned integers).
+__device__ __forceinline__ void report_min_T(Header* hdr, float T, bool inside)
+{
+    uint32_t v = inside ? __float_as_uint(fmaxf(T, 0.f)) : 0x3f800000u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o < v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v < hdr->min_T_bits) atomicMin(&hdr->min_T_bits, v);
+}
+
 __device__ __forceinline__ void write_pixel(const FwdPixel& s, size_t HW, size_t pid, const float* bg, float* final_T,
                                             uint32_t* n_contrib, float* out_color, float* out_others)
 {
@@ -235,17 +247,24 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
 
 // The blend (pass 2 of the segment-parallel forward when SPLIT).  LITE: colour + alpha plane only (surfel_math.h,
 // fwd_accumulate<true>); the other auxiliary planes, the distortion moments and the median contributor come out as zeros.
+//
+// spec (SPLIT && LITE only; Vidu4dSurfelForwardArgs::assume_unsaturated): no transmittance pre-pass ran.  A segment is
+// blended from T = 1 -- colour is linear in the start transmittance and, as long as no pixel saturates, no decision
+// depends on it -- and stores its colour and its transmittance PRODUCT; blend_combine_kernel scales by the product of
+// the predecessors and reports a pixel that did come near the saturation threshold (the frame is then blended again).
 template <bool SPLIT, bool LITE>
-__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
+__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        int64_t capacity, int max_seg, const float* __restrict__ rec,
                                                        const float* __restrict__ bg, float* __restrict__ seg_data,
                                                        float* __restrict__ out_color, float* __restrict__ out_others,
-                                                       uint32_t* depth_used)
+                                                       uint32_t* depth_used, int spec)
 {
     __shared__ float4 s_rec[FWD_BATCH * 5];
     __shared__ unsigned long long s_mask[4][4];
     const bool overflow = (int64_t)hdr->num_rendered > capacity;
+    if (SPLIT && LITE && spec && blockIdx.x == 0 && threadIdx.x == 0)  // (what blend_seg_T_kernel does when it runs)
+        hdr->split_used = !overflow && hdr->num_segments > 0;
     const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     TileCoord tc = wk.tc;
@@ -270,12 +289,15 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
         todo = min(todo - begin, SEG_LEN);
         // transmittance left by the earlier segments of this tile; below T_EPS the pixel saturated
         // inside one of them (the running product only decreases), and this segment adds nothing
-        const uint32_t first = wk.slot - (uint32_t)wk.seg;
-        for (int q = 0; q < wk.seg; q++)
-            s.T = s.T * seg_data[((size_t)(first + q) * SEG_FLOATS + SG_TSEG) * 256 + threadIdx.x];
-        dead = wk.seg > 0 && s.T < T_EPS;
-        done = done || dead;
+        if (!(LITE && spec)) {
+            const uint32_t first = wk.slot - (uint32_t)wk.seg;
+            for (int q = 0; q < wk.seg; q++)
+                s.T = s.T * seg_data[((size_t)(first + q) * SEG_FLOATS + SG_TSEG) * 256 + threadIdx.x];
+            dead = wk.seg > 0 && s.T < T_EPS;
+            done = done || dead;
+        }
     }
+    bool sat_local = false;  // (spec: a sample was refused for saturation although the walk started from T = 1)
     for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const bool have = (int)threadIdx.x < todo;
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
                     if (okA) {
                         const float4 q3 = s_rec[ja * 5 + 3], q4 = s_rec[ja * 5 + 4];
                         const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate<LITE>(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = true;
+                        if (!fwd_accumulate<LITE>(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = sat_local = true;
                     }
                 }
                 okB = okB && !done;
@@ -317,7 +339,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
                     if (okB) {
                         const float4 q3 = s_rec[jb * 5 + 3], q4 = s_rec[jb * 5 + 4];
                         const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate<LITE>(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = true;
+                        if (!fwd_accumulate<LITE>(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = sat_local = true;
                     }
                 }
             }
@@ -329,6 +351,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
         for (int ch = 0; ch < 3; ch++) d[(SG_C + ch) * 256] = s.C[ch];
         d[SG_TEND * 256] = dead ? -1.0f : s.T;
         d[SG_LAST * 256] = __uint_as_float(s.last_contributor);
+        if (LITE && spec) d[SG_TSEG * 256] = sat_local ? 0.f : s.T;  // the segment's own product (0: must not be trusted)
         if (!LITE) {  // (LITE: nobody reads the other fields -- blend_combine_kernel<true>, blend_bwd_kernel<true, true>)
             for (int ch = 0; ch < 3; ch++) d[(SG_N + ch) * 256] = s.N[ch];
             d[SG_D * 256] = s.D;
@@ -344,6 +367,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x
     if (inside)
         write_pixel(s, plane, frame_base + (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
     report_depth(depth_used, s.last_contributor);
+    report_min_T(hdr, s.T, inside);
 }
 
 // Pass 3: adds the segments of a split tile up in list order.  The colour / depth / normal / moment
@@ -360,7 +384,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
                                                            const float* __restrict__ bg,
                                                            float* __restrict__ seg_data,
                                                            float* __restrict__ out_color,
-                                                           float* __restrict__ out_others, uint32_t* depth_used)
+                                                           float* __restrict__ out_others, uint32_t* depth_used, int spec)
 {
     if ((int64_t)hdr->num_rendered > capacity || blockIdx.x >= hdr->num_split_pos) return;
     const int tile = (int)img.tile_order[blockIdx.x];
@@ -379,9 +403,22 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     FwdPixel s;
     float T_raw = 1.0f;
+    bool spec_failed = false;
     for (int q = 0; q < nseg; q++) {
-        const float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
+        float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
         const float T_start = T_raw;
+        if (LITE && spec) {
+            // the segment was blended from T = 1: scale by what its predecessors leave; a pixel that comes within 0.1 % of
+            // the saturation threshold (or saturated inside a segment: product stored as 0) means the frame needs the exact blend
+            const float T_end = T_start * d[SG_TSEG * 256];
+            for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(T_start, d[(SG_C + ch) * 256], s.C[ch]);
+            if (!(T_end >= T_EPS * 1.001f)) spec_failed = true;
+            d[SG_TEND * 256] = T_end;
+            T_raw = s.T = T_end;
+            const uint32_t last = __float_as_uint(d[SG_LAST * 256]);
+            if (last) s.last_contributor = last;
+            continue;
+        }
         const float T_end = d[SG_TEND * 256];
         T_raw = T_raw * d[SG_TSEG * 256];
         if (T_end < 0.f) continue;  // saturated before this segment
@@ -410,6 +447,8 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     // the caller's segment limit cut this tile short and this pixel had not saturated yet: its values are
     // incomplete -- tell the caller (who blends the frame again without the limit)
     if (nseg < nseg_all && px < W && py < H && T_raw >= T_EPS) hdr->truncated = 1;
+    if (spec_failed && px < W && py < H) hdr->truncated = 1;
+    report_min_T(hdr, s.T, px < W && py < H);
 
     // For the segment-parallel backward: replace each segment's partials by the sums over the segments
     // BEHIND it (what the back-to-front recurrences of the backward have accumulated when they reach
@@ -419,7 +458,11 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
         float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
         if (d[SG_TEND * 256] < 0.f) continue;
         if (LITE) {
-            const float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
+            float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
+            if (spec) {  // (the stored colours are relative to the segment's start transmittance)
+                const float T_start = q > 0 ? seg_data[((size_t)(first + q - 1) * SEG_FLOATS + SG_TEND) * 256 + threadIdx.x] : 1.0f;
+                c0 *= T_start, c1 *= T_start, c2 *= T_start;
+            }
             d[(SG_C + 0) * 256] = sufC[0];
             d[(SG_C + 1) * 256] = sufC[1];
             d[(SG_C + 2) * 256] = sufC[2];
@@ -451,14 +494,15 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
 
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
-                      float* out_others, uint32_t* depth_used, bool lite, hipStream_t stream)
+                      float* out_others, uint32_t* depth_used, bool lite, bool assume_unsaturated, hipStream_t stream)
 {
+    const int spec = (assume_unsaturated && lite && split && capacity > 0) ? 1 : 0;
     const int tiles = total_tiles(cam), grid_y = cam.grid_y * cam.frames;  // (stacked frames: a taller tile grid)
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
         auto kernel = lite ? &blend_fwd_kernel<false, true> : &blend_fwd_kernel<false, false>;
         hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
-                           point_list, capacity, 0, g.rec, background, b.seg_data, out_color, out_others, depth_used);
+                           point_list, capacity, 0, g.rec, background, b.seg_data, out_color, out_others, depth_used, 0);
         return;
     }
     // upper bounds; the device knows the exact counts.  The combine runs over ALL schedule positions: the
@@ -466,14 +510,15 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     // number of positions that hold split tiles is not bounded by capacity / SPLIT_MIN.
     const int segs = (int)seg_capacity(capacity);
     const int split_tiles = tiles;
-    hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y,
-                       g.hdr, img, point_list, capacity, max_seg, g.rec, b.seg_data);
+    if (!spec)
+        hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y,
+                           g.hdr, img, point_list, capacity, max_seg, g.rec, b.seg_data);
     auto kernel = lite ? &blend_fwd_kernel<true, true> : &blend_fwd_kernel<true, false>;
     hipLaunchKernelGGL(kernel, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
-                       point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used);
+                       point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used, spec);
     auto combine = lite ? &blend_combine_kernel<true> : &blend_combine_kernel<false>;
     hipLaunchKernelGGL(combine, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
-                       capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used);
+                       capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used, spec);
 }
 
 // ---------------------------------------------------------------------------------------------

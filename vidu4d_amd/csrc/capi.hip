@@ -328,7 +328,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
         // segment_split: 0 off, 1 on, k > 1: on, at most k segments per tile (Header::truncated reports a miss)
         const int max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
         launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, max_seg, a->background, a->out_color, a->out_others,
-                         a->depth_used, a->aux_planes == VIDU4D_AUX_ALPHA, stream);
+                         a->depth_used, a->aux_planes == VIDU4D_AUX_ALPHA, a->assume_unsaturated != 0, stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
     return VIDU4D_OK;

@@ -127,6 +127,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    if (idx == 0) a.geom.hdr->min_T_bits = 0x3f800000u;  // 1.0f (the header is fresh memory)
     if (idx >= a.P) return;
     const FrameIndex fi = frame_index(a.cam, idx);
     const Camera cam = load_camera(a.cam, fi.frame);
@@ -148,7 +149,10 @@ __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(Pre
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
     const int frame_tiles = a.cam.grid_x * a.cam.grid_y, num_tiles = frame_tiles * a.cam.frames;
     for (int t = threadIdx.x; t < num_tiles; t += BIN_THREADS) s_hist[t] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.geom.hdr->scan_arrivals = 0;  // (the header is fresh memory)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (the header is fresh memory)
+        a.geom.hdr->scan_arrivals = 0;
+        a.geom.hdr->min_T_bits = 0x3f800000u;  // 1.0f
+    }
     __syncthreads();
     const int first = blockIdx.x * BIN_THREADS * a.iters;
     for (int it = 0; it < a.iters; it++) {

@@ -61,7 +61,8 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t split_used;    // the forward blended long tiles segment-parallel (seg_data is valid)
     uint32_t truncated;     // a pixel was still unsaturated after the last segment the caller allowed (max_seg)
     uint32_t scan_arrivals; // workgroups of tile_scan_fused_kernel that have finished their columns (reset per forward)
-    uint32_t pad[56];
+    uint32_t min_T_bits;    // bits of the smallest final transmittance of the frame (atomic min; reset per forward)
+    uint32_t pad[55];
 };
 
 struct GeomState {
@@ -260,7 +261,7 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
 // previous frames went saves the rest of pass 1); Header::truncated is set if that was not enough
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
-                      float* out_others, uint32_t* depth_used, bool lite, hipStream_t stream);
+                      float* out_others, uint32_t* depth_used, bool lite, bool assume_unsaturated, hipStream_t stream);
 
 struct BackwardArgs {
     CameraParams cam;
