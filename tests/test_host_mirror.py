@@ -281,3 +281,30 @@ def test_train_cli_flag_parsing_and_mesh_sampling(tmp_path):
     on_square = (np.abs(pts[:, 2]) < 1e-6) & (pts[:, 0] >= 0) & (pts[:, 0] <= 1) & (pts[:, 1] >= 0) & (pts[:, 1] <= 1)
     assert on_square.mean() > 0.99                      # area-weighted: the tiny triangle gets ~1e-6 of the samples
     assert abs((pts[on_square, 0] > pts[on_square, 1]).mean() - 0.5) < 0.05   # both halves of the quad
+
+
+def test_speculation_bookkeeping_of_the_deferred_check():
+    """_C's host-side policy for assume_unsaturated (no GPU involved): the header's smallest-transmittance word feeds a
+    slowly recovering minimum per image shape, and a frame that reports `truncated` rests speculation."""
+    import struct
+    import torch
+    from vidu4d_amd import _C
+    key = ("test-shape",)
+    bits = lambda x: struct.unpack("i", struct.pack("f", x))[0]  # noqa: E731
+    for d in (_C._min_T_hint, _C._no_spec, _C._unlimited, _C._capacity_hint):
+        d.pop(key, None)
+    slot = torch.zeros(16, dtype=torch.int32)
+    slot[0], slot[8] = 1000, bits(0.25)
+    assert _C.check_slots([(slot, None, 2000, key)]) is True
+    assert abs(_C._min_T_hint[key] - 0.25) < 1e-7 and _C._min_T_hint[key] > _C.SPEC_MIN_T
+    slot[8] = bits(1e-5)                       # a frame with saturated pixels: the hint drops at once ...
+    assert _C.check_slots([(slot, None, 2000, key)]) is True
+    assert _C._min_T_hint[key] < _C.SPEC_MIN_T
+    slot[8] = bits(0.25)                       # ... and recovers only halfway per frame
+    _C.check_slots([(slot, None, 2000, key)])
+    assert 0.12 < _C._min_T_hint[key] < 0.13
+    slot[6] = 1                                # truncated: the step is replayed, speculation rests
+    assert _C.check_slots([(slot, None, 2000, key)]) is False
+    assert _C._no_spec[key] == _C.SPEC_REST and _C._unlimited[key] == 4
+    for d in (_C._min_T_hint, _C._no_spec, _C._unlimited, _C._capacity_hint):
+        d.pop(key, None)
