@@ -26,7 +26,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def run(st, dL_dcolor, dL_dothers, cull=True):
+def run(st, dL_dcolor, dL_dothers, cull=True, lite=False):
     """Runs the emulated pipeline on the oracle's inputs / binning (st = oracle forward state)."""
     L = lib()
     inp = st["_inputs"]
@@ -44,12 +44,13 @@ def run(st, dL_dcolor, dL_dothers, cull=True):
     out["color"] = np.zeros((3, H, W), np.float32)
     out["others"] = np.zeros((8, H, W), np.float32)
     L.emul_render_fwd(C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]), _p(out["rec"]), _p(inp["bg"]),
-                      _p(out["final_T"]), _p(out["n_contrib"]), _p(out["color"]), _p(out["others"]), C.c_int(int(cull)))
+                      _p(out["final_T"]), _p(out["n_contrib"]), _p(out["color"]), _p(out["others"]), C.c_int(int(cull)),
+                      C.c_int(int(lite)))
     acc = np.zeros((P, 20), np.float64)
     dc = np.ascontiguousarray(dL_dcolor, np.float32)
     do = np.ascontiguousarray(dL_dothers, np.float32)
     L.emul_render_bwd(C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]), _p(out["rec"]), _p(inp["bg"]),
-                      _p(out["final_T"]), _p(out["n_contrib"]), _p(dc), _p(do), _p(acc), C.c_int(int(cull)))
+                      _p(out["final_T"]), _p(out["n_contrib"]), _p(dc), _p(do), _p(acc), C.c_int(int(cull)), C.c_int(int(lite)))
     accf = acc.astype(np.float32)
     out["acc"] = accf
     g = dict(dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dmeans2D=np.zeros((P, 3), np.float32),

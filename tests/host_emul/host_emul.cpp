@@ -51,7 +51,7 @@ extern "C" void emul_preprocess(int P, int D, int M, const float* means3D, const
 
 extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec,
                                 const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                                float* out_others, int cull)
+                                float* out_others, int cull, int lite)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const size_t HW = (size_t)W * H;
@@ -67,7 +67,9 @@ extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint
                 PairEval e;
                 if (cull && (pixx < r[R_BOX] || pixx > r[R_BOX + 2] || pixy < r[R_BOX + 1] || pixy > r[R_BOX + 3])) continue;
                 if (!eval_pair_flat(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
-                if (!fwd_accumulate(s, e, r + R_NX, r + R_RGB, i - r0 + 1)) break;
+                // (lite: the colour + alpha-plane instance the blend kernels run for aux_planes == VIDU4D_AUX_ALPHA)
+                if (!(lite ? fwd_accumulate<true>(s, e, r + R_NX, r + R_RGB, i - r0 + 1)
+                           : fwd_accumulate<false>(s, e, r + R_NX, r + R_RGB, i - r0 + 1))) break;
             }
             const size_t pid = (size_t)py * W + px;
             final_T[pid] = s.T; final_T[pid + HW] = s.dist1; final_T[pid + 2 * HW] = s.dist2;
@@ -82,7 +84,8 @@ extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint
 
 extern "C" void emul_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib,
-                                const float* dL_dcolor, const float* dL_dothers, double* acc /*[P][20]*/, int cull)
+                                const float* dL_dcolor, const float* dL_dothers, double* acc /*[P][20]*/, int cull,
+                                int lite)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const size_t HW = (size_t)W * H;
@@ -100,6 +103,11 @@ extern "C" void emul_render_bwd(int W, int H, const uint32_t* ranges, const uint
             for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = dL_dothers[pid + (2 + c) * HW];
             s.dL_dmedian_depth = dL_dothers[pid + 5 * HW]; s.dL_dreg = dL_dothers[pid + 6 * HW];
             s.dL_dmax_dweight = dL_dothers[pid + 7 * HW];
+            if (lite) {  // (as blend_bwd_kernel<*, true>: the dead planes and the state behind them are not read)
+                s.final_D = s.final_D2 = 0.f; s.median_contributor = 0;
+                s.dL_ddepth = s.dL_dmedian_depth = s.dL_dreg = s.dL_dmax_dweight = 0.f;
+                for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = 0.f;
+            }
             s.T = s.T_final; s.final_A = 1.0f - s.T_final;
             s.bg_dot_dpixel = bg[0] * s.dL_dpixel[0] + bg[1] * s.dL_dpixel[1] + bg[2] * s.dL_dpixel[2];
             const uint32_t r0 = ranges[2 * tile];
@@ -110,8 +118,13 @@ extern "C" void emul_render_bwd(int W, int H, const uint32_t* ranges, const uint
                 if (cull && (pixx < r[R_BOX] || pixx > r[R_BOX + 2] || pixy < r[R_BOX + 1] || pixy > r[R_BOX + 3])) continue;
                 if (!eval_pair_flat(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
                 float g[ACC_FLOATS];
-                bwd_pair(s, e, r + 6, r[R_OPAC], r + R_NX, r + R_RGB, pixx, pixy,
-                         (uint32_t)ci + 1 == s.median_contributor, g);
+                if (lite) {
+                    const PairGrad pg = bwd_pair_core<true>(s, e, r + R_NX, r + R_RGB, false);
+                    bwd_pair_geometry<true>(s, e, pg, r + 6, r[R_OPAC], pixx, pixy, g);
+                } else {
+                    bwd_pair(s, e, r + 6, r[R_OPAC], r + R_NX, r + R_RGB, pixx, pixy,
+                             (uint32_t)ci + 1 == s.median_contributor, g);
+                }
                 for (int k = 0; k < ACC_FLOATS; k++) acc[(size_t)id * ACC_FLOATS + k] += (double)g[k];
             }
         }

@@ -54,3 +54,30 @@ def test_contribution_box_is_conservative(seed):
     b = emul.run(st, dc.numpy(), do.numpy(), cull=False)
     for k in ("color", "others", "n_contrib", "final_T", "acc"):
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("case", ["ragged", "deg2", "huge", "init_opacity"])
+def test_alpha_only_instances_equal_the_full_math_on_zero_planes(case):
+    """The LITE instances of the blend arithmetic (fwd_accumulate<true>, bwd_pair_core<true>, bwd_pair_geometry<true>:
+    what the kernels run for aux_planes == VIDU4D_AUX_ALPHA), host-compiled: colour, alpha plane, transmittance and
+    last contributor are bit-identical to the full instances, every other plane is zero, and the per-surfel gradient
+    accumulators equal the full backward's for upstream gradients that are zero on the dead planes -- against the
+    oracle's analytic backward as well."""
+    sc = make_case(case)
+    st = oracle_forward(sc)
+    dc, do = make_upstream_grads(sc.width, sc.height)
+    do = do.clone()
+    do[[0, 2, 3, 4, 5, 6, 7]] = 0.0
+    full = emul.run(st, dc.numpy(), do.numpy())
+    do_nan = do.numpy().copy()
+    do_nan[[0, 2, 3, 4, 5, 6, 7]] = np.nan   # (the dead planes are never read)
+    lite = emul.run(st, dc.numpy(), do_nan, lite=True)
+    assert np.array_equal(lite["color"], full["color"]) and np.array_equal(lite["others"][1], full["others"][1])
+    assert np.array_equal(lite["final_T"][0], full["final_T"][0]) and np.array_equal(lite["n_contrib"][0], full["n_contrib"][0])
+    assert not lite["others"][[0, 2, 3, 4, 5, 6, 7]].any() and not lite["final_T"][1:].any() and not lite["n_contrib"][1].any()
+    assert full["others"][0].any()
+    scale = np.abs(full["acc"]).max(axis=0) + 1e-30
+    assert (np.abs(lite["acc"] - full["acc"]) <= 2e-6 * scale).all(), np.abs(lite["acc"] - full["acc"]).max(axis=0) / scale
+    g = so.backward(st, dc, do)
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert_close(k, lite["grads"][k], g[k])
