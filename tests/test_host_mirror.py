@@ -308,3 +308,34 @@ def test_speculation_bookkeeping_of_the_deferred_check():
     assert _C._no_spec[key] == _C.SPEC_REST and _C._unlimited[key] == 4
     for d in (_C._min_T_hint, _C._no_spec, _C._unlimited, _C._capacity_hint):
         d.pop(key, None)
+
+
+def test_depth_only_sort_with_tie_fix_up_is_the_reference_order():
+    """The tile sort's algorithm (csrc/binning.hip), restated in numpy: LSD passes on the four depth bytes of keys that
+    arrive in ARBITRARY order (the emission order inside a group is not deterministic), then every run of equal depths
+    put in id order (runs longer than the cap fall back to the full (id bytes, depth bytes) sequence) == the reference's
+    stable sort by depth of id-ordered entries, i.e. ascending (depth, id) -- for few ties, clone clouds and one long run."""
+    rng = np.random.default_rng(5)
+
+    def product_order(keys, run_cap=32):
+        k = keys.copy()
+        for shift in (32, 40, 48, 56):                       # stable counting passes on the depth bytes
+            k = k[np.argsort((k >> np.uint64(shift)) & np.uint64(255), kind="stable")]
+        d = (k >> np.uint64(32)).astype(np.uint64)
+        starts = np.flatnonzero(np.r_[True, d[1:] != d[:-1]])
+        ends = np.r_[starts[1:], len(k)]
+        if (ends - starts).max() > run_cap:                  # a long run: the full LSD sequence on the list as it stands
+            for shift in (0, 8, 16, 24, 32, 40, 48, 56):
+                k = k[np.argsort((k >> np.uint64(shift)) & np.uint64(255), kind="stable")]
+            return k
+        for a, b in zip(starts, ends):
+            if b - a > 1:
+                k[a:b] = np.sort(k[a:b])                     # equal depths: the 64-bit keys order by id
+        return k
+
+    for n, n_depths in ((5000, 10 ** 9), (5000, 2000), (3000, 40), (900, 1)):
+        depth = rng.integers(0x40000000, 0x40000000 + n_depths, size=n, dtype=np.uint64)   # float bits of [2, 4)
+        ids = rng.permutation(n).astype(np.uint64)           # distinct ids, arbitrary arrival order
+        keys = (depth << np.uint64(32)) | ids
+        want = np.sort(keys)                                 # ascending (depth, id)
+        assert np.array_equal(product_order(keys), want), (n, n_depths)
