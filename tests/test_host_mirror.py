@@ -339,3 +339,46 @@ def test_depth_only_sort_with_tie_fix_up_is_the_reference_order():
         keys = (depth << np.uint64(32)) | ids
         want = np.sort(keys)                                 # ascending (depth, id)
         assert np.array_equal(product_order(keys), want), (n, n_depths)
+
+
+def test_speculated_segment_blend_algorithm_in_numpy():
+    """The algorithm behind assume_unsaturated (csrc/blend.hip), restated for one pixel in fp32 numpy: segments blended
+    from T = 1 and scaled by the running product of their predecessors == the sequential front-to-back blend while the
+    transmittance stays above the saturation threshold; when it does not, the combine's check fires (the frame is then
+    blended exactly)."""
+    rng = np.random.default_rng(9)
+    T_EPS, SEG = np.float32(1e-4), 512
+
+    def sequential(alpha, col):
+        T, C, last = np.float32(1), np.zeros(3, np.float32), 0
+        for i, (a, c) in enumerate(zip(alpha, col)):
+            test_T = np.float32(T * np.float32(1 - a))
+            if test_T < T_EPS:
+                break
+            C = (C + c * np.float32(a * T)).astype(np.float32)
+            T, last = test_T, i + 1
+        return C, T, last
+
+    def speculated(alpha, col):
+        T_run, C, last, failed = np.float32(1), np.zeros(3, np.float32), 0, False
+        for s0 in range(0, len(alpha), SEG):
+            C_loc, T_loc, last_loc, sat = *sequential(alpha[s0:s0 + SEG], col[s0:s0 + SEG]), False
+            if last_loc < len(alpha[s0:s0 + SEG]):
+                sat = True                                   # a sample was refused although the walk started from T = 1
+            T_end = np.float32(T_run * (np.float32(0) if sat else T_loc))
+            C = (C + T_run * C_loc).astype(np.float32)
+            failed |= not (T_end >= T_EPS * np.float32(1.001))
+            if last_loc:
+                last = s0 + last_loc
+            T_run = T_end
+        return C, T_run, last, failed
+
+    for n, a_max, expect_fail in ((3000, 0.002, False), (1800, 0.004, False), (3000, 0.02, True), (700, 0.9, True)):
+        alpha = rng.uniform(0.0, a_max, size=n).astype(np.float32)
+        col = rng.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+        C0, T0, last0 = sequential(alpha, col)
+        C1, T1, last1, failed = speculated(alpha, col)
+        assert failed == expect_fail, (n, a_max, T0)
+        if not failed:
+            assert last1 == last0 == n
+            assert abs(T1 - T0) <= 2e-6 * T0 and np.abs(C1 - C0).max() <= 2e-6 * np.abs(C0).max()
