@@ -31,21 +31,30 @@ def _worker(rank, world, port, out):
         m._rotation.data = torch.nn.functional.normalize(torch.randn(200, 4, generator=torch.Generator().manual_seed(1)), dim=1)
         tr = Stage3Trainer(m)
         assert tr.world == world
-        # rank-dependent "frame" gradients
+        # rank-dependent "frame" gradients on everything a loss of this path reaches; SH degree 1: only the first three
+        # rest rows can have a gradient (the kernels write zeros above them), and only those cross the wire
+        m.active_sh_degree = 1
+        assert tr.live_sh_rows() == 3 and tr._packs_rest()
+        assert not any(p is m._regist_feat for p in tr.exchanged_params())
+
+        def frame_grads(r):
+            gg = torch.Generator().manual_seed(100 + r)
+            gs = [torch.randn(q.shape, generator=gg) * 1e-3 for q in tr.exchanged_params()]
+            for q, t in zip(tr.exchanged_params(), gs):
+                if q is m._features_rest:
+                    t[:, 3:] = 0.0
+            return gs
         g = torch.Generator().manual_seed(100 + rank)
-        local = [torch.randn(p.shape, generator=g) * 1e-3 for p in tr.surfel_params()]
-        for p, gr in zip(tr.surfel_params(), local):
+        for p, gr in zip(tr.exchanged_params(), frame_grads(rank)):
             p.grad = gr.clone()
+        m._regist_feat.grad = torch.full_like(m._regist_feat, float(rank + 1))   # stays local: nothing exchanges it
         tr.allreduce_gradients()
-        want = []
-        for i, p in enumerate(tr.surfel_params()):
-            acc = torch.zeros_like(p)
-            for r in range(world):
-                gg = torch.Generator().manual_seed(100 + r)
-                gs = [torch.randn(q.shape, generator=gg) * 1e-3 for q in tr.surfel_params()]
-                acc += gs[i]
-            want.append(acc / world)
-        ok_grad = all(torch.allclose(p.grad, w, atol=1e-7) for p, w in zip(tr.surfel_params(), want))
+        assert tr._flat.numel() == sum(p.numel() for p in tr.exchanged_params()) - 200 * 12 * 3
+        all_g = [frame_grads(r) for r in range(world)]
+        want = [sum(all_g[r][i] for r in range(world)) / world for i in range(len(tr.exchanged_params()))]
+        ok_grad = all(torch.allclose(p.grad, w, atol=1e-7) for p, w in zip(tr.exchanged_params(), want))
+        ok_grad = ok_grad and bool((m._regist_feat.grad == float(rank + 1)).all())
+        m._regist_feat.grad = None
         tr.gs_optimizer.step()
         # densification statistics: local, then reduced on use
         n = m._xyz.shape[0]
@@ -141,7 +150,7 @@ def _train_worker(rank, world, port, out):
             gathered = [torch.zeros_like(sig) for _ in range(world)]
             dist.all_gather(gathered, sig)
             identical = all(torch.equal(gathered[0], t) for t in gathered)
-        out[rank] = (same, identical, m._xyz.shape[0], norms)
+        out[rank] = (same, identical, m._xyz.shape[0], norms, [p.detach().clone() for p in tr.surfel_params()])
     finally:
         dist.destroy_process_group()
 
@@ -156,7 +165,54 @@ def test_full_train_steps_keep_two_gloo_replicas_identical():
     mp.spawn(_train_worker, args=(world, port, out), nprocs=world, join=True)
     assert len(out) == world
     for r in range(world):
-        same, identical, n, norms = out[r]
+        same, identical, n, norms, _ = out[r]
         assert same and identical, "replicas diverged"
         assert all(np.isfinite(norms))
     assert out[0][2] == out[1][2] and out[0][2] != 150, "the densify step did not change the surfel count"
+
+
+def test_two_rank_step_equals_the_one_rank_step_over_the_same_frames(monkeypatch):
+    """The convention the exchange implements: every rank back-propagates the loss of ITS frames, the gradients are
+    summed over the ranks and divided by the world size (DDP's mean, lab4d/engine/trainer.py:126-131), then clip,
+    densify and Adam run identically everywhere.  So two ranks with two frames each must end where ONE process ends
+    that back-propagates the two frame pairs one after the other into the same gradient buffer, halves it, and
+    finishes the step -- same surfels through three steps including a densify / prune, up to fp32 summation order."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker, args=(world, port, out), nprocs=world, join=True)
+    got = out[0][4]
+
+    from vidu4d_amd.gs import gaussian_renderer as gr
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    monkeypatch.setattr(gr, "GaussianRasterizer", _TorchRasterizer)
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    opts = dict(fg_motion="gs-bob", densify_from_iter=0, densification_interval=2, densify_grad_threshold=1e-9,
+                opacity_reset_interval=1000, frame_streams=False)
+    m = DeformableSurfels(opts, num_frames=8, device="cpu")
+    n = 150
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    m.init_from_points(0.25 * d / np.linalg.norm(d, axis=1, keepdims=True), rng.uniform(size=(n, 3)).astype(np.float32))
+    with torch.no_grad():
+        m._opacity.fill_(1.0)
+        m._opacity[:20] = -10.0
+    tr = Stage3Trainer(m, opts)
+    assert tr.world == 1
+    for step in range(3):
+        if step % 1000 == 0:
+            m.oneupSHdegree()
+        tr.begin_gradients()
+        for rank in range(world):
+            ids = [(2 * (step * world + rank)) % 8, (2 * (step * world + rank) + 1) % 8]
+            tr._forward_backward(synthetic_batch(m, ids, 32, 32, seed=step), step)   # gradients accumulate
+            tr.gather_densification_stats(step)
+        for p in tr.exchanged_params():
+            p.grad.div_(world)
+        tr.finish_step(step)
+    want = [p.detach() for p in tr.surfel_params()]
+    assert [tuple(a.shape) for a in got] == [tuple(b.shape) for b in want]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(b.abs().max()) + 1e-9), float((a - b).abs().max())

@@ -90,6 +90,8 @@ def load_checkpoint(load_path: str, model, trainer=None, map_location=None, rese
             "initialised bones and cameras.  Build the model with the checkpoint's frame_info (number of videos "
             "and frames), train the networks (--gs_optim_warp=True) or pass allow_random_networks=True.")
     if trainer is not None:  # fresh optimizer over the re-created parameters, step counter from the file
-        trainer.__init__(model, trainer.cfg.__dict__ | {"gs_optim_warp": trainer.optim_warp})
+        # (the trainer's FULL option dict: num_rounds / iters_per_round / optim_warp_neus_iters size the networks'
+        # schedule and are not among _Args' defaults; a trainer that loaded a checkpoint is a resumed one, trainer.py:37)
+        trainer.__init__(model, trainer.opts | {"gs_optim_warp": trainer.optim_warp}, is_resumed=True)
         trainer.current_steps = 0 if reset_steps else int(ckpt.get("current_steps", 0))
     return ckpt

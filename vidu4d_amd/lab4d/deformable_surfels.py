@@ -209,7 +209,9 @@ class DeformableSurfels(GaussianModel):
         tab = self.__dict__.get("_warp_table")
         if tab is None or tab["version"] != version:
             with torch.no_grad():
-                ids = torch.arange(self.num_frames, device=self._xyz.device)
+                # frame ids are RAW ids (vidloader.stage3_batch: frame_map[idx] + frame_offset_raw[vid]; the time
+                # embeddings are raw-indexed, nets.TimeEmbedding): the table covers every raw frame, not just the kept ones
+                ids = torch.arange(int(self.frame_offset_raw[-1]), device=self._xyz.device)
                 t_art, rest_art = self.warp.articulation.get_vals_and_mean(ids)
                 se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
                 cq, ct = self.camera_mlp.get_vals(ids)

@@ -79,9 +79,14 @@ def compute_losses(rendered: dict, batch: dict, step: int, cfg) -> dict:
 
 
 class Stage3Trainer:
-    def __init__(self, model: DeformableSurfels, opts: dict | None = None):
+    def __init__(self, model: DeformableSurfels, opts: dict | None = None, is_resumed: bool | None = None):
         self.model = model
-        self.cfg = _Args(opts or model.opts)
+        # the FULL option dict is kept (checkpoint.load_checkpoint re-initialises from it: num_rounds, iters_per_round,
+        # optim_warp_neus_iters are not among _Args' defaults)
+        self.opts = dict(opts or model.opts)
+        self.cfg = _Args(self.opts)
+        # trainer.py:37: a run that starts from a checkpoint (Stage-3 on a Stage-2 checkpoint always does)
+        self.is_resumed = bool(self.opts.get("load_path", "")) if is_resumed is None else bool(is_resumed)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.current_steps = 0
@@ -109,12 +114,15 @@ class Stage3Trainer:
         m.optimizer = self.gs_optimizer
         self._flat = None
         self._pending_reduce = None
+        self._rest_slot = None      # (N, k, 3) view of the flat buffer while only k < 15 SH rest rows are exchanged
+        self._net_slots = []        # the networks' places in the flat buffer (gs_optim_warp=True)
+        self._chunk_split = None    # where the second collective starts
         # --gs_optim_warp=False (the README's Stage-3 command): warp and camera networks come from the
         # Stage-2 checkpoint and are never stepped (trainer.py:592-598).  Upstream still back-propagates
         # into them; freezing them is results-equivalent for the surfels up to the gradient clip (upstream's
         # check_grad, :861-869, puts the unused warp gradients into the norm it clips by -- DESIGN.md §5) and skips
         # the weight-gradient GEMMs and the (M,N,B,.) broadcast reductions of the warp backward.
-        o = opts or model.opts
+        o = self.opts
         self.optim_warp = bool(o.get("gs_optim_warp", False))
         self.optim_warp_from = int(o.get("optim_warp_neus_iters", 12000))
         net_params = [(n, prm) for mod_name, mod in (("warp", m.warp), ("camera_mlp", m.camera_mlp))
@@ -133,10 +141,24 @@ class Stage3Trainer:
                 lrs.append(c.learning_rate * (10.0 if any(n.endswith(e[1:]) or e in n for e in explicit) else 1.0))
             total = max(2, int(o.get("num_rounds", 1)) * int(o.get("iters_per_round", 200)))
             self.optimizer = torch.optim.AdamW(groups, lr=c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4)
+            # trainer.py:268-275: a resumed run starts the networks at the full rate and decays to lr / 5; a fresh one
+            # warms up from lr / 25 over two rounds
+            if self.is_resumed:
+                div_factor, final_div_factor, pct_start = 1.0, 5.0, 0.0
+            else:
+                div_factor, final_div_factor = 25.0, 1.0
+                pct_start = min(0.5, 2.0 / max(1, int(o.get("num_rounds", 1))))
             self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
-                self.optimizer, lrs, total, pct_start=min(0.5, 2.0 / max(1, int(o.get("num_rounds", 1)))),
-                cycle_momentum=False, anneal_strategy="linear", div_factor=25.0, final_div_factor=1.0)
+                self.optimizer, lrs, total, pct_start=pct_start, cycle_momentum=False, anneal_strategy="linear",
+                div_factor=div_factor, final_div_factor=final_div_factor)
         self._net_params = [prm for _, prm in net_params]
+        self.iters_per_round = max(1, int(o.get("iters_per_round", 200)))
+        # Upstream zeroes the networks' gradients only when their optimizer steps and at the start of a round
+        # (trainer.py:449, :592-598): until optim_warp_neus_iters they ACCUMULATE over the steps of a round and enter
+        # check_grad's clip norm (:861-869), which scales the surfel gradients too.  Reproduced: the per-step network
+        # gradients (after the exchange) are added to these buffers; a parameter autograd never touched keeps
+        # grad = None (AdamW then skips it, weight decay included).
+        self._net_accum = [None] * len(self._net_params)
 
     # ---- the path's only exchange
     def surfel_params(self):
@@ -146,25 +168,77 @@ class Stage3Trainer:
             ps.append(m.learnable_bkgd)
         return ps
 
+    def live_sh_rows(self) -> int:
+        """Rows of `_features_rest` (N, 15, 3) that can receive a gradient: the bands up to the active SH degree
+        (forward.cu:20-71 reads (deg + 1)^2 coefficients; the backward writes zeros above them)."""
+        m = self.model
+        return min(int(m._features_rest.shape[1]), (int(m.active_sh_degree) + 1) ** 2 - 1)
+
     def exchanged_params(self):
-        """Everything the ranks must agree on after a step: the surfels, and the networks when they train."""
-        return self.surfel_params() + (self._net_params if self.optim_warp else [])
+        """Everything whose gradient the ranks must agree on: the surfel tensors a loss of this path reaches -- NOT
+        `_regist_feat` (only the feature-matching losses --rgb_loss_only drops read it: its gradient is None on every
+        rank and the optimizer skips it) -- the small ones first, the SH rest bands last (the two chunks of the
+        exchange), and the networks when they train."""
+        m = self.model
+        ps = [m._xyz, m._features_dc, m._opacity, m._scaling, m._rotation]
+        if self.cfg.gs_learnable_bg:
+            ps.append(m.learnable_bkgd)
+        ps.append(m._features_rest)
+        return ps + (self._net_params if self.optim_warp else [])
+
+    def _packs_rest(self) -> bool:
+        """More than one rank and SH bands above the active degree: their gradients are exact zeros on every rank
+        (no kernel writes them), so only the live rows [:, :k] cross the wire -- packed into the flat buffer before the
+        collective, unpacked after it.  Results-identical; at degree 0 (the first 1000 steps) 45 of 58 floats per
+        surfel stay home."""
+        return self.world > 1 and self.live_sh_rows() < int(self.model._features_rest.shape[1])
 
     def bind_flat_gradients(self):
         """Makes every exchanged parameter's .grad a view of ONE persistent fp32 buffer and zeroes it (this is
         the step's zero_grad): autograd then accumulates straight into the buffer the all-reduce, the norm for
         the clip and the fused Adam read -- no gather / scatter copies around the collective.  Re-bound every
-        step because densify / prune re-create the surfel parameters."""
+        step because densify / prune re-create the surfel parameters.  Layout: [xyz | f_dc | opacity | scaling |
+        rotation | bg] (chunk 0) [f_rest (live rows only while the SH degree is below 3) | networks] (chunk 1)."""
         ps = self.exchanged_params()
-        n = sum(p.numel() for p in ps)
+        rest = self.model._features_rest
+        pack = self._packs_rest()
+        k = self.live_sh_rows()
+        net_ids = {id(p) for p in self._net_params} if self.optim_warp else set()
+        sizes = [(rest.shape[0] * k * rest.shape[2]) if (p is rest and pack) else p.numel() for p in ps]
+        n = sum(sizes)
         if self._flat is None or self._flat.numel() != n or self._flat.device != ps[0].device:
             self._flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
-        elif not self.__dict__.pop("_flat_is_zero", False):  # (the one-launch Adam left it zero-filled)
-            self._flat.zero_()
+            fresh = True
+        else:
+            fresh = self.__dict__.pop("_flat_is_zero", False)  # (the one-launch Adam left every gradient zero-filled)
+            if not fresh:
+                self._flat.zero_()
+        self.__dict__.pop("_flat_is_zero", None)
         off = 0
-        for p in ps:
-            p.grad = self._flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self._rest_slot = None
+        self._net_slots = []
+        self._chunk_split = None
+        for p, sz in zip(ps, sizes):
+            if p is rest:
+                self._chunk_split = off
+            if p is rest and pack:
+                # the full-size gradient the kernels write lives outside the flat buffer; its live rows are copied in
+                # and out around the collective
+                full = self.__dict__.get("_rest_full")
+                if full is None or full.shape != rest.shape or full.device != rest.device:
+                    full = self._rest_full = torch.zeros_like(rest)
+                elif not fresh:
+                    full.zero_()
+                p.grad = full
+                self._rest_slot = self._flat[off:off + sz].view(rest.shape[0], k, rest.shape[2])
+            elif id(p) in net_ids:
+                # fresh per-step gradient (None when autograd never reaches the parameter); it is packed into the
+                # buffer for the collective and then ADDED to the round's accumulated gradient (_fold_net_gradients)
+                p.grad = None
+                self._net_slots.append(self._flat[off:off + sz].view_as(p))
+            else:
+                p.grad = self._flat[off:off + sz].view_as(p)
+            off += sz
         return self._flat
 
     def _flat_needed(self):
@@ -175,6 +249,8 @@ class Stage3Trainer:
 
     def begin_gradients(self):
         """The step's zero_grad: the flat buffer where it is needed (bind_flat_gradients), else plain `grad = None`."""
+        if self.optim_warp and self.current_steps % self.iters_per_round == 0:
+            self._net_accum = [None] * len(self._net_params)   # trainer.py:449: zero_grad at the start of a round
         if self._flat_needed():
             return self.bind_flat_gradients()
         self._flat = None
@@ -182,42 +258,100 @@ class Stage3Trainer:
             p.grad = None
         return None
 
+    def _bound(self, p) -> bool:
+        if p is self.model._features_rest and self._rest_slot is not None:
+            return p.grad is self.__dict__.get("_rest_full")
+        if self.optim_warp and any(p is q for q in self._net_params):
+            return True  # (packed by hand below)
+        return p.grad is not None and p.grad.untyped_storage().data_ptr() == self._flat.untyped_storage().data_ptr()
+
     def allreduce_gradients(self, async_op: bool = False):
-        """Sum of the flat gradient buffer over the ranks (the mean is folded into clip_gradients).  With async_op
-        the collective is left in flight (RCCL runs it on its own stream) and `wait_gradients` joins it, so that
-        work that does not read the gradients -- the densification statistics -- overlaps it."""
+        """Sum of the flat gradient buffer over the ranks, issued as TWO collectives (the small tensors, then the SH
+        rest bands + networks): `wait_gradients` joins them one after the other, so that the norm of chunk 0 is taken
+        while chunk 1 is still on the wire.  The mean (/ world) is folded into the clip coefficient where the one-launch
+        Adam applies it, else applied in wait_gradients.  With async_op the collectives are left in flight (RCCL runs
+        them on its own stream) and work that does not read the gradients -- the densification statistics -- overlaps
+        them."""
         if self.world == 1:
             return
-        if self._flat is None or any(p.grad is None or p.grad.untyped_storage().data_ptr() != self._flat.untyped_storage().data_ptr()
-                                     for p in self.exchanged_params()):
+        if self._flat is None or not all(self._bound(p) for p in self.exchanged_params()):
             # gradients that were not produced into the flat buffer (a caller that set them by hand): gather them
             ps = self.exchanged_params()
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
+            nets = {id(p) for p in self._net_params} if self.optim_warp else set()
+            grads = [p.grad for p in ps]
             self.bind_flat_gradients()
             for p, g_ in zip(ps, grads):
-                p.grad.copy_(g_)
-        self._pending_reduce = dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True)
+                if id(p) in nets:
+                    p.grad = g_
+                elif g_ is not None:
+                    p.grad.copy_(g_)
+        if self._rest_slot is not None and self._rest_slot.numel():
+            self._rest_slot.copy_(self.model._features_rest.grad[:, :self._rest_slot.shape[1]])
+        for p, slot in zip(self._net_params if self.optim_warp else [], self._net_slots):
+            if p.grad is not None:
+                slot.copy_(p.grad)
+        split = self._chunk_split if self._chunk_split else 0
+        chunks = [c for c in (self._flat[:split], self._flat[split:]) if c.numel()]
+        self._pending_reduce = [(c, dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True)) for c in chunks]
         if not async_op:
             self.wait_gradients()
 
     def wait_gradients(self):
-        if self._pending_reduce is not None:
-            self._pending_reduce.wait()
-            self._pending_reduce = None
-            self._flat.div_(self.world)
+        """Joins the exchange.  Leaves the MEAN over the ranks in the gradients -- or, where the one-launch Adam
+        consumes them (_fold_clip_into_adam), the SUM together with `_mean_scale = 1 / world`, which clip_gradients
+        folds into the coefficient (one pass over 46 MB less) -- and the squared norm of every chunk, taken as the
+        chunk arrives."""
+        if self._pending_reduce is None:
+            return
+        fold = self._fold_clip_into_adam()
+        self._chunk_sq = []
+        for chunk, work in self._pending_reduce:
+            work.wait()
+            if fold:
+                from ..gs.surfel_optim import clip_coef
+                self._chunk_sq.append(clip_coef([chunk], 1.0)[0].square())
+            else:
+                chunk.div_(self.world)
+        self._pending_reduce = None
+        self._mean_scale = 1.0 / self.world if fold else 1.0
+        if self._rest_slot is not None and self._rest_slot.numel():
+            self.model._features_rest.grad[:, :self._rest_slot.shape[1]].copy_(self._rest_slot)
+        self._fold_net_gradients(from_slots=True)
+
+    def _fold_net_gradients(self, from_slots: bool):
+        """Adds this step's (exchanged) network gradients to the round's accumulated ones and makes those the
+        parameters' .grad -- what upstream's never-zeroed .grad holds when check_grad and, later, AdamW read it."""
+        if not self.optim_warp:
+            return
+        for i, p in enumerate(self._net_params):
+            if p.grad is None:
+                g = None
+            elif from_slots:
+                g = self._net_slots[i]
+            else:
+                g = p.grad
+            if g is not None:
+                self._net_accum[i] = g.detach().clone() if self._net_accum[i] is None else self._net_accum[i].add_(g)
+            p.grad = self._net_accum[i]
 
     def clip_gradients(self, max_norm: float = 5.0):
-        """clip_grad_norm_ over the exchanged parameters (trainer.py:861-869), one norm over the flat buffer."""
+        """clip_grad_norm_ over the parameters that have a gradient (trainer.py:861-869)."""
         if self._fold_clip_into_adam():
             # norm and coefficient from one launch; the surfel Adam multiplies the gradients by the coefficient on the
             # way in (csrc/optim.hip)
             from ..gs.surfel_optim import clip_coef
+            sq = self.__dict__.pop("_chunk_sq", None)
+            scale = self.__dict__.pop("_mean_scale", 1.0)
+            if sq:  # (after an exchange: the chunk norms are there, the gradients still hold the sum over the ranks)
+                norm = torch.stack(sq).sum().sqrt() * scale
+                self._clip_coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0) * scale
+                return norm
             grads = [self._flat] if self._flat is not None else [p.grad for p in self.exchanged_params()]
             if not any(g is not None for g in grads):
                 return None
             norm, self._clip_coef = clip_coef(grads, max_norm)
             return norm
-        if self._flat is None:
+        if self._flat is None or self.optim_warp or self._rest_slot is not None:
             return torch.nn.utils.clip_grad_norm_(self.exchanged_params(), max_norm)
         norm = torch.linalg.vector_norm(self._flat)
         self._flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
@@ -243,6 +377,7 @@ class Stage3Trainer:
         if self.optimizer is not None and step >= self.optim_warp_from:
             self.optimizer.step()
             self.scheduler.step()
+            self._net_accum = [None] * len(self._net_params)   # optimizer.zero_grad() (trainer.py:596-598)
 
     def _sync_densification_stats(self):
         if self.world == 1:
@@ -309,14 +444,30 @@ class Stage3Trainer:
         else:
             self.begin_gradients()
             losses = self._forward_backward(batch, step)
+        if self.world == 1:
+            self._fold_net_gradients(from_slots=False)
         self.allreduce_gradients(async_op=True)   # in flight while the statistics below are gathered
+        self.gather_densification_stats(step)
+        self.finish_step(step)
+        return {k: v.detach() for k, v in losses.items()}
 
+    def gather_densification_stats(self, step: int):
+        """max_radii2D / xyz_gradient_accum / denom from the frames rendered last (trainer.py:549-556); does not read the
+        parameter gradients, so it runs while the exchange is in flight."""
+        m = self.model
+        if step >= self.cfg.densify_until_iter:
+            return
         with torch.no_grad():
-            if step < c.densify_until_iter:
-                for i in range(len(m._radii_batch)):
-                    vis, radii = m._visibility_filter_batch[i], m._radii_batch[i]
-                    m.max_radii2D.copy_(torch.where(vis, torch.maximum(m.max_radii2D, radii.float()), m.max_radii2D))
-                    m.add_densification_stats(m._viewspace_points_batch[i], vis)
+            for i in range(len(m._radii_batch)):
+                vis, radii = m._visibility_filter_batch[i], m._radii_batch[i]
+                m.max_radii2D.copy_(torch.where(vis, torch.maximum(m.max_radii2D, radii.float()), m.max_radii2D))
+                m.add_densification_stats(m._viewspace_points_batch[i], vis)
+
+    def finish_step(self, step: int):
+        """Everything after the step's gradients exist: join the exchange, clip, the densify / prune / opacity-reset
+        cadence, the optimizers (trainer.py:547-598)."""
+        m, c = self.model, self.cfg
+        with torch.no_grad():
             self.wait_gradients()
             self.clip_gradients(5.0)              # check_grad precedes the densification upstream (trainer.py:547)
             if step < c.densify_until_iter:
@@ -345,10 +496,9 @@ class Stage3Trainer:
                     m.prune_points(radius_neighbor_count(m.get_xyz, 0.004) <= 20)
         # (parameters re-created by densify / prune / reset_opacity have no gradient and are skipped, as upstream)
         self._optimizer_step(step)
-        for p in self.exchanged_params():
+        for p in self.surfel_params():
             p.grad = None
         self.current_steps += 1
-        return {k: v.detach() for k, v in losses.items()}
 
 
 def make_intrinsics_inv(M: int, H: int, W: int, tanfov: float = 0.5, device="cpu") -> torch.Tensor:
