@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 13
+#define VIDU4D_SURFEL_ABI 14
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -429,11 +429,18 @@ int vidu4d_densify_apply(int N, const int32_t* inclusive_counts, int n_orig, int
  *      field under --rgb_loss_only (lab4d/engine/model.py:586-693, :835-842, :895-1012) together with the learnable-
  *      background composite in front of it (lab4d/nnutils/deformable_gaussian.py:1216-1218).
  *      color[m] (3,H,W), allmap[m] (8,H,W): the rasterizer outputs of frame m (M <= 8); bkgd (3) learnable background
- *      or NULL; rgb (M,H,W,3), mask / vis2d (M,H,W,1) targets; det (M) 1/0 per frame or NULL.  losses (4) =
- *      {rgb, mask, dist, rgb + mask + dist}, each term already multiplied by its weight.  sums (32 floats) and partials
+ *      or NULL; rgb (M,H,W,3), mask / vis2d (M,H,W,1) targets; det (M) 1/0 per frame or NULL.  losses (5) =
+ *      {rgb, mask, dist, normal, their sum}, each term already multiplied by its weight.  sums (32 floats) and partials
  *      (VIDU4D_LOSS_BLOCKS * 16 floats) are scratch that must stay untouched between forward and backward.
- *      The backward takes g_losses (4, device: upstream gradients of the three terms and of their sum, the latter is
- *      added to each) and writes every plane of g_color[m] / g_allmap[m] and g_bkgd (3). ---- */
+ *      The backward takes g_losses (5, device: upstream gradients of the four terms and of their sum, the latter is
+ *      added to each) and writes every plane of g_color[m] / g_allmap[m] and g_bkgd (3).
+ *      normal_wt != 0 adds the normal-consistency term (compute_reg_loss, model.py:817-834, with its sum over the FRAME
+ *      axis): lambda * mean_{H,W,3}(1 - sum_m rend_normal_m * surf_normal_m), where rend_normal = allmap[2:5] rotated by
+ *      view3x3[m] (row-major 3x3, out_j = sum_i n_i M[i][j]) and surf_normal is what gs.gaussian_renderer.render derives
+ *      from the depth planes (gs/gaussian_renderer/__init__.py:118-151, gs/utils/point_utils.py:9-37; depth_ratio as
+ *      pipe.depth_ratio) -- evaluated inside the kernels from rays_d[m] (H*W,3) / rays_o[m] (3) with surf_depth
+ *      (M*H*W floats) as the workspace between forward and backward, or, when surf_normal[m] (3,H,W) is given, read
+ *      from there (its gradient then goes to g_surf_normal[m], if not NULL, instead of the depth planes). ---- */
 #define VIDU4D_LOSS_MAX_FRAMES 8
 #define VIDU4D_LOSS_BLOCKS 512
 #define VIDU4D_LOSS_SUMS_FLOATS 32
@@ -453,11 +460,18 @@ typedef struct Vidu4dStage3LossArgs {
     int64_t plane_stride;   /* floats between two planes of color[m] / allmap[m] and of the gradient planes; 0 = H*W.
                                M*H*W when the frames come from one stacked rasterizer call ((3,M,H,W) / (8,M,H,W)
                                tensors, color[m] = base + m*H*W) */
+    float normal_wt, depth_ratio;
+    const float* rays_d[VIDU4D_LOSS_MAX_FRAMES];
+    const float* rays_o[VIDU4D_LOSS_MAX_FRAMES];
+    const float* view3x3[VIDU4D_LOSS_MAX_FRAMES];
+    const float* surf_normal[VIDU4D_LOSS_MAX_FRAMES];
+    float* surf_depth;
 } Vidu4dStage3LossArgs;
 typedef struct Vidu4dStage3LossGrads {
     float* g_color[VIDU4D_LOSS_MAX_FRAMES];
     float* g_allmap[VIDU4D_LOSS_MAX_FRAMES];
     float* g_bkgd;
+    float* g_surf_normal[VIDU4D_LOSS_MAX_FRAMES];
 } Vidu4dStage3LossGrads;
 int vidu4d_stage3_loss_forward(const Vidu4dStage3LossArgs* args, void* stream);
 int vidu4d_stage3_loss_backward(const Vidu4dStage3LossArgs* args, const float* g_losses,

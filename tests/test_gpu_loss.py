@@ -17,8 +17,9 @@ def _cfg(**kw):
     return _Args(dict(dict(lambda_normal=0.05, lambda_dist=100.0, lambda_dssim=0.0, rgb_wt=0.1, mask_wt=0.1), **kw))
 
 
-def _planes(rendered, mask, dist):
-    """(M,H,W,3) / (M,H,W,1) maps -> per-frame (3,H,W) colour and (8,H,W) auxiliary planes (alpha = plane 1, distortion = 6)."""
+def _planes(rendered, mask, dist, rend_normal=None):
+    """(M,H,W,3) / (M,H,W,1) maps -> per-frame (3,H,W) colour and (8,H,W) auxiliary planes (alpha = plane 1, normal =
+    planes 2-4 (identity view), distortion = 6)."""
     M = rendered.shape[0]
     colors, allmaps = [], []
     for m in range(M):
@@ -26,6 +27,8 @@ def _planes(rendered, mask, dist):
         am = torch.zeros(8, *rendered.shape[1:3], device=rendered.device)
         am[1], am[6] = mask[m, ..., 0], dist[m, ..., 0]
         am[0], am[2:6], am[7] = 0.3, 0.7, 0.1  # (planes the loss must not read)
+        if rend_normal is not None:
+            am[2:5] = rend_normal[m].permute(2, 0, 1)
         allmaps.append(am.requires_grad_(True))
     return colors, allmaps
 
@@ -37,13 +40,17 @@ def test_fused_loss_matches_the_reference_numbers(gpu_device, case, through_tota
     dev = gpu_device
     r = load("refpy_losses.npz", dev)
     step = int(r[f"{case}_step"])
-    colors, allmaps = _planes(r[f"{case}_in_rendered"], r[f"{case}_in_mask"], r[f"{case}_in_rend_dist"])
+    # the reference's rend_normal goes in as planes 2-4 (identity view), its surf_normal as caller-supplied planes: the
+    # normal-consistency term of the kernel (sum over the FRAME axis, model.py:831) against the reference's own number
+    colors, allmaps = _planes(r[f"{case}_in_rendered"], r[f"{case}_in_mask"], r[f"{case}_in_rend_dist"],
+                              r[f"{case}_in_rend_normal"])
+    surf = [t.permute(2, 0, 1).contiguous().requires_grad_(True) for t in r[f"{case}_in_surf_normal"]]
     batch = {"rgb": r[f"{case}_batch_rgb"], "mask": r[f"{case}_batch_mask"], "vis2d": r[f"{case}_batch_vis2d"],
              "is_detected": r[f"{case}_batch_is_detected"]}
-    losses = stage3_loss(colors, allmaps, None, batch, step, _cfg())
-    for k in ("rgb", "mask", "dist_loss"):
+    losses = stage3_loss(colors, allmaps, None, batch, step, _cfg(), surf_normals=surf)
+    for k in ("rgb", "mask", "dist_loss", "normal_loss"):
         close(losses[k], r[f"{case}_loss_{k}"], what=f"{case}:{k}", rtol=2e-5, atol=1e-8)
-    terms = losses["rgb"] + losses["mask"] + losses["dist_loss"]
+    terms = ((losses["rgb"] + losses["mask"]) + losses["normal_loss"]) + losses["dist_loss"]
     assert float(losses["total"]) == float(terms) or (terms.isnan() and losses["total"].isnan())
     if through_total:  # the kernel's own sum, started from the cached unit gradient (what Stage3Trainer does)
         losses["total"].backward(gradient=unit_gradient(dev))
@@ -55,8 +62,16 @@ def test_fused_loss_matches_the_reference_numbers(gpu_device, case, through_tota
     close(g_r, r[f"{case}_g_rendered"], what="g_rendered", rtol=1e-4, atol=1e-9)
     close(g_m, r[f"{case}_g_mask"], what="g_mask", rtol=1e-4, atol=1e-9)
     close(g_d, r[f"{case}_g_rend_dist"], what="g_rend_dist", rtol=1e-4, atol=1e-9)
+    g_rn = torch.stack([a.grad[2:5].permute(1, 2, 0) for a in allmaps])
+    close(g_rn, r[f"{case}_g_rend_normal"], what="g_rend_normal", rtol=1e-4, atol=1e-12)
+    if step > 8000:
+        g_sn = torch.stack([t.grad.permute(1, 2, 0) for t in surf])
+        close(g_sn, r[f"{case}_g_surf_normal"], what="g_surf_normal", rtol=1e-4, atol=1e-12)
+        assert float(g_rn.abs().max()) > 0
+    else:
+        assert all(t.grad is None or float(t.grad.abs().max()) == 0.0 for t in surf)
     for a in allmaps:
-        assert float(a.grad[[0, 2, 3, 4, 5, 7]].abs().max()) == 0.0
+        assert float(a.grad[[0, 5, 7]].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("M,H,W,step,det", [(2, 64, 48, 100, None), (3, 33, 57, 9000, [1, 0, 1]), (1, 16, 16, 0, [0])])
@@ -148,3 +163,131 @@ def test_trainer_step_fused_loss_equals_torch_loss(gpu_device):
         assert abs(out[True][0][k] - out[False][0][k]) <= 2e-5 * abs(out[False][0][k]) + 1e-9, k
     a, b = out[True][1], out[False][1]
     assert torch.allclose(a, b, rtol=1e-3, atol=2e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("stacked", [False, True])
+@pytest.mark.parametrize("M,H,W,ratio", [(2, 40, 56, 0.0), (3, 33, 47, 0.3)])
+def test_fused_normal_term_matches_the_torch_chain(gpu_device, M, H, W, ratio, stacked):
+    """The normal-consistency term evaluated INSIDE the loss kernels (depth planes -> surf_normal stencil, planes 2-4 ->
+    rend_normal) against the elementwise torch chain of render() (gs/gaussian_renderer/__init__.py:118-151, pinned by
+    tests/golden/refpy_render.npz) followed by compute_losses: values and the gradients of all 8 planes, on planes with
+    empty pixels (alpha = 0: 0 / 0 depth), per-frame tensors and the (8,M,H,W) layout of a stacked call."""
+    from vidu4d_amd.gs.cameras import KCamera
+    from vidu4d_amd.gs.point_utils import depth_to_normal
+    from vidu4d_amd.lab4d.loss_fused import stage3_loss
+    from vidu4d_amd.lab4d.stage3 import compute_losses, make_intrinsics_inv
+    dev = gpu_device
+    g = torch.Generator().manual_seed(M * 10 + H)
+    rnd = lambda *s: torch.rand(*s, generator=g).to(dev)  # noqa: E731
+    Kinv = make_intrinsics_inv(1, H, W)[0]
+    cams = [KCamera(H=H, W=W, left=Kinv[0, 2], right=Kinv[0, 2] + Kinv[0, 0] * W, top=Kinv[1, 2] + Kinv[1, 1] * H,
+                    bottom=Kinv[1, 2], data_device=dev) for _ in range(2)]
+    cams = [cams[m % 2] for m in range(M)]
+    cfg = _cfg(lambda_dist=2.0, lambda_normal=0.05)
+    step = 9000
+    batch = {"rgb": rnd(M, H, W, 3), "mask": (rnd(M, H, W, 1) > 0.6).float(), "vis2d": (rnd(M, H, W, 1) > 0.1).float()}
+    color0 = rnd(3, M, H, W)
+    allmap0 = rnd(8, M, H, W)
+    allmap0[1] = 0.05 + 0.9 * allmap0[1]                    # alpha
+    allmap0[0] = allmap0[1] * (2.0 + rnd(M, H, W))          # alpha-weighted depth
+    allmap0[5] = 2.0 + rnd(M, H, W)
+    allmap0[2:5] = allmap0[2:5] - 0.5
+    allmap0[4] = -allmap0[1] * (0.5 + rnd(M, H, W))        # (roughly along the stencil's normals: a term well off lambda)
+    hole = rnd(M, H, W) < 0.1                               # pixels nothing was blended into
+    allmap0[:, hole] = 0.0
+    bg0 = rnd(3)
+    res = {}
+    for name in ("fused", "torch"):
+        color = color0.clone().requires_grad_(True)
+        allmap = allmap0.clone().requires_grad_(True)
+        bg = bg0.clone().requires_grad_(True)
+        if name == "fused":
+            if stacked:
+                losses = stage3_loss(color, allmap, bg, batch, step, cfg, cameras=cams, depth_ratio=ratio)
+            else:
+                colors = [color[:, m].contiguous() for m in range(M)]
+                allmaps = [allmap[:, m].contiguous() for m in range(M)]
+                losses = stage3_loss(colors, allmaps, bg, batch, step, cfg, cameras=cams, depth_ratio=ratio)
+        else:
+            rn, sn, comp = [], [], []
+            for m in range(M):
+                am = allmap[:, m]
+                alpha = am[1:2]
+                normal = (am[2:5].permute(1, 2, 0) @ cams[m].world_view_transform[:3, :3].T).permute(2, 0, 1)
+                med = torch.nan_to_num(am[5:6], 0, 0)
+                expd = torch.nan_to_num(am[0:1] / alpha, 0, 0)
+                sd = expd * (1 - ratio) + ratio * med
+                rn.append(normal.permute(1, 2, 0))
+                sn.append((depth_to_normal(cams[m], sd).permute(2, 0, 1) * alpha.detach()).permute(1, 2, 0))
+                comp.append((color[:, m] + (1 - alpha) * bg[:, None, None]).permute(1, 2, 0))
+            rendered = {"rendered": torch.stack(comp), "mask": allmap[1][..., None], "rend_dist": allmap[6][..., None],
+                        "rend_normal": torch.stack(rn), "surf_normal": torch.stack(sn)}
+            losses = compute_losses(rendered, batch, step, cfg)
+        total = losses["rgb"] * 1.5 + losses["mask"] * 0.5 + losses["dist_loss"] + losses["normal_loss"] * 2.0
+        total.backward()
+        res[name] = ([float(losses[k]) for k in ("rgb", "mask", "dist_loss", "normal_loss")],
+                     [color.grad.clone(), allmap.grad.clone(), bg.grad.clone()])
+    assert np.allclose(res["fused"][0], res["torch"][0], rtol=2e-5, atol=1e-9), (res["fused"][0], res["torch"][0])
+    assert abs(res["torch"][0][3] - 0.05) > 1e-3   # (the term is not trivially lambda * 1)
+    for i, (a, b) in enumerate(zip(res["fused"][1], res["torch"][1])):
+        if i == 1:
+            # planes 0 and 1 of an empty pixel: 0 / 0 in both (torch's division backward; the rasterizer's backward never
+            # reads a pixel without contributors)
+            assert torch.equal(a.isnan(), b.isnan()) and bool(a.isnan().any())
+            assert not bool(a[2:].isnan().any())
+            a, b = torch.nan_to_num(a), torch.nan_to_num(b)
+            for k in range(8):
+                assert torch.allclose(a[k], b[k], rtol=2e-4, atol=2e-6 * float(b[k].abs().max()) + 1e-12), k
+        else:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-12), i
+
+
+def test_train_step_with_the_regularisers_on_equals_the_unfused_path(gpu_device):
+    """Step > 8000 (lambda_normal on, BASELINE configs[4] "depth/normal reg on"): Stage3Trainer.train_step on the
+    default path -- fused warp, ONE stacked rasterizer launch set with all 8 planes, the loss kernels with the normal
+    term inside -- against the same step with every extension off (per-frame render() calls with the torch
+    post-processing chain, torch losses, torch Adam semantics are the same SurfelAdam): same losses, same gradients of
+    every surfel tensor, same parameters after the step."""
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    dev = gpu_device
+    out = {}
+    off = dict(fused_loss=False, stacked_frames=False, frame_streams=False, fused_warp=False, canonical_params=False)
+    for name, extra in (("default", {}), ("off", off)):
+        torch.manual_seed(0)
+        rng = np.random.default_rng(2)
+        m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0, lambda_dist=10.0) | extra, num_frames=8, device=dev)
+        pts = rng.normal(size=(6000, 3)).astype(np.float32)
+        # (a BALL, not a shell: surfels at many depths behind each pixel, so that the distortion term is far above its
+        # fp32 noise floor)
+        pts = 0.3 * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(6000, 1)).astype(np.float32)
+        m.init_from_points(pts, rng.uniform(size=(6000, 3)).astype(np.float32))
+        if name == "off":
+            m.pipeline.fused_post = False
+        with torch.no_grad():
+            m._opacity.fill_(-1.0)
+        m.active_sh_degree = 3
+        tr = Stage3Trainer(m)
+        tr.current_steps = 8001
+        batch = synthetic_batch(m, [1, 4], 64, 80, seed=3)
+        tr.bind_flat_gradients()
+        losses = tr._forward_backward(batch, tr.current_steps)
+        grads = {k: getattr(m, k).grad.clone() for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")}
+        for p in tr.surfel_params():
+            p.grad = None
+        after = tr.train_step(batch)
+        out[name] = ({k: float(v) for k, v in losses.items()}, grads, m._xyz.detach().clone(), {k: float(v) for k, v in after.items()})
+    d, o = out["default"], out["off"]
+    assert o[0]["normal_loss"] != 0.0 and o[0]["dist_loss"] != 0.0
+    for k in ("rgb", "mask", "normal_loss", "dist_loss"):
+        # (the distortion of a pixel is a difference of O(1) fp32 sums that nearly cancel on this thin object -- mapped
+        # depths within 1 % of each other -- so the two warps' 1e-7 differences in the camera-space centres move the
+        # mean by percents of its tiny value; csrc/loss.hip's distortion term itself is pinned on random planes above)
+        rtol = 5e-2 if k == "dist_loss" else 3e-5
+        assert abs(d[0][k] - o[0][k]) <= rtol * abs(o[0][k]) + 1e-9, (k, d[0][k], o[0][k])
+        assert abs(d[3][k] - o[3][k]) <= rtol * abs(o[3][k]) + 1e-9, (k, d[3][k], o[3][k])
+    for k in d[1]:
+        a, b = d[1][k], o[1][k]
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), k
+        assert torch.allclose(a, b, rtol=2e-3, atol=3e-6 * float(b.abs().max())), (k, float((a - b).abs().max()), float(b.abs().max()))
+    assert float((d[2] - o[2]).abs().median()) <= 1e-6

@@ -174,9 +174,9 @@ def test_product_matches_real_reference(gpu_device, config, variant, monkeypatch
     if config == "object_split":
         assert R > 200_000  # (long lists: the split is really exercised)
     radii = to_np(rf["radii"])
-    # configurations without a measurement of their own take the frozen budgets of the nearest measured one:
-    # object_split (no saturation, thousands of samples per pixel) those of the 1080p slice, world_kcam those of cfgA
-    cfg = {"object_split": "cfgE_slice", "world_kcam": "cfgA"}.get(config, config)
+    # a configuration without a measurement of its own takes the frozen budgets of the nearest measured one:
+    # object_split (no saturation, thousands of samples per pixel) those of the 1080p slice
+    cfg = {"object_split": "cfgE_slice"}.get(config, config)
     if variant == "strict":
         assert ints["R"] == R and np.array_equal(ints["radii"], radii), "radii"
         assert np.array_equal(ints["point_list"], ref.state("point_list", R)), "sorted surfel list"

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class ForwardArgs(C.Structure):
@@ -62,13 +62,16 @@ class Stage3LossArgs(C.Structure):
                 ("allmap", C.c_void_p * LOSS_MAX_FRAMES), ("bkgd", C.c_void_p), ("rgb", C.c_void_p),
                 ("mask", C.c_void_p), ("vis2d", C.c_void_p), ("det", C.c_void_p), ("lambda_dssim", C.c_float),
                 ("rgb_wt", C.c_float), ("mask_wt", C.c_float), ("dist_wt", C.c_float), ("sums", C.c_void_p),
-                ("partials", C.c_void_p), ("losses", C.c_void_p), ("plane_stride", C.c_int64)]
+                ("partials", C.c_void_p), ("losses", C.c_void_p), ("plane_stride", C.c_int64),
+                ("normal_wt", C.c_float), ("depth_ratio", C.c_float), ("rays_d", C.c_void_p * LOSS_MAX_FRAMES),
+                ("rays_o", C.c_void_p * LOSS_MAX_FRAMES), ("view3x3", C.c_void_p * LOSS_MAX_FRAMES),
+                ("surf_normal", C.c_void_p * LOSS_MAX_FRAMES), ("surf_depth", C.c_void_p)]
 
 
 class Stage3LossGrads(C.Structure):
     """struct Vidu4dStage3LossGrads"""
     _fields_ = [("g_color", C.c_void_p * LOSS_MAX_FRAMES), ("g_allmap", C.c_void_p * LOSS_MAX_FRAMES),
-                ("g_bkgd", C.c_void_p)]
+                ("g_bkgd", C.c_void_p), ("g_surf_normal", C.c_void_p * LOSS_MAX_FRAMES)]
 
 
 SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)

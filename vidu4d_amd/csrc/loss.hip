@@ -9,6 +9,12 @@
 //   mask map = (alpha - mask)^2 * w * vis2d * is_detected              :640-651, :945-952
 //   term     = mean over the entries > 0 (over everything when there is none), times its weight   apply_loss_weights :980-1012
 //   dist     = weight * mean(distortion plane)                         compute_reg_loss :835-842
+//   normal   = weight * mean over (H, W, 3) of (1 - SUM OVER THE FRAMES of rend_normal * surf_normal)   :817-834 -- the
+//              `.sum(dim=0)` upstream wrote for the (3,H,W) layout of 2DGS runs over the frame axis of the (M,H,W,3)
+//              maps here; reproduced.  rend_normal = allmap[2:5] rotated by the view block, surf_normal = the
+//              depth-to-normal stencil of gs.gaussian_renderer.render (post_math.h), evaluated IN these kernels from
+//              the depth / alpha planes (or read from planes the caller supplies): the seven maps render() derives
+//              per frame and their backward never reach HBM.  Switched on by normal_wt != 0 (step > 8000 upstream).
 // The torch statement of this (vidu4d_amd/lab4d/stage3.py::compute_losses) is pinned against the imported reference by
 // tests/golden/refpy_losses.npz; tests compare these kernels with it, values and gradients, on those cases.
 //
@@ -22,13 +28,16 @@
 #include <stdint.h>
 
 #include "../../include/vidu4d_surfel.h"
+#include "post_math.h"
 
 namespace {
+
+using post::V3;
 
 constexpr int BLOCKS = VIDU4D_LOSS_BLOCKS;
 constexpr int THREADS = 256;
 // first-level sums
-enum { S_L1, S_VIS, S_POSW, S_NEGW, S_MF, S_NMF, S_RGB_N, S_RGB_SUM, S_MV, S_DIST, N1 };
+enum { S_L1, S_VIS, S_POSW, S_NEGW, S_MF, S_NMF, S_RGB_N, S_RGB_SUM, S_MV, S_DIST, S_NRM, N1 };
 // second-level sums
 enum { S_MASK_POS, S_MASK_N, S_MASK_ALL, N2 };
 // derived scalars stored after the raw sums in `sums`
@@ -78,6 +87,15 @@ __device__ __forceinline__ Pixel load_pixel(const Vidu4dStage3LossArgs& a, size_
     return q;
 }
 
+// rend_normal of pixel p of frame m: allmap[2:5] rotated by the frame's view block (n_out_j = sum_i n_i M[i][j]).
+__device__ __forceinline__ V3 rend_normal_at(const Vidu4dStage3LossArgs& a, int m, size_t PS, size_t p)
+{
+    const float* aux = a.allmap[m];
+    const float* M = a.view3x3[m];
+    const float n0 = aux[2 * PS + p], n1 = aux[3 * PS + p], n2 = aux[4 * PS + p];
+    return {n0 * M[0] + n1 * M[3] + n2 * M[6], n0 * M[1] + n1 * M[4] + n2 * M[7], n0 * M[2] + n1 * M[5] + n2 * M[8]};
+}
+
 __global__ __launch_bounds__(THREADS) void loss_stats1_kernel(Vidu4dStage3LossArgs a, float* partial)
 {
     const size_t HW = (size_t)a.H * a.W, total = HW * a.M;
@@ -100,6 +118,24 @@ __global__ __launch_bounds__(THREADS) void loss_stats1_kernel(Vidu4dStage3LossAr
         s[S_RGB_SUM] += mv > 0.f ? mv : 0.f;
         s[S_MV] += mv;
         s[S_DIST] += q.dist;
+        if (a.normal_wt != 0.f) {
+            const int m = (int)(e / HW);
+            const size_t p = e - (size_t)m * HW;
+            const size_t PS = a.plane_stride ? (size_t)a.plane_stride : HW;
+            const V3 rn = rend_normal_at(a, m, PS, p);
+            V3 sn;
+            if (a.surf_normal[m]) {
+                const float* t = a.surf_normal[m];
+                sn = {t[p], t[HW + p], t[2 * HW + p]};
+            } else {
+                const float* aux = a.allmap[m];
+                const float ratio = a.depth_ratio;
+                a.surf_depth[e] = post::surf_depth_at(aux, PS, p, ratio);   // (the backward's stencil reads the plane)
+                sn = post::surf_normal_at(a.W, a.H, (int)(p / a.W), (int)(p % a.W), q.a, a.rays_d[m], a.rays_o[m],
+                                          [&](size_t n) { return post::surf_depth_at(aux, PS, n, ratio); });
+            }
+            s[S_NRM] += rn.x * sn.x + rn.y * sn.y + rn.z * sn.z;
+        }
     }
     block_partials<N1>(s, partial + blockIdx.x * 16);
 }
@@ -133,6 +169,8 @@ __global__ __launch_bounds__(64) void loss_reduce1_kernel(Vidu4dStage3LossArgs a
     S[D_RGB_COEF] = coef;
     a.losses[0] = l1 * coef * a.rgb_wt;
     a.losses[2] = a.dist_wt != 0.f ? a.dist_wt * s[S_DIST] / numel : 0.f;
+    // mean over the (1, H, W, 3) map left by the sum over the frame axis: 3 H W entries, whatever M is
+    a.losses[3] = a.normal_wt != 0.f ? a.normal_wt * (1.0f - s[S_NRM] / (3.0f * (float)((size_t)a.H * a.W))) : 0.f;
 }
 
 __device__ __forceinline__ float mask_map(const Pixel& q, const float* S, float& dmap_da)
@@ -172,11 +210,13 @@ __global__ __launch_bounds__(64) void loss_reduce2_kernel(Vidu4dStage3LossArgs a
     S[D_MASK_INV] = pos ? 1.0f / s[S_MASK_N] : 1.0f / numel;
     const float mask_term = (pos ? s[S_MASK_POS] / s[S_MASK_N] : s[S_MASK_ALL] / numel) * a.mask_wt;
     a.losses[1] = mask_term;
-    a.losses[3] = (a.losses[0] + mask_term) + a.losses[2];  // the sum the trainer back-propagates (losses[0], [2]: reduce1)
+    // the sum the trainer back-propagates, in the order of its dict (rgb, mask, normal_loss, dist_loss; [0], [2], [3]: reduce1)
+    a.losses[4] = ((a.losses[0] + mask_term) + a.losses[3]) + a.losses[2];
 }
 
-// g (4): upstream gradients of the three terms and, g[3], of their sum losses[3] (added to each).  Writes g_color[m] (3,H,W), g_allmap[m] (8,H,W) completely and the
-// per-block partials of d / d learnable_bkgd.
+// g (5): upstream gradients of the four terms and, g[4], of their sum losses[4] (added to each).  Writes g_color[m] (3,H,W),
+// g_allmap[m] (8,H,W) completely (and g_surf_normal[m] when the caller supplied the surf_normal planes) and the per-block
+// partials of d / d learnable_bkgd.
 __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3LossArgs a, const float* g, Vidu4dStage3LossGrads o,
                                                                float* partial)
 {
@@ -184,10 +224,12 @@ __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3Loss
     const size_t PS = a.plane_stride ? (size_t)a.plane_stride : HW;
     const float numel = (float)total;
     const float* S = a.sums;
-    const float g_rgb = (g[0] + g[3]) * a.rgb_wt * S[D_RGB_COEF] * (1.0f - a.lambda_dssim) / (3.0f * numel);  // per |r - t| entry
-    const float g_mask = (g[1] + g[3]) * a.mask_wt * S[D_MASK_INV];
+    const float g_rgb = (g[0] + g[4]) * a.rgb_wt * S[D_RGB_COEF] * (1.0f - a.lambda_dssim) / (3.0f * numel);  // per |r - t| entry
+    const float g_mask = (g[1] + g[4]) * a.mask_wt * S[D_MASK_INV];
     const bool only_pos = S[D_MASK_USE_POS] != 0.f;
-    const float g_dist = a.dist_wt != 0.f ? (g[2] + g[3]) * a.dist_wt / numel : 0.f;
+    const float g_dist = a.dist_wt != 0.f ? (g[2] + g[4]) * a.dist_wt / numel : 0.f;
+    // d normal_loss / d (rend_normal . surf_normal summed over everything) = -weight / (3 H W)
+    const float g_nrm = a.normal_wt != 0.f ? -(g[3] + g[4]) * a.normal_wt / (3.0f * (float)HW) : 0.f;
     float bg[3] = {0.f, 0.f, 0.f};
     for (size_t e = (size_t)blockIdx.x * THREADS + threadIdx.x; e < total; e += (size_t)BLOCKS * THREADS) {
         const int m = (int)(e / HW);
@@ -208,9 +250,46 @@ __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3Loss
             }
         }
         float* gm = o.g_allmap[m];
-        gm[p] = 0.f;
+        float g_depth = 0.f, g_median = 0.f, g_n[3] = {0.f, 0.f, 0.f};
+        if (a.normal_wt != 0.f) {
+            const int W = a.W, H = a.H, i = (int)(p / W), j = (int)(p % W);
+            const float* aux = a.allmap[m];
+            const float* M = a.view3x3[m];
+            V3 sn;   // d / d rend_normal(p) = g_nrm * surf_normal(p)
+            if (a.surf_normal[m]) {
+                const float* t = a.surf_normal[m];
+                sn = {t[p], t[HW + p], t[2 * HW + p]};
+                if (o.g_surf_normal[m]) {   // d / d surf_normal(p) = g_nrm * rend_normal(p)
+                    const V3 rn = rend_normal_at(a, m, PS, p);
+                    float* gs = o.g_surf_normal[m];
+                    gs[p] = g_nrm * rn.x, gs[HW + p] = g_nrm * rn.y, gs[2 * HW + p] = g_nrm * rn.z;
+                }
+            } else {
+                const float* sd = a.surf_depth + (size_t)m * HW;
+                sn = post::surf_normal_at(W, H, i, j, q.a, a.rays_d[m], a.rays_o[m], [&](size_t n) { return sd[n]; });
+                // the depth of this pixel enters the surf_normal of its four neighbours (whose upstream gradient is
+                // g_nrm * their rend_normal), then the expected / median depth, then planes 0, 1 and 5
+                const float gd = post::depth_grad_through_normals(
+                    W, H, i, j, sd, a.rays_d[m], a.rays_o[m], [&](int qi, int qj, float& alpha_q) {
+                        const size_t n = (size_t)qi * W + qj;
+                        alpha_q = aux[PS + n];
+                        const V3 rn = rend_normal_at(a, m, PS, n);
+                        return V3{g_nrm * rn.x, g_nrm * rn.y, g_nrm * rn.z};
+                    });
+                const float ge = gd * (1.0f - a.depth_ratio), gmed = gd * a.depth_ratio;
+                const float a0 = aux[p];
+                const float gr = post::is_finite(a0 / q.a) ? ge : 0.f;  // nan_to_num passes the gradient where its input is finite
+                g_depth = gr / q.a;                                      // (0 / 0 where nothing was blended, as torch: never read)
+                ga += -gr * a0 / (q.a * q.a);
+                g_median = post::is_finite(aux[5 * PS + p]) ? gmed : 0.f;
+            }
+            const float r0 = g_nrm * sn.x, r1 = g_nrm * sn.y, r2 = g_nrm * sn.z;
+            for (int c = 0; c < 3; c++) g_n[c] = M[3 * c] * r0 + M[3 * c + 1] * r1 + M[3 * c + 2] * r2;
+        }
+        gm[p] = g_depth;
         gm[PS + p] = ga;
-        for (int k = 2; k < 6; k++) gm[k * PS + p] = 0.f;
+        for (int k = 0; k < 3; k++) gm[(2 + k) * PS + p] = g_n[k];
+        gm[5 * PS + p] = g_median;
         gm[6 * PS + p] = g_dist;
         gm[7 * PS + p] = 0.f;
     }
@@ -231,6 +310,11 @@ int check(const Vidu4dStage3LossArgs* a)
     if (!a->rgb || !a->mask || !a->vis2d || !a->sums || !a->losses || !a->partials) return VIDU4D_E_INVALID;
     for (int m = 0; m < a->M; m++)
         if (!a->color[m] || !a->allmap[m]) return VIDU4D_E_INVALID;
+    if (a->normal_wt != 0.f)
+        for (int m = 0; m < a->M; m++) {
+            if (!a->view3x3[m]) return VIDU4D_E_INVALID;
+            if (!a->surf_normal[m] && (!a->rays_d[m] || !a->rays_o[m] || !a->surf_depth)) return VIDU4D_E_INVALID;
+        }
     return VIDU4D_OK;
 }
 

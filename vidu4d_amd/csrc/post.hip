@@ -17,33 +17,11 @@
 #include <stdint.h>
 
 #include "../../include/vidu4d_surfel.h"
+#include "post_math.h"
 
 namespace {
 
-struct V3 {
-    float x, y, z;
-};
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float finite_or_zero(float v) { return (v == v && fabsf(v) <= 3.402823466e38f) ? v : 0.f; }
-__device__ __forceinline__ bool is_finite(float v) { return v == v && fabsf(v) <= 3.402823466e38f; }
-
-__device__ __forceinline__ float surf_depth_at(const float* __restrict__ allmap, size_t HW, size_t p, float ratio)
-{
-    const float expd = finite_or_zero(allmap[p] / allmap[HW + p]);
-    const float med = finite_or_zero(allmap[5 * HW + p]);
-    return expd * (1.0f - ratio) + ratio * med;
-}
-
-__device__ __forceinline__ V3 point_at(const float* __restrict__ rays_d, const float* __restrict__ rays_o, size_t p,
-                                       float depth)
-{
-    return {depth * rays_d[3 * p] + rays_o[0], depth * rays_d[3 * p + 1] + rays_o[1],
-            depth * rays_d[3 * p + 2] + rays_o[2]};
-}
-
-constexpr float NORM_EPS = 1e-12f;  // torch.nn.functional.normalize
+using namespace post;
 
 __global__ __launch_bounds__(256) void post_fwd_kernel(int W, int H, const float* __restrict__ allmap,
                                                       const float* __restrict__ rays_d,
@@ -65,48 +43,11 @@ __global__ __launch_bounds__(256) void post_fwd_kernel(int W, int H, const float
     depth_expected[p] = expd;
     depth_median[p] = med;
     surf_depth[p] = expd * (1.0f - ratio) + ratio * med;
-    V3 n = {0.f, 0.f, 0.f};
-    if (i > 0 && i < H - 1 && j > 0 && j < W - 1) {
-        const size_t up = p - W, dn = p + W, lf = p - 1, rt = p + 1;
-        const V3 dx = point_at(rays_d, rays_o, dn, surf_depth_at(allmap, HW, dn, ratio)) -
-                      point_at(rays_d, rays_o, up, surf_depth_at(allmap, HW, up, ratio));
-        const V3 dy = point_at(rays_d, rays_o, rt, surf_depth_at(allmap, HW, rt, ratio)) -
-                      point_at(rays_d, rays_o, lf, surf_depth_at(allmap, HW, lf, ratio));
-        const V3 c = cross(dx, dy);
-        const float inv = alpha / fmaxf(sqrtf(dot(c, c)), NORM_EPS);
-        n = {c.x * inv, c.y * inv, c.z * inv};
-    }
+    const V3 n = surf_normal_at(W, H, i, j, alpha, rays_d, rays_o,
+                                [&](size_t q) { return surf_depth_at(allmap, HW, q, ratio); });
     surf_normal[p] = n.x;
     surf_normal[HW + p] = n.y;
     surf_normal[2 * HW + p] = n.z;
-}
-
-// vjp of the normal at interior pixel q w.r.t. its two difference vectors
-__device__ __forceinline__ void normal_vjp(int W, int H, const float* __restrict__ allmap,
-                                           const float* __restrict__ sd, const float* __restrict__ rays_d,
-                                           const float* __restrict__ rays_o, const float* __restrict__ g_sn, int qi,
-                                           int qj, V3& g_dx, V3& g_dy)
-{
-    g_dx = g_dy = {0.f, 0.f, 0.f};
-    if (qi <= 0 || qi >= H - 1 || qj <= 0 || qj >= W - 1) return;
-    const size_t HW = (size_t)W * H, q = (size_t)qi * W + qj;
-    const V3 dx = point_at(rays_d, rays_o, q + W, sd[q + W]) - point_at(rays_d, rays_o, q - W, sd[q - W]);
-    const V3 dy = point_at(rays_d, rays_o, q + 1, sd[q + 1]) - point_at(rays_d, rays_o, q - 1, sd[q - 1]);
-    const V3 c = cross(dx, dy);
-    const float len = sqrtf(dot(c, c));
-    const float alpha = allmap[HW + q];
-    const V3 g = {g_sn[q] * alpha, g_sn[HW + q] * alpha, g_sn[2 * HW + q] * alpha};  // d/d(unit normal)
-    V3 g_c;
-    if (len > NORM_EPS) {  // n = c / len
-        const float inv = 1.0f / len;
-        const V3 nh = {c.x * inv, c.y * inv, c.z * inv};
-        const float proj = dot(nh, g);
-        g_c = {(g.x - nh.x * proj) * inv, (g.y - nh.y * proj) * inv, (g.z - nh.z * proj) * inv};
-    } else {                // n = c / eps
-        g_c = {g.x / NORM_EPS, g.y / NORM_EPS, g.z / NORM_EPS};
-    }
-    g_dx = cross(dy, g_c);  // c = dx x dy
-    g_dy = cross(g_c, dx);
 }
 
 __global__ __launch_bounds__(256) void post_bwd_kernel(int W, int H, const float* __restrict__ allmap,
@@ -126,18 +67,12 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(int W, int H, const float
     for (int c = 0; c < 3; c++) g_allmap[(2 + c) * HW + p] = M[3 * c] * r0 + M[3 * c + 1] * r1 + M[3 * c + 2] * r2;
     // depth: direct terms + the point's part in the four neighbouring normals
     float gd = g_sd ? g_sd[p] : 0.f;
-    if (g_sn) {
-        V3 a, b, gp = {0.f, 0.f, 0.f};
-        normal_vjp(W, H, allmap, sd, rays_d, rays_o, g_sn, i - 1, j, a, b);  // P(p) is the "+" end of its dx
-        gp = {gp.x + a.x, gp.y + a.y, gp.z + a.z};
-        normal_vjp(W, H, allmap, sd, rays_d, rays_o, g_sn, i + 1, j, a, b);  // "-" end
-        gp = {gp.x - a.x, gp.y - a.y, gp.z - a.z};
-        normal_vjp(W, H, allmap, sd, rays_d, rays_o, g_sn, i, j - 1, a, b);  // "+" end of its dy
-        gp = {gp.x + b.x, gp.y + b.y, gp.z + b.z};
-        normal_vjp(W, H, allmap, sd, rays_d, rays_o, g_sn, i, j + 1, a, b);  // "-" end
-        gp = {gp.x - b.x, gp.y - b.y, gp.z - b.z};
-        gd += gp.x * rays_d[3 * p] + gp.y * rays_d[3 * p + 1] + gp.z * rays_d[3 * p + 2];
-    }
+    if (g_sn)
+        gd += depth_grad_through_normals(W, H, i, j, sd, rays_d, rays_o, [&](int qi, int qj, float& alpha_q) {
+            const size_t q = (size_t)qi * W + qj;
+            alpha_q = allmap[HW + q];
+            return V3{g_sn[q], g_sn[HW + q], g_sn[2 * HW + q]};
+        });
     const float ge = (g_exp ? g_exp[p] : 0.f) + gd * (1.0f - ratio);
     const float gm = (g_med ? g_med[p] : 0.f) + gd * ratio;
     const float a0 = allmap[p], alpha = allmap[HW + p];

@@ -393,14 +393,17 @@ class Stage3Trainer:
         # the depth / normal maps are only read by the regularisers, whose weights are 0 until step 8000
         need_geometry = step > 8000 and (self.cfg.lambda_normal != 0.0)
         M = int(batch["frameid"].shape[0])
-        if m._xyz.is_cuda and not need_geometry and M <= 8 and m.opts.get("fused_loss", True):
-            # colour / silhouette / distortion terms and their gradient planes in five launches (csrc/loss.hip)
+        if m._xyz.is_cuda and M <= 8 and m.opts.get("fused_loss", True) and \
+                (not need_geometry or m.opts.get("fused_normal_loss", True)):
+            # colour / silhouette / distortion / normal-consistency terms and their gradient planes in five launches
+            # (csrc/loss.hip); with the normal term on, the depth / normal post-processing of render() runs inside them
             from .loss_fused import stage3_loss
             # colour and silhouette terms read the colour and the alpha plane; the distortion term (plane 6) only counts
-            # once lambda_dist does: until then the blend kernels carry nothing else (aux_planes, csrc/blend.hip LITE)
+            # once lambda_dist does, the normal term reads planes 0-5: until then the blend kernels carry nothing else
+            # (aux_planes, csrc/blend.hip LITE)
             from ..diff_surfel_rasterization import AUX_ALPHA
             lam_d = float(self.cfg.lambda_dist) if step > 8000 else 0.0
-            aux = AUX_ALPHA if (lam_d == 0.0 and m.opts.get("alpha_only_blend", True)) else 0
+            aux = AUX_ALPHA if (lam_d == 0.0 and not need_geometry and m.opts.get("alpha_only_blend", True)) else 0
             rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=("raw",),
                                        aux_planes=aux)
             if "raw_stacked" in rendered:   # the frames came out of one stacked launch set: (3,M,H,W), (8,M,H,W)
@@ -408,12 +411,10 @@ class Stage3Trainer:
             else:
                 colors, allmaps = zip(*rendered["raw"])
             from .loss_fused import unit_gradient
-            losses = stage3_loss(colors, allmaps, getattr(m, "learnable_bkgd", None), batch, step, self.cfg)
+            cams = m.get_gs_Kcamera(batch["Kinv"], batch["H"], batch["W"]) if need_geometry else None  # (cached)
+            losses = stage3_loss(colors, allmaps, getattr(m, "learnable_bkgd", None), batch, step, self.cfg,
+                                 cameras=cams, depth_ratio=float(getattr(m.pipeline, "depth_ratio", 0.0)))
             total = losses.pop("total")  # (summed by the kernel; the backward starts from a cached 1.0)
-            z = self.__dict__.get("_zero_loss")
-            if z is None or z.device != m._xyz.device:
-                z = self._zero_loss = torch.zeros((), device=m._xyz.device)
-            losses["normal_loss"] = z
             total.backward(gradient=unit_gradient(m._xyz.device))
             return losses
         else:
