@@ -103,35 +103,83 @@ def cpu_baseline(scene, n_images: int):
             "fwd_only_images_per_s": n_images / t_fwd}
 
 
-def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int):
+def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: int = 0, seed: int = 0, barrier=None):
     """Second figure of SURVEY.md 8(d): images/s of the FULL Stage-3 fitting step (bob LBS warp with frozen,
     randomly initialised warp / camera networks -> rasterize 2 frames -> losses -> backward -> gradient clip ->
-    densification statistics -> Adam) on an object-centric synthetic sequence of the same size."""
+    densification statistics -> Adam) on an object-centric synthetic sequence of the same size.
+    start_step > 8000: the regularised regime of the second third of a Stage-3 run (lambda_normal on: all 8 planes
+    through the blend kernels, depth / normal post-processing + normal-consistency term inside the loss kernels;
+    BASELINE.json configs[4] "depth/normal reg on")."""
     import numpy as np
     from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
     from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
-    rng = np.random.default_rng(0)
-    torch.manual_seed(0)
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
     frames = 120
     m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=frames, device=dev)
     d = rng.normal(size=(n_surfels, 3)).astype(np.float32)
     pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(n_surfels, 1)).astype(np.float32) ** (1 / 3)
     m.init_from_points(pts.astype(np.float32), rng.uniform(size=(n_surfels, 3)).astype(np.float32))
     tr = Stage3Trainer(m)
+    if start_step:
+        m.active_sh_degree = m.max_sh_degree   # (reached at step 3000)
+        tr.current_steps = start_step
     batches = [synthetic_batch(m, [(2 * i) % frames, (2 * i + 1) % frames], H, W, seed=i) for i in range(8)]
     for i in range(6):
         tr.train_step(batches[i % 8])
     torch.cuda.synchronize(dev)
+    if barrier is not None:
+        barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         tr.train_step(batches[i % 8])
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
-    return {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps,
+    regime = ("losses as the reference's --rgb_loss_only run before step 8000 (colour + silhouette, lambda_dist = 0), so the "
+              "blend kernels run their colour + alpha-plane instances (aux_planes); the op-level `value` above drives all 8 planes"
+              if start_step <= 8000 else
+              f"steps {start_step}.. of the schedule: normal-consistency regulariser on (lambda_normal = 0.05, model.py:817-842), "
+              "all 8 planes through the blend kernels, depth / normal post-processing inside the loss kernels")
+    return {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps, "seconds": dt * steps,
             "config": f"{n_surfels} surfels in a unit ball 3 units from the camera, {W}x{H}, 25 bones, 120 frames, "
-                      "warp / camera networks frozen (--gs_optim_warp=False), densify off; losses as the reference's "
-                      "--rgb_loss_only run before step 8000 (colour + silhouette, lambda_dist = 0), so the blend kernels run "
-                      "their colour + alpha-plane instances (aux_planes); the op-level `value` above drives all 8 planes"}
+                      "warp / camera networks frozen (--gs_optim_warp=False), densify off; " + regime}
+
+
+# xGMI: 7 links per GPU, ~153 GB/s each (task statement / MI355X guide); one kernel-boundary-sized latency per collective phase
+XGMI_LINKS, XGMI_LINK_GBPS, COLLECTIVE_LATENCY_MS = 7, 153.0, 0.02
+
+
+def exchange_model_ms(payload_bytes: float, n: int) -> dict:
+    """MODELLED time of the step's one all-reduce of `payload_bytes` over n GPUs of one node (no multi-GPU node was
+    available to measure it).  Three algorithms bracket what RCCL does on a fully connected xGMI node:
+      ring_one_link   a single ring, each hop over ONE link: 2 (n-1)/n S / 153 GB/s            (pessimistic)
+      ring_all_links  RCCL's multi-ring schedule over all 7 links at 70 % of their sum            (typical, large messages)
+      direct_rs_ag    reduce-scatter + all-gather with every peer at once, S/n per link per phase (what xGMI's
+                      point-to-point topology allows)"""
+    if n <= 1:
+        return {"ring_one_link": 0.0, "ring_all_links": 0.0, "direct_rs_ag": 0.0}
+    s = float(payload_bytes)
+    lat = COLLECTIVE_LATENCY_MS
+    links = min(XGMI_LINKS, n - 1)              # links of one GPU that lead to a peer inside the group
+    eff = 0.7 if links > 1 else 1.0
+    wire = 2.0 * (n - 1) / n * s                # bytes every GPU sends (and receives) in a ring all-reduce
+    return {"ring_one_link": wire / (XGMI_LINK_GBPS * 1e9) * 1e3 + 2 * lat,
+            "ring_all_links": wire / (eff * links * XGMI_LINK_GBPS * 1e9) * 1e3 + 2 * lat,
+            "direct_rs_ag": 2.0 * (s / n) / (XGMI_LINK_GBPS * 1e9) * 1e3 + 2 * lat}
+
+
+def scaling_model(ms_per_step_1gpu: float, payload_bytes: float, overlapped: bool) -> dict:
+    """MODELLED weak scaling (images/s at N GPUs / images/s at 1 GPU) from the MEASURED 1-GPU step and the exchange
+    model above.  serial: the exchange sits between backward and optimizer (the fitting loop: Adam needs the reduced
+    gradient); overlapped: it runs beside the next step's kernels (bench.py's op-level loop, double-buffered gradient
+    buffers) and costs only what exceeds a step."""
+    out = {}
+    for n in (2, 4, 8):
+        ex = exchange_model_ms(payload_bytes, n)
+        out[str(n)] = {k: round(n * ms_per_step_1gpu / (max(ms_per_step_1gpu, v) if overlapped else ms_per_step_1gpu + v), 2)
+                       for k, v in ex.items()}
+        out[str(n)]["exchange_ms"] = {k: round(v, 3) for k, v in ex.items()}
+    return out
 
 
 def torch_cpu_baseline(scene, n_images: int, threads: int):
@@ -173,6 +221,40 @@ def torch_cpu_baseline_bounded(args, limit_s: float = 150.0):
                           f"{args.torch_cpu_images / limit_s:.4f} images/s)"}
 
 
+def replicas_main(args, world, rank, local_rank):
+    """BASELINE.json configs[3]: `world` independent sequences, one process per GPU, nothing exchanged -- an RCCL
+    barrier before the timed loop and one after it (the pattern of lab4d/utils/gpu_utils.py:6-128 /
+    scripts/run_rendering_parallel.py:47-68: a pool of per-GPU workers).  Each rank fits ITS OWN sequence (own seed);
+    value = world * steps * 2 frames / the slowest rank's time."""
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29513")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    steps = max(1, args.fit_steps)
+    r = fit_step_rate(dev, args.surfels, args.res, args.height or args.res, steps, seed=rank, barrier=dist.barrier)
+    dist.barrier()
+    tt = torch.tensor([r["seconds"]], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        secs = float(tt.item())
+        out = {"metric": f"train images/sec (full Stage-3 fitting step), {world} independent sequence(s) one per GPU",
+               "value": world * steps * 2 / secs, "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": 6,
+               "ms_per_step": 1e3 * secs / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[3]: independent sequences, 1 per GPU, RCCL barrier at start / end only; "
+                                      + r["config"], "parallelism": f"replicas x{world}"}}
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,7 +278,17 @@ def main():
                                                             "frame, on separate HIP streams with --frame-streams 1")
     ap.add_argument("--repeats", type=int, default=5, help="further timed regions of --steps steps (median / p10 / p90)")
     ap.add_argument("--fit-steps", type=int, default=30, help="steps of the full Stage-3 fitting loop timed for "
-                                                              "\"fit_step\" (0 = skip)")
+                                                              "\"fit_step\" and \"fit_step_geometry\" (0 = skip)")
+    ap.add_argument("--exchange", choices=["overlapped", "serial"], default="overlapped",
+                    help="N > 1: overlapped = the step's all-reduce runs beside the next step's kernels (two gradient "
+                         "buffers, joined before its buffer is reused: the op-level loop has no optimizer between steps); "
+                         "serial = joined at the end of its step")
+    ap.add_argument("--per-frame-surface", type=int, default=1,
+                    help="also time the reference's per-frame GaussianRasterizer.forward surface (one call per frame) "
+                         "-> \"value_per_frame_calls\"")
+    ap.add_argument("--replicas", type=int, default=0,
+                    help="BASELINE.json configs[3]: N independent Stage-3 sequences, one per GPU, RCCL barrier at start "
+                         "and end only; prints the aggregate images/s of the full fitting step")
     ap.add_argument("--_torch_cpu_child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--_threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -210,10 +302,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.replicas:
+        args.gpus = args.replicas
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.replicas and (args.replicas == 1 or "WORLD_SIZE" in os.environ):
+        return replicas_main(args, world, rank, local_rank)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under torchrun: start the ranks ourselves (one process per GPU over RCCL) and relay rank 0's line
         import subprocess
@@ -264,15 +360,18 @@ def main():
     opac = scene.opacities.clone().requires_grad_(True)
     scales = scene.scales.clone().requires_grad_(True)
     shs = scene.shs.clone().requires_grad_(True)
-    flat = torch.empty(N * GRAD_FLOATS_PER_SURFEL, device=dev) if use_dist else None
+    # the step's gradients are produced into one of TWO persistent flat buffers, alternately, so that the all-reduce of
+    # step i can still be on the wire while step i + 1 fills the other one (--exchange overlapped)
+    flats = [torch.empty(N * GRAD_FLOATS_PER_SURFEL, device=dev) for _ in range(2)] if use_dist else None
+    pending = [None, None]
     use_distributed_exchange = use_dist
     opac_f, scales_f, shs_f = opac, scales, shs
-    counter = {"slot": 0, "R": 0.0, "n": 0}
+    counter = {"slot": 0, "R": 0.0, "n": 0, "buf": 0}
 
     # The frames of a step are independent until their gradients are summed: like Stage3Trainer, each one
     # is queued on its own HIP stream, so the tail of one frame's blend kernels overlaps the next frame's
     # projection / binning instead of leaving CUs idle (--frame-streams 0: one stream).
-    mode = {"streams": bool(args.frame_streams)}
+    mode = {"streams": bool(args.frame_streams), "stacked": bool(args.stacked)}
     side = [torch.cuda.Stream(device=dev) for _ in range(FRAMES_PER_STEP)]
 
     def one_frame(i):
@@ -296,8 +395,13 @@ def main():
         # the path's only exchange: canonical-surfel gradients, once per optimizer step.  (After the capacity
         # check, so that a repeated step on one rank cannot add a collective the other ranks do not make.)
         if use_distributed_exchange:
-            # (the shared-parameter gradients already live in `flat`: their .grad tensors are views of it)
-            dist.all_reduce(flat)
+            # (the shared-parameter gradients already live in the flat buffer: their .grad tensors are views of it)
+            b = counter["buf"]
+            pending[b] = dist.all_reduce(flats[b], async_op=True)   # RCCL's stream waits for the kernels queued so far
+            if args.exchange == "serial":
+                pending[b].wait()
+                pending[b] = None
+            counter["buf"] = b ^ 1
 
     if use_dist:
         # one persistent flat exchange buffer; the shared parameters' .grad are views of it (autograd accumulates
@@ -307,7 +411,21 @@ def main():
         for name, n in (("means", N * 3), ("opac", N), ("scales", N * 2), ("rot", N * 4), ("shs", N * 48)):
             offs[name] = (o, o + n)
             o += n
-        flat_view = {k: flat[a:b] for k, (a, b) in offs.items()}
+        flat_views = [{k: f[a:b] for k, (a, b) in offs.items()} for f in flats]
+
+    def claim_flat():
+        """This step's gradient buffer, zeroed, with the shared parameters' .grad bound to it; joins the collective that
+        last used it (two steps ago)."""
+        b = counter["buf"]
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        flats[b].zero_()
+        fv = flat_views[b]
+        opac.grad = fv["opac"].view_as(opac)
+        scales.grad = fv["scales"].view_as(scales)
+        shs.grad = fv["shs"].view_as(shs)
+        return fv
 
     rs_frames = [rs] * FRAMES_PER_STEP
     dc_st, do_st = torch.stack([dc] * FRAMES_PER_STEP, 1).contiguous(), torch.stack([do] * FRAMES_PER_STEP, 1).contiguous()
@@ -324,29 +442,18 @@ def main():
         return m.grad, r.grad
 
     def step_once():
-        if args.stacked:
-            if use_dist:
-                flat.zero_()
-                opac.grad = flat_view["opac"].view_as(opac)
-                scales.grad = flat_view["scales"].view_as(scales)
-                shs.grad = flat_view["shs"].view_as(shs)
-            else:
-                for t in (opac, scales, shs):
-                    t.grad = None
+        if use_dist:
+            flat_view = claim_flat()
+        else:
+            for t in (opac, scales, shs):
+                t.grad = None
+        if mode["stacked"]:
             gm, gr = stacked_frames()
             if use_dist:
                 torch.sum(gm, 0, out=flat_view["means"].view(N, 3))
                 torch.sum(gr, 0, out=flat_view["rot"].view(N, 4))
                 return None
             return gm.sum(0), gr.sum(0)
-        if use_dist:
-            flat.zero_()
-            opac.grad = flat_view["opac"].view_as(opac)
-            scales.grad = flat_view["scales"].view_as(scales)
-            shs.grad = flat_view["shs"].view_as(shs)
-        else:
-            for t in (opac, scales, shs):
-                t.grad = None
         use_streams = mode["streams"]
         main = torch.cuda.current_stream(dev)
         ready = main.record_event() if use_streams else None
@@ -370,6 +477,10 @@ def main():
         return sum(g[0] for g in per_frame), sum(g[1] for g in per_frame)
 
     def sync():
+        for b in range(2):   # (an all-reduce still in flight belongs to the region that issued it)
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -414,11 +525,55 @@ def main():
             step()
         sync()
         rep_rates.append(world * args.steps * FRAMES_PER_STEP / (time.perf_counter() - r0))
+    # ---- the reference's own surface: one GaussianRasterizer.forward call per frame (here: on separate HIP streams),
+    # timed the same way -- `value` above runs the frames of a step through ONE stacked launch set (an extension)
+    per_frame = None
+    if args.stacked and args.per_frame_surface:
+        mode["stacked"] = False
+        for _ in range(min(args.warmup, 10)):
+            step()
+        sync()
+        p0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        pf_elapsed = time.perf_counter() - p0
+        pf_rates = []
+        for _ in range(max(0, args.repeats)):
+            sync()
+            r0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            pf_rates.append(world * args.steps * FRAMES_PER_STEP / (time.perf_counter() - r0))
+        mode["stacked"] = True
+        per_frame = (pf_elapsed, pf_rates)
     gc.enable()
     if use_dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, per_frame[0] if per_frame else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        if per_frame:
+            per_frame = (float(tt[1].item()), per_frame[1])
+
+    # what the dominant kernel's tile walk looks like on this workload (a counting pass behind one extra step, outside
+    # every timed region): lane utilisation = contributing (pixel, surfel) pairs / (64 lanes x pair evaluations)
+    walk = None
+    if rank == 0:
+        lib = _lib.load()
+        cnt = torch.zeros(16, dtype=torch.int64, device=dev)
+        lib.vidu4d_surfel_blend_stats(cnt.data_ptr())
+        step()
+        torch.cuda.synchronize(dev)
+        lib.vidu4d_surfel_blend_stats(None)
+        c = [int(x) for x in cnt.tolist()]
+        if c[1]:
+            walk = {"list_entries_staged": c[0], "pair_evaluations": c[1], "evaluations_with_a_contributor": c[2],
+                    "contributing_pairs": c[3], "lane_utilisation": c[3] / (64.0 * c[1]),
+                    "rows_touched_per_contributing_evaluation": c[4] / max(1, c[2]),
+                    "contributing_lanes_histogram_le_4_8_16_32_64": c[5:10], "per": "step (its frames, one or more launches)"}
+    if use_dist:
+        dist.barrier()
 
     images = world * args.steps * FRAMES_PER_STEP
     value = images / elapsed
@@ -437,13 +592,28 @@ def main():
                    "frames_of_a_step": "one stacked launch set" if args.stacked else
                                        ("one call per frame, separate HIP streams" if args.frame_streams else "one call per frame")},
     }
+    if world > 1 or use_dist:
+        out["config"]["exchange"] = ("all-reduce of the step's flat gradient buffer joined before its buffer is reused, two steps "
+                                     "later (the op-level loop has no optimizer between steps)" if args.exchange == "overlapped"
+                                     else "all-reduce joined at the end of its step")
+
+    def summary(rates):
+        import statistics
+        q = sorted(rates)
+        pick = lambda f: q[min(len(q) - 1, max(0, int(round(f * (len(q) - 1)))))]  # noqa: E731
+        return {"n": len(q), "unit": "images/s", "median": statistics.median(q), "p10": pick(0.1), "p90": pick(0.9),
+                "min": q[0], "max": q[-1], "note": "this rank's clock; each region = --steps steps"}
 
     if rep_rates:
-        import statistics
-        q = sorted(rep_rates)
-        pick = lambda f: q[min(len(q) - 1, max(0, int(round(f * (len(q) - 1)))))]  # noqa: E731
-        out["repeats"] = {"n": len(q), "unit": "images/s", "median": statistics.median(q), "p10": pick(0.1), "p90": pick(0.9),
-                          "min": q[0], "max": q[-1], "note": "this rank's clock; each region = --steps steps"}
+        out["repeats"] = summary(rep_rates)
+    if per_frame:
+        out["value_per_frame_calls"] = {
+            "value": images / per_frame[0], "unit": "images/s", "ms_per_step": 1e3 * per_frame[0] / args.steps,
+            "surface": "GaussianRasterizer.forward once per frame (the reference's call pattern, "
+                       "deformable_gaussian.py:1175-1228), frames of a step on separate HIP streams; same steps / barriers "
+                       "as `value`", "steps": args.steps}
+        if per_frame[1]:
+            out["value_per_frame_calls"]["repeats"] = summary(per_frame[1])
     if rank == 0:
         # ---- roofline of the dominant kernel (live HIP-event stage timers, see above)
         from vidu4d_amd import _C
@@ -488,6 +658,8 @@ def main():
                 limiter = json.load(open(tpath)).get(dom, {}).get("limiter", {})
             except Exception:
                 limiter = {}
+            if walk:
+                limiter = dict(limiter, tile_walk=walk)
             out["roofline"] = {"bound": limiter.get("bound", "hbm"), "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "limiter": limiter,
                                "avg_launch_ms": stages[dom]["ms_avg"],
@@ -497,6 +669,26 @@ def main():
                                "frames_per_launch": units, "algorithmic_bytes_per_launch": launch_bytes}
         if world == 1 and args.fit_steps > 0:
             out["fit_step"] = fit_step_rate(dev, N, W, H, args.fit_steps)
+            out["fit_step_geometry"] = fit_step_rate(dev, N, W, H, args.fit_steps, start_step=8001)
+        if world == 1:
+            # MODELLED multi-GPU figures (no multi-GPU node is reachable from the build box; the driver
+            # measures the real curve when it has one): measured 1-GPU step + the all-reduce cost model above
+            payload = N * GRAD_FLOATS_PER_SURFEL * 4
+            sm = {"label": "MODELLED, not measured: measured 1-GPU step + cost model of one all-reduce per step",
+                  "assumptions": {"xgmi_links_per_gpu": XGMI_LINKS, "GBps_per_link": XGMI_LINK_GBPS,
+                                  "latency_ms_per_collective_phase": COLLECTIVE_LATENCY_MS,
+                                  "ring_all_links_efficiency": 0.7, "weak_scaling": "per-GPU work fixed (2 frames per step)"},
+                  "op_level": {"ms_per_step_1gpu": out["ms_per_step"], "payload_bytes": payload,
+                               "speedup_exchange_overlapped": scaling_model(out["ms_per_step"], payload, True),
+                               "speedup_exchange_serial": scaling_model(out["ms_per_step"], payload, False)}}
+            for key in ("fit_step", "fit_step_geometry"):
+                if key in out:
+                    # Stage3Trainer's exchange: 58 floats per surfel + 3 (learnable background); regist_feat and SH bands
+                    # above the active degree stay home (stage3.py: exchanged_params / _packs_rest)
+                    pay = N * GRAD_FLOATS_PER_SURFEL * 4 + 12
+                    sm[key] = {"ms_per_step_1gpu": out[key]["ms_per_step"], "payload_bytes": pay,
+                               "speedup_exchange_serial": scaling_model(out[key]["ms_per_step"], pay, False)}
+            out["scaling_modelled"] = sm
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
         if world == 1 and args.torch_cpu_images > 0:

@@ -107,6 +107,7 @@ class BackwardArgs(C.Structure):
 _P = C.c_void_p
 SYMBOLS = {
     "vidu4d_surfel_abi_version": (C.c_int, []),
+    "vidu4d_surfel_blend_stats": (C.c_int, [_P]),
     "vidu4d_last_error": (C.c_char_p, []),
     "vidu4d_surfel_geom_bytes": (C.c_size_t, [C.c_int]),
     "vidu4d_surfel_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),

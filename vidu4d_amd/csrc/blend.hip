@@ -777,6 +777,94 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x
     }
 }
 
+// Diagnostic (vidu4d_surfel_blend_stats): what the backward's walk looks like for the frame at hand, counted by walking
+// every tile whole with the backward's own staging, cull masks and skip rules (no recurrences, no gradients).
+//   [0] list entries staged (per workgroup batch, summed)          [1] (entry, wave) trips that evaluate the pair
+//   [2] trips in which some lane contributes                       [3] contributing lanes (pairs) in total
+//   [4] 16-lane rows with a contributing lane, summed over [2]     [5..9] trips of [2] with <= 4, 8, 16, 32, 64 lanes
+__global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int grid_x, int grid_y, ImageState img,
+                                                             const uint32_t* __restrict__ point_list,
+                                                             const float* __restrict__ rec,
+                                                             unsigned long long* __restrict__ out)
+{
+    __shared__ float4 s_rec[BWD_BATCH * 5];
+    __shared__ unsigned long long s_mask[4][4];
+    __shared__ uint32_t s_max;
+    TileCoord tc;
+    tc.tile = (int)img.tile_order[blockIdx.x];
+    tc.tx = tc.tile % grid_x;
+    tc.ty = tc.tile / grid_x;
+    size_t HW;
+    const size_t frame_base = frame_of_tile(tc, W, H, grid_y, HW);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
+    const uint32_t r0 = img.ranges[2 * tc.tile];
+    const uint32_t last = inside ? img.n_contrib[frame_base + (size_t)py * W + px] : 0;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    uint32_t wave_last = last;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)wave_last, d, 64);
+        wave_last = o > wave_last ? o : wave_last;
+    }
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+    if (lane == 0) atomicMax(&s_max, wave_last);
+    __syncthreads();
+    const int n_used = (int)s_max;
+    unsigned long long c_staged = 0, c_trips = 0, c_full = 0, c_lanes = 0, c_rows = 0, c_hist[5] = {0, 0, 0, 0, 0};
+    for (int hi = n_used; hi > 0; hi -= BWD_BATCH) {
+        const int cnt = hi < BWD_BATCH ? hi : BWD_BATCH;
+        __syncthreads();
+        const bool have = (int)threadIdx.x < cnt;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) box = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)]);
+        if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        __syncthreads();
+        if (wave == 0) c_staged += (unsigned long long)cnt;
+        for (int k = 0; k < BWD_BATCH / 64; k++) {
+            unsigned long long m = uniform_u64(s_mask[wave][k]);
+            while (m) {
+                const int j = k * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t contributor = (uint32_t)(hi - 1 - j);
+                if (contributor >= wave_last) continue;
+                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+                const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
+                PairEval e;
+                const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && contributor < last;
+                const unsigned long long b = __ballot(ok);
+                c_trips++;
+                if (!b) continue;
+                const int n = __builtin_popcountll(b);
+                c_full++;
+                c_lanes += (unsigned long long)n;
+                c_rows += (unsigned long long)(((b & 0xffffull) != 0) + ((b & 0xffff0000ull) != 0) + ((b & 0xffff00000000ull) != 0) +
+                                               ((b & 0xffff000000000000ull) != 0));
+                c_hist[n <= 4 ? 0 : n <= 8 ? 1 : n <= 16 ? 2 : n <= 32 ? 3 : 4]++;
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(out + 0, c_staged);
+        atomicAdd(out + 1, c_trips);
+        atomicAdd(out + 2, c_full);
+        atomicAdd(out + 3, c_lanes);
+        atomicAdd(out + 4, c_rows);
+        for (int i = 0; i < 5; i++) atomicAdd(out + 5 + i, c_hist[i]);
+    }
+}
+
+void launch_blend_bwd_stats(const BackwardArgs& a, unsigned long long* counters, hipStream_t stream)
+{
+    const int tiles = total_tiles(a.cam), grid_y = a.cam.grid_y * a.cam.frames;
+    hipLaunchKernelGGL(blend_bwd_stats_kernel, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.img,
+                       a.point_list, a.geom.rec, counters);
+}
+
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
 {
     const int tiles = total_tiles(a.cam), grid_y = a.cam.grid_y * a.cam.frames;

@@ -43,6 +43,7 @@ struct StageSpan {
     int stage;
 };
 static bool g_prof_on = false;
+static unsigned long long* g_blend_stats = nullptr;  // vidu4d_surfel_blend_stats: device counters, or NULL (off)
 static std::vector<StageSpan> g_spans;      // recorded, not yet harvested
 static std::vector<StageSpan> g_span_pool;  // reusable event pairs
 static double g_stage_ms[ST_COUNT];
@@ -76,6 +77,11 @@ struct StageTimer {
 extern "C" int vidu4d_surfel_profile_enable(int on)
 {
     g_prof_on = on != 0;
+    return VIDU4D_OK;
+}
+extern "C" int vidu4d_surfel_blend_stats(unsigned long long* device_counters)
+{
+    g_blend_stats = device_counters;
     return VIDU4D_OK;
 }
 extern "C" int vidu4d_surfel_profile_stage_count(void) { return ST_COUNT; }
@@ -409,6 +415,7 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
         StageTimer t(ST_BLEND_BWD, stream);
         launch_blend_bwd(ba, stream);
     }
+    if (g_blend_stats && ba.point_list) launch_blend_bwd_stats(ba, g_blend_stats, stream);
     STAGE_CHECK(a->debug, stream, "blend_backward");
     {
         StageTimer t(ST_PREPROCESS_BWD, stream);

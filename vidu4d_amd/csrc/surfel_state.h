@@ -299,6 +299,7 @@ struct BackwardArgs {
     bool lite;            // only dL_dcolor and plane 1 of dL_dothers are live (aux_planes == alpha only)
 };
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream);
+void launch_blend_bwd_stats(const BackwardArgs& a, unsigned long long* counters, hipStream_t stream);  // diagnostic
 void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
 
