@@ -791,6 +791,69 @@ def gen_densify(out_dir):
     npz(os.path.join(out_dir, "refpy_densify.npz"), **out)
 
 
+class _PlyElementStandIn:
+    """What plyfile.PlyElement.describe(structured_array, "vertex") + PlyData([el]).write(path) put on disk for an
+    all-float32 vertex element (plyfile is not installed here): the header plyfile writes for it -- `ply`, the binary
+    little-endian format line, `element vertex N`, one `property float <name>` per field of the structured dtype IN
+    THE ARRAY'S FIELD ORDER, `end_header` -- followed by the array's bytes.  Field names, their order and the record
+    layout all come from the reference's save_ply; this stand-in only does the file framing."""
+
+    def __init__(self, data, name):
+        self.data, self.name = data, name
+
+    @classmethod
+    def describe(cls, data, name):
+        return cls(data, name)
+
+
+class _PlyDataStandIn:
+    def __init__(self, elements):
+        self.elements = elements
+
+    def write(self, path):
+        import numpy as np
+        with open(path, "wb") as f:
+            f.write(b"ply\nformat binary_little_endian 1.0\n")
+            for el in self.elements:
+                f.write(("element %s %d\n" % (el.name, len(el.data))).encode("ascii"))
+                for field in el.data.dtype.names:
+                    assert el.data.dtype[field] == np.dtype("f4")
+                    f.write(("property float %s\n" % field).encode("ascii"))
+            f.write(b"end_header\n")
+            for el in self.elements:
+                f.write(el.data.astype(el.data.dtype.newbyteorder("<")).tobytes())
+
+
+def gen_ply(out_dir):
+    """gs/scene/gaussian_model.py:189-220: construct_list_of_attributes + save_ply of the reference's GaussianModel on
+    seeded tensors (the attribute list, the channel-major f_dc / f_rest flattening, the zero normals, the record layout).
+    The file the reference writes is kept whole (a few KiB): the product's writer must produce the same bytes and its
+    reader must read it back."""
+    import tempfile
+    import numpy as np
+    import torch
+    import gs.scene.gaussian_model as ref_gm
+    g = torch.Generator().manual_seed(2024)
+    N = 23
+    gm = ref_gm.GaussianModel(sh_degree=3)
+    t = {"_xyz": torch.randn(N, 3, generator=g), "_features_dc": torch.randn(N, 1, 3, generator=g),
+         "_features_rest": torch.randn(N, 15, 3, generator=g), "_opacity": torch.randn(N, 1, generator=g),
+         "_scaling": torch.randn(N, 2, generator=g), "_rotation": torch.randn(N, 4, generator=g)}
+    for k, v in t.items():
+        setattr(gm, k, torch.nn.Parameter(v.clone()))
+    saved = (ref_gm.PlyData, ref_gm.PlyElement)
+    ref_gm.PlyData, ref_gm.PlyElement = _PlyDataStandIn, _PlyElementStandIn
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "sub", "point_cloud.ply")
+            gm.save_ply(path)
+            raw = open(path, "rb").read()
+    finally:
+        ref_gm.PlyData, ref_gm.PlyElement = saved
+    npz(os.path.join(out_dir, "refpy_ply.npz"), file_bytes=np.frombuffer(raw, dtype=np.uint8),
+        attributes=np.array(gm.construct_list_of_attributes()), **{"in" + k: v for k, v in t.items()})
+
+
 def gen_losses(out_dir):
     """lab4d/engine/model.py: get_mask_balance_wt :586-611, compute_recon_loss (gs branch) :613-693,
     compute_reg_loss :803-842, mask_losses :895-978, apply_loss_weights :980-1012 -- called on a bare namespace
@@ -890,7 +953,7 @@ def main():
     dsr = install_environment()
     import torch
     torch.set_num_threads(1)  # bit-reproducible reductions
-    todo = args.only.split(",") if args.only else ["quat", "warp", "camera", "render", "loop", "densify", "losses", "vidloader"]
+    todo = args.only.split(",") if args.only else ["quat", "warp", "camera", "render", "loop", "densify", "ply", "losses", "vidloader"]
     if "quat" in todo:
         gen_quat(args.out)
     if "warp" in todo:
@@ -902,6 +965,8 @@ def main():
         gen_loop(args.out, dsr)
     if "densify" in todo:
         gen_densify(args.out)
+    if "ply" in todo:
+        gen_ply(args.out)
     if "losses" in todo:
         gen_losses(args.out)
     if "vidloader" in todo:

@@ -1,5 +1,7 @@
 """GPU tests of the callers around the rasterizer: gs.gaussian_renderer.render (dict contract),
 KCamera-driven rendering of warped surfels, and the Stage-3 fitting loop."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -148,3 +150,30 @@ def test_fused_post_processing_matches_torch_composite(gpu_device):
             assert torch.isfinite(a).all()
             assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-12), ratio
 
+
+
+def test_forward_only_render_entry_consumes_a_checkpoint(gpu_device, tmp_path):
+    """lab4d/render.py (reference :279-354): a checkpoint written by the trainer -> every frame rendered forward-only at
+    --render_res -> rgb.pth with the reference's two arrays; the images are what the model itself renders."""
+    from vidu4d_amd.lab4d import checkpoint as ck
+    from vidu4d_amd.lab4d import render as rd
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, make_intrinsics_inv
+    dev = gpu_device
+    m = _model(dev, n=3000, frames=6, seed=3)
+    with torch.no_grad():
+        m._opacity.fill_(1.0)
+        m._features_dc.normal_(0.0, 1.0)
+    m.active_sh_degree = m.max_sh_degree
+    tr = Stage3Trainer(m)
+    logdir = tmp_path / "logdir" / "toy-gs"
+    ck.save_checkpoint(tr, str(logdir), round_count=2)
+    save_dir = rd.main(["--logroot", str(tmp_path / "logdir"), "--seqname", "toy", "--logname", "gs", "--num_frames", "6",
+                        "--render_res", "64", "--load_suffix", "latest", "--chunk", "4"])
+    out = torch.load(os.path.join(save_dir, "rgb.pth"), weights_only=False)
+    assert out["rgb"].shape == (6, 64, 64, 3) and out["rgb"].dtype == np.float16
+    assert out["mask"].shape == (6, 64, 64, 3) and np.isfinite(out["mask"].astype(np.float32)).all()
+    with torch.no_grad():
+        fid = torch.arange(6, device=dev)
+        want = m.render_frames(fid, make_intrinsics_inv(6, 64, 64), [64] * 6, [64] * 6)["rendered"].clamp(0, 1)
+    assert float(out["rgb"].astype(np.float32).max()) > 0.1
+    assert np.abs(out["rgb"].astype(np.float32) - want.cpu().numpy()).max() <= 2e-3   # (float16 storage)

@@ -272,3 +272,29 @@ def check_losses(case, dev):
 @pytest.mark.parametrize("case", LOSS_CASES)
 def test_stage3_losses(case):
     check_losses(case, "cpu")
+
+
+def test_ply_bytes_match_the_reference_writer(tmp_path):
+    """gs/scene/gaussian_model.py:189-220 through the imported reference (make_refpy_golden.py::gen_ply): the product's
+    save_ply writes the SAME FILE -- attribute list and order (x y z nx ny nz f_dc_* f_rest_* opacity scale_* rot_*),
+    channel-major flattening of the SH tensors, zero normals, float32 little-endian records -- and load_ply reads the
+    reference's file back into the reference's tensors."""
+    import numpy as np
+    from vidu4d_amd.gs.gaussian_model import GaussianModel
+    r = np.load(os.path.join(G, "refpy_ply.npz"))
+    m = GaussianModel(3, device="cpu")
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        setattr(m, k, torch.nn.Parameter(torch.tensor(r["in" + k])))
+    assert m.construct_list_of_attributes() == [str(a) for a in r["attributes"]]
+    path = str(tmp_path / "out" / "point_cloud.ply")
+    m.save_ply(path)
+    want = r["file_bytes"].tobytes()
+    got = open(path, "rb").read()
+    assert got[:got.index(b"end_header\n")] == want[:want.index(b"end_header\n")], "PLY header differs from the reference's"
+    assert got == want
+    ref_path = str(tmp_path / "ref.ply")
+    open(ref_path, "wb").write(want)
+    m2 = GaussianModel(3, device="cpu")
+    m2.load_ply(ref_path)
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert np.array_equal(getattr(m2, k).detach().numpy(), r["in" + k]), k

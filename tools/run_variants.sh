@@ -5,7 +5,7 @@ cp vidu4d_amd/csrc/libvidu4d_surfel.so /tmp/product.so
 for v in ${@:-variants/*.so}; do
   cp $v vidu4d_amd/csrc/libvidu4d_surfel.so
   for st in ${STACKED:-1}; do
-  timeout 300 python bench.py --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 3 --stacked $st 2>/dev/null | V=$v ST=$st python -c '
+  timeout 300 python bench.py --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 3 --per-frame-surface 0 --stacked $st 2>/dev/null | V=$v ST=$st python -c '
 import json, os, sys
 d = json.loads(sys.stdin.readlines()[-1])
 keep = os.environ.get("STAGES", "blend")   # STAGES=all prints every stage timer

@@ -252,8 +252,13 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
 // blended from T = 1 -- colour is linear in the start transmittance and, as long as no pixel saturates, no decision
 // depends on it -- and stores its colour and its transmittance PRODUCT; blend_combine_kernel scales by the product of
 // the predecessors and reports a pixel that did come near the saturation threshold (the frame is then blended again).
+#ifdef SURFEL_FWD_WAVES_PER_EU
+#define SURFEL_FWD_OCC __attribute__((amdgpu_waves_per_eu(SURFEL_FWD_WAVES_PER_EU, SURFEL_FWD_WAVES_PER_EU)))
+#else
+#define SURFEL_FWD_OCC
+#endif
 template <bool SPLIT, bool LITE>
-__global__ __launch_bounds__(256) void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
+__global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        int64_t capacity, int max_seg, const float* __restrict__ rec,
                                                        const float* __restrict__ bg, float* __restrict__ seg_data,
@@ -607,8 +612,16 @@ __device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
 // blend_combine_kernel); everything else is the single-workgroup loop restricted to the segment.
 // LITE: only dL/dcolour and dL/d(alpha plane) are read (the caller promised zeros elsewhere, aux_planes); the forward
 // that filled the state may itself have run LITE (no distortion moments, no median contributor: never read here).
+// Register budget of the full instances: 80 VGPRs = 6 waves per SIMD (the allocator takes 88 = 5 waves when left alone;
+// no spills at 80, 10-13 spilled registers at 72).  Round 3, stacked launch at the headline size: 509 -> 497 us; 4 waves
+// per SIMD measure the same as 5 -- the kernel is bound by VALU issue, not by latency, the sixth wave only fills bubbles.
+// The LITE instances need 64-66 registers and are left to the allocator (7 waves, the LDS limit).
+#ifndef SURFEL_BWD_WAVES_PER_EU
+#define SURFEL_BWD_WAVES_PER_EU 6
+#endif
 template <bool SPLIT, bool LITE>
-__global__ __launch_bounds__(256) void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LITE ? 1 : SURFEL_BWD_WAVES_PER_EU, LITE ? 8 : SURFEL_BWD_WAVES_PER_EU)))
+void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        const float* __restrict__ rec, const float* __restrict__ bg,
                                                        const float* __restrict__ seg_data, int max_seg,

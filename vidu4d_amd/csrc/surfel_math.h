@@ -626,8 +626,8 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
         dL_dalpha += (1.0f - s.accum_alpha_rec) * s.dL_daccum;
         dL_dalpha *= s.T;
         dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot_dpixel;
-        for (int ch = 0; ch < 3; ch++) s.accum_rec[ch] = alpha * rgb[ch] + one_m_alpha * s.accum_rec[ch];
-        s.accum_alpha_rec = alpha + one_m_alpha * s.accum_alpha_rec;
+        for (int ch = 0; ch < 3; ch++) s.accum_rec[ch] = fmaf(alpha, rgb[ch] - s.accum_rec[ch], s.accum_rec[ch]);
+        s.accum_alpha_rec = fmaf(alpha, 1.0f - s.accum_alpha_rec, s.accum_alpha_rec);
         PairGrad r;
         r.w = w;
         r.dL_dalpha = dL_dalpha;
@@ -656,12 +656,15 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
     dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot_dpixel;
 
     // fold this sample into the running "what lies behind" values (see the struct comment)
+    // x <- x + alpha (c - x): the differences are the ones dL_dalpha was just built from, so each running value costs one
+    // FMA instead of a multiplication and an FMA (8 of the ~210 VALU instructions of a pair evaluation: blend_bwd -2.4 %).
+    // backward.cu:337-380 writes alpha c + (1 - alpha) x; the two round differently by an ulp of x.
     for (int ch = 0; ch < 3; ch++) {
-        s.accum_rec[ch] = alpha * rgb[ch] + one_m_alpha * s.accum_rec[ch];
-        s.accum_normal_rec[ch] = alpha * normal[ch] + one_m_alpha * s.accum_normal_rec[ch];
+        s.accum_rec[ch] = fmaf(alpha, rgb[ch] - s.accum_rec[ch], s.accum_rec[ch]);
+        s.accum_normal_rec[ch] = fmaf(alpha, normal[ch] - s.accum_normal_rec[ch], s.accum_normal_rec[ch]);
     }
-    s.accum_depth_rec = alpha * c_d + one_m_alpha * s.accum_depth_rec;
-    s.accum_alpha_rec = alpha + one_m_alpha * s.accum_alpha_rec;
+    s.accum_depth_rec = fmaf(alpha, c_d - s.accum_depth_rec, s.accum_depth_rec);
+    s.accum_alpha_rec = fmaf(alpha, 1.0f - s.accum_alpha_rec, s.accum_alpha_rec);
     dL_dz += w * s.dL_ddepth;
     PairGrad r;
     r.w = w;
