@@ -20,13 +20,14 @@ GROUPS = [
     "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY",
     "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS",
     "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS_ATOMIC SQ_INSTS_VMEM",
+    "SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INSTS SQ_ACTIVE_INST_VMEM",
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("kernel")
-    ap.add_argument("--bench-args", default="--steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --no-stage-timers --frame-streams 0")
+    ap.add_argument("--bench-args", default="--steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --no-stage-timers --frame-streams 0 --per-frame-surface 0")
     ap.add_argument("--out", default="")
     ap.add_argument("--groups", default="0,1,2")
     args = ap.parse_args()

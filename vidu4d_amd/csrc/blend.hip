@@ -30,6 +30,7 @@
 //     combine); callers that read only colour + alpha plane get the LITE instances (aux_planes), which carry
 //     nothing else.
 #include <algorithm>
+#include <cstdlib>
 
 #include "surfel_state.h"
 
@@ -878,17 +879,30 @@ void launch_blend_bwd_stats(const BackwardArgs& a, unsigned long long* counters,
                        a.point_list, a.geom.rec, counters);
 }
 
+// (experiments, tools/occ_probe.sh: VIDU4D_BWD_PAD_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups
+// resident per CU)
+static int bwd_pad_lds()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VIDU4D_BWD_PAD_LDS");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
 {
     const int tiles = total_tiles(a.cam), grid_y = a.cam.grid_y * a.cam.frames;
+    const int pad = bwd_pad_lds();
     if (a.split && a.seg_data) {
         auto kernel = a.lite ? &blend_bwd_kernel<true, true> : &blend_bwd_kernel<true, false>;
-        hipLaunchKernelGGL(kernel, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), 0, stream, a.cam.W, a.cam.H,
+        hipLaunchKernelGGL(kernel, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), pad, stream, a.cam.W, a.cam.H,
                            a.cam.grid_x, grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data,
                            a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc);
     } else {
         auto kernel = a.lite ? &blend_bwd_kernel<false, true> : &blend_bwd_kernel<false, false>;
-        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.geom.hdr,
+        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), pad, stream, a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.geom.hdr,
                            a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0, a.dL_dcolor, a.dL_dothers, a.acc);
     }
 }
