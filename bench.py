@@ -420,11 +420,17 @@ def main():
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        flats[b].zero_()
         fv = flat_views[b]
-        opac.grad = fv["opac"].view_as(opac)
-        scales.grad = fv["scales"].view_as(scales)
-        shs.grad = fv["shs"].view_as(shs)
+        # opacity / scale / SH gradients are written by the rasterizer's backward straight into the buffer (one stacked
+        # call produces each of them exactly once: _C.gradient_buffers) and adopted by autograd as .grad; the per-frame
+        # surface has two calls per step and accumulates the second into them, so it starts from zeros
+        for t in (opac, scales, shs):
+            t.grad = None
+        if not mode["stacked"]:
+            flats[b].zero_()
+            opac.grad = fv["opac"].view_as(opac)
+            scales.grad = fv["scales"].view_as(scales)
+            shs.grad = fv["shs"].view_as(shs)
         return fv
 
     rs_frames = [rs] * FRAMES_PER_STEP
@@ -448,7 +454,12 @@ def main():
             for t in (opac, scales, shs):
                 t.grad = None
         if mode["stacked"]:
-            gm, gr = stacked_frames()
+            if use_dist:
+                with native.gradient_buffers(dL_dopacity=flat_view["opac"].view_as(opac), dL_dscales=flat_view["scales"].view_as(scales),
+                                             dL_dsh=flat_view["shs"].view_as(shs)):
+                    gm, gr = stacked_frames()
+            else:
+                gm, gr = stacked_frames()
             if use_dist:
                 torch.sum(gm, 0, out=flat_view["means"].view(N, 3))
                 torch.sum(gr, 0, out=flat_view["rot"].view(N, 4))

@@ -49,7 +49,8 @@ def _worker(rank, world, port, out):
             p.grad = gr.clone()
         m._regist_feat.grad = torch.full_like(m._regist_feat, float(rank + 1))   # stays local: nothing exchanges it
         tr.allreduce_gradients()
-        assert tr._flat.numel() == sum(p.numel() for p in tr.exchanged_params()) - 200 * 12 * 3
+        live = sum(p.numel() for p in tr.exchanged_params()) - 200 * 12 * 3   # the dead SH rows stay home
+        assert live <= tr._flat.numel() < live + 64 * len(tr.exchanged_params())  # (every tensor starts 256-byte aligned)
         all_g = [frame_grads(r) for r in range(world)]
         want = [sum(all_g[r][i] for r in range(world)) / world for i in range(len(tr.exchanged_params()))]
         ok_grad = all(torch.allclose(p.grad, w, atol=1e-7) for p, w in zip(tr.exchanged_params(), want))

@@ -232,3 +232,43 @@ def test_train_step_on_one_rank_leaves_the_gradients_unbound(gpu_device):
     # and the public entry point runs on that path
     out = t1.train_step(batch)
     assert t1._flat is None and all(torch.isfinite(v) for v in out.values())
+
+
+def test_direct_gradient_outputs_into_the_flat_buffer(gpu_device):
+    """Frame-parallel path: the canonical parameters' gradients are written by the rasterizer's backward straight into
+    the flat exchange buffer (_C.gradient_buffers) and adopted by autograd -- the same gradients autograd allocates
+    itself, .grad of every exchanged parameter a view of the buffer afterwards (nothing for the collective to gather),
+    also while only the live SH rows are exchanged."""
+    import numpy as np
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    dev = gpu_device
+
+    def make():
+        torch.manual_seed(0)
+        rng = np.random.default_rng(4)
+        m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=8, device=dev)
+        m.init_from_points(rng.normal(size=(3001, 3)).astype(np.float32) * 0.25, rng.uniform(size=(3001, 3)).astype(np.float32))
+        return m, Stage3Trainer(m)
+    for degree, world in ((3, 1), (1, 2)):
+        m1, t1 = make()
+        m2, t2 = make()
+        m1.active_sh_degree = m2.active_sh_degree = degree
+        t2.world = world                       # (what decides whether only the live SH rows are packed; no collective is run)
+        batch = synthetic_batch(m1, [1, 5], 48, 48, seed=2)
+        t1.begin_gradients()
+        assert t1._flat is None
+        t1._forward_backward(batch, 0)
+        t2.bind_flat_gradients(direct=True)
+        assert set(t2._direct) == {"dL_dsh_dc", "dL_dopacity", "dL_dscales", "dL_dsh_rest"}
+        t2._forward_backward(batch, 0)
+        flat_ptr = t2._flat.untyped_storage().data_ptr()
+        for a, b in zip(t1.exchanged_params(), t2.exchanged_params()):
+            assert b.grad is not None and t2._bound(b)
+            if b is not m2._features_rest or world == 1:
+                assert b.grad.untyped_storage().data_ptr() == flat_ptr
+            # (two executions of the blend backward: the order of its float atomics differs, nothing else)
+            assert torch.allclose(a.grad, b.grad, rtol=0, atol=5e-6 * float(a.grad.abs().max())), float((a.grad - b.grad).abs().max())
+        for t in (t1, t2):
+            for p in t.surfel_params():
+                p.grad = None

@@ -14,7 +14,9 @@ Set VIDU4D_SURFEL_EXACT=1 to size exactly first (one host sync before the sort, 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import math
 import os
 
 import torch
@@ -352,6 +354,35 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return num_rendered, out_color, out_others, radii, geom, binning, img
 
 
+# ---- caller-supplied gradient outputs.  The backward writes every gradient of the SHARED parameters (opacity, scales, SH)
+# exactly once, so a caller that keeps a persistent gradient buffer -- the flat exchange buffer of the frame-parallel
+# path (lab4d/stage3.py, bench.py) -- can have them written there instead of into fresh tensors: autograd then adopts the
+# returned tensor as `.grad` (no accumulation pass over a pre-bound, zero-filled .grad: 2 x 46 MB per step at 200 k
+# surfels).  One-shot: the first backward call inside the context takes the buffers.  Process-wide state of a
+# single-threaded caller, like the capacity hints above.
+_grad_out: dict = {}
+
+
+@contextlib.contextmanager
+def gradient_buffers(**buffers):
+    """buffers: dL_dopacity (P,1), dL_dscales (P,2), dL_dsh (P,M,3) or dL_dsh_dc (P,1,3) / dL_dsh_rest (P,15,3): contiguous
+    fp32 tensors on the device, 16-byte aligned."""
+    global _grad_out
+    old, _grad_out = _grad_out, {k: v for k, v in buffers.items() if v is not None}
+    try:
+        yield
+    finally:
+        _grad_out = old
+
+
+def _grad_output(name, shape, opt):
+    t = _grad_out.pop(name, None)
+    if (t is not None and t.numel() == math.prod(shape) and t.is_contiguous() and t.dtype == torch.float32
+            and t.device == opt["device"] and t.data_ptr() % 16 == 0):
+        return t.view(shape)   # (a fresh tensor object over the caller's memory: autograd may adopt it as .grad)
+    return torch.empty(shape, **opt)
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
@@ -385,13 +416,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dmeans3D = torch.empty(lead + (3,), **opt)
     dL_dmeans2D = torch.empty(lead + (3,), **opt)
     dL_dcolors = torch.empty(lead + (3,), **opt)
-    dL_dopacity = torch.empty((P, 1), **opt)
+    dL_dopacity = _grad_output("dL_dopacity", (P, 1), opt)
     dL_dtransMat = torch.empty(lead + (9,), **opt)
     if sh_rest is not None:
-        dL_dsh = (torch.empty((P, 1, 3), **opt), torch.empty((P, 15, 3), **opt))
+        dL_dsh = (_grad_output("dL_dsh_dc", (P, 1, 3), opt), _grad_output("dL_dsh_rest", (P, 15, 3), opt))
     else:
-        dL_dsh = torch.empty((P, M, 3), **opt)
-    dL_dscales = torch.empty((P, 2), **opt)
+        dL_dsh = _grad_output("dL_dsh", (P, M, 3), opt)
+    dL_dscales = _grad_output("dL_dscales", (P, 2), opt)
     dL_drotations = torch.empty(lead + (4,), **opt)
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations

@@ -15,6 +15,8 @@ consumed (sum, sum, max) and the densify / prune decision is replayed identicall
 a step-seeded generator, so the replicas never diverge."""
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -193,19 +195,34 @@ class Stage3Trainer:
         surfel stay home."""
         return self.world > 1 and self.live_sh_rows() < int(self.model._features_rest.shape[1])
 
-    def bind_flat_gradients(self):
+    def bind_flat_gradients(self, direct: bool = False):
         """Makes every exchanged parameter's .grad a view of ONE persistent fp32 buffer and zeroes it (this is
         the step's zero_grad): autograd then accumulates straight into the buffer the all-reduce, the norm for
         the clip and the fused Adam read -- no gather / scatter copies around the collective.  Re-bound every
         step because densify / prune re-create the surfel parameters.  Layout: [xyz | f_dc | opacity | scaling |
-        rotation | bg] (chunk 0) [f_rest (live rows only while the SH degree is below 3) | networks] (chunk 1)."""
+        rotation | bg] (chunk 0) [f_rest (live rows only while the SH degree is below 3) | networks] (chunk 1).
+        direct (what begin_gradients asks for): the canonical parameters a stacked rasterizer call differentiates are NOT
+        pre-bound -- their slices are handed to the rasterizer's backward as output buffers (_gradient_outputs) and
+        become their .grad when autograd adopts what it returns."""
         ps = self.exchanged_params()
         rest = self.model._features_rest
         pack = self._packs_rest()
         k = self.live_sh_rows()
         net_ids = {id(p) for p in self._net_params} if self.optim_warp else set()
         sizes = [(rest.shape[0] * k * rest.shape[2]) if (p is rest and pack) else p.numel() for p in ps]
-        n = sum(sizes)
+        # every tensor starts on a 256-byte boundary (the rasterizer's backward writes some of them in place with 16-byte
+        # stores, _C.gradient_buffers); the few padding floats stay zero
+        starts, n = [], 0
+        for sz in sizes:
+            starts.append(n)
+            n += (sz + 63) // 64 * 64
+        # tensors whose gradient the rasterizer's backward produces directly and exactly once (canonical parameters through
+        # one stacked call): handed over as output buffers -- no zero fill, no accumulation pass (self._direct)
+        m = self.model
+        direct_ok = (direct and ps[0].is_cuda and m.opts.get("stacked_frames", True) and m.opts.get("canonical_params", True)
+                     and m.opts.get("fused_loss", True) and m.opts.get("direct_gradient_outputs", True)
+                     and m._features_rest.shape[1] == 15)
+        self._direct = {}
         if self._flat is None or self._flat.numel() != n or self._flat.device != ps[0].device:
             self._flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
             fresh = True
@@ -214,11 +231,13 @@ class Stage3Trainer:
             if not fresh:
                 self._flat.zero_()
         self.__dict__.pop("_flat_is_zero", None)
-        off = 0
         self._rest_slot = None
         self._net_slots = []
         self._chunk_split = None
-        for p, sz in zip(ps, sizes):
+        names = {id(m._features_dc): "dL_dsh_dc", id(m._opacity): "dL_dopacity", id(m._scaling): "dL_dscales"}
+        if not pack:
+            names[id(rest)] = "dL_dsh_rest"
+        for p, sz, off in zip(ps, sizes, starts):
             if p is rest:
                 self._chunk_split = off
             if p is rest and pack:
@@ -227,19 +246,31 @@ class Stage3Trainer:
                 full = self.__dict__.get("_rest_full")
                 if full is None or full.shape != rest.shape or full.device != rest.device:
                     full = self._rest_full = torch.zeros_like(rest)
-                elif not fresh:
+                elif not fresh and not direct_ok:
                     full.zero_()
-                p.grad = full
+                if direct_ok:   # (written whole by the backward, dead bands as zeros)
+                    p.grad = None
+                    self._direct["dL_dsh_rest"] = full
+                else:
+                    p.grad = full
                 self._rest_slot = self._flat[off:off + sz].view(rest.shape[0], k, rest.shape[2])
             elif id(p) in net_ids:
                 # fresh per-step gradient (None when autograd never reaches the parameter); it is packed into the
                 # buffer for the collective and then ADDED to the round's accumulated gradient (_fold_net_gradients)
                 p.grad = None
                 self._net_slots.append(self._flat[off:off + sz].view_as(p))
+            elif direct_ok and id(p) in names:
+                p.grad = None                      # (autograd adopts the tensor the backward returns: a view of the buffer)
+                self._direct[names[id(p)]] = self._flat[off:off + sz].view_as(p)
             else:
                 p.grad = self._flat[off:off + sz].view_as(p)
-            off += sz
         return self._flat
+
+    def _gradient_outputs(self):
+        """Context for the step's backward: the flat buffer's slices of the canonical parameters as the rasterizer's
+        gradient outputs (bind_flat_gradients decided which)."""
+        from .. import _C
+        return _C.gradient_buffers(**(self.__dict__.get("_direct") or {})) if self._flat is not None else contextlib.nullcontext()
 
     def _flat_needed(self):
         """One rank, surfels on the GPU, frozen networks: nothing reads the gradients but the one-launch clip and the
@@ -252,7 +283,7 @@ class Stage3Trainer:
         if self.optim_warp and self.current_steps % self.iters_per_round == 0:
             self._net_accum = [None] * len(self._net_params)   # trainer.py:449: zero_grad at the start of a round
         if self._flat_needed():
-            return self.bind_flat_gradients()
+            return self.bind_flat_gradients(direct=True)
         self._flat = None
         for p in self.exchanged_params():
             p.grad = None
@@ -260,7 +291,9 @@ class Stage3Trainer:
 
     def _bound(self, p) -> bool:
         if p is self.model._features_rest and self._rest_slot is not None:
-            return p.grad is self.__dict__.get("_rest_full")
+            full = self.__dict__.get("_rest_full")
+            return p.grad is not None and full is not None and \
+                p.grad.untyped_storage().data_ptr() == full.untyped_storage().data_ptr()
         if self.optim_warp and any(p is q for q in self._net_params):
             return True  # (packed by hand below)
         return p.grad is not None and p.grad.untyped_storage().data_ptr() == self._flat.untyped_storage().data_ptr()
@@ -415,7 +448,8 @@ class Stage3Trainer:
             losses = stage3_loss(colors, allmaps, getattr(m, "learnable_bkgd", None), batch, step, self.cfg,
                                  cameras=cams, depth_ratio=float(getattr(m.pipeline, "depth_ratio", 0.0)))
             total = losses.pop("total")  # (summed by the kernel; the backward starts from a cached 1.0)
-            total.backward(gradient=unit_gradient(m._xyz.device))
+            with self._gradient_outputs():
+                total.backward(gradient=unit_gradient(m._xyz.device))
             return losses
         else:
             outputs = None if need_geometry else ("render", "acc", "rend_dist")
