@@ -804,3 +804,47 @@ def test_stacked_frames_without_surfels(gpu_device):
     e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
     color, radii, allmap = dsr.rasterize_frames(e(2, 0, 3), e(2, 0, 3), e(0, 16, 3), e(0, 1), e(0, 2), e(2, 0, 4), [rs, rs])
     assert color.shape == (3, 2, 48, 64) and radii.shape == (2, 0) and float(color.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("which", ["spread", "wide_range", "ties", "one_depth", "mostly_one_depth"])
+def test_long_list_sort_msd_split(gpu_device, which, monkeypatch):
+    """Lists beyond the LDS capacity with the segment split on: binning.hip's MSD split on the leading differing depth bits
+    + in-LDS bucket sorts (and its fall-backs to the global-memory sort) must leave the reference's order -- ascending
+    (depth, surfel id) -- bit for bit: point_list / ranges against the oracle, images and gradients after them.
+    wide_range: depths over several binades (the digit sits in the exponent); ties: clones (equal depths inside buckets);
+    one_depth: every surfel of the long lists at ONE depth (no differing bit: nothing to split on); mostly_one_depth: three
+    quarters at one depth (a bucket beyond the LDS capacity)."""
+    from vidu4d_amd import _C
+    monkeypatch.setattr(_C, "_SPLIT", "1")
+    n = 24_000
+    sc = make_scene(n, 96, 80, seed=77, sigma_px=1.0)
+    g = torch.Generator().manual_seed(78)
+    sc.means3D[:, 0] = (torch.rand(n, generator=g) - 0.5) * 0.2 * sc.means3D[:, 2]
+    sc.means3D[:, 1] = (torch.rand(n, generator=g) - 0.5) * 0.2 * sc.means3D[:, 2]
+    sc.opacities[:] = 0.05
+    if which == "wide_range":
+        z = torch.exp(torch.rand(n, generator=g) * 4.0 - 0.5)          # 0.6 .. 33
+        sc.means3D[:, :2] *= (z / sc.means3D[:, 2])[:, None]
+        sc.means3D[:, 2] = z
+        sc.scales *= (z / 3.0)[:, None]
+    elif which == "ties":
+        pick = torch.randperm(n, generator=g)[:3000]
+        for name in ("means3D", "scales", "rotations", "opacities", "shs"):
+            t = getattr(sc, name)
+            setattr(sc, name, torch.cat([t, t[pick], t[pick[:500]]], 0).contiguous())
+    elif which in ("one_depth", "mostly_one_depth"):
+        same = torch.ones(n, dtype=torch.bool) if which == "one_depth" else torch.rand(n, generator=g) < 0.75
+        sc.means3D[same, :2] *= (3.0 / sc.means3D[same, 2])[:, None]
+        sc.means3D[same, 2] = 3.0
+    st = oracle_forward(sc)
+    assert int((st["ranges"][:, 1] - st["ranges"][:, 0]).max()) > 2 * 3584
+    d, shs, cols, out = _native_forward(sc, gpu_device)
+    R, color, others, radii, geom, binning, img = out
+    gx, gy = st["grid"]
+    assert R == st["num_rendered"] and np.array_equal(to_np(radii), st["radii"])
+    assert np.array_equal(_state("point_list", out, sc, torch.int32, R).view(np.uint32), st["point_list"]), "sorted surfel list"
+    assert np.array_equal(_state("ranges", out, sc, torch.int32, gx * gy * 2).view(np.uint32).reshape(-1, 2), st["ranges"])
+    # (the segment-parallel blend re-associates the transmittance product: a pixel within an ulp of a threshold may flip,
+    # test_segment_parallel_*; the images are compared with that budget)
+    assert_close("color", color, st["color"], outlier_fraction=2e-4)
+    assert_close("alpha", others[1], st["others"][1], outlier_fraction=2e-4)

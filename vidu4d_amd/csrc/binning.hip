@@ -303,6 +303,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, 
                                                              int64_t capacity)
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    if (idx == 0) g.hdr->num_buckets = 0;  // (work list of the long-list sort that follows this launch)
     if ((int64_t)g.hdr->num_rendered > capacity) {  // binning buffer too small: render nothing, flag it
         if (idx == 0) g.hdr->overflow = 1;
         return;
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraPa
                                                                        int64_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cur[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) g.hdr->num_buckets = 0;  // (work list of the long-list sort that follows)
     if ((int64_t)g.hdr->num_rendered > capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) g.hdr->overflow = 1;
         return;
@@ -382,30 +384,22 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
 // to 1024 entries, <4, true, TILE_SORT_CAP> (56 KiB: 2 per CU) the longer ones; a workgroup whose tile belongs
 // to the other launch exits at once.  (One launch with the large buffers ran the typical 600-entry lists of
 // the headline scene in two rounds of 512 workgroups: 42 us instead of 25.)
+// One list: src[0 .. n) -> sorted into entries[start ..) / point_list[start ..).  `depth_bits`: only the low depth_bits
+// bits of the depth words differ inside the list (32: unknown) -- the byte passes above them are not even counted.
+// long_src (global-memory path only): the list may start in `scratch` (after an MSD split) instead of `entries`.
 template <int WAVES, bool IN_LDS, int CAP>
-__global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
-                                                              const uint32_t* __restrict__ ranges,
-                                                              const uint32_t* num_ptr, int64_t capacity,
-                                                              uint64_t* entries, uint64_t* scratch,
-                                                              uint32_t* __restrict__ point_list, int id_bytes,
-                                                              int skip_long, int min_len)
+__device__ __forceinline__ void sort_one_list(const uint64_t* __restrict__ src, uint32_t start, int n, int depth_bits,
+                                              uint64_t* entries, uint64_t* scratch, uint32_t* __restrict__ point_list,
+                                              int id_bytes, uint64_t (*s_buf)[IN_LDS ? CAP : 1], uint32_t (*s_cnt)[256],
+                                              uint32_t* s_scan, uint32_t* s_long_run)
 {
     constexpr int THREADS = WAVES * 64;
-    __shared__ uint64_t s_buf[IN_LDS ? 2 : 1][IN_LDS ? CAP : 1];
-    __shared__ uint32_t s_cnt[WAVES][256];  // per-wave digit counts, then per-wave destination cursors
-    __shared__ uint32_t s_scan[16];
-    if ((int64_t)*num_ptr > capacity) return;
-    const uint32_t tile = tile_order[blockIdx.x];  // longest list first
-    const uint32_t start = ranges[2 * tile];
-    const int n = (int)(ranges[2 * tile + 1] - start);
-    if (n == 0 || n < min_len) return;
-    if (IN_LDS ? ((skip_long || CAP < TILE_SORT_CAP) && n > CAP) : n <= TILE_SORT_CAP) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_lds = IN_LDS && n <= CAP;
     uint64_t* A;
     uint64_t* B;
     if (in_lds) {
-        for (int i = threadIdx.x; i < n; i += THREADS) s_buf[0][i] = entries[start + i];
+        for (int i = threadIdx.x; i < n; i += THREADS) s_buf[0][i] = src[i];
         A = s_buf[0];
         B = s_buf[IN_LDS ? 1 : 0];
     } else {
@@ -475,9 +469,9 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
     // TIE_RUN_MAX (degenerate scenes: a plane of surfels at one depth) sends the list, as it stands, through the full
     // LSD sequence, which does not care about the order it starts from.
     constexpr int TIE_RUN_MAX = 32;
-    __shared__ uint32_t s_long_run;
-    for (int pass = 0; pass < 4; pass++) radix_pass(32 + 8 * pass);
-    if (threadIdx.x == 0) s_long_run = 0;
+    for (int pass = 0; pass < 4; pass++)
+        if (8 * pass < depth_bits) radix_pass(32 + 8 * pass);
+    if (threadIdx.x == 0) *s_long_run = 0;
     __syncthreads();
     for (int i = threadIdx.x; i + 1 < n; i += THREADS) {
         const uint32_t d = (uint32_t)(A[i] >> 32);
@@ -485,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
         int j = i + 1;
         while (j + 1 < n && j - i < TIE_RUN_MAX && (uint32_t)(A[j + 1] >> 32) == d) j++;
         if (j - i >= TIE_RUN_MAX) {
-            s_long_run = 1;
+            *s_long_run = 1;
             continue;
         }
         for (int a = i + 1; a <= j; a++) {  // insertion sort of A[i..j] (equal depths: the keys order by id)
@@ -499,12 +493,216 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
         }
     }
     __syncthreads();
-    if (s_long_run)
+    if (*s_long_run)
         for (int pass = 0; pass < id_bytes + 4; pass++) radix_pass(8 * (pass < id_bytes ? pass : 4 + pass - id_bytes));
     for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t key = A[i];
         point_list[start + i] = (uint32_t)key;
         if (A != entries + start) entries[start + i] = key;
+    }
+    __syncthreads();  // (a persistent caller reuses the shared arrays for its next list)
+}
+
+template <int WAVES, bool IN_LDS, int CAP>
+__global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
+                                                              const uint32_t* __restrict__ ranges,
+                                                              const uint32_t* num_ptr, int64_t capacity,
+                                                              uint64_t* entries, uint64_t* scratch,
+                                                              uint32_t* __restrict__ point_list, int id_bytes,
+                                                              int skip_long, int min_len)
+{
+    __shared__ uint64_t s_buf[IN_LDS ? 2 : 1][IN_LDS ? CAP : 1];
+    __shared__ uint32_t s_cnt[WAVES][256];  // per-wave digit counts, then per-wave destination cursors
+    __shared__ uint32_t s_scan[16];
+    __shared__ uint32_t s_long_run;
+    if ((int64_t)*num_ptr > capacity) return;
+    const uint32_t tile = tile_order[blockIdx.x];  // longest list first
+    const uint32_t start = ranges[2 * tile];
+    const int n = (int)(ranges[2 * tile + 1] - start);
+    if (n == 0 || n < min_len) return;
+    if (IN_LDS ? ((skip_long || CAP < TILE_SORT_CAP) && n > CAP) : n <= TILE_SORT_CAP) return;
+    sort_one_list<WAVES, IN_LDS, CAP>(entries + start, start, n, 32, entries, scratch, point_list, id_bytes, s_buf, s_cnt,
+                                      s_scan, &s_long_run);
+}
+
+// ---- Lists longer than TILE_SORT_CAP: MSD split, then in-LDS bucket sorts (round 3).
+// A 16-wave workgroup per long tile finds the highest depth bit that differs inside the list, takes the 8 bits from there
+// down as the digit, and moves the list -- one stable counting pass, entries -> scratch -- into up to 256 buckets in
+// digit (= depth) order; every non-empty bucket is appended to a work list.  bucket_sort_kernel then sorts the buckets
+// on their remaining low bits entirely inside LDS, one 4-wave workgroup per bucket at a time, and writes them back to
+// `entries` / `point_list` in place: a 25 k-entry list crosses global memory twice instead of six to eight times, and
+// its ~40-100 buckets are sorted by as many workgroups instead of one.  A list with a bucket beyond the LDS capacity
+// (thousands of surfels within one 2^-8 slice of the list's depth range) takes the global-memory sort as before.
+struct SortBucket {
+    uint32_t start, count, low_bits, pad;
+};
+constexpr int MSD_MIN = 1024;  // lists longer than this are split (when the long pass runs at all)
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void tile_split_kernel(const uint32_t* __restrict__ tile_order,
+                                                               const uint32_t* __restrict__ ranges, Header* hdr,
+                                                               int64_t capacity, uint64_t* entries, uint64_t* scratch,
+                                                               uint32_t* __restrict__ point_list, int id_bytes,
+                                                               SortBucket* __restrict__ buckets, uint32_t max_buckets)
+{
+    constexpr int THREADS = WAVES * 64;
+    __shared__ uint64_t s_buf[1][1];
+    __shared__ uint32_t s_cnt[WAVES][256];
+    __shared__ uint32_t s_scan[16];
+    __shared__ uint32_t s_long_run, s_vary, s_slot;
+    if ((int64_t)hdr->num_rendered > capacity) return;
+    const uint32_t tile = tile_order[blockIdx.x];
+    const uint32_t start = ranges[2 * tile];
+    const int n = (int)(ranges[2 * tile + 1] - start);
+    if (n <= MSD_MIN) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t* A = entries + start;
+    // 1. which depth bits differ inside the list, and -- in the same pass -- the histogram of depth byte 2 (bits 16-23:
+    //    the top mantissa bits when the whole list lies inside one binade, the usual case for an object in front of the
+    //    camera).  Only a list whose depths differ above bit 23 (or only below bit 20) pays a second counting pass, on the
+    //    8 bits below its highest differing bit.
+    const int chunk = ((n + THREADS - 1) / THREADS) << 6;
+    const int w_lo = min(wave * chunk, n);
+    const int w_hi = (w_lo + chunk < n) ? w_lo + chunk : n;
+    if (threadIdx.x == 0) s_vary = 0;
+    for (int i = threadIdx.x; i < WAVES * 256; i += THREADS) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t first = (uint32_t)(A[0] >> 32);
+    uint32_t vary = 0;
+    for (int i = w_lo + lane; i < w_hi; i += 64) {
+        const uint32_t dep = (uint32_t)(A[i] >> 32);
+        vary |= dep ^ first;
+        atomicAdd(&s_cnt[wave][(dep >> 16) & 255u], 1u);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vary |= (uint32_t)__shfl_xor((int)vary, d, 64);
+    if (lane == 0 && vary) atomicOr(&s_vary, vary);
+    __syncthreads();
+    vary = s_vary;
+    const int msb = vary ? 31 - __builtin_clz(vary) : 0;
+    // digit = (depth >> low) & 255 with nothing differing above bit low + 7: byte 2 as counted when the highest differing bit
+    // is one of its upper four (>= 16 buckets' worth of spread), else the 8 bits below the highest differing bit
+    const int low = (msb >= 20 && msb <= 23) ? 16 : (msb > 7 ? msb - 7 : 0);
+    const int shift = 32 + low;
+    if (low != 16) {  // (wave-uniform, workgroup-uniform)
+        __syncthreads();
+        for (int i = threadIdx.x; i < WAVES * 256; i += THREADS) (&s_cnt[0][0])[i] = 0;
+        __syncthreads();
+        for (int i = w_lo + lane; i < w_hi; i += 64) atomicAdd(&s_cnt[wave][(uint32_t)(A[i] >> shift) & 255u], 1u);
+        __syncthreads();
+    }
+    const int d = threadIdx.x & 255;
+    uint32_t tot = 0;
+    if (threadIdx.x < 256)
+        for (int w = 0; w < WAVES; w++) tot += s_cnt[w][d];
+    const bool too_big = __syncthreads_or(tot > (uint32_t)TILE_SORT_CAP) || vary == 0;
+    uint32_t nonempty_total;
+    const uint32_t my_slot = block_exclusive_scan(threadIdx.x < 256 && tot ? 1u : 0u, s_scan, nonempty_total);
+    __syncthreads();
+    if (threadIdx.x == 0) s_slot = too_big ? 0xffffffffu : atomicAdd(&hdr->num_buckets, nonempty_total);
+    __syncthreads();
+    if (too_big || s_slot + nonempty_total > max_buckets) {
+        // (the work list is sized for every long list; the test only guards a caller who passed a smaller buffer)
+        sort_one_list<WAVES, false, 1>(A, start, n, 32, entries, scratch, point_list, id_bytes, s_buf, s_cnt, s_scan, &s_long_run);
+        return;
+    }
+    uint32_t total;
+    const uint32_t dbase = block_exclusive_scan(tot, s_scan, total);
+    if (threadIdx.x < 256) {
+        uint32_t run = dbase;
+        for (int w = 0; w < WAVES; w++) {
+            const uint32_t c = s_cnt[w][d];
+            s_cnt[w][d] = run;
+            run += c;
+        }
+        if (tot) buckets[s_slot + my_slot] = SortBucket{start + dbase, tot, (uint32_t)low, 0u};
+    }
+    __syncthreads();
+    // 3. stable scatter into the buckets (entries -> scratch)
+    uint64_t* B = scratch + start;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (int base = w_lo; base < w_hi; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < w_hi;
+        const uint64_t key = valid ? A[i] : ~0ull;
+        const uint32_t dg = (uint32_t)(key >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+        if (!valid) peers = ~peers;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((dg >> b) & 1u);
+            peers &= ((dg >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        if (valid) {
+            const uint32_t old = s_cnt[wave][dg];
+            if (before == 0) s_cnt[wave][dg] = old + (uint32_t)__popcll(peers);
+            B[old + before] = key;
+        }
+    }
+}
+
+// Buckets of at most SMALL_BUCKET entries (most of them: a 5 k-entry list falls into ~40-100 buckets): one WAVE per bucket,
+// no barriers -- every lane ranks its (up to four) keys against all keys of the bucket, read back from a wave-private LDS
+// copy with broadcast reads; the full 64-bit (depth, id) keys are distinct, so the rank IS the sorted position and no tie
+// pass is needed.
+constexpr int SMALL_BUCKET = 256;
+__global__ __launch_bounds__(256) void bucket_sort_small_kernel(const Header* hdr, int64_t capacity,
+                                                               const SortBucket* __restrict__ buckets, uint64_t* entries,
+                                                               const uint64_t* __restrict__ scratch,
+                                                               uint32_t* __restrict__ point_list)
+{
+    __shared__ uint64_t s_keys[4][SMALL_BUCKET];
+    if ((int64_t)hdr->num_rendered > capacity) return;
+    const uint32_t nb = hdr->num_buckets;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* keys = s_keys[wave];
+    for (uint32_t b = blockIdx.x * 4 + wave; b < nb; b += gridDim.x * 4) {
+        const SortBucket k = buckets[b];
+        const int n = (int)k.count;
+        if (n > SMALL_BUCKET) continue;  // wave-uniform
+        uint64_t mine[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = j * 64 + lane;
+            mine[j] = i < n ? scratch[k.start + i] : ~0ull;
+            if (i < n) keys[i] = mine[j];
+        }
+        __builtin_amdgcn_wave_barrier();  // (LDS serves one wave's instructions in order: its reads see its writes)
+        uint32_t rank[4] = {0, 0, 0, 0};
+        for (int i = 0; i < n; i++) {
+            const uint64_t q = keys[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) rank[j] += q < mine[j] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (j * 64 + lane < n) {
+                entries[k.start + rank[j]] = mine[j];
+                point_list[k.start + rank[j]] = (uint32_t)mine[j];
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Two instances share the larger buckets by size, as the tile sorts do: CAP 1024 (16 KiB of LDS: 8 workgroups per CU) takes
+// the buckets of (MIN, 1024] entries, CAP TILE_SORT_CAP the larger ones.
+template <int CAP, int MIN>
+__global__ __launch_bounds__(256) void bucket_sort_kernel(const Header* hdr, int64_t capacity, const SortBucket* __restrict__ buckets,
+                                                         uint64_t* entries, uint64_t* scratch,
+                                                         uint32_t* __restrict__ point_list, int id_bytes)
+{
+    __shared__ uint64_t s_buf[2][CAP];
+    __shared__ uint32_t s_cnt[4][256];
+    __shared__ uint32_t s_scan[16];
+    __shared__ uint32_t s_long_run;
+    if ((int64_t)hdr->num_rendered > capacity) return;
+    const uint32_t nb = hdr->num_buckets;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const SortBucket k = buckets[b];
+        if ((int)k.count > CAP || (int)k.count <= MIN) continue;  // (wave-uniform: the other instance's bucket)
+        sort_one_list<4, true, CAP>(scratch + k.start, k.start, (int)k.count, (int)k.low_bits, entries, scratch, point_list,
+                                    id_bytes, s_buf, s_cnt, s_scan, &s_long_run);
     }
 }
 
@@ -517,13 +715,25 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
     if (long_pass) {
         // the long tiles lead the schedule, but it is sorted by length CLASS only (a long tile may sit behind
         // shorter ones of its class), so every position gets a workgroup; the short ones exit at once
-        hipLaunchKernelGGL((tile_sort_kernel<16, false, 1>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order,
-                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0, 0);
+        // (the bucket work list lives at the start of seg_data, which nobody touches before the blend)
+        SortBucket* buckets = reinterpret_cast<SortBucket*>(b.seg_data);
+        const uint32_t max_buckets = (uint32_t)std::min<int64_t>(256 * (capacity / MSD_MIN + 1), 0x7fffffff);
+        hipLaunchKernelGGL((tile_split_kernel<16>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order, img.ranges, g.hdr,
+                           capacity, b.entries, b.scratch, b.point_list, id_bytes, buckets, max_buckets);
+        const int grid = (int)std::min<int64_t>(std::max<int64_t>(capacity / 512, 1), 2048);
+        hipLaunchKernelGGL((bucket_sort_kernel<TILE_SORT_CAP, 1024>), dim3(grid), dim3(256), 0, stream, g.hdr, capacity, buckets,
+                           b.entries, b.scratch, b.point_list, id_bytes);
+        hipLaunchKernelGGL((bucket_sort_kernel<1024, SMALL_BUCKET>), dim3(grid), dim3(256), 0, stream, g.hdr, capacity, buckets,
+                           b.entries, b.scratch, b.point_list, id_bytes);
+        hipLaunchKernelGGL(bucket_sort_small_kernel, dim3(grid), dim3(256), 0, stream, g.hdr, capacity, buckets, b.entries,
+                           b.scratch, b.point_list);
     }
     constexpr int SMALL_CAP = 1024;
-    hipLaunchKernelGGL((tile_sort_kernel<4, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
-                       img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes,
-                       long_pass ? 1 : 0, SMALL_CAP + 1);
+    static_assert(MSD_MIN == SMALL_CAP, "with the long pass on, the split takes every list the small in-LDS sort does not");
+    if (!long_pass)
+        hipLaunchKernelGGL((tile_sort_kernel<4, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
+                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0,
+                           SMALL_CAP + 1);
     hipLaunchKernelGGL((tile_sort_kernel<4, true, SMALL_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
                        img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 1, 0);
 }

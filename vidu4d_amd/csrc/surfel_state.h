@@ -62,7 +62,8 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t truncated;     // a pixel was still unsaturated after the last segment the caller allowed (max_seg)
     uint32_t scan_arrivals; // workgroups of tile_scan_fused_kernel that have finished their columns (reset per forward)
     uint32_t min_T_bits;    // bits of the smallest final transmittance of the frame (atomic min; reset per forward)
-    uint32_t pad[55];
+    uint32_t num_buckets;   // buckets the MSD split of the long lists queued for bucket_sort_kernel (reset by the schedule)
+    uint32_t pad[54];
 };
 
 struct GeomState {
