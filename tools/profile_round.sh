@@ -10,15 +10,15 @@ R=$(pwd); export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- \
-  python $R/bench.py --steps 30 --warmup 5 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 "$@" > $OUT/trace_bench.log 2>&1
+  python $R/bench.py --steps 30 --warmup 5 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --per-frame-surface 0 "$@" > $OUT/trace_bench.log 2>&1
 tail -1 $OUT/trace_bench.log
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $OUT/$c -o pmc --output-format csv -- \
-    python $R/bench.py --steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --no-stage-timers "$@" > $OUT/$c.log 2>&1
+    python $R/bench.py --steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --per-frame-surface 0 --no-stage-timers "$@" > $OUT/$c.log 2>&1
 done
 # SQ counters (8 SQ slots per pass): instruction mix and stall buckets of the blend kernels
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY \
   --kernel-trace -d $OUT/SQ -o pmc --output-format csv -- \
-  python $R/bench.py --steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --no-stage-timers "$@" > $OUT/SQ.log 2>&1
+  python $R/bench.py --steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --per-frame-surface 0 --no-stage-timers "$@" > $OUT/SQ.log 2>&1
 cd $R
 python tools/parse_profiles.py $OUT $TAG

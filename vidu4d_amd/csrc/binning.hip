@@ -536,7 +536,8 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
 struct SortBucket {
     uint32_t start, count, low_bits, pad;
 };
-constexpr int MSD_MIN = 1024;  // lists longer than this are split (when the long pass runs at all)
+constexpr int MSD_MIN = 1024;
+// lists longer than this are split (when the long pass runs at all)
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tile_split_kernel(const uint32_t* __restrict__ tile_order,
@@ -642,11 +643,10 @@ __global__ __launch_bounds__(WAVES * 64) void tile_split_kernel(const uint32_t* 
     }
 }
 
-// Buckets of at most SMALL_BUCKET entries (most of them: a 5 k-entry list falls into ~40-100 buckets): one WAVE per bucket,
-// no barriers -- every lane ranks its (up to four) keys against all keys of the bucket, read back from a wave-private LDS
-// copy with broadcast reads; the full 64-bit (depth, id) keys are distinct, so the rank IS the sorted position and no tie
-// pass is needed.
-constexpr int SMALL_BUCKET = 256;
+// Buckets of at most SMALL_BUCKET entries: one WAVE per bucket, one key per lane, no barriers -- every lane ranks its key
+// against all keys of the bucket, read back from a wave-private LDS copy with broadcast reads; the full 64-bit (depth, id)
+// keys are distinct, so the rank IS the sorted position and no tie pass is needed.
+constexpr int SMALL_BUCKET = 64;
 __global__ __launch_bounds__(256) void bucket_sort_small_kernel(const Header* hdr, int64_t capacity,
                                                                const SortBucket* __restrict__ buckets, uint64_t* entries,
                                                                const uint64_t* __restrict__ scratch,
@@ -661,26 +661,15 @@ __global__ __launch_bounds__(256) void bucket_sort_small_kernel(const Header* hd
         const SortBucket k = buckets[b];
         const int n = (int)k.count;
         if (n > SMALL_BUCKET) continue;  // wave-uniform
-        uint64_t mine[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = j * 64 + lane;
-            mine[j] = i < n ? scratch[k.start + i] : ~0ull;
-            if (i < n) keys[i] = mine[j];
-        }
+        const uint64_t mine = lane < n ? scratch[k.start + lane] : ~0ull;
+        if (lane < n) keys[lane] = mine;
         __builtin_amdgcn_wave_barrier();  // (LDS serves one wave's instructions in order: its reads see its writes)
-        uint32_t rank[4] = {0, 0, 0, 0};
-        for (int i = 0; i < n; i++) {
-            const uint64_t q = keys[i];
-#pragma unroll
-            for (int j = 0; j < 4; j++) rank[j] += q < mine[j] ? 1u : 0u;
+        uint32_t rank = 0;
+        for (int i = 0; i < n; i++) rank += keys[i] < mine ? 1u : 0u;
+        if (lane < n) {
+            entries[k.start + rank] = mine;
+            point_list[k.start + rank] = (uint32_t)mine;
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (j * 64 + lane < n) {
-                entries[k.start + rank[j]] = mine[j];
-                point_list[k.start + rank[j]] = (uint32_t)mine[j];
-            }
         __builtin_amdgcn_wave_barrier();
     }
 }
