@@ -13,15 +13,20 @@ forward + backward through the public `GaussianRasterizer` autograd op with upst
 the colour image and all 8 auxiliary planes.  Frames are sharded one-frame-per-GPU-per-slot across
 ranks (rank r renders frames r, r+N, ...: frame-parallel, weak scaling); with N > 1 every step ends
 with ONE RCCL all-reduce of the flat canonical-surfel gradient buffer (58 floats per surfel), the
-only exchange the path has.  value = N * K * FRAMES_PER_STEP / max-over-ranks time.
+only exchange the path has; it runs beside the next step's kernels on two alternating buffers (the op-level loop has no
+optimizer between steps; --exchange serial joins it in its step).  value = N * K * FRAMES_PER_STEP / max-over-ranks time.
 As in Stage3Trainer, the frames of a step are queued on separate HIP streams and the rasterizer's
 host wait for the pair count is deferred to one check per step (--frame-streams 0: one stream).
 
 `--gpus N` (N > 1) without a torchrun environment spawns the N ranks itself (python -m torch.distributed.run on
 127.0.0.1) and relays rank 0's line; it never prints an n_gpus: 1 line for N > 1.  After the contract's timed
 region of exactly K steps (-> "value"), `--repeats` further regions of K steps each give "repeats" (median,
-p10, p90 of images/s).  "fit_step" is the second figure of SURVEY.md 8(d): the full Stage-3 fitting step (bob
-warp + raster + losses + backward + clip + densify statistics + Adam) at the same size.
+p10, p90 of images/s).  "value_per_frame_calls" times the same steps through the reference's own surface (one
+GaussianRasterizer.forward per frame).  "fit_step" is the second figure of SURVEY.md 8(d): the full Stage-3 fitting
+step (bob warp + raster + losses + backward + clip + densify statistics + Adam) at the same size; "fit_step_geometry"
+the same step after step 8000 (normal-consistency regulariser on).  "scaling_modelled" (N = 1 only): MODELLED multi-GPU
+speed-ups from the measured step and an all-reduce cost model, assumptions included.  `--replicas N`: BASELINE
+configs[3], N independent sequences with an RCCL barrier at start and end.
 
 Extra objects on the JSON line: "roofline" (dominant kernel: algorithmic bytes per launch /
 its average launch duration, measured with HIP events on the launch stream over extra steps of
