@@ -2,7 +2,9 @@
 opacity reset at 600, SH degree step at 1000, frozen warp / camera networks (the fused HIP warp), once on the trainer's
 default path (canonical parameters, alpha-only blend, stacked frames, fused loss) and once with those extensions off.
 Prints surfel counts, the loss trajectory of both runs and the final image error against the teacher; every loss and
-parameter must stay finite.  Usage (GPU box): python tools/soak_fit.py [steps]"""
+parameter must stay finite.  Usage (GPU box): python tools/soak_fit.py [steps]
+SOAK_STEP0=7700 SOAK_DENSIFY_UNTIL=9000 SOAK_OPACITY_RESET=3000: the run crosses step 8000, where the normal-consistency
+regulariser switches on (model.py:817-842), with densification still going (round 3: profiles/r03_soak_fit_geometry.txt)."""
 import os, sys, time
 import numpy as np
 import torch
@@ -42,8 +44,12 @@ nets = {k: v for k, v in teacher.state_dict().items() if k.startswith(("warp.", 
 
 
 def run(tag, **opts):
-    s = model(8000, 2, densify_from_iter=200, densification_interval=100, densify_until_iter=1200, opacity_reset_interval=600,
-              densify_grad_threshold=5e-6, **opts)
+    s = model(8000, 2, densify_from_iter=200, densification_interval=100, densify_until_iter=int(os.environ.get("SOAK_DENSIFY_UNTIL", "1200")),
+              opacity_reset_interval=int(os.environ.get("SOAK_OPACITY_RESET", "600")),
+              densify_grad_threshold=5e-6,
+              # (the radius-outlier pass of step 8000, 10000, ... keeps points with > 20 neighbours within 0.004 --
+              # trainer.py:573-588, a fixed radius -- which on this sparse toy cloud is nobody: switched off here)
+              outlier_filtering_interval=10 ** 9, **opts)
     s.load_state_dict(nets, strict=False)
     for mod in (s.warp, s.camera_mlp):
         for p in mod.parameters():
@@ -80,6 +86,10 @@ def run(tag, **opts):
 
 h1, e1 = run("default path")
 h2, e2 = run("extensions off", canonical_params=False, alpha_only_blend=False, stacked_frames=False, fused_loss=False)
-assert h1[-1] < 0.5 * h1[0] and h2[-1] < 0.5 * h2[0], "the fit did not converge"
+# (once the normal-consistency term is on, the loss carries its constant lambda * (1 - ...) ~ 0.049 on a mostly empty image:
+# convergence is judged on the image error then)
+if int(os.environ.get("SOAK_STEP0", "0")) + STEPS <= 8000:
+    assert h1[-1] < 0.5 * h1[0] and h2[-1] < 0.5 * h2[0], "the fit did not converge"
+assert e1 < 0.01 and e2 < 0.01, (e1, e2)
 assert abs(e1 - e2) < 0.25 * max(e1, e2) + 0.01, (e1, e2)
 print("SOAK OK")

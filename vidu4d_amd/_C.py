@@ -75,10 +75,11 @@ def _f32c(t, name):
 
 
 def _check_cuda(*ts):
-    for t in ts:
+    for i, t in enumerate(ts):
         if t is not None and t.numel() and not t.is_cuda:
             raise RuntimeError("diff_surfel_rasterization: all tensors must be CUDA/HIP tensors "
-                               "(there is no CPU path in the MI355X build)")
+                               f"(there is no CPU path in the MI355X build); argument {i} of shape {tuple(t.shape)} "
+                               f"is on {t.device}")
 
 
 class deferred_capacity_check:

@@ -164,8 +164,10 @@ class DeformableSurfels(GaussianModel):
         cams = []
         Kh = Kinvs.detach().float().cpu()
         cache = self.__dict__.setdefault("_camera_cache", {})
-        dev = self._xyz.device if hasattr(self, "_xyz") and isinstance(self._xyz, torch.Tensor) and self._xyz.numel() \
-            else Kinvs.device
+        # (the model's device, also when it holds no surfel: a fit whose outlier pass pruned everything -- upstream's fixed
+        # radius 0.004 / 20 neighbours, trainer.py:573-588, does that to a sparse toy cloud -- must not move to the host)
+        dev = self._xyz.device if hasattr(self, "_xyz") and isinstance(self._xyz, torch.Tensor) and self._xyz.is_cuda \
+            else (self.device_ if self.device_.type == "cuda" else Kinvs.device)
         for i in range(Kh.shape[0]):
             Kinv, H, W = Kh[i], int(Hs[i]), int(Ws[i])
             left, right = Kinv[0, 2], Kinv[0, 2] + Kinv[0, 0] * W
