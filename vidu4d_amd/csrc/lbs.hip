@@ -200,7 +200,11 @@ constexpr int MAX_FRAMES = 8;
 // (3B, 3) bone map of the rest pose staged in LDS (225 FMAs per surfel), and the backward folds A^T (d/d x_bone) into the
 // centre's gradient instead of writing g_xbT: both kernels are bound by their traffic -- 100 feature-major floats per
 // surfel read (twice in the backward) and written -- of which the coordinates are three quarters.
-template <bool BACKWARD, int BCAP, bool XB_FROM_XYZ>
+// BX: the bone count when it is known at compile time (25: the reference's "bob" skeleton), 0 = any B <= BCAP.  With BX the
+// bone loops are straight-line code: every rawT / weight load of a loop can be in flight at once (the B-dependent `break`s of
+// the generic instance put each load behind a branch; the backward then waited for ~80 global loads one after the other --
+// 61 % of its wave cycles, rocprofv3 SQ_WAIT_ANY).
+template <bool BACKWARD, int BCAP, bool XB_FROM_XYZ, int BX>
 __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
                                                        const float* __restrict__ rawT,
                                                        const float* __restrict__ se3_qr,
@@ -234,14 +238,17 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
         }
         return xbT[(size_t)k * N + n];
     };
+    constexpr int NB = BX ? BX : BCAP;
     float w[BCAP];
+    uint32_t raw_pos = 0;  // bit b: the delta-skin logit of bone b is positive (the relu of the forward)
     int anchor = 0;
     float best = -3.0e38f;
 #pragma unroll
-    for (int b = 0; b < BCAP; b++) {
-        if (b >= B) break;
+    for (int b = 0; b < NB; b++) {
+        if (!BX && b >= B) break;
         const float x0 = bone_coord(3 * b), x1 = bone_coord(3 * b + 1), x2 = bone_coord(3 * b + 2);
         const float raw = rawT ? rawT[(size_t)b * N + n] : 0.f;
+        raw_pos |= raw > 0.f ? (1u << b) : 0u;
         w[b] = -((x0 * x0 + x1 * x1 + x2 * x2) + 0.1f * fmaxf(raw, 0.f));
         if (w[b] > best) {  // first maximum, like torch.argmax (the softmax keeps the order)
             best = w[b];
@@ -249,28 +256,28 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
         }
     }
     float sum = 0.f;
-    _Pragma("unroll") for (int b = 0; b < BCAP; b++) {
-        if (b >= B) break;
+    _Pragma("unroll") for (int b = 0; b < NB; b++) {
+        if (!BX && b >= B) break;
         w[b] = __expf(w[b] - best);
         sum += w[b];
     }
     const float isum = 1.0f / sum;
-    _Pragma("unroll") for (int b = 0; b < BCAP; b++)
-        if (b < B) w[b] *= isum;
+    _Pragma("unroll") for (int b = 0; b < NB; b++)
+        if (BX || b < B) w[b] *= isum;
 
     const Q p = qvec(cx_, cy_, cz_);
     const Q r = ldq(rot + 4 * n);
     float gw[BCAP];
     Q acc_p = {0, 0, 0, 0}, acc_r = {0, 0, 0, 0};
     if (BACKWARD)
-        _Pragma("unroll") for (int b = 0; b < BCAP; b++) gw[b] = 0.f;
+        _Pragma("unroll") for (int b = 0; b < NB; b++) gw[b] = 0.f;
 
     for (int m = 0; m < M; m++) {
         const float* sq = s_q[m];
         const unsigned long long hemi = s_sign[m][anchor];
         Q Qr = {0, 0, 0, 0}, Qd = {0, 0, 0, 0};
-        _Pragma("unroll") for (int b = 0; b < BCAP; b++) {
-            if (b >= B) break;
+        _Pragma("unroll") for (int b = 0; b < NB; b++) {
+            if (!BX && b >= B) break;
             const float ws = ((hemi >> b) & 1ull) ? w[b] : -w[b];
             Qr = qadd(Qr, qscale(ldq(sq + b * 4), ws));
             Qd = qadd(Qd, qscale(ldq(sq + MAX_BONES * 4 + b * 4), ws));
@@ -323,8 +330,8 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
         const float gq_q = qdot(g_q, q), gd_d = qdot(g_d, d);
         const Q g_Qr = qscale(qadd(g_q, qscale(q, -(gq_q + gd_d))), inv);
         const Q g_Qd = qscale(g_d, inv);
-        _Pragma("unroll") for (int b = 0; b < BCAP; b++) {
-            if (b >= B) break;
+        _Pragma("unroll") for (int b = 0; b < NB; b++) {
+            if (!BX && b >= B) break;
             const float sgn = ((hemi >> b) & 1ull) ? 1.0f : -1.0f;
             gw[b] += sgn * (qdot(g_Qr, ldq(sq + b * 4)) + qdot(g_Qd, ldq(sq + MAX_BONES * 4 + b * 4)));
         }
@@ -332,11 +339,11 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
     if (!BACKWARD) return;
     // back through the softmax and the logits
     float dot = 0.f;
-    _Pragma("unroll") for (int b = 0; b < BCAP; b++)
-        if (b < B) dot += w[b] * gw[b];
+    _Pragma("unroll") for (int b = 0; b < NB; b++)
+        if (BX || b < B) dot += w[b] * gw[b];
 #pragma unroll
-    for (int b = 0; b < BCAP; b++) {
-        if (b >= B) break;
+    for (int b = 0; b < NB; b++) {
+        if (!BX && b >= B) break;
         const float g_logit = w[b] * (gw[b] - dot);
         const float x0 = bone_coord(3 * b), x1 = bone_coord(3 * b + 1), x2 = bone_coord(3 * b + 2);
         const float g0 = -2.0f * x0 * g_logit, g1 = -2.0f * x1 * g_logit, g2 = -2.0f * x2 * g_logit;
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
             g_xbT[(size_t)(3 * b + 1) * N + n] = g1;
             g_xbT[(size_t)(3 * b + 2) * N + n] = g2;
         }
-        if (g_rawT) g_rawT[(size_t)b * N + n] = (rawT[(size_t)b * N + n] > 0.f) ? -0.1f * g_logit : 0.f;
+        if (g_rawT) g_rawT[(size_t)b * N + n] = ((raw_pos >> b) & 1u) ? -0.1f * g_logit : 0.f;
     }
     g_xyz[3 * n] = acc_p.x;
     g_xyz[3 * n + 1] = acc_p.y;
@@ -365,12 +372,16 @@ template <bool BACKWARD, typename... Args>
 void launch_lbs_skin(int M, int N, int B, bool from_xyz, hipStream_t stream, Args... args)
 {
     const dim3 grid((N + 255) / 256), block(256);
-    if (B <= 32) {
-        if (from_xyz) hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, true>), grid, block, 0, stream, M, N, B, args...);
-        else hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, false>), grid, block, 0, stream, M, N, B, args...);
+    if (B == 25 && from_xyz && BACKWARD) {
+        // the reference's "bob" skeleton, frozen bones: straight-line bone loops in the backward (-9 %; the forward is
+        // faster with the generic instance, whose 199 registers leave two waves per SIMD where this one has one)
+        hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, true, 25>), grid, block, 0, stream, M, N, B, args...);
+    } else if (B <= 32) {
+        if (from_xyz) hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, true, 0>), grid, block, 0, stream, M, N, B, args...);
+        else hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, false, 0>), grid, block, 0, stream, M, N, B, args...);
     } else {
-        if (from_xyz) hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, MAX_BONES, true>), grid, block, 0, stream, M, N, B, args...);
-        else hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, MAX_BONES, false>), grid, block, 0, stream, M, N, B, args...);
+        if (from_xyz) hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, MAX_BONES, true, 0>), grid, block, 0, stream, M, N, B, args...);
+        else hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, MAX_BONES, false, 0>), grid, block, 0, stream, M, N, B, args...);
     }
 }
 

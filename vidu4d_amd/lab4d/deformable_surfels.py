@@ -166,8 +166,11 @@ class DeformableSurfels(GaussianModel):
         cache = self.__dict__.setdefault("_camera_cache", {})
         # (the model's device, also when it holds no surfel: a fit whose outlier pass pruned everything -- upstream's fixed
         # radius 0.004 / 20 neighbours, trainer.py:573-588, does that to a sparse toy cloud -- must not move to the host)
-        dev = self._xyz.device if hasattr(self, "_xyz") and isinstance(self._xyz, torch.Tensor) and self._xyz.is_cuda \
-            else (self.device_ if self.device_.type == "cuda" else Kinvs.device)
+        own = getattr(self, "device_", None)
+        if isinstance(getattr(self, "_xyz", None), torch.Tensor) and (self._xyz.is_cuda or self._xyz.numel()):
+            dev = self._xyz.device
+        else:
+            dev = own if own is not None and own.type == "cuda" else Kinvs.device
         for i in range(Kh.shape[0]):
             Kinv, H, W = Kh[i], int(Hs[i]), int(Ws[i])
             left, right = Kinv[0, 2], Kinv[0, 2] + Kinv[0, 0] * W
