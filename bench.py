@@ -575,12 +575,13 @@ def main():
     # what the dominant kernel's tile walk looks like on this workload (a counting pass behind one extra step, outside
     # every timed region): lane utilisation = contributing (pixel, surfel) pairs / (64 lanes x pair evaluations)
     walk = None
+    lib = _lib.load()
+    cnt = torch.zeros(16, dtype=torch.int64, device=dev)
     if rank == 0:
-        lib = _lib.load()
-        cnt = torch.zeros(16, dtype=torch.int64, device=dev)
         lib.vidu4d_surfel_blend_stats(cnt.data_ptr())
-        step()
-        torch.cuda.synchronize(dev)
+    step()          # (every rank: the step carries the collective)
+    sync()
+    if rank == 0:
         lib.vidu4d_surfel_blend_stats(None)
         c = [int(x) for x in cnt.tolist()]
         if c[1]:
@@ -588,8 +589,6 @@ def main():
                     "contributing_pairs": c[3], "lane_utilisation": c[3] / (64.0 * c[1]),
                     "rows_touched_per_contributing_evaluation": c[4] / max(1, c[2]),
                     "contributing_lanes_histogram_le_4_8_16_32_64": c[5:10], "per": "step (its frames, one or more launches)"}
-    if use_dist:
-        dist.barrier()
 
     images = world * args.steps * FRAMES_PER_STEP
     value = images / elapsed
