@@ -449,7 +449,7 @@ int vidu4d_densify_apply(int N, const int32_t* inclusive_counts, int n_orig, int
  *      (M*H*W floats) as the workspace between forward and backward, or, when surf_normal[m] (3,H,W) is given, read
  *      from there (its gradient then goes to g_surf_normal[m], if not NULL, instead of the depth planes). ---- */
 #define VIDU4D_LOSS_MAX_FRAMES 8
-#define VIDU4D_LOSS_BLOCKS 512
+#define VIDU4D_LOSS_BLOCKS 1024
 #define VIDU4D_LOSS_SUMS_FLOATS 32
 typedef struct Vidu4dStage3LossArgs {
     int M, H, W;

@@ -53,7 +53,7 @@ class SkinFieldArgs(C.Structure):
                                   "rawT", "g_xbT", "g_rawT", "g_xyz", "relu_masks")]
 
 
-LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 8, 512, 32
+LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 8, 1024, 32
 
 
 class Stage3LossArgs(C.Structure):

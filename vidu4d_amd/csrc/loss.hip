@@ -144,16 +144,31 @@ __device__ __forceinline__ float ordered_sum(const float* partial, int k)
 {
     // one wave, fixed order: lane i adds blocks i, i + 64, ...; then a fixed butterfly
     float x = 0.f;
-    for (int b = threadIdx.x; b < BLOCKS; b += 64) x += partial[b * 16 + k];
+    for (int b = (threadIdx.x & 63); b < BLOCKS; b += 64) x += partial[b * 16 + k];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
     return x;
 }
 
-__global__ __launch_bounds__(64) void loss_reduce1_kernel(Vidu4dStage3LossArgs a, const float* partial)
+// The K second-stage sums of a reduce kernel, one WAVE per sum (the kernel runs K waves): the same fixed order per sum as a
+// single wave doing them one after the other, a quarter of its latency (16 -> 5 us for the 11 first-level sums).
+template <int K>
+__device__ __forceinline__ void ordered_sums(const float* partial, float (&s)[K])
+{
+    __shared__ float sh[K];
+    const int wave = threadIdx.x >> 6;
+    if (wave < K) {
+        const float x = ordered_sum(partial, wave);
+        if ((threadIdx.x & 63) == 0) sh[wave] = x;
+    }
+    __syncthreads();
+    for (int k = 0; k < K; k++) s[k] = sh[k];
+}
+
+__global__ __launch_bounds__(64 * N1) void loss_reduce1_kernel(Vidu4dStage3LossArgs a, const float* partial)
 {
     float s[N1];
-    for (int k = 0; k < N1; k++) s[k] = ordered_sum(partial, k);
+    ordered_sums<N1>(partial, s);
     if (threadIdx.x != 0) return;
     const float numel = (float)((size_t)a.H * a.W * a.M);
     float* S = a.sums;
@@ -197,10 +212,10 @@ __global__ __launch_bounds__(THREADS) void loss_stats2_kernel(Vidu4dStage3LossAr
     block_partials<N2>(s, partial + blockIdx.x * 16);
 }
 
-__global__ __launch_bounds__(64) void loss_reduce2_kernel(Vidu4dStage3LossArgs a, const float* partial)
+__global__ __launch_bounds__(64 * N2) void loss_reduce2_kernel(Vidu4dStage3LossArgs a, const float* partial)
 {
     float s[N2];
-    for (int k = 0; k < N2; k++) s[k] = ordered_sum(partial, k);
+    ordered_sums<N2>(partial, s);
     if (threadIdx.x != 0) return;
     const float numel = (float)((size_t)a.H * a.W * a.M);
     float* S = a.sums;
@@ -296,12 +311,10 @@ __global__ __launch_bounds__(THREADS) void loss_backward_kernel(Vidu4dStage3Loss
     block_partials<3>(bg, partial + blockIdx.x * 16);
 }
 
-__global__ __launch_bounds__(64) void loss_reduce_bg_kernel(const float* partial, float* g_bkgd)
+__global__ __launch_bounds__(192) void loss_reduce_bg_kernel(const float* partial, float* g_bkgd)
 {
-    for (int k = 0; k < 3; k++) {
-        const float x = ordered_sum(partial, k);
-        if (threadIdx.x == 0) g_bkgd[k] = x;
-    }
+    const float x = ordered_sum(partial, threadIdx.x >> 6);   // one wave per channel
+    if ((threadIdx.x & 63) == 0) g_bkgd[threadIdx.x >> 6] = x;
 }
 
 int check(const Vidu4dStage3LossArgs* a)
@@ -327,9 +340,9 @@ extern "C" int vidu4d_stage3_loss_forward(const Vidu4dStage3LossArgs* a, void* s
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
     hipLaunchKernelGGL(loss_stats1_kernel, dim3(BLOCKS), dim3(THREADS), 0, s, *a, a->partials);
-    hipLaunchKernelGGL(loss_reduce1_kernel, dim3(1), dim3(64), 0, s, *a, a->partials);
+    hipLaunchKernelGGL(loss_reduce1_kernel, dim3(1), dim3(64 * N1), 0, s, *a, a->partials);
     hipLaunchKernelGGL(loss_stats2_kernel, dim3(BLOCKS), dim3(THREADS), 0, s, *a, a->partials);
-    hipLaunchKernelGGL(loss_reduce2_kernel, dim3(1), dim3(64), 0, s, *a, a->partials);
+    hipLaunchKernelGGL(loss_reduce2_kernel, dim3(1), dim3(64 * N2), 0, s, *a, a->partials);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
@@ -344,6 +357,6 @@ extern "C" int vidu4d_stage3_loss_backward(const Vidu4dStage3LossArgs* a, const 
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
     hipLaunchKernelGGL(loss_backward_kernel, dim3(BLOCKS), dim3(THREADS), 0, s, *a, g_losses, *grads, a->partials);
-    if (a->bkgd) hipLaunchKernelGGL(loss_reduce_bg_kernel, dim3(1), dim3(64), 0, s, a->partials, grads->g_bkgd);
+    if (a->bkgd) hipLaunchKernelGGL(loss_reduce_bg_kernel, dim3(1), dim3(192), 0, s, a->partials, grads->g_bkgd);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
