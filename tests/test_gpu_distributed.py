@@ -1,0 +1,81 @@
+"""The frame-parallel trainer path on the GPU with more than one rank, on ONE device: two processes share cuda:0 and
+exchange through gloo (which stages device tensors through the host) -- not a performance configuration, but it runs
+exactly the code a multi-GPU RCCL job runs above the collective: gradients written by the rasterizer's backward straight
+into the flat exchange buffer, only the live SH rows on the wire, two collectives, chunk norms folded into the clip
+coefficient of the one-launch Adam, densification statistics reduced when consumed, device-side densify replayed
+identically.  After three steps on different frames (through a densify / prune) the replicas must hold identical surfels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+        from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(0)
+        torch.manual_seed(0)                       # identical networks and surfels on every rank
+        opts = dict(fg_motion="gs-bob", densify_from_iter=0, densification_interval=2, densify_grad_threshold=1e-9,
+                    opacity_reset_interval=1000)
+        m = DeformableSurfels(opts, num_frames=8, device=dev)
+        n = 3000
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        m.init_from_points(0.25 * d / np.linalg.norm(d, axis=1, keepdims=True), rng.uniform(size=(n, 3)).astype(np.float32))
+        with torch.no_grad():
+            m._opacity.fill_(1.0)
+            m._opacity[:200] = -10.0               # transparent: pruned by the densify step
+        tr = Stage3Trainer(m, opts)
+        assert tr.world == world and tr._fold_clip_into_adam() and tr._flat_needed()
+        seen = {}
+        for step in range(3):                      # step 2 densifies
+            ids = [(2 * (step * world + rank)) % 8, (2 * (step * world + rank) + 1) % 8]
+            batch = synthetic_batch(m, ids, 64, 64, seed=step)
+            tr.train_step(batch)
+            if step == 0:
+                seen = {"direct": sorted(tr._direct), "packed": tr._rest_slot is not None, "degree": m.active_sh_degree}
+        torch.cuda.synchronize()
+        sig = torch.cat([p.detach().reshape(-1) for p in tr.surfel_params()]).cpu()
+        sizes = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([sig.numel()]))
+        same = all(int(x) == sig.numel() for x in sizes)
+        identical = False
+        if same:
+            gathered = [torch.zeros_like(sig) for _ in range(world)]
+            dist.all_gather(gathered, sig)
+            identical = all(torch.equal(gathered[0], t) for t in gathered)
+        out[rank] = (same, identical, int(m._xyz.shape[0]), bool(torch.isfinite(sig).all()), seen)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_keep_identical_surfels(gpu_device):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        same, identical, n, finite, seen = out[r]
+        assert finite and same and identical, "replicas diverged"
+        # SH degree 1 at step 0: only three of the fifteen rest rows travel, written whole by the backward into a side buffer
+        assert seen["degree"] == 1 and seen["packed"]
+        assert seen["direct"] == ["dL_dopacity", "dL_dscales", "dL_dsh_dc", "dL_dsh_rest"]
+    assert out[0][2] == out[1][2] and out[0][2] != 3000, "the densify step did not change the surfel count"
