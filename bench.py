@@ -474,10 +474,11 @@ def main():
             else:
                 gm, gr = stacked_frames()
             if use_dist:
+                # (the exchanged payload carries the canonical centres' / orientations' gradients: the frames' sums)
                 torch.sum(gm, 0, out=flat_view["means"].view(N, 3))
                 torch.sum(gr, 0, out=flat_view["rot"].view(N, 4))
                 return None
-            return gm.sum(0), gr.sum(0)
+            return gm, gr   # (per-frame gradients, as the op returns them: in the fitting loop they enter the warp's backward)
         use_streams = mode["streams"]
         main = torch.cuda.current_stream(dev)
         ready = main.record_event() if use_streams else None
