@@ -642,7 +642,7 @@ def main():
         # ---- roofline of the dominant kernel (live HIP-event stage timers, see above)
         from vidu4d_amd import _C
         # num_rendered of this rank's frames (read once, outside the timed region)
-        Rs = []
+        Rs, longest = [], 0
         with torch.no_grad():
             for i in range(min(len(frames), 4)):
                 o = _C.rasterize_gaussians(scene.bg, means[i], torch.empty(0, device=dev), scene.opacities,
@@ -650,10 +650,12 @@ def main():
                                            scene.projmatrix, scene.tanfovx, scene.tanfovy, H, W, scene.shs, 3,
                                            scene.campos, False, False)
                 Rs.append(o[0])
+                longest = max(longest, int(o[4][:16].view(torch.int32)[2]))  # Header::max_tile_len
         R = sum(Rs) / len(Rs)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         K = (32 + higher_msb(T) + 7) // 8  # 8-bit radix passes over the (tile | depth) key
         out["config"]["num_rendered_mean"] = R
+        out["config"]["longest_tile_list"] = longest
         out["config"]["algorithmic_bytes_per_image"] = total_bytes(N, R, W * H, T, K)
         out["algorithmic_GBps_whole_op"] = total_bytes(N, R, W * H, T, K) * (images / world) / elapsed / 1e9
         if not args.no_stage_timers:

@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 14
+#define VIDU4D_SURFEL_ABI 15
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -144,6 +144,12 @@ typedef struct Vidu4dSurfelForwardArgs {
      * not those of the exact blend: blend it again with assume_unsaturated = 0.  Word 8 of the geometry buffer holds the
      * bits of the frame's smallest final transmittance (whatever the mode): what a caller bases the expectation on. */
     int assume_unsaturated;
+    /* ---- how tile lists beyond the LDS capacity are sorted (extension; only with segment_split != 0; the sorted list is
+     * the same either way).  0: MSD split on the leading differing depth bits + in-LDS bucket sorts (five small launches:
+     * pays off from ~10 k entries per list, object-centric frames); 1: one 16-wave workgroup per long list through global
+     * memory (two launches: cheaper while the longest lists hold a few thousand entries).  Callers decide from word 2 of the
+     * geometry buffer (the longest list of earlier frames). */
+    int long_list_sort;
 } Vidu4dSurfelForwardArgs;
 #define VIDU4D_AUX_ALPHA 0x02
 #define VIDU4D_SURFEL_MAX_FRAMES 8

@@ -806,16 +806,19 @@ def test_stacked_frames_without_surfels(gpu_device):
     assert color.shape == (3, 2, 48, 64) and radii.shape == (2, 0) and float(color.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["msd_split", "one_workgroup"])
 @pytest.mark.parametrize("which", ["spread", "wide_range", "ties", "one_depth", "mostly_one_depth"])
-def test_long_list_sort_msd_split(gpu_device, which, monkeypatch):
+def test_long_list_sort_msd_split(gpu_device, which, mode, monkeypatch):
     """Lists beyond the LDS capacity with the segment split on: binning.hip's MSD split on the leading differing depth bits
     + in-LDS bucket sorts (and its fall-backs to the global-memory sort) must leave the reference's order -- ascending
     (depth, surfel id) -- bit for bit: point_list / ranges against the oracle, images and gradients after them.
     wide_range: depths over several binades (the digit sits in the exponent); ties: clones (equal depths inside buckets);
     one_depth: every surfel of the long lists at ONE depth (no differing bit: nothing to split on); mostly_one_depth: three
-    quarters at one depth (a bucket beyond the LDS capacity)."""
+    quarters at one depth (a bucket beyond the LDS capacity).  mode: Vidu4dSurfelForwardArgs::long_list_sort -- the MSD split,
+    or the 16-wave workgroup per long list that _C picks while the longest lists of earlier frames stay short."""
     from vidu4d_amd import _C
     monkeypatch.setattr(_C, "_SPLIT", "1")
+    monkeypatch.setattr(_C, "MSD_SORT_FROM", 0 if mode == "msd_split" else 1 << 31)
     n = 24_000
     sc = make_scene(n, 96, 80, seed=77, sigma_px=1.0)
     g = torch.Generator().manual_seed(78)

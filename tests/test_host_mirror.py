@@ -310,6 +310,33 @@ def test_speculation_bookkeeping_of_the_deferred_check():
         d.pop(key, None)
 
 
+def test_long_list_sort_mode_follows_the_longest_list_of_earlier_frames():
+    """_C's host-side policy for Vidu4dSurfelForwardArgs::long_list_sort (no GPU involved): word 2 of the header (the longest
+    tile list) feeds a slowly decaying maximum per image shape; the MSD split is used from MSD_SORT_FROM entries on and
+    for shapes nothing is known about yet."""
+    import torch
+    from vidu4d_amd import _C
+    key = ("test-shape-sort",)
+    _C._len_hint.pop(key, None)
+    mode = lambda: 0 if _C._len_hint.get(key, 1 << 30) >= _C.MSD_SORT_FROM else 1  # noqa: E731  (as rasterize_gaussians)
+    assert mode() == 0                                   # unknown shape: the split (never slower by much)
+    slot = torch.zeros(16, dtype=torch.int32)
+    slot[0], slot[2] = 1000, 5000
+    _C.check_slots([(slot, None, 2000, key)])
+    assert _C._len_hint[key] == 5000 and mode() == 1     # a few thousand entries: one workgroup per long list
+    slot[2] = 25000
+    _C.check_slots([(slot, None, 2000, key)])
+    assert mode() == 0                                   # rises at once ...
+    slot[2] = 5000
+    _C.check_slots([(slot, None, 2000, key)])
+    assert _C._len_hint[key] == 22500 and mode() == 0    # ... and decays by a tenth per frame
+    for _ in range(10):
+        _C.check_slots([(slot, None, 2000, key)])
+    assert mode() == 1
+    for d in (_C._len_hint, _C._min_T_hint, _C._no_spec, _C._unlimited, _C._capacity_hint):
+        d.pop(key, None)
+
+
 def test_depth_only_sort_with_tie_fix_up_is_the_reference_order():
     """The tile sort's algorithm (csrc/binning.hip), restated in numpy: LSD passes on the four depth bytes of keys that
     arrive in ARBITRARY order (the emission order inside a group is not deterministic), then every run of equal depths

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class ForwardArgs(C.Structure):
@@ -29,7 +29,7 @@ class ForwardArgs(C.Structure):
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
         ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("raw_params", C.c_int), ("aux_planes", C.c_int),
-        ("assume_unsaturated", C.c_int),
+        ("assume_unsaturated", C.c_int), ("long_list_sort", C.c_int),
     ]
 
 

@@ -696,14 +696,16 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const Header* hdr, int
 }
 
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
-                      int64_t capacity, bool long_pass, hipStream_t stream)
+                      int64_t capacity, LongListSort mode, hipStream_t stream)
 {
     if (capacity <= 0 || num_tiles <= 0) return;
     int id_bytes = 1;
     while (id_bytes < 4 && ((uint64_t)(num_surfels > 0 ? num_surfels - 1 : 0) >> (8 * id_bytes))) id_bytes++;
-    if (long_pass) {
-        // the long tiles lead the schedule, but it is sorted by length CLASS only (a long tile may sit behind
-        // shorter ones of its class), so every position gets a workgroup; the short ones exit at once
+    constexpr int SMALL_CAP = 1024;
+    static_assert(MSD_MIN == SMALL_CAP, "the split takes every list the small in-LDS sort does not");
+    // the long tiles lead the schedule, but it is sorted by length CLASS only (a long tile may sit behind shorter ones of
+    // its class), so every position gets a workgroup; the ones a launch does not own exit at once
+    if (mode == LongListSort::msd_split) {
         // (the bucket work list lives at the start of seg_data, which nobody touches before the blend)
         SortBucket* buckets = reinterpret_cast<SortBucket*>(b.seg_data);
         const uint32_t max_buckets = (uint32_t)std::min<int64_t>(256 * (capacity / MSD_MIN + 1), 0x7fffffff);
@@ -716,13 +718,14 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
                            b.entries, b.scratch, b.point_list, id_bytes);
         hipLaunchKernelGGL(bucket_sort_small_kernel, dim3(grid), dim3(256), 0, stream, g.hdr, capacity, buckets, b.entries,
                            b.scratch, b.point_list);
-    }
-    constexpr int SMALL_CAP = 1024;
-    static_assert(MSD_MIN == SMALL_CAP, "with the long pass on, the split takes every list the small in-LDS sort does not");
-    if (!long_pass)
+    } else {
+        if (mode == LongListSort::one_workgroup)  // lists beyond the LDS capacity: 16 waves each, through global memory
+            hipLaunchKernelGGL((tile_sort_kernel<16, false, 1>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order,
+                               img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0, 0);
         hipLaunchKernelGGL((tile_sort_kernel<4, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
-                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0,
-                           SMALL_CAP + 1);
+                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes,
+                           mode == LongListSort::one_workgroup ? 1 : 0, SMALL_CAP + 1);
+    }
     hipLaunchKernelGGL((tile_sort_kernel<4, true, SMALL_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
                        img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 1, 0);
 }

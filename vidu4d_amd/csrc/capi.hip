@@ -325,7 +325,11 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
         STAGE_CHECK(a->debug, stream, "emit_keys");
         {
             StageTimer t(ST_SORT, stream);
-            launch_tile_sort(g, img, b, total_tiles(cam), P, capacity, a->segment_split != 0, stream);
+            launch_tile_sort(g, img, b, total_tiles(cam), P, capacity,
+                             a->segment_split == 0 ? LongListSort::in_lds_only
+                             : a->long_list_sort    ? LongListSort::one_workgroup
+                                                    : LongListSort::msd_split,
+                             stream);
         }
         STAGE_CHECK(a->debug, stream, "tile_sort");
     }

@@ -33,8 +33,14 @@ constexpr int TILE_SORT_CAP = 3584;  // list entries a tile can sort entirely in
 // is cut into segments of SEG_LEN entries, each blended by its own workgroup: front-to-back
 // compositing is associative, so a segment needs from its predecessors only the transmittance they
 // leave behind (one float per pixel).  See blend.hip for the three passes.
-constexpr int SEG_LEN = 512;
-constexpr int SPLIT_MIN = 1024;
+#ifndef SURFEL_SEG_LEN
+#define SURFEL_SEG_LEN 512
+#endif
+#ifndef SURFEL_SPLIT_MIN
+#define SURFEL_SPLIT_MIN 1024
+#endif
+constexpr int SEG_LEN = SURFEL_SEG_LEN;      // (a multiple of the blend kernels' batch sizes)
+constexpr int SPLIT_MIN = SURFEL_SPLIT_MIN;
 constexpr int SEG_FLOATS = 16;  // per (segment, pixel) values, slot-major: seg_data[(slot * 16 + k) * 256 + pixel]
 enum SegSlot {
     SG_TSEG = 0,   // product of (1 - alpha) over the segment (pass 1)
@@ -254,9 +260,13 @@ void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, 
 void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
                       const BinState& b, int64_t capacity, bool grouped, hipStream_t stream);
 // per-tile stable radix sort of the (depth, id) entries; fills point_list
-// long_pass: lists longer than TILE_SORT_CAP get a 16-wave workgroup of their own launch
+// How lists longer than the LDS capacity (TILE_SORT_CAP) are sorted (Vidu4dSurfelForwardArgs::long_list_sort):
+//   in_lds_only   -- the long-tile machinery is off (segment_split == 0): the 4-wave kernel runs them through global memory;
+//   msd_split     -- every list beyond 1024 entries is split on its leading differing depth bits, the buckets sorted in LDS;
+//   one_workgroup -- a 16-wave workgroup per long list through global memory, the rest in LDS.
+enum class LongListSort { in_lds_only, msd_split, one_workgroup };
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
-                      int64_t capacity, bool long_pass, hipStream_t stream);
+                      int64_t capacity, LongListSort mode, hipStream_t stream);
 // split: blend tiles longer than SPLIT_MIN segment-parallel (three launches instead of one)
 // max_seg: only the first max_seg segments of a split tile are blended (a caller that knows how deep the
 // previous frames went saves the rest of pass 1); Header::truncated is set if that was not enough
