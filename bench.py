@@ -597,7 +597,8 @@ def main():
             walk = {"list_entries_staged": c[0], "pair_evaluations": c[1], "evaluations_with_a_contributor": c[2],
                     "contributing_pairs": c[3], "lane_utilisation": c[3] / (64.0 * c[1]),
                     "rows_touched_per_contributing_evaluation": c[4] / max(1, c[2]),
-                    "contributing_lanes_histogram_le_4_8_16_32_64": c[5:10], "per": "step (its frames, one or more launches)"}
+                    "contributing_lanes_histogram_le_4_8_16_32_64": c[5:10],
+                    "evaluations_whose_footprint_misses_the_quadrant": c[10], "per": "step (its frames, one or more launches)"}
 
     images = world * args.steps * FRAMES_PER_STEP
     value = images / elapsed

@@ -254,9 +254,10 @@ int vidu4d_surfel_profile_enable(int on);
 /* Diagnostic: while device_counters (VIDU4D_BLEND_STATS u64, zeroed by the caller) is not NULL, every
  * vidu4d_surfel_backward call also counts what its tile walk looks like: [0] list entries staged, [1] (entry, wave)
  * pair evaluations, [2] those with a contributing lane, [3] contributing lanes, [4] 16-lane rows with a contributing
- * lane, [5..9] evaluations of [2] with <= 4 / 8 / 16 / 32 / 64 contributing lanes.  [3] / (64 [1]) is the lane
- * utilisation bench.py's roofline note quotes. */
-#define VIDU4D_BLEND_STATS 10
+ * lane, [5..9] evaluations of [2] with <= 4 / 8 / 16 / 32 / 64 contributing lanes, [10] evaluations of [1] in which no
+ * lane passes the pair test (the contribution box reaches the quadrant, the footprint does not).  [3] / (64 [1]) is the
+ * lane utilisation bench.py's roofline note quotes. */
+#define VIDU4D_BLEND_STATS 11
 int vidu4d_surfel_blend_stats(unsigned long long* device_counters);
 int vidu4d_surfel_profile_stage_count(void);
 const char* vidu4d_surfel_profile_stage_name(int stage);

@@ -44,7 +44,7 @@ extern "C" void emul_preprocess(int P, int D, int M, const float* means3D, const
         for (int k = 0; k < 3; k++) { r[R_NX + k] = o.normal[k]; r[R_RGB + k] = rgb[k]; }
         r[R_DEPTH] = o.depth;
         memcpy(&r[R_CLAMP], &mask, 4);
-        contribution_box(o.T, o.center[0], o.center[1], opacities[i], r + R_BOX);
+        contribution_footprint(o.T, o.center[0], o.center[1], opacities[i], r + R_FOOT);
         radii[i] = o.radius; tiles[i] = o.tiles;
     }
 }
@@ -65,7 +65,7 @@ extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint
             for (uint32_t i = r0; i < r1; i++) {
                 const float* r = rec + (size_t)point_list[i] * REC_FLOATS;
                 PairEval e;
-                if (cull && (pixx < r[R_BOX] || pixx > r[R_BOX + 2] || pixy < r[R_BOX + 1] || pixy > r[R_BOX + 3])) continue;
+                if (cull && !footprint_hits(footprint_test(r + R_FOOT, r[R_CX], r[R_CY]), pixx, pixx, pixy, pixy)) continue;
                 if (!eval_pair_flat(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
                 // (lite: the colour + alpha-plane instance the blend kernels run for aux_planes == VIDU4D_AUX_ALPHA)
                 if (!(lite ? fwd_accumulate<true>(s, e, r + R_NX, r + R_RGB, i - r0 + 1)
@@ -115,7 +115,7 @@ extern "C" void emul_render_bwd(int W, int H, const uint32_t* ranges, const uint
                 const uint32_t id = point_list[r0 + ci];
                 const float* r = rec + (size_t)id * REC_FLOATS;
                 PairEval e;
-                if (cull && (pixx < r[R_BOX] || pixx > r[R_BOX + 2] || pixy < r[R_BOX + 1] || pixy > r[R_BOX + 3])) continue;
+                if (cull && !footprint_hits(footprint_test(r + R_FOOT, r[R_CX], r[R_CY]), pixx, pixx, pixy, pixy)) continue;
                 if (!eval_pair_flat(r, r + 3, r + 6, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) continue;
                 float g[ACC_FLOATS];
                 if (lite) {

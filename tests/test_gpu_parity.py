@@ -48,7 +48,7 @@ def _check_forward(sc, st, out, colors=None):
     assert R == st["num_rendered"]
     assert np.array_equal(to_np(radii), st["radii"])
     assert np.array_equal(_state("tiles_touched", out, sc, torch.int32, P).astype(np.uint32), st["tiles_touched"])
-    rec = _state("records", out, sc, torch.float32, P * 24).reshape(P, 24)
+    rec = _state("records", out, sc, torch.float32, P * 28).reshape(P, 28)
     vis = st["radii"] > 0
     assert np.array_equal(rec[vis, 0:9], st["transMat"][vis]), "homography must be bit-exact (feeds the binning)"
     assert np.array_equal(rec[vis, 9:11], st["means2D"][vis])

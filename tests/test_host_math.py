@@ -33,11 +33,13 @@ def test_header_math_matches_oracle(case):
         assert_close(k, e["grads"][k], g[k])
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_contribution_box_is_conservative(seed):
-    """The per-surfel pixel box that prunes (wave, surfel) work must never drop a contributing pair:
-    the emulated pipeline with and without the box gives bit-identical images and gradients, on
-    scenes that include edge-on, sub-pixel, screen-filling and near-plane surfels."""
+@pytest.mark.parametrize("seed", range(12))
+def test_contribution_footprint_is_conservative(seed):
+    """The per-surfel footprint (conic rho3d <= rc + rho2d disc, surfel_math.h contribution_footprint / footprint_hits)
+    that prunes (wave, surfel) work must never drop a contributing pair: the emulated pipeline with the test applied PER
+    PIXEL (the tightest rectangle; the kernels apply it per 8x8 quadrant) and without it gives bit-identical images and
+    gradient accumulators, on scenes that include edge-on, sub-pixel, screen-filling, strongly foreshortened and
+    near-plane surfels."""
     import torch
     from vidu4d_amd.synthetic import make_scene
     kinds = [dict(sigma_px=1.5), dict(sigma_px=0.15), dict(sigma_px=20.0, big_fraction=0.2), dict(sigma_px=4.0),
@@ -48,6 +50,11 @@ def test_contribution_box_is_conservative(seed):
     sc.means3D[::7, 2] = 0.2 + 0.3 * torch.rand(sc.means3D[::7].shape[0], generator=g)
     sc.scales[::5, 1] *= 1e-3
     sc.scales[::11, 0] *= 30.0
+    if seed >= 6:   # large tilted surfels close to the camera: strong perspective inside one footprint
+        sc.means3D[1::3, 2] = 0.25 + 0.5 * torch.rand(sc.means3D[1::3].shape[0], generator=g)
+        sc.scales[1::3] = 0.05 + 0.4 * torch.rand(sc.scales[1::3].shape, generator=g)
+        q = torch.randn(sc.rotations[1::3].shape, generator=g)
+        sc.rotations[1::3] = q / q.norm(dim=1, keepdim=True)
     st = oracle_forward(sc)
     dc, do = make_upstream_grads(sc.width, sc.height)
     a = emul.run(st, dc.numpy(), do.numpy(), cull=True)

@@ -59,32 +59,40 @@ __device__ __forceinline__ size_t frame_of_tile(TileCoord& tc, int W, int H, int
     return (size_t)frame * W * H;
 }
 
-// Stages one surfel record (q0..q4) into LDS slot `slot` and returns q5, the contribution box.
-__device__ __forceinline__ float4 stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
+// Stages one surfel record (q0..q4) into LDS slot `slot` and returns its footprint (q5, q6: surfel_math.h
+// contribution_footprint) ready for the quadrant tests.  `NoFootprint()`: what a thread without an entry passes on.
+__device__ __forceinline__ FootprintTest stage_record(float4* s_rec, int slot, const float* rec, uint32_t id)
 {
     const float4* src = reinterpret_cast<const float4*>(rec + (size_t)id * REC_FLOATS);
-    const float4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], box = src[5];
+    const float4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], f0 = src[5], f1 = src[6];
     float4* dst = s_rec + slot * 5;
     dst[0] = a;
     dst[1] = b;
     dst[2] = c;
     dst[3] = d;
     dst[4] = e;
-    return box;
+    const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    return footprint_test(f, c.y, c.z);
 }
 
-// Per-wave cull masks.  Thread t staged list entry t of the batch and knows its contribution box;
-// for each of the four 8x8 pixel quadrants of the tile (one per wave) a wave64 ballot says which
-// of the 64 entries this wave staged can touch that quadrant.  s_mask[q][w] = entries 64w..64w+63
+__device__ __forceinline__ FootprintTest no_footprint()
+{
+    const float f[8] = {0.f, 0.f, 0.f, -1.f, 0.f, 0.f, -1.f, 0.f};
+    return footprint_test(f, 0.f, 0.f);
+}
+
+// Per-wave cull masks.  Thread t staged list entry t of the batch and knows its footprint (the conic rho3d <= rc and
+// the rho2d disc); for each of the four 8x8 pixel quadrants of the tile (one per wave) a wave64 ballot says which
+// of the 64 entries this wave staged can reach a pixel centre of that quadrant.  s_mask[q][w] = entries 64w..64w+63
 // relevant to quadrant q.  Afterwards wave q walks only the set bits: entries that cannot
 // contribute to its pixels cost nothing.
-__device__ __forceinline__ void publish_cull_masks(unsigned long long (*s_mask)[4], bool valid, float4 box, int tile_x0,
-                                                   int tile_y0, int wave, int lane)
+__device__ __forceinline__ void publish_cull_masks(unsigned long long (*s_mask)[4], bool valid, const FootprintTest& foot,
+                                                   int tile_x0, int tile_y0, int wave, int lane)
 {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float rx0 = (float)(tile_x0 + (q & 1) * 8) + 0.5f, ry0 = (float)(tile_y0 + (q >> 1) * 8) + 0.5f;
-        const bool hit = valid && !(box.z < rx0 || box.x > rx0 + 7.0f || box.w < ry0 || box.y > ry0 + 7.0f);
+        const bool hit = valid && footprint_hits(foot, rx0, rx0 + 7.0f, ry0, ry0 + 7.0f);
         const unsigned long long m = __ballot(hit);
         if (lane == 0) s_mask[q][wave] = m;
     }
@@ -226,9 +234,9 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
     for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
         __syncthreads();
         const bool have = (int)threadIdx.x < todo;
-        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (have) box = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
-        publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        FootprintTest foot = no_footprint();
+        if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
@@ -307,9 +315,9 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
     for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const bool have = (int)threadIdx.x < todo;
-        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (have) box = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
-        publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        FootprintTest foot = no_footprint();
+        if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
         __syncthreads();
         if (__all(done)) continue;  // this wave's 64 pixels are saturated; it keeps helping to stage
 #pragma unroll 1
@@ -730,13 +738,13 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
         {
             // threads 0..127 stage (back to front: slot t <-> list entry hi-1-t), all zero the accumulators
             const bool have = (int)threadIdx.x < cnt;
-            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+            FootprintTest foot = no_footprint();
             if (have) {
                 const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)];
                 s_id[threadIdx.x] = id;
-                box = stage_record(s_rec, threadIdx.x, rec, id);
+                foot = stage_record(s_rec, threadIdx.x, rec, id);
             }
-            if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
+            if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
             for (int i = threadIdx.x; i < BWD_BATCH * ACC_FLOATS / 4; i += 256)
                 reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -796,6 +804,8 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
 //   [0] list entries staged (per workgroup batch, summed)          [1] (entry, wave) trips that evaluate the pair
 //   [2] trips in which some lane contributes                       [3] contributing lanes (pairs) in total
 //   [4] 16-lane rows with a contributing lane, summed over [2]     [5..9] trips of [2] with <= 4, 8, 16, 32, 64 lanes
+//   [10] trips of [1] in which no lane passes the pair test itself (the contribution box reaches the quadrant, the
+//        footprint does not; the rest of [1] - [2] found every pixel it reaches finished)
 __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int grid_x, int grid_y, ImageState img,
                                                              const uint32_t* __restrict__ point_list,
                                                              const float* __restrict__ rec,
@@ -829,14 +839,14 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
     if (lane == 0) atomicMax(&s_max, wave_last);
     __syncthreads();
     const int n_used = (int)s_max;
-    unsigned long long c_staged = 0, c_trips = 0, c_full = 0, c_lanes = 0, c_rows = 0, c_hist[5] = {0, 0, 0, 0, 0};
+    unsigned long long c_staged = 0, c_trips = 0, c_full = 0, c_lanes = 0, c_rows = 0, c_hist[5] = {0, 0, 0, 0, 0}, c_geo_empty = 0;
     for (int hi = n_used; hi > 0; hi -= BWD_BATCH) {
         const int cnt = hi < BWD_BATCH ? hi : BWD_BATCH;
         __syncthreads();
         const bool have = (int)threadIdx.x < cnt;
-        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (have) box = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)]);
-        if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, box, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        FootprintTest foot = no_footprint();
+        if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)]);
+        if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
         __syncthreads();
         if (wave == 0) c_staged += (unsigned long long)cnt;
         for (int k = 0; k < BWD_BATCH / 64; k++) {
@@ -849,9 +859,11 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
                 const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
                 const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
                 PairEval e;
-                const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && contributor < last;
+                const bool geo = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && inside;
+                const bool ok = geo && contributor < last;
                 const unsigned long long b = __ballot(ok);
                 c_trips++;
+                if (!__ballot(geo)) c_geo_empty++;
                 if (!b) continue;
                 const int n = __builtin_popcountll(b);
                 c_full++;
@@ -869,6 +881,7 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
         atomicAdd(out + 3, c_lanes);
         atomicAdd(out + 4, c_rows);
         for (int i = 0; i < 5; i++) atomicAdd(out + 5 + i, c_hist[i]);
+        atomicAdd(out + 10, c_geo_empty);
     }
 }
 

@@ -114,9 +114,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         const float opacity = a.raw_params ? act_opacity(a.opacities[shared]) : a.opacities[shared];
         rec[2] = make_float4(o.T[8], o.center[0], o.center[1], opacity);
         rec[3] = make_float4(o.normal[0], o.normal[1], o.normal[2], o.depth);
-        float box[4];
-        contribution_box(o.T, o.center[0], o.center[1], opacity, box);
-        rec[5] = make_float4(box[0], box[1], box[2], box[3]);
+        float f[8];
+        contribution_footprint(o.T, o.center[0], o.center[1], opacity, f);
+        rec[5] = make_float4(f[0], f[1], f[2], f[3]);
+        rec[6] = make_float4(f[4], f[5], f[6], f[7]);
     }
     a.radii[idx] = radius;
     a.geom.tiles_touched[idx] = tiles;

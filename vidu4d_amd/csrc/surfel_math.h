@@ -31,15 +31,15 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_EPS = 0.0001f;
 
-// Per-surfel record written by preprocess and gathered by the blend kernels (6 x float4 = 96 B).
+// Per-surfel record written by preprocess and gathered by the blend kernels (7 x float4 = 112 B).
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z cx cy opacity
 //   q3 = n.x n.y n.z depth   | q4 = r g b clampmask(bits)
-//   q5 = conservative pixel-space box outside which the surfel cannot contribute (x0 y0 x1 y1)
-constexpr int REC_FLOATS = 24;
-constexpr int REC_LDS_FLOATS = 20;  // q0..q4 are staged in LDS; q5 only feeds the per-wave cull masks
+//   q5, q6 = the footprint outside which the surfel cannot contribute (contribution_footprint below)
+constexpr int REC_FLOATS = 28;
+constexpr int REC_LDS_FLOATS = 20;  // q0..q4 are staged in LDS; q5, q6 only feed the per-wave cull masks
 enum RecSlot {
     R_TU = 0, R_TV = 3, R_TW = 6, R_CX = 9, R_CY = 10, R_OPAC = 11, R_NX = 12, R_DEPTH = 15, R_RGB = 16, R_CLAMP = 19,
-    R_BOX = 20
+    R_FOOT = 20  // 8 floats: contribution_footprint
 };
 
 // Per-surfel gradient accumulator filled by the backward blend (20 floats = 80 B):
@@ -476,62 +476,106 @@ SURFEL_HD bool eval_pair_flat(const float Tu[3], const float Tv[3], const float 
     return (pz != 0.0f) & !(e.depth < NEAR_PLANE) & !(power > 0.0f) & !(e.alpha < ALPHA_MIN);
 }
 
-// Conservative pixel-space box of the pixels a surfel can contribute to.  A pair contributes only if
-// alpha = min(0.99, o*exp(-rho/2)) >= 1/255 with rho = min(rho3d, rho2d), i.e. only if
-// rho3d <= rc or rho2d <= rc with rc = 2 ln(255 o).  {rho2d <= rc} is a disc of radius sqrt(rc/2)
-// around the projected centre; {rho3d <= rc} is the projection of the splat-space disc of radius
-// sqrt(rc), whose exact screen AABB follows from the homography like the reference's 1-sigma box
-// (forward.cu:133-163) with the first two columns scaled by sqrt(rc) -- evaluated relative to the
-// projected centre so that fp32 cancellation stays far below the safety margin.  If that conic is
-// not an ellipse in front of the camera plane the box is unbounded.  Margin: 1 px + 0.2 %.
-// This only prunes work: pixels inside the box still run the exact per-pixel test.
+// Which pixels a surfel can contribute to.  A pair contributes only if alpha = min(0.99, o*exp(-rho/2)) >= 1/255 with
+// rho = min(rho3d, rho2d), i.e. only if rho3d <= rc or rho2d <= rc with rc = 2 ln(255 o).  {rho2d <= rc} is a disc of
+// radius sqrt(rc/2) around the projected centre; {rho3d <= rc} is the projection of the splat-space disc of radius
+// sqrt(rc).  Margins: BOX_MARGIN_PX on lengths, 0.01 % + 1e-4 on rc, 1 % on the conic's form.
 #ifndef SURFEL_BOX_MARGIN_PX
 #define SURFEL_BOX_MARGIN_PX 0.02f
 #endif
 constexpr float BOX_MARGIN_PX = SURFEL_BOX_MARGIN_PX;
 
-SURFEL_HD void contribution_box(const float T[9], float cx, float cy, float opacity, float box[4])
+// The footprint for the blend kernels' per-quadrant culls (round 3; rounds 1-2 used its bounding box).
+// rho3d <= rc is a conic in the pixel plane: with k = x Tw - Tu, l = y Tw - Tv the intersection is s = (n_x, n_y) / n_z,
+// n = k x l = Tu x Tv + x (Tv x Tw) + y (Tw x Tu) -- LINEAR in the pixel -- so rho3d <= rc <=> n_x^2 + n_y^2 - rc n_z^2 <= 0,
+// a quadratic Q(x, y).  Where that is an ellipse it is stored by its centre and its form in offsets from the centre,
+// scaled so that the inside is q(du, dv) = A du^2 + 2 B du dv + C dv^2 <= 1:
+//   f[0..2] = A, B, C   f[3] = squared radius of the rho2d disc around the projected centre (with the margin)
+//   f[4], f[5] = conic centre minus projected centre   f[6] = limit q is compared with: 1 + margin; 3e38 where the
+//   conic is not a (numerically clear) ellipse: every rectangle hits; -1 (and f[3] = -1) where alpha >= 1/255 is
+//   out of reach: nothing hits.
+// Everything is evaluated relative to the projected centre (fp32 cancellation far below the margins: 1 % on q, i.e.
+// 0.5 % on the axes, and BOX_MARGIN_PX on the rectangle).  This only prunes work, like the box.
+SURFEL_HD void contribution_footprint(const float T[9], float cx, float cy, float opacity, float f[8])
 {
     const float BIG = 3.0e38f;
+    for (int k = 0; k < 8; k++) f[k] = 0.f;
     const float oa = opacity * 255.0f;
     if (!(oa >= 1.0f)) {  // can never reach alpha >= 1/255 (also catches NaN)
-        box[0] = box[1] = BIG;
-        box[2] = box[3] = -BIG;
+        f[3] = -1.0f;
+        f[6] = -1.0f;
         return;
     }
     const float rc = 2.0f * logf(oa) * 1.0001f + 1e-4f;
-    const float r2 = sqrtf(0.5f * rc);
-    float x0 = cx - r2, x1 = cx + r2, y0 = cy - r2, y1 = cy + r2;
-    // centred homography rows: screen coordinates relative to (cx, cy)
-    const float Tw0 = T[6], Tw1 = T[7], Tw2 = T[8];
-    const float Ux = T[0] - cx * Tw0, Uy = T[1] - cx * Tw1, Uz = T[2] - cx * Tw2;
-    const float Vx = T[3] - cy * Tw0, Vy = T[4] - cy * Tw1, Vz = T[5] - cy * Tw2;
-    const float d = rc * (Tw0 * Tw0 + Tw1 * Tw1) - Tw2 * Tw2;
-    if (d < -1e-3f * Tw2 * Tw2) {
-        const float f = 1.0f / d;
-        const float ex = f * (rc * (Ux * Tw0 + Uy * Tw1) - Uz * Tw2);
-        const float ey = f * (rc * (Vx * Tw0 + Vy * Tw1) - Vz * Tw2);
-        const float hx2 = ex * ex - f * (rc * (Ux * Ux + Uy * Uy) - Uz * Uz);
-        const float hy2 = ey * ey - f * (rc * (Vx * Vx + Vy * Vy) - Vz * Vz);
-        const float hx = sqrtf(fmaxf(hx2, 0.f)), hy = sqrtf(fmaxf(hy2, 0.f));
-        if (hx == hx && hy == hy && ex == ex && ey == ey) {
-            x0 = fminf(x0, cx + ex - hx);
-            x1 = fmaxf(x1, cx + ex + hx);
-            y0 = fminf(y0, cy + ey - hy);
-            y1 = fmaxf(y1, cy + ey + hy);
-        } else {
-            x0 = y0 = -BIG;
-            x1 = y1 = BIG;
-        }
-    } else {
-        x0 = y0 = -BIG;
-        x1 = y1 = BIG;
-    }
-    const float mx = BOX_MARGIN_PX + 2e-3f * (x1 - x0), my = BOX_MARGIN_PX + 2e-3f * (y1 - y0);
-    box[0] = x0 - mx;
-    box[1] = y0 - my;
-    box[2] = x1 + mx;
-    box[3] = y1 + my;
+    const float rd = sqrtf(0.5f * rc) + BOX_MARGIN_PX;
+    f[3] = rd * rd;
+    f[6] = BIG;
+    const float* Tu = T;
+    const float* Tv = T + 3;
+    const float* Tw = T + 6;
+    const float c0[3] = {Tu[1] * Tv[2] - Tu[2] * Tv[1], Tu[2] * Tv[0] - Tu[0] * Tv[2], Tu[0] * Tv[1] - Tu[1] * Tv[0]};
+    const float c1[3] = {Tv[1] * Tw[2] - Tv[2] * Tw[1], Tv[2] * Tw[0] - Tv[0] * Tw[2], Tv[0] * Tw[1] - Tv[1] * Tw[0]};
+    const float c2[3] = {Tw[1] * Tu[2] - Tw[2] * Tu[1], Tw[2] * Tu[0] - Tw[0] * Tu[2], Tw[0] * Tu[1] - Tw[1] * Tu[0]};
+    const float m0[3] = {c0[0] + cx * c1[0] + cy * c2[0], c0[1] + cx * c1[1] + cy * c2[1], c0[2] + cx * c1[2] + cy * c2[2]};
+    // Q(u, v) = A u^2 + 2 B u v + C v^2 + 2 D u + 2 E v + F in offsets (u, v) from the projected centre
+    const float A = c1[0] * c1[0] + c1[1] * c1[1] - rc * c1[2] * c1[2];
+    const float B = c1[0] * c2[0] + c1[1] * c2[1] - rc * c1[2] * c2[2];
+    const float C = c2[0] * c2[0] + c2[1] * c2[1] - rc * c2[2] * c2[2];
+    const float D = m0[0] * c1[0] + m0[1] * c1[1] - rc * m0[2] * c1[2];
+    const float E = m0[0] * c2[0] + m0[1] * c2[1] - rc * m0[2] * c2[2];
+    const float F = m0[0] * m0[0] + m0[1] * m0[1] - rc * m0[2] * m0[2];
+    const float det = A * C - B * B;
+    if (!(A > 0.f && C > 0.f && det > 1e-5f * A * C)) return;  // not an ellipse, or too thin to trust: every rectangle hits
+    const float uc = (E * B - D * C) / det, vc = (D * B - E * A) / det;
+    const float K = -(F + D * uc + E * vc);  // -Q at the centre: > 0 inside
+    const float ik = 1.0f / K;
+    const float a = A * ik, b = B * ik, c = C * ik;
+    if (!(K > 0.f) || !(a == a && b == b && c == c && uc == uc && vc == vc) || !(a < BIG && c < BIG) ||
+        !(fabsf(uc) < 1e6f && fabsf(vc) < 1e6f))
+        return;
+    f[0] = a;
+    f[1] = b;
+    f[2] = c;
+    f[4] = uc;
+    f[5] = vc;
+    f[6] = 1.01f;
+}
+
+// Can the surfel with footprint f and projected centre (cx, cy) contribute to a pixel centre inside
+// [x0, x1] x [y0, y1]?  Exact for the rectangle up to the margins: q is convex with its minimum (0) at the conic centre,
+// so its minimum over a rectangle that does not hold the centre lies on an edge facing the centre; on the edge
+// u = ue it is at v = -B ue / C clamped to the edge, and likewise for v = ve.
+struct FootprintTest {
+    float A, B, C, rd2, lim, cx, cy, ecx, ecy, rBC, rBA;
+};
+
+SURFEL_HD FootprintTest footprint_test(const float f[8], float cx, float cy)
+{
+    FootprintTest t;
+    t.A = f[0];
+    t.B = f[1];
+    t.C = f[2];
+    t.rd2 = f[3];
+    t.lim = f[6];
+    t.cx = cx;
+    t.cy = cy;
+    t.ecx = cx + f[4];
+    t.ecy = cy + f[5];
+    t.rBC = t.C > 0.f ? -t.B * fast_rcp(t.C) : 0.f;
+    t.rBA = t.A > 0.f ? -t.B * fast_rcp(t.A) : 0.f;
+    return t;
+}
+
+SURFEL_HD bool footprint_hits(const FootprintTest& t, float x0, float x1, float y0, float y1)
+{
+    const float ddx = fmaxf(fmaxf(x0 - t.cx, t.cx - x1), 0.f), ddy = fmaxf(fmaxf(y0 - t.cy, t.cy - y1), 0.f);
+    const float u0 = x0 - t.ecx - BOX_MARGIN_PX, u1 = x1 - t.ecx + BOX_MARGIN_PX;
+    const float v0 = y0 - t.ecy - BOX_MARGIN_PX, v1 = y1 - t.ecy + BOX_MARGIN_PX;
+    const float ue = fmaxf(u0, fminf(0.f, u1)), ve = fmaxf(v0, fminf(0.f, v1));  // the rectangle's point nearest the centre, per axis
+    const float vs = fmaxf(v0, fminf(t.rBC * ue, v1)), us = fmaxf(u0, fminf(t.rBA * ve, u1));
+    const float q1 = ue * (t.A * ue + 2.0f * t.B * vs) + t.C * vs * vs;
+    const float q2 = us * (t.A * us + 2.0f * t.B * ve) + t.C * ve * ve;
+    return (ddx * ddx + ddy * ddy <= t.rd2) | (fminf(q1, q2) <= t.lim);
 }
 
 SURFEL_HD float map_depth(float depth)

@@ -74,7 +74,7 @@ struct Header {           // first 256 bytes of the geometry buffer
 
 struct GeomState {
     Header* hdr;
-    float* rec;              // [P][24]   (surfel_math.h RecSlot)
+    float* rec;              // [P][28]   (surfel_math.h RecSlot)
     uint32_t* tiles_touched; // [P]
 };
 
