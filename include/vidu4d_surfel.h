@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 15
+#define VIDU4D_SURFEL_ABI 16
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -346,9 +346,19 @@ typedef struct Vidu4dSkinFieldArgs {
     float* g_xyz;        /* backward output (N, 3) */
     uint32_t* relu_masks; /* optional, D * 64 * ceil(N / 32) words: the forward records which hidden units are active,
                              the backward then skips its recomputation of the hidden layers (NULL: it recomputes) */
+    /* optional (extension, ABI 16): the weights as vidu4d_skin_field_pack arranged them for the forward / backward
+     * kernel (16-byte aligned).  The kernels then copy that image into LDS instead of gathering it from the arrays
+     * above, which costs every launch ~20 us; b_in is still read from b_in.  NULL: gather. */
+    const float* packed_fwd;
+    const float* packed_bwd;
 } Vidu4dSkinFieldArgs;
 int vidu4d_skin_field_forward(const Vidu4dSkinFieldArgs* args, void* stream);
 int vidu4d_skin_field_backward(const Vidu4dSkinFieldArgs* args, void* stream);
+/* the kernels' weight image: vidu4d_skin_field_packed_floats(B, D, backward) floats (0: unsupported shape), written by
+ * vidu4d_skin_field_pack from args' weight arrays (N, xyz, b_in and the output pointers are not read).  Valid while
+ * the weights and the bone map stay what they were. */
+int vidu4d_skin_field_packed_floats(int B, int D, int backward);
+int vidu4d_skin_field_pack(const Vidu4dSkinFieldArgs* args, int backward, float* out, void* stream);
 
 /* ---- mean squared distance of every point to its 3 nearest other points (exact): replaces
  *      simple-knn's distCUDA2 (gs/submodules/simple-knn/spatial.cu:15-25, simple_knn.cu:185-221), used

@@ -120,15 +120,20 @@ def test_skin_field_kernel_matches_the_torch_path(gpu_device, N, B, D):
     xyz0 = (0.3 * torch.randn(N, 3, generator=g)).to(dev)
     Gx, Gr = torch.randn(3 * B, N, generator=g).to(dev), torch.randn(B, N, generator=g).to(dev)
     res = {}
-    for name in ("fused", "torch"):
+    for name in ("fused", "fused, weights gathered per launch", "torch"):
         xyz = xyz0.clone().requires_grad_(True)
-        if name == "fused":
-            xbT, rawT = skin_field(xyz, bias[0], prepare_skin_field(sm, A, c0))
+        if name.startswith("fused"):
+            tab = prepare_skin_field(sm, A, c0)
+            tab["pack"] = name == "fused"      # (default: the kernels copy the image vidu4d_skin_field_pack made)
+            xbT, rawT = skin_field(xyz, bias[0], tab)
+            assert ("packed_fwd" in tab) == tab["pack"]
         else:
             xbT = torch.addmm(c0[:, None], A, xyz.t())
             rawT = sm.delta_raw_T(xbT, bias[0])
         ((xbT * Gx).sum() + (rawT * Gr).sum()).backward()
         res[name] = [t.detach().cpu().numpy() for t in (xbT, rawT, xyz.grad)]
+    for a, b in zip(res["fused"], res["fused, weights gathered per launch"]):
+        assert np.array_equal(a, b)            # the same LDS contents either way
     for a, b, what in zip(res["fused"], res["torch"], ("xbT", "rawT", "g_xyz")):
         scale = max(1e-3, float(np.abs(b).max()))
         assert a.shape == b.shape and np.isfinite(a).all()

@@ -30,13 +30,14 @@ def main():
     ap.add_argument("--bench-args", default="--steps 4 --warmup 2 --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 0 --no-stage-timers --frame-streams 0 --per-frame-surface 0")
     ap.add_argument("--out", default="")
     ap.add_argument("--groups", default="0,1,2")
+    ap.add_argument("--script", default="bench.py", help="the workload, relative to the repo root (its arguments: --bench-args)")
     args = ap.parse_args()
     env = dict(os.environ, TMPDIR="/tmp")
     res = defaultdict(dict)
     for gi in [int(x) for x in args.groups.split(",")]:
         d = f"/tmp/pmc_{os.getpid()}_{gi}"
         cmd = ["rocprofv3", "--pmc"] + GROUPS[gi].split() + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-                                                              sys.executable, os.path.join(ROOT, "bench.py")] + args.bench_args.split()
+                                                              sys.executable, os.path.join(ROOT, args.script)] + args.bench_args.split()
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not files:

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class ForwardArgs(C.Structure):
@@ -50,7 +50,7 @@ class SkinFieldArgs(C.Structure):
     """struct Vidu4dSkinFieldArgs"""
     _fields_ = [("N", C.c_int), ("B", C.c_int), ("W", C.c_int), ("D", C.c_int)] + [
         (n, C.c_void_p) for n in ("xyz", "bone_A", "bone_c", "w_in", "b_in", "w_hid", "b_hid", "w_out", "b_out", "xbT",
-                                  "rawT", "g_xbT", "g_rawT", "g_xyz", "relu_masks")]
+                                  "rawT", "g_xbT", "g_rawT", "g_xyz", "relu_masks", "packed_fwd", "packed_bwd")]
 
 
 LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 8, 1024, 32
@@ -140,6 +140,8 @@ SYMBOLS = {
     "vidu4d_post_backward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "vidu4d_skin_field_forward": (C.c_int, [C.POINTER(SkinFieldArgs), _P]),
     "vidu4d_skin_field_backward": (C.c_int, [C.POINTER(SkinFieldArgs), _P]),
+    "vidu4d_skin_field_packed_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "vidu4d_skin_field_pack": (C.c_int, [C.POINTER(SkinFieldArgs), C.c_int, _P, _P]),
     "vidu4d_stage3_loss_forward": (C.c_int, [C.POINTER(Stage3LossArgs), _P]),
     "vidu4d_stage3_loss_backward": (C.c_int, [C.POINTER(Stage3LossArgs), _P, C.POINTER(Stage3LossGrads), _P]),
     "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P]),

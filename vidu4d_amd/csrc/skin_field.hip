@@ -40,10 +40,13 @@ constexpr int W = VIDU4D_SKIN_FIELD_WIDTH;          // hidden width: two row blo
 constexpr int IN_MAX = VIDU4D_SKIN_FIELD_IN_MAX;    // padded 3B: three row blocks
 constexpr int OUT_MAX = VIDU4D_SKIN_FIELD_OUT_MAX;  // padded B: one row block
 constexpr int MAX_HIDDEN = VIDU4D_SKIN_FIELD_MAX_HIDDEN;
-// waves per workgroup share the staged weights: 16 (4 per SIMD, <= 128 registers each) forward, 8 (2 per SIMD, <= 256
-// registers) backward
+// waves per workgroup share the staged weights: 16 (4 per SIMD, <= 128 registers each) forward, 12 (3 per SIMD, <= 168
+// registers: no spills since the row addresses stopped being hoisted) backward
+#ifndef SKIN_BWD_THREADS
+#define SKIN_BWD_THREADS 768
+#endif
 template <bool BACKWARD>
-constexpr int threads_of() { return BACKWARD ? 512 : 1024; }
+constexpr int threads_of() { return BACKWARD ? SKIN_BWD_THREADS : 1024; }
 static_assert(W == 64 && IN_MAX == 96 && OUT_MAX == 32, "row-block structure");
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -56,7 +59,8 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c)
 }
 
 // Schedule hint for the unrolled layer loops: N LDS reads (the A operands of the next step), then N MFMAs, repeated.
-// Without it the scheduler hoists all 64-96 operand reads of a layer to its top and spills the accumulators.
+// Without it the scheduler hoists all 64-96 operand reads of a layer to its top and spills the accumulators.  (Reading two
+// steps ahead instead of one measures the same: a lone wave's MFMA pair already covers the LDS round trip.)
 template <int N>
 __device__ __forceinline__ void interleave_reads_and_mfmas()
 {
@@ -99,6 +103,8 @@ __host__ __device__ inline Plan make_plan(int B, int D, bool backward)
     return p;
 }
 
+// Fills `lds` (LDS, or -- vidu4d_skin_field_pack -- a global buffer that later launches copy into LDS linearly: the
+// gather below costs a workgroup ~20 us, a third of a forward at 200k surfels, and the weights are constants).
 template <bool BACKWARD>
 __device__ void stage(const Vidu4dSkinFieldArgs& a, const Plan& p, float* lds)
 {
@@ -134,7 +140,8 @@ __device__ void stage(const Vidu4dSkinFieldArgs& a, const Plan& p, float* lds)
     }
     for (int e = threadIdx.x; e < (a.D + 1) * 64; e += THREADS) {
         const int layer = e >> 6, j = e & 63;
-        lds[p.bias + e] = layer == 0 ? a.b_in[j] : (layer < a.D ? a.b_hid[(layer - 1) * W + j] : (j < OUT_MAX ? a.b_out[j] : 0.f));
+        lds[p.bias + e] = layer == 0 ? (a.b_in ? a.b_in[j] : 0.f)
+                                     : (layer < a.D ? a.b_hid[(layer - 1) * W + j] : (j < OUT_MAX ? a.b_out[j] : 0.f));
     }
     for (int e = threadIdx.x; e < IN_MAX; e += THREADS) {
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -142,6 +149,16 @@ __device__ void stage(const Vidu4dSkinFieldArgs& a, const Plan& p, float* lds)
         reinterpret_cast<float4*>(lds + p.bone)[e] = r;
     }
     __syncthreads();
+}
+
+// Row offsets of the feature-major arrays are row * N + surfel.  N is a kernel argument and the rows of a lane are
+// compile-time patterns, so the compiler hoists every row's 64-bit address out of the tile loop -- 32 registers for the
+// forward's output rows, 96 for the backward's 48 gradient rows -- and spills.  An N it cannot see through is multiplied
+// again per tile (scalar unit) and the addresses stay 32-bit offsets until they are used.
+__device__ __forceinline__ uint32_t opaque_uniform(uint32_t v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
 }
 
 // acc = bias of `layer` in the D layout
@@ -169,21 +186,35 @@ __device__ __forceinline__ uint32_t relu_tiles(f32x16 (&h)[2])
 
 // Hidden layers of the forward for one tile; h = last hidden activations (D layout), masks[l] = active units of layer l.
 __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, const Plan& p, const float* lds, int lane,
-                                               int n, bool valid, float x, float y, float z, float* xbT_out,
+                                               int n, uint32_t Ns, bool valid, float x, float y, float z, float* xbT_out,
                                                f32x16 (&h)[2], uint32_t (&masks)[MAX_HIDDEN], uint32_t* mask_out,
                                                size_t mask_stride)
 {
     const int half = lane >> 5;
     load_bias(h, lds, p, 0, half);
+    // (bone rows and first-layer weights beyond 3B are staged as zeros, rows up to IN_MAX exist: no conditions on k.  Two
+    // k-pairs per trip, all eight LDS reads of a trip in flight before the first use -- a trip per k-pair waited for two
+    // LDS round trips in sequence and made the 76 MFMAs of this layer take as long as the whole tile's matrix time)
     const float4* bone = reinterpret_cast<const float4*>(lds + p.bone);
-    for (int t = 0; t < p.T1; t++) {
-        const int k = t + p.T1 * half;
-        const float4 bc = bone[k < IN_MAX ? k : IN_MAX - 1];
-        const float xb = (k < 3 * a.B) ? fmaf(bc.x, x, fmaf(bc.y, y, fmaf(bc.z, z, bc.w))) : 0.f;
-        if (xbT_out && valid && k < 3 * a.B) xbT_out[(size_t)k * a.N + n] = xb;
-        const float* s = lds + p.s_in + (t * 2) * 64 + lane;
-        h[0] = mfma(s[0], xb, h[0]);
-        h[1] = mfma(s[64], xb, h[1]);
+    const int B3 = 3 * a.B;
+    for (int t = 0; t < p.T1; t += 2) {
+        const bool two = t + 1 < p.T1;
+        const int ta = t, tb = two ? t + 1 : t;
+        const int ka = ta + p.T1 * half, kb = tb + p.T1 * half;
+        const float4 ba = bone[ka], bb = bone[kb];
+        const float* sa = lds + p.s_in + (ta * 2) * 64 + lane;
+        const float* sb = lds + p.s_in + (tb * 2) * 64 + lane;
+        const float wa0 = sa[0], wa1 = sa[64], wb0 = sb[0], wb1 = sb[64];
+        const float xa = fmaf(ba.x, x, fmaf(ba.y, y, fmaf(ba.z, z, ba.w)));
+        const float xb = two ? fmaf(bb.x, x, fmaf(bb.y, y, fmaf(bb.z, z, bb.w))) : 0.f;
+        if (xbT_out && valid) {
+            if (ka < B3) xbT_out[(uint32_t)ka * Ns + (uint32_t)n] = xa;
+            if (two && kb < B3) xbT_out[(uint32_t)kb * Ns + (uint32_t)n] = xb;
+        }
+        h[0] = mfma(wa0, xa, h[0]);
+        h[1] = mfma(wa1, xa, h[1]);
+        h[0] = mfma(wb0, xb, h[0]);
+        h[1] = mfma(wb1, xb, h[1]);
     }
     masks[0] = relu_tiles(h);
     if (mask_out) mask_out[0] = masks[0];
@@ -209,12 +240,35 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
 }
 
 template <bool BACKWARD>
+__global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_pack_kernel(Vidu4dSkinFieldArgs a, float* out)
+{
+    const Plan p = make_plan(a.B, a.D, BACKWARD);
+    stage<BACKWARD>(a, p, out);
+}
+
+template <bool BACKWARD>
 __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu4dSkinFieldArgs a)
 {
     constexpr int THREADS = threads_of<BACKWARD>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const Plan p = make_plan(a.B, a.D, BACKWARD);
-    stage<BACKWARD>(a, p, lds);
+    const float* packed = BACKWARD ? a.packed_bwd : a.packed_fwd;
+    if (packed) {
+        // the image vidu4d_skin_field_pack made of everything but the step's first-layer bias (every section of the plan
+        // is a multiple of 4 floats)
+        const int bias4 = p.bias / 4;
+        for (int e = threadIdx.x; e < p.total / 4; e += THREADS) {
+            float4 v = reinterpret_cast<const float4*>(packed)[e];
+            if (e >= bias4 && e < bias4 + W / 4) {
+                const float* b = a.b_in + 4 * (e - bias4);
+                v = make_float4(b[0], b[1], b[2], b[3]);
+            }
+            reinterpret_cast<float4*>(lds)[e] = v;
+        }
+        __syncthreads();
+    } else {
+        stage<BACKWARD>(a, p, lds);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int tiles = (a.N + 31) / 32;
     // (tile = (round * waves + wave) * workgroups + workgroup: a partial last round is spread over all CUs and SIMDs)
@@ -222,6 +276,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
         const int n = tile * 32 + (lane & 31);
         const bool valid = n < a.N;
         const int nn = valid ? n : a.N - 1;
+        const uint32_t Ns = opaque_uniform((uint32_t)a.N);  // (rows * N < 2^32: check_args)
         const float x = a.xyz[3 * nn], y = a.xyz[3 * nn + 1], z = a.xyz[3 * nn + 2];
         f32x16 h[2];
         uint32_t masks[MAX_HIDDEN];
@@ -231,7 +286,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
         if (BACKWARD && mask_slot) {
             for (int l = 0; l < a.D; l++) masks[l] = mask_slot[l * mask_layer_stride];
         } else {
-            hidden_forward(a, p, lds, lane, n, valid, x, y, z, BACKWARD ? nullptr : a.xbT, h, masks,
+            hidden_forward(a, p, lds, lane, n, Ns, valid, x, y, z, BACKWARD ? nullptr : a.xbT, h, masks,
                            BACKWARD ? nullptr : mask_slot, mask_layer_stride);
         }
         if (!BACKWARD) {
@@ -250,7 +305,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
 #pragma unroll
                 for (int v = 0; v < 16; v++) {
                     const int j = rowv(v, half);
-                    if (j < a.B) a.rawT[(size_t)j * a.N + n] = out[v];
+                    if (j < a.B) a.rawT[(uint32_t)j * Ns + (uint32_t)n] = out[v];
                 }
             }
             continue;
@@ -262,12 +317,21 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
 #pragma unroll
             for (int v = 0; v < 16; v++) g[ob][v] = 0.f;
         {
-            const float* s = lds + p.t_out + lane;
-            for (int t = 0; t < p.T3; t++) {
+            // (the upstream gradients of the tile first, all loads in flight: one global round trip, not T3 of them)
+            constexpr int T3_MAX = (OUT_MAX + 1) / 2;
+            float gj[T3_MAX];
+#pragma unroll
+            for (int t = 0; t < T3_MAX; t++) {
                 const int j = t + p.T3 * half;
-                const float gj = j < a.B ? a.g_rawT[(size_t)j * a.N + nn] : 0.f;
-                g[0] = mfma(s[(t * 2) * 64], gj, g[0]);
-                g[1] = mfma(s[(t * 2 + 1) * 64], gj, g[1]);
+                gj[t] = (t < p.T3 && j < a.B) ? a.g_rawT[(uint32_t)j * Ns + (uint32_t)nn] : 0.f;
+            }
+            const float* s = lds + p.t_out + lane;
+#pragma unroll
+            for (int t = 0; t < T3_MAX; t++) {
+                if (t < p.T3) {  // (uniform)
+                    g[0] = mfma(s[(t * 2) * 64], gj[t], g[0]);
+                    g[1] = mfma(s[(t * 2 + 1) * 64], gj[t], g[1]);
+                }
             }
         }
 #pragma unroll 1
@@ -298,7 +362,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int k = 32 * ob + rowv(v, half);
-                gx[ob][v] = (a.g_xbT && k < 3 * a.B) ? a.g_xbT[(size_t)k * a.N + nn] : 0.f;
+                gx[ob][v] = (a.g_xbT && k < 3 * a.B) ? a.g_xbT[(uint32_t)k * Ns + (uint32_t)nn] : 0.f;
             }
         {
             const uint32_t m = masks[0];
@@ -338,7 +402,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
 
 int check_args(const Vidu4dSkinFieldArgs* a, bool backward)
 {
-    if (!a || a->N < 0 || a->B <= 0 || a->B > OUT_MAX || 3 * a->B > IN_MAX || a->W != W || a->D < 1 || a->D > MAX_HIDDEN)
+    if (!a || a->N < 0 || (int64_t)a->N * IN_MAX > 0x7fffffffll || a->B <= 0 || a->B > OUT_MAX || 3 * a->B > IN_MAX || a->W != W || a->D < 1 || a->D > MAX_HIDDEN)
         return VIDU4D_E_INVALID;
     if (a->N == 0) return VIDU4D_OK;
     if (!a->xyz || !a->bone_A || !a->bone_c || !a->w_in || !a->b_in || !a->w_out || !a->b_out) return VIDU4D_E_INVALID;
@@ -373,7 +437,30 @@ int launch(const Vidu4dSkinFieldArgs* a, void* stream)
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
+template <bool BACKWARD>
+int pack(const Vidu4dSkinFieldArgs* a, float* out, void* stream)
+{
+    if (!a || a->B <= 0 || a->B > OUT_MAX || 3 * a->B > IN_MAX || a->W != W || a->D < 1 || a->D > MAX_HIDDEN || !out)
+        return VIDU4D_E_INVALID;
+    if (!a->bone_A || !a->bone_c || !a->w_in || !a->w_out || !a->b_out || (a->D > 1 && (!a->w_hid || !a->b_hid)))
+        return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(skin_field_pack_kernel<BACKWARD>, dim3(1), dim3(threads_of<BACKWARD>()), 0, (hipStream_t)stream, *a, out);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}
+
 }  // namespace
+
+extern "C" int vidu4d_skin_field_packed_floats(int B, int D, int backward)
+{
+    if (B <= 0 || B > OUT_MAX || 3 * B > IN_MAX || D < 1 || D > MAX_HIDDEN) return 0;
+    return make_plan(B, D, backward != 0).total;
+}
+
+extern "C" int vidu4d_skin_field_pack(const Vidu4dSkinFieldArgs* a, int backward, float* out, void* stream)
+{
+    return backward ? pack<true>(a, out, stream) : pack<false>(a, out, stream);
+}
 
 extern "C" int vidu4d_skin_field_forward(const Vidu4dSkinFieldArgs* a, void* stream) { return launch<false>(a, stream); }
 

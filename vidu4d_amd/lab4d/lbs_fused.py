@@ -179,12 +179,32 @@ def prepare_skin_field(sm, A, c0) -> dict:
     return tab
 
 
+def pack_skin_field(tab) -> None:
+    """Adds tab["packed_fwd"] / tab["packed_bwd"]: the weights as the kernels keep them in LDS (vidu4d_skin_field_pack),
+    so that a launch copies 46 / 75 KB linearly instead of gathering them (~20 us per launch).  The tables are constants
+    of a fused-path model (skin_field_supported: frozen weights); call again after changing them."""
+    dev = tab["bone_A"].device
+    lib = _lib.load()
+    a = _lib.SkinFieldArgs()
+    a.N, a.B, a.W, a.D = 0, tab["B"], _lib.SKIN_FIELD["width"], tab["D"]
+    for k in ("bone_A", "bone_c", "w_in", "w_hid", "b_hid", "w_out", "b_out"):
+        setattr(a, k, None if tab.get(k) is None else tab[k].data_ptr())
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for backward, key in ((0, "packed_fwd"), (1, "packed_bwd")):
+        n = lib.vidu4d_skin_field_packed_floats(tab["B"], tab["D"], backward)
+        if n <= 0:
+            raise RuntimeError("skin_field: unsupported shape")
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(lib.vidu4d_skin_field_pack(a, backward, out.data_ptr(), st), "skin field pack")
+        tab[key] = out
+
+
 def _skin_field_args(tab, N, xyz, b_in, **ptrs):
     p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     a = _lib.SkinFieldArgs()
     a.N, a.B, a.W, a.D = N, tab["B"], _lib.SKIN_FIELD["width"], tab["D"]
     a.xyz, a.b_in = xyz.data_ptr(), b_in.data_ptr()
-    for k in ("bone_A", "bone_c", "w_in", "w_hid", "b_hid", "w_out", "b_out"):
+    for k in ("bone_A", "bone_c", "w_in", "w_hid", "b_hid", "w_out", "b_out", "packed_fwd", "packed_bwd"):
         setattr(a, k, p(tab.get(k)))
     for k, v in ptrs.items():
         setattr(a, k, p(v))
@@ -201,6 +221,8 @@ class _SkinField(Function):
                                "treats the skinning network as constant")
         N = xyz.shape[0]
         x, b = _c(xyz), _c(b_in).reshape(-1)
+        if "packed_fwd" not in tab and tab.get("pack", True):
+            pack_skin_field(tab)
         xbT = torch.empty(3 * tab["B"], N, dtype=torch.float32, device=xyz.device) if want_xb else None
         rawT = torch.empty(tab["B"], N, dtype=torch.float32, device=xyz.device)
         # which hidden units are active, per layer / 32-surfel tile / lane: spares the backward its recomputation
