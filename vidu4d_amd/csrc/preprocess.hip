@@ -185,35 +185,36 @@ template <bool SH_LDS>
 __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];  // [256][49] when SH_LDS
-    // workgroups are laid out per frame (pre_blocks(N) each): the SH rows of a workgroup are 256 consecutive rows of
-    // the array the frames share
+    // a workgroup takes 256 consecutive rows of the arrays the frames share and evaluates them for EVERY frame of a stacked
+    // launch: the SH tile is loaded once (round 3: a workgroup per (frame, 256 rows) read the 38 MB of SH rows per frame)
     const int N = a.cam.frames > 1 ? a.cam.frame_surfels : a.P;
-    const int per_frame = pre_blocks(N);
-    const int frame = blockIdx.x / per_frame;
-    const int block_first = (blockIdx.x - frame * per_frame) * PRE_BLOCK;  // (row in the shared arrays)
+    const int block_first = blockIdx.x * PRE_BLOCK;  // (row in the shared arrays)
     const int shared = block_first + threadIdx.x;
-    const int idx = frame * N + shared;
     const int rows = (N - block_first) < PRE_BLOCK ? (N - block_first) : PRE_BLOCK;
     if (SH_LDS) {
         sh_tile_load(s_sh, a.shs, a.sh_dc, a.sh_rest, block_first, rows);
         __syncthreads();
     }
     if (shared >= N) return;
-    float rgb[3];
-    uint32_t clamp_mask = 0;
-    if (a.colors_precomp == nullptr) {
-        const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-        const float* cp = a.cam.fc[frame].campos;
-        const float campos[3] = {cp[0], cp[1], cp[2]};
-        const float* sh = SH_LDS ? s_sh + threadIdx.x * SH_STRIDE : a.shs + (size_t)shared * a.cam.sh_coeffs * 3;
-        sh_forward(a.cam.sh_degree, p_world, campos, sh, rgb, clamp_mask);
-    } else {
-        rgb[0] = a.colors_precomp[3 * idx];
-        rgb[1] = a.colors_precomp[3 * idx + 1];
-        rgb[2] = a.colors_precomp[3 * idx + 2];
+    const int F = a.cam.frames > 1 ? a.cam.frames : 1;
+    for (int frame = 0; frame < F; frame++) {
+        const int idx = frame * N + shared;
+        float rgb[3];
+        uint32_t clamp_mask = 0;
+        if (a.colors_precomp == nullptr) {
+            const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+            const float* cp = a.cam.fc[frame].campos;
+            const float campos[3] = {cp[0], cp[1], cp[2]};
+            const float* sh = SH_LDS ? s_sh + threadIdx.x * SH_STRIDE : a.shs + (size_t)shared * a.cam.sh_coeffs * 3;
+            sh_forward(a.cam.sh_degree, p_world, campos, sh, rgb, clamp_mask);
+        } else {
+            rgb[0] = a.colors_precomp[3 * idx];
+            rgb[1] = a.colors_precomp[3 * idx + 1];
+            rgb[2] = a.colors_precomp[3 * idx + 2];
+        }
+        reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS)[4] =
+            make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
     }
-    reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS)[4] =
-        make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
 }
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
@@ -223,7 +224,7 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
     // (the canonical pair sh_dc / sh_rest only exists on the LDS path; capi checks its alignment)
     const bool sh_lds = a.colors_precomp == nullptr && a.cam.sh_coeffs == 16 &&
                         (a.sh_dc != nullptr || (a.shs != nullptr && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0));
-    const int color_blocks = a.cam.frames > 1 ? a.cam.frames * pre_blocks(a.cam.frame_surfels) : pre_blocks(a.P);
+    const int color_blocks = a.cam.frames > 1 ? pre_blocks(a.cam.frame_surfels) : pre_blocks(a.P);
     if (sh_lds)
         hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(color_blocks), dim3(PRE_BLOCK),
                            (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);
@@ -246,7 +247,7 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
 // LDS tile with row stride 49 words (odd => the per-thread column walk is bank-conflict free), the
 // gradients are written back into the same tile and leave with coalesced 16-byte stores.
 
-// Stacked frames (cam.frames > 1): workgroups are laid out per frame like the colour kernel's; gradients of what the
+// Stacked frames (cam.frames > 1): workgroups are laid out per frame (pre_blocks(N) each); gradients of what the
 // frames share (opacity, scale, SH rows) are ADDED to arrays the caller zero-filled -- the SH tile leaves with
 // lane-contiguous float atomics (merged per cache line by the memory side, as the blend backward's flush) -- while the
 // per-frame outputs (centres, orientations, screen-space statistic, colours, homography) are plain stores.
