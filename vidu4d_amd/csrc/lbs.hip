@@ -204,8 +204,35 @@ constexpr int MAX_FRAMES = 8;
 // bone loops are straight-line code: every rawT / weight load of a loop can be in flight at once (the B-dependent `break`s of
 // the generic instance put each load behind a branch; the backward then waited for ~80 global loads one after the other --
 // 61 % of its wave cycles, rocprofv3 SQ_WAIT_ANY).
+#ifndef LBS_BX_WAVES_PER_EU
+#define LBS_BX_WAVES_PER_EU 1
+#endif
+#ifndef LBS_FENCE_EVERY
+#define LBS_FENCE_EVERY 0
+#endif
+// (straight-line bone loops: without a fence the scheduler hoists the LDS reads of all 25 iterations -- 8 floats per bone
+// and frame -- to the top of a loop and the backward needs 374 registers; a scheduling fence every few bones bounds what is
+// in flight)
+// PIN(...): the named values are final HERE in program order (an empty asm the compiler must feed them through), so what
+// went into them is dead behind this point.  Bounds the live ranges inside the straight-line bone loops of the BX
+// instances: left alone the compiler defers the serial accumulations (blended quaternions, A^T d x_bone) and keeps the
+// products of all 25 bones -- and the LDS rows they came from -- alive: 374 registers; pinned: 227 (backward), 72 (forward).
+#define PIN3(a, b_, c)                                              \
+    do {                                                            \
+        if (BX) asm volatile("" : "+v"(a), "+v"(b_), "+v"(c)); \
+    } while (0)
+#define PINQ(q_)                                                                         \
+    do {                                                                                 \
+        if (BX) asm volatile("" : "+v"(q_.w), "+v"(q_.x), "+v"(q_.y), "+v"(q_.z)); \
+    } while (0)
+#define BONE_FENCE(b)                                                                                          \
+    do {                                                                                                       \
+        if (BX && BACKWARD && LBS_FENCE_EVERY > 0 && ((b) % (LBS_FENCE_EVERY > 0 ? LBS_FENCE_EVERY : 1)) == (LBS_FENCE_EVERY > 0 ? LBS_FENCE_EVERY : 1) - 1) \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
 template <bool BACKWARD, int BCAP, bool XB_FROM_XYZ, int BX>
-__global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BX && BACKWARD) ? LBS_BX_WAVES_PER_EU : 1, 8)))
+void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
                                                        const float* __restrict__ rawT,
                                                        const float* __restrict__ se3_qr,
                                                        const float* __restrict__ se3_qd,
@@ -231,29 +258,35 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
     if (n >= N) return;
 
     const float cx_ = xyz[3 * n], cy_ = xyz[3 * n + 1], cz_ = xyz[3 * n + 2];
+    int map_off = 0;  // (made opaque before the backward's last loop: rows re-read from LDS, not kept -- see sq_off below)
     auto bone_coord = [&](int k) {
         if (XB_FROM_XYZ) {
-            const float4 r = s_map[k];
+            const float4 r = s_map[k + map_off];
             return fmaf(r.x, cx_, fmaf(r.y, cy_, fmaf(r.z, cz_, r.w)));
         }
-        return xbT[(size_t)k * N + n];
+        return xbT[(uint32_t)k * (uint32_t)N + (uint32_t)n];
     };
     constexpr int NB = BX ? BX : BCAP;
     float w[BCAP];
     uint32_t raw_pos = 0;  // bit b: the delta-skin logit of bone b is positive (the relu of the forward)
     int anchor = 0;
     float best = -3.0e38f;
+    float rawv[BX ? BX : 1];
+    if (BX)  // (all global loads of the loop below first)
+        _Pragma("unroll") for (int b = 0; b < NB; b++) rawv[b] = rawT ? rawT[(uint32_t)b * (uint32_t)N + (uint32_t)n] : 0.f;
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         if (!BX && b >= B) break;
         const float x0 = bone_coord(3 * b), x1 = bone_coord(3 * b + 1), x2 = bone_coord(3 * b + 2);
-        const float raw = rawT ? rawT[(size_t)b * N + n] : 0.f;
+        const float raw = BX ? rawv[BX ? b : 0] : (rawT ? rawT[(uint32_t)b * (uint32_t)N + (uint32_t)n] : 0.f);
         raw_pos |= raw > 0.f ? (1u << b) : 0u;
         w[b] = -((x0 * x0 + x1 * x1 + x2 * x2) + 0.1f * fmaxf(raw, 0.f));
         if (w[b] > best) {  // first maximum, like torch.argmax (the softmax keeps the order)
             best = w[b];
             anchor = b;
         }
+        if (BX) asm volatile("" : "+v"(w[b]), "+v"(best));
+        BONE_FENCE(b);
     }
     float sum = 0.f;
     _Pragma("unroll") for (int b = 0; b < NB; b++) {
@@ -281,6 +314,9 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
             const float ws = ((hemi >> b) & 1ull) ? w[b] : -w[b];
             Qr = qadd(Qr, qscale(ldq(sq + b * 4), ws));
             Qd = qadd(Qd, qscale(ldq(sq + MAX_BONES * 4 + b * 4), ws));
+            PINQ(Qr);
+            PINQ(Qd);
+            BONE_FENCE(b);
         }
         const float inv = 1.0f / sqrtf(qdot(Qr, Qr));
         const Q q = qscale(Qr, inv), d = qscale(Qd, inv);
@@ -330,14 +366,27 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
         const float gq_q = qdot(g_q, q), gd_d = qdot(g_d, d);
         const Q g_Qr = qscale(qadd(g_q, qscale(q, -(gq_q + gd_d))), inv);
         const Q g_Qd = qscale(g_d, inv);
+        // (the bone quaternions are read from LDS AGAIN here: at offsets it can see through the compiler keeps the 200 floats
+        // the blend loop above loaded alive across the whole frame body instead.  An opaque OFFSET, not an opaque pointer:
+        // that would lose its address space and turn the reads into flat loads)
+        int sq_off = 0;
+        asm volatile("" : "+v"(sq_off));
+        const float* sq2 = sq + sq_off;
         _Pragma("unroll") for (int b = 0; b < NB; b++) {
             if (!BX && b >= B) break;
             const float sgn = ((hemi >> b) & 1ull) ? 1.0f : -1.0f;
-            gw[b] += sgn * (qdot(g_Qr, ldq(sq + b * 4)) + qdot(g_Qd, ldq(sq + MAX_BONES * 4 + b * 4)));
+            gw[b] += sgn * (qdot(g_Qr, ldq(sq2 + b * 4)) + qdot(g_Qd, ldq(sq2 + MAX_BONES * 4 + b * 4)));
+            if (BX && BACKWARD) asm volatile("" : "+v"(gw[b]));
+            BONE_FENCE(b);
         }
     }
     if (!BACKWARD) return;
-    // back through the softmax and the logits
+    // back through the softmax and the logits.  (Row offsets of the feature-major outputs from an N the compiler cannot
+    // see through: the same expressions as the loads' at the top, whose 64-bit addresses it otherwise keeps alive -- two
+    // registers per row -- for the whole kernel)
+    uint32_t Ns = (uint32_t)N;
+    asm volatile("" : "+s"(Ns));
+    asm volatile("" : "+v"(map_off));
     float dot = 0.f;
     _Pragma("unroll") for (int b = 0; b < NB; b++)
         if (BX || b < B) dot += w[b] * gw[b];
@@ -348,16 +397,18 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(int M, int N, int B, cons
         const float x0 = bone_coord(3 * b), x1 = bone_coord(3 * b + 1), x2 = bone_coord(3 * b + 2);
         const float g0 = -2.0f * x0 * g_logit, g1 = -2.0f * x1 * g_logit, g2 = -2.0f * x2 * g_logit;
         if (XB_FROM_XYZ) {  // d xyz += A^T d x_bone
-            const float4 r0 = s_map[3 * b], r1 = s_map[3 * b + 1], r2 = s_map[3 * b + 2];
+            const float4 r0 = s_map[3 * b + map_off], r1 = s_map[3 * b + 1 + map_off], r2 = s_map[3 * b + 2 + map_off];
             acc_p.x += r0.x * g0 + r1.x * g1 + r2.x * g2;
             acc_p.y += r0.y * g0 + r1.y * g1 + r2.y * g2;
             acc_p.z += r0.z * g0 + r1.z * g1 + r2.z * g2;
         } else {
-            g_xbT[(size_t)(3 * b) * N + n] = g0;
-            g_xbT[(size_t)(3 * b + 1) * N + n] = g1;
-            g_xbT[(size_t)(3 * b + 2) * N + n] = g2;
+            g_xbT[(uint32_t)(3 * b) * Ns + (uint32_t)n] = g0;
+            g_xbT[(uint32_t)(3 * b + 1) * Ns + (uint32_t)n] = g1;
+            g_xbT[(uint32_t)(3 * b + 2) * Ns + (uint32_t)n] = g2;
         }
-        if (g_rawT) g_rawT[(size_t)b * N + n] = ((raw_pos >> b) & 1u) ? -0.1f * g_logit : 0.f;
+        if (g_rawT) g_rawT[(uint32_t)b * Ns + (uint32_t)n] = ((raw_pos >> b) & 1u) ? -0.1f * g_logit : 0.f;
+        PIN3(acc_p.x, acc_p.y, acc_p.z);
+        BONE_FENCE(b);
     }
     g_xyz[3 * n] = acc_p.x;
     g_xyz[3 * n + 1] = acc_p.y;
@@ -372,9 +423,13 @@ template <bool BACKWARD, typename... Args>
 void launch_lbs_skin(int M, int N, int B, bool from_xyz, hipStream_t stream, Args... args)
 {
     const dim3 grid((N + 255) / 256), block(256);
-    if (B == 25 && from_xyz && BACKWARD) {
-        // the reference's "bob" skeleton, frozen bones: straight-line bone loops in the backward (-9 %; the forward is
-        // faster with the generic instance, whose 199 registers leave two waves per SIMD where this one has one)
+#ifndef LBS_BX_FORWARD
+#define LBS_BX_FORWARD 0
+#endif
+    if (B == 25 && from_xyz && (BACKWARD || LBS_BX_FORWARD)) {
+        // the reference's "bob" skeleton, frozen bones: straight-line bone loops in the backward (round 3: 76 -> 69 us as
+        // they were, 374 registers = one wave per SIMD; 44 us with the accumulators pinned per bone -- 227 registers, two
+        // waves).  The forward measures the same either way (25 / 26 us) and keeps the generic instance.
         hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, true, 25>), grid, block, 0, stream, M, N, B, args...);
     } else if (B <= 32) {
         if (from_xyz) hipLaunchKernelGGL((lbs_skin_kernel<BACKWARD, 32, true, 0>), grid, block, 0, stream, M, N, B, args...);
