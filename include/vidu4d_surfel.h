@@ -135,14 +135,15 @@ typedef struct Vidu4dSurfelForwardArgs {
      * gives, bit for bit; the other planes come out as zeros, and the state kept for the backward holds no distortion
      * moments and no median contributor.  Any other value: everything is computed. */
     int aux_planes;
-    /* ---- speculation for the segment-parallel blend (extension; only with segment_split != 0 and aux_planes ==
-     * VIDU4D_AUX_ALPHA, ignored otherwise).  != 0: the caller expects that NO pixel of the frame saturates (transmittance
-     * stays above 1e-4: Stage-3 frames early in a fit).  The transmittance pre-pass of the segment-parallel blend is then
-     * skipped: every segment is blended from T = 1 and scaled by the product of its predecessors in the combine pass
-     * (colour is linear in the start transmittance; without saturation no threshold depends on it).  If some pixel does
-     * come within 0.1 % of the threshold, word 6 of the geometry buffer (`truncated`) is set -- the frame's outputs are then
-     * not those of the exact blend: blend it again with assume_unsaturated = 0.  Word 8 of the geometry buffer holds the
-     * bits of the frame's smallest final transmittance (whatever the mode): what a caller bases the expectation on. */
+    /* ---- segment-parallel blend without its transmittance pre-pass (extension; only with segment_split != 0 and
+     * aux_planes == VIDU4D_AUX_ALPHA, ignored otherwise).  != 0: every segment is blended from T = 1 and scaled by the
+     * product of its predecessors in the combine pass (colour is linear in the start transmittance; while a pixel stays
+     * clear of the saturation threshold no decision depends on it), and the combine pass blends the one segment in which a
+     * pixel comes within 0.1 % of the threshold (transmittance 1e-4) again, in list order, from the exact start: the
+     * pixel's last contributor and final transmittance are those of the exact blend, its colour equals it up to fp32
+     * re-association of the segments in front.  (The field is named after rounds 1-2, when such a frame was only reported --
+     * word 6 of the geometry buffer, `truncated` -- and had to be blended again with assume_unsaturated = 0.)  Word 8 of
+     * the geometry buffer holds the bits of the frame's smallest final transmittance (whatever the mode). */
     int assume_unsaturated;
     /* ---- how tile lists beyond the LDS capacity are sorted (extension; only with segment_split != 0; the sorted list is
      * the same either way).  0: MSD split on the leading differing depth bits + in-LDS bucket sorts (five small launches:

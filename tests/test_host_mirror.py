@@ -283,30 +283,24 @@ def test_train_cli_flag_parsing_and_mesh_sampling(tmp_path):
     assert abs((pts[on_square, 0] > pts[on_square, 1]).mean() - 0.5) < 0.05   # both halves of the quad
 
 
-def test_speculation_bookkeeping_of_the_deferred_check():
-    """_C's host-side policy for assume_unsaturated (no GPU involved): the header's smallest-transmittance word feeds a
-    slowly recovering minimum per image shape, and a frame that reports `truncated` rests speculation."""
-    import struct
+def test_deferred_check_bookkeeping():
+    """_C's host-side policy after a deferred forward (no GPU involved): the pair count feeds the capacity hint, an
+    overflow or a frame the segment limit cut short (`truncated`) makes the check fail -- the step is replayed -- and the
+    next frames of the shape run without the limit."""
     import torch
     from vidu4d_amd import _C
     key = ("test-shape",)
-    bits = lambda x: struct.unpack("i", struct.pack("f", x))[0]  # noqa: E731
-    for d in (_C._min_T_hint, _C._no_spec, _C._unlimited, _C._capacity_hint):
+    for d in (_C._unlimited, _C._capacity_hint, _C._len_hint):
         d.pop(key, None)
     slot = torch.zeros(16, dtype=torch.int32)
-    slot[0], slot[8] = 1000, bits(0.25)
+    slot[0] = 1000
     assert _C.check_slots([(slot, None, 2000, key)]) is True
-    assert abs(_C._min_T_hint[key] - 0.25) < 1e-7 and _C._min_T_hint[key] > _C.SPEC_MIN_T
-    slot[8] = bits(1e-5)                       # a frame with saturated pixels: the hint drops at once ...
-    assert _C.check_slots([(slot, None, 2000, key)]) is True
-    assert _C._min_T_hint[key] < _C.SPEC_MIN_T
-    slot[8] = bits(0.25)                       # ... and recovers only halfway per frame
-    _C.check_slots([(slot, None, 2000, key)])
-    assert 0.12 < _C._min_T_hint[key] < 0.13
-    slot[6] = 1                                # truncated: the step is replayed, speculation rests
+    assert _C._capacity_hint[key] >= 1000 and key not in _C._unlimited
+    assert _C.check_slots([(slot, None, 900, key)]) is False      # more pairs than the buffer held
+    slot[6] = 1                                                    # truncated
     assert _C.check_slots([(slot, None, 2000, key)]) is False
-    assert _C._no_spec[key] == _C.SPEC_REST and _C._unlimited[key] == 4
-    for d in (_C._min_T_hint, _C._no_spec, _C._unlimited, _C._capacity_hint):
+    assert _C._unlimited[key] == 4
+    for d in (_C._unlimited, _C._capacity_hint, _C._len_hint):
         d.pop(key, None)
 
 
@@ -333,7 +327,7 @@ def test_long_list_sort_mode_follows_the_longest_list_of_earlier_frames():
     for _ in range(10):
         _C.check_slots([(slot, None, 2000, key)])
     assert mode() == 1
-    for d in (_C._len_hint, _C._min_T_hint, _C._no_spec, _C._unlimited, _C._capacity_hint):
+    for d in (_C._len_hint, _C._unlimited, _C._capacity_hint):
         d.pop(key, None)
 
 
@@ -368,16 +362,17 @@ def test_depth_only_sort_with_tie_fix_up_is_the_reference_order():
         assert np.array_equal(product_order(keys), want), (n, n_depths)
 
 
-def test_speculated_segment_blend_algorithm_in_numpy():
+def test_relative_segment_blend_algorithm_in_numpy():
     """The algorithm behind assume_unsaturated (csrc/blend.hip), restated for one pixel in fp32 numpy: segments blended
-    from T = 1 and scaled by the running product of their predecessors == the sequential front-to-back blend while the
-    transmittance stays above the saturation threshold; when it does not, the combine's check fires (the frame is then
-    blended exactly)."""
+    from T = 1 and scaled by the running product of their predecessors; the first segment whose end would lie within
+    0.1 % of the saturation threshold (or below it) is blended again, in order, from that running product, and ends the
+    pixel == the sequential front-to-back blend: the same last contributor and, where the pixel saturates, bit for bit
+    the same final transmittance whenever the running product is what the sequential blend has at that point."""
     rng = np.random.default_rng(9)
     T_EPS, SEG = np.float32(1e-4), 512
 
-    def sequential(alpha, col):
-        T, C, last = np.float32(1), np.zeros(3, np.float32), 0
+    def sequential(alpha, col, T0=np.float32(1)):
+        T, C, last = np.float32(T0), np.zeros(3, np.float32), 0
         for i, (a, c) in enumerate(zip(alpha, col)):
             test_T = np.float32(T * np.float32(1 - a))
             if test_T < T_EPS:
@@ -386,26 +381,28 @@ def test_speculated_segment_blend_algorithm_in_numpy():
             T, last = test_T, i + 1
         return C, T, last
 
-    def speculated(alpha, col):
-        T_run, C, last, failed = np.float32(1), np.zeros(3, np.float32), 0, False
+    def relative(alpha, col):
+        T_run, C, last, repaired = np.float32(1), np.zeros(3, np.float32), 0, False
         for s0 in range(0, len(alpha), SEG):
-            C_loc, T_loc, last_loc, sat = *sequential(alpha[s0:s0 + SEG], col[s0:s0 + SEG]), False
-            if last_loc < len(alpha[s0:s0 + SEG]):
-                sat = True                                   # a sample was refused although the walk started from T = 1
+            a_seg, c_seg = alpha[s0:s0 + SEG], col[s0:s0 + SEG]
+            C_loc, T_loc, last_loc = sequential(a_seg, c_seg)
+            sat = last_loc < len(a_seg)                      # a sample was refused although the walk started from T = 1
             T_end = np.float32(T_run * (np.float32(0) if sat else T_loc))
+            if not (T_end >= T_EPS * np.float32(1.001)):     # saturates in here (or nearly): again, from the exact start
+                C_abs, T_fin, last_abs = sequential(a_seg, c_seg, T_run)
+                C = (C + C_abs).astype(np.float32)
+                return C, T_fin, (s0 + last_abs if last_abs else last), True
             C = (C + T_run * C_loc).astype(np.float32)
-            failed |= not (T_end >= T_EPS * np.float32(1.001))
             if last_loc:
                 last = s0 + last_loc
             T_run = T_end
-        return C, T_run, last, failed
+        return C, T_run, last, repaired
 
-    for n, a_max, expect_fail in ((3000, 0.002, False), (1800, 0.004, False), (3000, 0.02, True), (700, 0.9, True)):
+    for n, a_max, expect_repair in ((3000, 0.002, False), (1800, 0.004, False), (3000, 0.02, True), (700, 0.9, True)):
         alpha = rng.uniform(0.0, a_max, size=n).astype(np.float32)
         col = rng.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
         C0, T0, last0 = sequential(alpha, col)
-        C1, T1, last1, failed = speculated(alpha, col)
-        assert failed == expect_fail, (n, a_max, T0)
-        if not failed:
-            assert last1 == last0 == n
-            assert abs(T1 - T0) <= 2e-6 * T0 and np.abs(C1 - C0).max() <= 2e-6 * np.abs(C0).max()
+        C1, T1, last1, repaired = relative(alpha, col)
+        assert repaired == expect_repair, (n, a_max, T0)
+        assert last1 == last0 and (repaired or last0 == n)
+        assert abs(T1 - T0) <= 2e-6 * T0 and np.abs(C1 - C0).max() <= 2e-6 * np.abs(C0).max()

@@ -47,16 +47,11 @@ MSD_SORT_FROM = int(os.environ.get("VIDU4D_MSD_SORT_FROM", "10000"))  # longest 
 # transmittance pass then skips the tail of long lists that saturate early.  A frame that needed more
 # sets Header::truncated, check_deferred() reports it like an overflow, and the next calls run unlimited.
 _unlimited: dict = {}
-# Speculation for the segment-parallel alpha-only blend (Vidu4dSurfelForwardArgs::assume_unsaturated): deferred callers
-# whose previous frames of the shape kept every pixel's transmittance well above the saturation threshold skip the
-# transmittance pre-pass; a frame in which a pixel comes near it after all sets Header::truncated like a missed
-# segment limit (the step is replayed exactly) and speculation rests for SPEC_REST calls.
+# The segment-parallel alpha-only blend runs without its transmittance pre-pass (Vidu4dSurfelForwardArgs::
+# assume_unsaturated): segments are blended from T = 1 and scaled in the combine, which blends the one segment a pixel
+# saturates in again from the exact start (round 3; until then a saturating frame raised Header::truncated and was
+# replayed with the pre-pass, so only callers that could replay speculated, and only on frames known not to saturate).
 _SPEC = os.environ.get("VIDU4D_SURFEL_SPEC", "1") == "1"
-SPEC_MIN_T = 4e-4    # smallest final transmittance of the previous frames above which a frame is speculated on
-SPEC_REST = 20
-_min_T_hint: dict = {}
-_no_spec: dict = {}
-_spec_force = False   # (tests: speculate whatever the hints say)
 _pinned: dict = {}
 
 
@@ -124,14 +119,6 @@ def _note_longest_list(slot, key):
     _len_hint[key] = max(int(slot[2]), int(0.9 * _len_hint.get(key, 0)))
 
 
-def _note_min_T(slot, key):
-    """Header word 8: bits of the frame's smallest final transmittance -> a slowly recovering minimum per shape."""
-    import struct
-    t = struct.unpack("f", struct.pack("I", int(slot[8]) & 0xFFFFFFFF))[0]
-    prev = _min_T_hint.get(key)
-    _min_T_hint[key] = t if prev is None else min(t, 0.5 * (prev + t))
-
-
 def check_slots(frames) -> bool:
     ok = True
     for slot, stat, cap, key in frames:
@@ -139,11 +126,9 @@ def check_slots(frames) -> bool:
         _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
         if stat is not None:
             _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
-        _note_min_T(slot, key)
         _note_longest_list(slot, key)
         if int(slot[6]):
             _unlimited[key] = 4
-            _no_spec[key] = SPEC_REST
             ok = False
         ok = ok and n <= cap
     return ok
@@ -162,11 +147,9 @@ def check_deferred() -> bool:
         _capacity_hint[key] = max(int(n * 1.25) + 4096, int(0.98 * _capacity_hint.get(key, 0)))
         if stat is not None:
             _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
-        _note_min_T(slot, key)
         _note_longest_list(slot, key)
-        if int(slot[6]):  # the segment limit cut a tile short (or a speculated frame saturated): this frame is incomplete,
-            _unlimited[key] = 4   # the next ones run unlimited and unspeculated
-            _no_spec[key] = SPEC_REST
+        if int(slot[6]):  # the segment limit cut a tile short: this frame is incomplete,
+            _unlimited[key] = 4   # the next ones run unlimited
             ok = False
         ok = ok and n <= cap
     _pending.clear()
@@ -299,14 +282,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # long lists: the MSD split + bucket sorts from ~10 k entries per list on, one workgroup per list through global memory
     # below (dense Stage-3 ball, 5 k-entry lists: 81 us against 109; 3 %-coverage object, 25 k: 171 against 78)
     a.long_list_sort = 0 if _len_hint.get(key, 1 << 30) >= MSD_SORT_FROM else 1
-    if a.segment_split and int(aux_planes) == _lib.AUX_ALPHA and not debug:
-        if _spec_force:
-            a.assume_unsaturated, a.segment_split = 1, 1
-        elif _SPEC and _deferred:
-            if _no_spec.get(key, 0) > 0:
-                _no_spec[key] -= 1
-            elif _min_T_hint.get(key, 0.0) > SPEC_MIN_T:
-                a.assume_unsaturated, a.segment_split = 1, 1  # (every segment counts when nothing saturates: no limit)
+    if a.segment_split and int(aux_planes) == _lib.AUX_ALPHA and _SPEC:
+        a.assume_unsaturated = 1
 
     if P == 0:  # rasterize_points.cu:105: nothing is launched, outputs are zeros
         out_color.zero_()

@@ -258,9 +258,10 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
 // fwd_accumulate<true>); the other auxiliary planes, the distortion moments and the median contributor come out as zeros.
 //
 // spec (SPLIT && LITE only; Vidu4dSurfelForwardArgs::assume_unsaturated): no transmittance pre-pass ran.  A segment is
-// blended from T = 1 -- colour is linear in the start transmittance and, as long as no pixel saturates, no decision
-// depends on it -- and stores its colour and its transmittance PRODUCT; blend_combine_kernel scales by the product of
-// the predecessors and reports a pixel that did come near the saturation threshold (the frame is then blended again).
+// blended from T = 1 -- colour is linear in the start transmittance and, as long as the pixel does not saturate, no
+// decision depends on it -- and stores its colour and its transmittance PRODUCT; blend_combine_kernel scales by the
+// product of the predecessors and blends the ONE segment in which a pixel comes near the saturation threshold again,
+// in order, from the exact start (round 3: until then such a frame was reported and blended again with the pre-pass).
 #ifdef SURFEL_FWD_WAVES_PER_EU
 #define SURFEL_FWD_OCC __attribute__((amdgpu_waves_per_eu(SURFEL_FWD_WAVES_PER_EU, SURFEL_FWD_WAVES_PER_EU)))
 #else
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
 // LITE (colour + alpha plane only): the segments hold colour, end transmittance and last contributor, nothing else.
 template <bool LITE>
 __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
-                                                           ImageState img, int64_t capacity, int max_seg,
+                                                           ImageState img, const uint32_t* __restrict__ point_list,
+                                                           const float* __restrict__ rec, int64_t capacity, int max_seg,
                                                            const float* __restrict__ bg,
                                                            float* __restrict__ seg_data,
                                                            float* __restrict__ out_color,
@@ -417,16 +419,28 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     FwdPixel s;
     float T_raw = 1.0f;
-    bool spec_failed = false;
+    // spec: the segment in which this pixel saturates (or comes within 0.1 % of it), and what the segments before it leave
+    int repair_q = -1;
+    float repair_T = 1.0f;
     for (int q = 0; q < nseg; q++) {
         float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
         const float T_start = T_raw;
         if (LITE && spec) {
-            // the segment was blended from T = 1: scale by what its predecessors leave; a pixel that comes within 0.1 % of
-            // the saturation threshold (or saturated inside a segment: product stored as 0) means the frame needs the exact blend
+            // the segment was blended from T = 1: scale by what its predecessors leave.  A pixel that stays clear of the
+            // saturation threshold to the segment's end never met it inside (the running product only decreases); one that
+            // does not (or saturated inside a segment even from T = 1: product stored as 0) has this segment blended again
+            // below, in order, from the exact start transmittance -- and everything behind it is dead.
+            if (repair_q >= 0) {
+                d[SG_TEND * 256] = -1.0f;
+                continue;
+            }
             const float T_end = T_start * d[SG_TSEG * 256];
+            if (!(T_end >= T_EPS * 1.001f)) {
+                repair_q = q;
+                repair_T = T_start;
+                continue;
+            }
             for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(T_start, d[(SG_C + ch) * 256], s.C[ch]);
-            if (!(T_end >= T_EPS * 1.001f)) spec_failed = true;
             d[SG_TEND * 256] = T_end;
             T_raw = s.T = T_end;
             const uint32_t last = __float_as_uint(d[SG_LAST * 256]);
@@ -454,6 +468,66 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
             s.median_weight = d[SG_MED_W * 256];
         }
     }
+    if constexpr (LITE) if (spec) {
+        // ---- the saturating segments, blended again for the pixels that saturate in them: the loop of blend_fwd_kernel,
+        // restricted to the segment and to those pixels, from the exact transmittance (the product of the predecessors'
+        // products in list order: what blend_seg_T_kernel + blend_fwd_kernel use for their start)
+        __shared__ float4 s_rec[FWD_BATCH * 5];
+        __shared__ unsigned long long s_mask[4][4];
+        const bool inside = px < W && py < H;
+        const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
+        const uint32_t r0 = img.ranges[2 * tile], r1 = img.ranges[2 * tile + 1];
+        for (int q = 0; q < nseg; q++) {
+            const bool mine = inside && repair_q == q;
+            if (!__syncthreads_or(mine)) continue;
+            FwdPixel t;  // the segment's partial sums, from the exact start
+            t.T = repair_T;
+            bool done = !mine;
+            const int begin = q * SEG_LEN;
+            int todo = min((int)(r1 - r0) - begin, SEG_LEN);
+            for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
+                if (__syncthreads_count(done) == 256) break;
+                const bool have = (int)threadIdx.x < todo;
+                FootprintTest foot = no_footprint();
+                if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+                publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
+                __syncthreads();
+                if (__all(done)) continue;
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
+                    unsigned long long m = uniform_u64(s_mask[wave][k]);
+                    while (m) {
+                        const int j = k * 64 + __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
+                        const float Tu[3] = {a0.x, a0.y, a0.z}, Tv[3] = {a0.w, a1.x, a1.y}, Tw[3] = {a1.z, a1.w, a2.x};
+                        PairEval e;
+                        const bool ok = eval_pair_flat(Tu, Tv, Tw, a2.y, a2.z, a2.w, pixx, pixy, e) && !done;
+                        if (!__any(ok)) continue;
+                        if (ok) {
+                            const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                            const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                            if (!fwd_accumulate<true>(t, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // (s_rec / s_mask are staged again for the next segment)
+            if (mine) {
+                float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
+                for (int ch = 0; ch < 3; ch++) {
+                    d[(SG_C + ch) * 256] = t.C[ch];  // (absolute, unlike the speculated segments': SG_TSEG says so)
+                    s.C[ch] += t.C[ch];
+                }
+                d[SG_TSEG * 256] = -2.0f;
+                d[SG_TEND * 256] = t.T;
+                d[SG_LAST * 256] = __uint_as_float(t.last_contributor);
+                s.T = t.T;
+                if (t.last_contributor) s.last_contributor = t.last_contributor;
+                T_raw = 0.f;  // (saturated: not cut short by a segment limit)
+            }
+        }
+    }
     if (px < W && py < H)
         write_pixel(s, plane, frame_base + (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
 
@@ -461,7 +535,6 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     // the caller's segment limit cut this tile short and this pixel had not saturated yet: its values are
     // incomplete -- tell the caller (who blends the frame again without the limit)
     if (nseg < nseg_all && px < W && py < H && T_raw >= T_EPS) hdr->truncated = 1;
-    if (spec_failed && px < W && py < H) hdr->truncated = 1;
     report_min_T(hdr, s.T, px < W && py < H);
 
     // For the segment-parallel backward: replace each segment's partials by the sums over the segments
@@ -473,7 +546,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
         if (d[SG_TEND * 256] < 0.f) continue;
         if (LITE) {
             float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
-            if (spec) {  // (the stored colours are relative to the segment's start transmittance)
+            if (spec && d[SG_TSEG * 256] != -2.0f) {  // (the stored colours are relative to the segment's start transmittance)
                 const float T_start = q > 0 ? seg_data[((size_t)(first + q - 1) * SEG_FLOATS + SG_TEND) * 256 + threadIdx.x] : 1.0f;
                 c0 *= T_start, c1 *= T_start, c2 *= T_start;
             }
@@ -532,7 +605,7 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
                        point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used, spec);
     auto combine = lite ? &blend_combine_kernel<true> : &blend_combine_kernel<false>;
     hipLaunchKernelGGL(combine, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
-                       capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used, spec);
+                       point_list, g.rec, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used, spec);
 }
 
 // ---------------------------------------------------------------------------------------------
