@@ -187,6 +187,26 @@ def scaling_model(ms_per_step_1gpu: float, payload_bytes: float, overlapped: boo
     return out
 
 
+# what of the fitting step follows the rasterizer's backward on the compute stream before the optimizer needs the
+# gradients: the warp's backward (lbs_skin 44 us + skin_field 64 us + its torch glue) -- rocprofv3, profiles/r03_fit_step_*
+WARP_BACKWARD_MS = 0.15
+
+
+def fit_scaling_model(ms_per_step_1gpu: float, n_surfels: int) -> dict:
+    """MODELLED weak scaling of the fitting step as Stage3Trainer exchanges: the SH rest bands (45 of the 58 floats per
+    surfel) go on the wire behind the rasterizer's backward and ride beside the warp's backward (WARP_BACKWARD_MS of
+    compute that does not touch them); the 13 small floats per surfel (+ background) follow behind the whole backward.
+    Serial cost = what of the first collective outlasts the warp's backward + the second collective."""
+    out = {}
+    rest, small = n_surfels * 45 * 4, n_surfels * 13 * 4 + 12
+    for n in (2, 4, 8):
+        e_rest, e_small = exchange_model_ms(rest, n), exchange_model_ms(small, n)
+        serial = {k: max(0.0, e_rest[k] - WARP_BACKWARD_MS) + e_small[k] for k in e_rest}
+        out[str(n)] = {k: round(n * ms_per_step_1gpu / (ms_per_step_1gpu + v), 2) for k, v in serial.items()}
+        out[str(n)]["serial_exchange_ms"] = {k: round(v, 3) for k, v in serial.items()}
+    return out
+
+
 def torch_cpu_baseline(scene, n_images: int, threads: int):
     """The pure-PyTorch CPU render BASELINE.json's north_star asks to be timed beside the GPU number
     (oracle/torch_render.py: vectorised forward, autograd backward)."""
@@ -715,7 +735,11 @@ def main():
                     # above the active degree stay home (stage3.py: exchanged_params / _packs_rest)
                     pay = N * GRAD_FLOATS_PER_SURFEL * 4 + 12
                     sm[key] = {"ms_per_step_1gpu": out[key]["ms_per_step"], "payload_bytes": pay,
-                               "speedup_exchange_serial": scaling_model(out[key]["ms_per_step"], pay, False)}
+                               "speedup_exchange_serial": scaling_model(out[key]["ms_per_step"], pay, False),
+                               # as Stage3Trainer issues it: the SH rest bands' collective behind the rasterizer's
+                               # backward, beside the warp's backward (allreduce_gradients)
+                               "speedup_rest_bands_beside_the_warp_backward": fit_scaling_model(out[key]["ms_per_step"], N),
+                               "warp_backward_ms_assumed": WARP_BACKWARD_MS}
             out["scaling_modelled"] = sm
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)

@@ -1,7 +1,8 @@
 """The frame-parallel trainer path on the GPU with more than one rank, on ONE device: two processes share cuda:0 and
 exchange through gloo (which stages device tensors through the host) -- not a performance configuration, but it runs
 exactly the code a multi-GPU RCCL job runs above the collective: gradients written by the rasterizer's backward straight
-into the flat exchange buffer, only the live SH rows on the wire, two collectives, chunk norms folded into the clip
+into the flat exchange buffer, only the live SH rows on the wire, their collective issued behind the rasterizer's backward
+(before the warp's), chunk norms folded into the clip
 coefficient of the one-launch Adam, densification statistics reduced when consumed, device-side densify replayed
 identically.  After three steps on different frames (through a densify / prune) the replicas must hold identical surfels."""
 import os
@@ -22,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, early=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,7 +34,7 @@ def _worker(rank, world, port, out):
         rng = np.random.default_rng(0)
         torch.manual_seed(0)                       # identical networks and surfels on every rank
         opts = dict(fg_motion="gs-bob", densify_from_iter=0, densification_interval=2, densify_grad_threshold=1e-9,
-                    opacity_reset_interval=1000)
+                    opacity_reset_interval=1000, early_exchange=early)
         m = DeformableSurfels(opts, num_frames=8, device=dev)
         n = 3000
         d = rng.normal(size=(n, 3)).astype(np.float32)
@@ -49,7 +50,8 @@ def _worker(rank, world, port, out):
             batch = synthetic_batch(m, ids, 64, 64, seed=step)
             tr.train_step(batch)
             if step == 0:
-                seen = {"direct": sorted(tr._direct), "packed": tr._rest_slot is not None, "degree": m.active_sh_degree}
+                seen = {"direct": sorted(tr._direct), "packed": tr._rest_slot is not None, "degree": m.active_sh_degree,
+                        "early": tr._side_stream is not None}
         torch.cuda.synchronize()
         sig = torch.cat([p.detach().reshape(-1) for p in tr.surfel_params()]).cpu()
         sizes = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
@@ -60,7 +62,7 @@ def _worker(rank, world, port, out):
             gathered = [torch.zeros_like(sig) for _ in range(world)]
             dist.all_gather(gathered, sig)
             identical = all(torch.equal(gathered[0], t) for t in gathered)
-        out[rank] = (same, identical, int(m._xyz.shape[0]), bool(torch.isfinite(sig).all()), seen)
+        out[rank] = (same, identical, int(m._xyz.shape[0]), bool(torch.isfinite(sig).all()), seen, sig.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -73,9 +75,23 @@ def test_two_ranks_on_one_gpu_keep_identical_surfels(gpu_device):
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert len(out) == world
     for r in range(world):
-        same, identical, n, finite, seen = out[r]
+        same, identical, n, finite, seen, _sig = out[r]
         assert finite and same and identical, "replicas diverged"
         # SH degree 1 at step 0: only three of the fifteen rest rows travel, written whole by the backward into a side buffer
         assert seen["degree"] == 1 and seen["packed"]
         assert seen["direct"] == ["dL_dopacity", "dL_dscales", "dL_dsh_dc", "dL_dsh_rest"]
+        assert seen["early"], "the SH rest bands' collective was not issued behind the rasterizer's backward"
     assert out[0][2] == out[1][2] and out[0][2] != 3000, "the densify step did not change the surfel count"
+    # the same three steps with every collective issued behind the whole backward (early_exchange off): the early one waits
+    # for the event behind the rasterizer's backward only -- had it started before the gradients were written, or read the
+    # buffer while something else wrote it, the 45 SH floats of every surfel would differ
+    port2 = _free_port()
+    late = mgr.dict()
+    mp.spawn(_worker, args=(world, port2, late, False), nprocs=world, join=True)
+    assert not late[0][4]["early"]
+    # (the blend backward accumulates with float atomics, so two runs agree to rounding, not bit for bit -- and Adam turns a
+    # sign flip of a gradient that is zero up to rounding into a full step: a few parameters may differ by their rate)
+    a, b = out[0][5], late[0][5]
+    assert a.shape == b.shape
+    differing = float(np.mean(np.abs(a - b) > 1e-4 * (1.0 + np.abs(b))))
+    assert differing < 2e-3, f"early and late exchange disagree in {differing:.2e} of the parameters"

@@ -350,18 +350,22 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 # surfels).  One-shot: the first backward call inside the context takes the buffers.  Process-wide state of a
 # single-threaded caller, like the capacity hints above.
 _grad_out: dict = {}
+_grad_written = None
 
 
 @contextlib.contextmanager
-def gradient_buffers(**buffers):
+def gradient_buffers(on_written=None, **buffers):
     """buffers: dL_dopacity (P,1), dL_dscales (P,2), dL_dsh (P,M,3) or dL_dsh_dc (P,1,3) / dL_dsh_rest (P,15,3): contiguous
-    fp32 tensors on the device, 16-byte aligned."""
-    global _grad_out
-    old, _grad_out = _grad_out, {k: v for k, v in buffers.items() if v is not None}
+    fp32 tensors on the device, 16-byte aligned.  on_written: called (once) right after the backward that took the buffers
+    has been queued -- the place to record the event a collective over them waits for, while the rest of the step's
+    backward is still to come."""
+    global _grad_out, _grad_written
+    old, _grad_out = (_grad_out, _grad_written), {k: v for k, v in buffers.items() if v is not None}
+    _grad_written = on_written
     try:
         yield
     finally:
-        _grad_out = old
+        _grad_out, _grad_written = old
 
 
 def _grad_output(name, shape, opt):
@@ -405,6 +409,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dmeans3D = torch.empty(lead + (3,), **opt)
     dL_dmeans2D = torch.empty(lead + (3,), **opt)
     dL_dcolors = torch.empty(lead + (3,), **opt)
+    n_buffers = len(_grad_out)
     dL_dopacity = _grad_output("dL_dopacity", (P, 1), opt)
     dL_dtransMat = torch.empty(lead + (9,), **opt)
     if sh_rest is not None:
@@ -412,6 +417,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     else:
         dL_dsh = _grad_output("dL_dsh", (P, M, 3), opt)
     dL_dscales = _grad_output("dL_dscales", (P, 2), opt)
+    took_buffers = len(_grad_out) < n_buffers
     dL_drotations = torch.empty(lead + (4,), **opt)
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
@@ -464,6 +470,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     b.raw_params, b.aux_planes = int(bool(raw_params)), int(aux_planes)
     b.dL_dscales, b.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
     _lib.check(lib.vidu4d_surfel_backward(C.byref(b), _stream(dev)), "surfel backward")
+    global _grad_written
+    if _grad_written is not None and took_buffers:
+        cb, _grad_written = _grad_written, None
+        cb()
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -118,7 +118,10 @@ class Stage3Trainer:
         self._pending_reduce = None
         self._rest_slot = None      # (N, k, 3) view of the flat buffer while only k < 15 SH rest rows are exchanged
         self._net_slots = []        # the networks' places in the flat buffer (gs_optim_warp=True)
-        self._chunk_split = None    # where the second collective starts
+        self._chunk_split = None    # where the second collective (the SH rest bands) starts
+        self._net_split = None      # ... and the third (the networks' gradients, when they train)
+        self._rest_ready = None     # event: the rasterizer's backward has written the SH gradients (this step)
+        self._side_stream = None
         # --gs_optim_warp=False (the README's Stage-3 command): warp and camera networks come from the
         # Stage-2 checkpoint and are never stepped (trainer.py:592-598).  Upstream still back-propagates
         # into them; freezing them is results-equivalent for the surfels up to the gradient clip (upstream's
@@ -234,6 +237,8 @@ class Stage3Trainer:
         self._rest_slot = None
         self._net_slots = []
         self._chunk_split = None
+        self._net_split = None
+        self._rest_ready = None
         names = {id(m._features_dc): "dL_dsh_dc", id(m._opacity): "dL_dopacity", id(m._scaling): "dL_dscales"}
         if not pack:
             names[id(rest)] = "dL_dsh_rest"
@@ -255,6 +260,8 @@ class Stage3Trainer:
                     p.grad = full
                 self._rest_slot = self._flat[off:off + sz].view(rest.shape[0], k, rest.shape[2])
             elif id(p) in net_ids:
+                if self._net_split is None:
+                    self._net_split = off
                 # fresh per-step gradient (None when autograd never reaches the parameter); it is packed into the
                 # buffer for the collective and then ADDED to the round's accumulated gradient (_fold_net_gradients)
                 p.grad = None
@@ -270,7 +277,18 @@ class Stage3Trainer:
         """Context for the step's backward: the flat buffer's slices of the canonical parameters as the rasterizer's
         gradient outputs (bind_flat_gradients decided which)."""
         from .. import _C
-        return _C.gradient_buffers(**(self.__dict__.get("_direct") or {})) if self._flat is not None else contextlib.nullcontext()
+        if self._flat is None:
+            return contextlib.nullcontext()
+        direct = self.__dict__.get("_direct") or {}
+        # more than one rank: note when the SH gradients -- 45 of the 58 floats per surfel -- are written, so that their
+        # collective can start then instead of after the warp's backward (allreduce_gradients)
+        early = self._note_rest_written if (self.world > 1 and "dL_dsh_rest" in direct and
+                                            self.model.opts.get("early_exchange", True)) else None
+        return _C.gradient_buffers(on_written=early, **direct)
+
+    def _note_rest_written(self):
+        self._rest_ready = torch.cuda.Event()
+        self._rest_ready.record(torch.cuda.current_stream(self._flat.device))
 
     def _flat_needed(self):
         """One rank, surfels on the GPU, frozen networks: nothing reads the gradients but the one-launch clip and the
@@ -299,9 +317,9 @@ class Stage3Trainer:
         return p.grad is not None and p.grad.untyped_storage().data_ptr() == self._flat.untyped_storage().data_ptr()
 
     def allreduce_gradients(self, async_op: bool = False):
-        """Sum of the flat gradient buffer over the ranks, issued as TWO collectives (the small tensors, then the SH
-        rest bands + networks): `wait_gradients` joins them one after the other, so that the norm of chunk 0 is taken
-        while chunk 1 is still on the wire.  The mean (/ world) is folded into the clip coefficient where the one-launch
+        """Sum of the flat gradient buffer over the ranks, issued as up to THREE collectives (the SH rest bands, the small
+        tensors, the networks): `wait_gradients` joins them one after the other, so that the norm of one chunk is taken
+        while the next is still on the wire.  The mean (/ world) is folded into the clip coefficient where the one-launch
         Adam applies it, else applied in wait_gradients.  With async_op the collectives are left in flight (RCCL runs
         them on its own stream) and work that does not read the gradients -- the densification statistics -- overlaps
         them."""
@@ -318,14 +336,32 @@ class Stage3Trainer:
                     p.grad = g_
                 elif g_ is not None:
                     p.grad.copy_(g_)
-        if self._rest_slot is not None and self._rest_slot.numel():
-            self._rest_slot.copy_(self.model._features_rest.grad[:, :self._rest_slot.shape[1]])
         for p, slot in zip(self._net_params if self.optim_warp else [], self._net_slots):
             if p.grad is not None:
                 slot.copy_(p.grad)
         split = self._chunk_split if self._chunk_split else 0
-        chunks = [c for c in (self._flat[:split], self._flat[split:]) if c.numel()]
-        self._pending_reduce = [(c, dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True)) for c in chunks]
+        nets = self._net_split if self._net_split else self._flat.numel()
+        self._pending_reduce = []
+        rest = self._flat[split:nets]
+        ready, self._rest_ready = self._rest_ready, None
+        if ready is not None and rest.numel():
+            # the SH rest bands were written by the rasterizer's backward, before the warp's: their collective waits for
+            # that event only (a side stream that has seen nothing else), i.e. it runs while the compute stream is still in
+            # the warp's backward and the statistics.  Issued here, after the step's capacity check, so that every rank
+            # issues the same collectives whether or not it had to replay its step.
+            dev = self._flat.device
+            if self._side_stream is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ready)
+                if self._rest_slot is not None and self._rest_slot.numel():
+                    self._rest_slot.copy_(self.model._features_rest.grad[:, :self._rest_slot.shape[1]])
+                self._pending_reduce.append((rest, dist.all_reduce(rest, op=dist.ReduceOp.SUM, async_op=True)))
+            rest = None
+        elif self._rest_slot is not None and self._rest_slot.numel():
+            self._rest_slot.copy_(self.model._features_rest.grad[:, :self._rest_slot.shape[1]])
+        chunks = [c for c in (self._flat[:split], rest, self._flat[nets:]) if c is not None and c.numel()]
+        self._pending_reduce += [(c, dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True)) for c in chunks]
         if not async_op:
             self.wait_gradients()
 
