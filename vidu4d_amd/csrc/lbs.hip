@@ -207,12 +207,6 @@ constexpr int MAX_FRAMES = 8;
 #ifndef LBS_BX_WAVES_PER_EU
 #define LBS_BX_WAVES_PER_EU 1
 #endif
-#ifndef LBS_FENCE_EVERY
-#define LBS_FENCE_EVERY 0
-#endif
-// (straight-line bone loops: without a fence the scheduler hoists the LDS reads of all 25 iterations -- 8 floats per bone
-// and frame -- to the top of a loop and the backward needs 374 registers; a scheduling fence every few bones bounds what is
-// in flight)
 // PIN(...): the named values are final HERE in program order (an empty asm the compiler must feed them through), so what
 // went into them is dead behind this point.  Bounds the live ranges inside the straight-line bone loops of the BX
 // instances: left alone the compiler defers the serial accumulations (blended quaternions, A^T d x_bone) and keeps the
@@ -224,11 +218,6 @@ constexpr int MAX_FRAMES = 8;
 #define PINQ(q_)                                                                         \
     do {                                                                                 \
         if (BX) asm volatile("" : "+v"(q_.w), "+v"(q_.x), "+v"(q_.y), "+v"(q_.z)); \
-    } while (0)
-#define BONE_FENCE(b)                                                                                          \
-    do {                                                                                                       \
-        if (BX && BACKWARD && LBS_FENCE_EVERY > 0 && ((b) % (LBS_FENCE_EVERY > 0 ? LBS_FENCE_EVERY : 1)) == (LBS_FENCE_EVERY > 0 ? LBS_FENCE_EVERY : 1) - 1) \
-            __builtin_amdgcn_sched_barrier(0);                                                                 \
     } while (0)
 template <bool BACKWARD, int BCAP, bool XB_FROM_XYZ, int BX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BX && BACKWARD) ? LBS_BX_WAVES_PER_EU : 1, 8)))
@@ -286,7 +275,6 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
             anchor = b;
         }
         if (BX) asm volatile("" : "+v"(w[b]), "+v"(best));
-        BONE_FENCE(b);
     }
     float sum = 0.f;
     _Pragma("unroll") for (int b = 0; b < NB; b++) {
@@ -316,7 +304,6 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
             Qd = qadd(Qd, qscale(ldq(sq + MAX_BONES * 4 + b * 4), ws));
             PINQ(Qr);
             PINQ(Qd);
-            BONE_FENCE(b);
         }
         const float inv = 1.0f / sqrtf(qdot(Qr, Qr));
         const Q q = qscale(Qr, inv), d = qscale(Qd, inv);
@@ -377,7 +364,6 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
             const float sgn = ((hemi >> b) & 1ull) ? 1.0f : -1.0f;
             gw[b] += sgn * (qdot(g_Qr, ldq(sq2 + b * 4)) + qdot(g_Qd, ldq(sq2 + MAX_BONES * 4 + b * 4)));
             if (BX && BACKWARD) asm volatile("" : "+v"(gw[b]));
-            BONE_FENCE(b);
         }
     }
     if (!BACKWARD) return;
@@ -408,7 +394,6 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
         }
         if (g_rawT) g_rawT[(uint32_t)b * Ns + (uint32_t)n] = ((raw_pos >> b) & 1u) ? -0.1f * g_logit : 0.f;
         PIN3(acc_p.x, acc_p.y, acc_p.z);
-        BONE_FENCE(b);
     }
     g_xyz[3 * n] = acc_p.x;
     g_xyz[3 * n + 1] = acc_p.y;
