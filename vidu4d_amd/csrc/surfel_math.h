@@ -327,6 +327,14 @@ SURFEL_HD void sh_forward(int deg, const float p_world[3], const float campos[3]
 
 // SH backward of one surfel (backward.cu:20-139): writes dsh[M][3] (zeros beyond the active
 // degree) and adds the view-direction term to dmean.
+// SURFEL_PIN3: the three values are final here in program order (device code: an empty asm they are fed through), so what
+// went into them is dead -- bounds live ranges in unrolled accumulation loops (see lbs.hip).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SURFEL_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#else
+#define SURFEL_PIN3(a, b, c) ((void)0)
+#endif
+
 SURFEL_HD void sh_backward(int deg, int M, const float p_world[3], const float campos[3], const float* sh,
                            uint32_t clamp_mask, const float dcol[3], float* dsh, float dmean[3])
 {
@@ -350,6 +358,7 @@ SURFEL_HD void sh_backward(int deg, int M, const float p_world[3], const float c
                 dsh[3 * k] = b[k] * dRGB[0];
                 dsh[3 * k + 1] = b[k] * dRGB[1];
                 dsh[3 * k + 2] = b[k] * dRGB[2];
+                SURFEL_PIN3(ddir[0], ddir[1], ddir[2]);
             } else {
                 dsh[3 * k] = dsh[3 * k + 1] = dsh[3 * k + 2] = 0.f;
             }
