@@ -25,7 +25,9 @@ p10, p90 of images/s).  "value_per_frame_calls" times the same steps through the
 GaussianRasterizer.forward per frame).  "fit_step" is the second figure of SURVEY.md 8(d): the full Stage-3 fitting
 step (bob warp + raster + losses + backward + clip + densify statistics + Adam) at the same size; "fit_step_geometry"
 the same step after step 8000 (normal-consistency regulariser on).  "scaling_modelled" (N = 1 only): MODELLED multi-GPU
-speed-ups from the measured step and an all-reduce cost model, assumptions included.  `--replicas N`: BASELINE
+speed-ups from the measured step and an all-reduce cost model, assumptions included (fitting steps: also as
+Stage3Trainer issues the exchange, the SH rest bands' collective beside the warp's backward).  "host_enqueue_ms_per_step":
+time until the timed region's launches were queued (the host runs into the launch queue's back-pressure: ~ the GPU time).  `--replicas N`: BASELINE
 configs[3], N independent sequences with an RCCL barrier at start and end.
 
 Extra objects on the JSON line: "roofline" (dominant kernel: algorithmic bytes per launch /

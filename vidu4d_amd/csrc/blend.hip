@@ -13,8 +13,9 @@
 //   * the tile's depth-sorted surfel list is staged 256 (forward) / 128 (backward) entries at a
 //     time into LDS as 80-byte records (five ds_write_b128 per lane, conflict-free at a 20-dword
 //     stride) and read back with wave-uniform (broadcast) ds_read_b128;
-//   * while staging, every thread tests its entry's conservative contribution box against the four
-//     quadrants; wave64 ballots turn that into one 64-bit mask per (quadrant, staging wave), and each
+//   * while staging, every thread tests its entry's footprint (the conic rho3d <= rc in the pixel plane and the rho2d
+//     disc, surfel_math.h: conservative by its margins only) against the four quadrants' rectangles of pixel centres;
+//     wave64 ballots turn that into one 64-bit mask per (quadrant, staging wave), and each
 //     wave then iterates only over the set bits with scalar bit tricks (s_ff1 / s_and): list entries
 //     that cannot reach a wave's 64 pixels are never evaluated.  The pair evaluation itself is
 //     branch-free; the only branches in the loop are wave-uniform;
@@ -25,10 +26,11 @@
 //     The reference issues up to 16 global atomics per (pixel, entry).  Measured alternatives to the register
 //     reduce-scatter (round 2): an LDS transposition, exact-f32 MFMA contraction of the pixel axis
 //     (tools/experiments/blend_bwd_mfma_contraction.hip.txt), per-lane LDS atomics for sparse entries, pair
-//     compaction, a 4x4-block row walk -- none was faster;
+//     compaction, a 4x4-block row walk, a 2x2-block quad walk (round 3) -- none was faster;
 //   * long lists are blended segment-parallel (SPLIT instances: transmittance pre-pass, per-segment blend, in-order
 //     combine); callers that read only colour + alpha plane get the LITE instances (aux_planes), which carry
-//     nothing else.
+//     nothing else and need no pre-pass: their segments are blended from T = 1 and the combine blends the one segment
+//     a pixel saturates in again from the exact start.
 #include <algorithm>
 #include <cstdlib>
 
