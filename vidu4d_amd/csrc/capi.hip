@@ -268,6 +268,7 @@ extern "C" int vidu4d_surfel_forward_plan(const Vidu4dSurfelForwardArgs* a, void
     pa.tile_count = img.tile_count;
     pa.group_counts = img.group_counts;
     pa.iters = bin_iters(P);
+    pa.stage_records = 0;  // (launch_preprocess_fwd decides)
     const int num_tiles = total_tiles(pa.cam);
     const bool grouped = use_grouped_binning(num_tiles);
     {

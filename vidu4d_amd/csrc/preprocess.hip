@@ -8,6 +8,8 @@
 // MI355X notes: one thread per surfel, 256-thread workgroups (4 wave64).  The reference's
 // per-surfel prefix sum + global 64-bit sort is replaced by tile binning (binning.hip): this kernel
 // only counts, per tile, how many surfels touch it.
+#include <cstdlib>
+
 #include "surfel_state.h"
 #include "wave_utils.h"
 
@@ -93,8 +95,11 @@ __device__ __forceinline__ void sh_tile_store(const float* s_sh, float* dL_dsh, 
 }
 
 // Projection of surfel idx; writes record / radius / tile count and returns the tile rect.
+// stage: NULL, or this lane's seven float4 slots of its wave's LDS staging buffer -- the record then goes there and the
+// caller stores the wave's 64 records lane-contiguously (flush_staged_records): a record is 112 bytes, so the direct
+// stores below are 16-byte pieces at a 112-byte lane stride.
 __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const Camera& cam, int idx, int shared,
-                                                   Projected& o)
+                                                   Projected& o, float4* stage = nullptr)
 {
     const float p_world[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
     float2 sc = reinterpret_cast<const float2*>(a.scales)[shared];
@@ -108,7 +113,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         tiles = o.tiles;
         radius = o.radius;
         // (q4 = colour and clamp mask is written by surfel_color_kernel)
-        float4* rec = reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
+        float4* rec = stage ? stage : reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS);
         rec[0] = make_float4(o.T[0], o.T[1], o.T[2], o.T[3]);
         rec[1] = make_float4(o.T[4], o.T[5], o.T[6], o.T[7]);
         const float opacity = a.raw_params ? act_opacity(a.opacities[shared]) : a.opacities[shared];
@@ -118,10 +123,27 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         contribution_footprint(o.T, o.center[0], o.center[1], opacity, f);
         rec[5] = make_float4(f[0], f[1], f[2], f[3]);
         rec[6] = make_float4(f[4], f[5], f[6], f[7]);
+        // (staged path: the colour kernel, which ran before this one, left q4 in a compact array)
+        if (stage) rec[4] = reinterpret_cast<const float4*>(a.geom.colour)[idx];
     }
     a.radii[idx] = radius;
     a.geom.tiles_touched[idx] = tiles;
     return tiles;
+}
+
+// The 64 records a wave staged in LDS (7 float4 each), stored with consecutive lanes on consecutive 16-byte pieces.
+// visible: ballot of the lanes that wrote one.
+__device__ __forceinline__ void flush_staged_records(const float4* stage, float* rec, int idx0, unsigned long long visible,
+                                                     int lane)
+{
+    if (!visible) return;
+    float4* dst = reinterpret_cast<float4*>(rec + (size_t)idx0 * REC_FLOATS);
+    constexpr int PARTS = REC_FLOATS / 4;
+#pragma unroll
+    for (int i0 = 0; i0 < 64 * PARTS; i0 += 64) {
+        const int i = i0 + lane, r = i / PARTS;
+        if ((visible >> r) & 1ull) dst[i] = stage[i];
+    }
 }
 
 // Atomic path (more than BIN_MAX_TILES tiles): per-tile pair counts with global atomics.
@@ -156,18 +178,27 @@ __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(Pre
     }
     __syncthreads();
     const int first = blockIdx.x * BIN_THREADS * a.iters;
+    // (optional: per-wave staging of the records behind the histogram, launch_preprocess_fwd)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PARTS = REC_FLOATS / 4;
+    float4* stage = a.stage_records
+                        ? reinterpret_cast<float4*>(s_hist + ((num_tiles + 3) & ~3)) + (size_t)wave * 64 * PARTS
+                        : nullptr;
     for (int it = 0; it < a.iters; it++) {
         const int idx = first + it * BIN_THREADS + threadIdx.x;
+        bool visible = false;
         if (idx < a.P) {
             const FrameIndex fi = frame_index(a.cam, idx);
             const Camera cam = load_camera(a.cam, fi.frame);
             Projected o;
-            if (preprocess_one(a, cam, idx, fi.shared, o)) {
+            if (preprocess_one(a, cam, idx, fi.shared, o, stage ? stage + lane * PARTS : nullptr)) {
+                visible = true;
                 uint32_t* hist = s_hist + fi.frame * frame_tiles;
                 for (int y = o.y0; y < o.y1; y++)
                     for (int x = o.x0; x < o.x1; x++) atomicAdd(&hist[y * cam.grid_x + x], 1u);
             }
         }
+        if (stage) flush_staged_records(stage, a.geom.rec, first + it * BIN_THREADS + wave * 64, __ballot(visible), lane);
     }
     __syncthreads();
     uint32_t* row = a.group_counts + (size_t)blockIdx.x * num_tiles;
@@ -212,9 +243,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs 
             rgb[1] = a.colors_precomp[3 * idx + 1];
             rgb[2] = a.colors_precomp[3 * idx + 2];
         }
-        reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS)[4] =
-            make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
+        // (staged path: a compact array the projection kernel folds into the records it stores whole; else straight into q4)
+        float4* dst = a.stage_records ? reinterpret_cast<float4*>(a.geom.colour) + idx
+                                      : reinterpret_cast<float4*>(a.geom.rec + (size_t)idx * REC_FLOATS) + 4;
+        *dst = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_mask));
     }
+}
+
+// VIDU4D_STAGE_RECORDS=0: the projection kernel stores its records directly (A/B of the LDS staging)
+static bool stage_records_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VIDU4D_STAGE_RECORDS");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
 }
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
@@ -225,14 +269,27 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
     const bool sh_lds = a.colors_precomp == nullptr && a.cam.sh_coeffs == 16 &&
                         (a.sh_dc != nullptr || (a.shs != nullptr && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0));
     const int color_blocks = a.cam.frames > 1 ? pre_blocks(a.cam.frame_surfels) : pre_blocks(a.P);
+    // grouped path: histogram + (if it fits) a staging buffer of 64 records per wave -- the records then leave with
+    // lane-contiguous stores, the colour kernel's q4 included (it writes a compact array the projection kernel reads)
+    PreprocessArgs g = a;
+    g.stage_records = 0;
+    const size_t hist = (size_t)((num_tiles + 3) & ~3) * sizeof(uint32_t);
+    const size_t staged = hist + (size_t)(BIN_THREADS / 64) * 64 * REC_FLOATS * sizeof(float);
+    if (use_grouped_binning(num_tiles)) {
+        static int big_lds = -1;  // (one attribute call; benign if raced)
+        if (big_lds < 0)
+            big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&preprocess_fwd_grouped_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        g.stage_records = (big_lds == 1 && staged <= 160 * 1024 && stage_records_enabled()) ? 1 : 0;
+    }
     if (sh_lds)
         hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(color_blocks), dim3(PRE_BLOCK),
-                           (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, a);
+                           (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, g);
     else
-        hipLaunchKernelGGL(surfel_color_kernel<false>, dim3(color_blocks), dim3(PRE_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(surfel_color_kernel<false>, dim3(color_blocks), dim3(PRE_BLOCK), 0, stream, g);
     if (use_grouped_binning(num_tiles))
         hipLaunchKernelGGL(preprocess_fwd_grouped_kernel, dim3(bin_groups(a.P)), dim3(BIN_THREADS),
-                           (size_t)num_tiles * sizeof(uint32_t), stream, a);
+                           g.stage_records ? staged : hist, stream, g);
     else
         hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
 }

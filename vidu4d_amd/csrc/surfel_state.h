@@ -76,6 +76,7 @@ struct GeomState {
     Header* hdr;
     float* rec;              // [P][28]   (surfel_math.h RecSlot)
     uint32_t* tiles_touched; // [P]
+    float* colour;           // [P][4]    rgb + clamp mask on their way into the records (preprocess.hip, staged path)
 };
 
 struct ImageState {
@@ -123,6 +124,7 @@ inline size_t carve_geom(char* base, int P, GeomState& g)
     carve(p, g.hdr, 1);
     carve(p, g.rec, (size_t)P * REC_FLOATS);
     carve(p, g.tiles_touched, (size_t)P);
+    carve(p, g.colour, (size_t)P * 4);
     return (size_t)(p - base) + 256;
 }
 
@@ -252,6 +254,7 @@ struct PreprocessArgs {
     uint32_t* tile_count;    // atomic path: [tiles][TILE_SLICES], zeroed before the launch
     uint32_t* group_counts;  // grouped path: [groups][tiles]
     int iters;               // grouped path: surfel batches per workgroup
+    int stage_records;       // grouped path: records staged per wave in LDS and stored lane-contiguously (set by the launcher)
 };
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
 // counts -> ranges (exclusive scan over tiles), total -> header; atomic path: counts reset to 0 (they
