@@ -329,6 +329,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, 
 // Grouped path: the same 1024-thread groups as the projection; each group owns, in every tile's
 // segment, the sub-range [ranges[t].x + prefix[group][t], +count[group][t]) and hands out its slots
 // with LDS atomics.
+template <bool COMPACT>
 __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraParams cam, int P, int iters,
                                                                        const int32_t* radii, GeomState g,
                                                                        ImageState img, uint64_t* entries,
@@ -348,13 +349,24 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraPa
     for (int it = 0; it < iters; it++) {
         const int idx = first + it * BIN_THREADS + threadIdx.x;
         if (idx >= P) continue;
-        const int radius = radii[idx];
-        if (radius <= 0) continue;
-        const float4 q2 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[2];
-        const float4 q3 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[3];
+        // COMPACT: centre, depth and radius as the projection kernel left them in one 16-byte slot per surfel
+        // (preprocess.hip, staged path); else from the radius array and two strided pieces of the record
+        int radius;
+        float cx, cy, depth;
+        if (COMPACT) {
+            const float4 c = reinterpret_cast<const float4*>(g.colour)[idx];
+            cx = c.x, cy = c.y, depth = c.z, radius = __float_as_int(c.w);
+            if (radius <= 0) continue;
+        } else {
+            radius = radii[idx];
+            if (radius <= 0) continue;
+            const float4 q2 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[2];
+            const float4 q3 = reinterpret_cast<const float4*>(g.rec + (size_t)idx * REC_FLOATS)[3];
+            cx = q2.y, cy = q2.z, depth = q3.w;
+        }
         int x0, y0, x1, y1;
-        tile_rect(q2.y, q2.z, radius, cam.grid_x, cam.grid_y, x0, y0, x1, y1);
-        const uint64_t entry = ((uint64_t)__float_as_uint(q3.w) << 32) | (uint32_t)idx;
+        tile_rect(cx, cy, radius, cam.grid_x, cam.grid_y, x0, y0, x1, y1);
+        const uint64_t entry = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
         uint32_t* cur = s_cur + (cam.frames > 1 ? (idx / cam.frame_surfels) * frame_tiles : 0);
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) entries[atomicAdd(&cur[y * cam.grid_x + x], 1u)] = entry;
@@ -365,10 +377,11 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
                       const BinState& b, int64_t capacity, bool grouped, hipStream_t stream)
 {
     if (P <= 0) return;
-    if (grouped)
-        hipLaunchKernelGGL(emit_keys_grouped_kernel, dim3(bin_groups(P)), dim3(BIN_THREADS),
-                           (size_t)total_tiles(cam) * sizeof(uint32_t), stream, cam, P, bin_iters(P), radii, g,
-                           img, b.entries, capacity);
+    if (grouped) {
+        auto kernel = preprocess_stages_records(total_tiles(cam)) ? &emit_keys_grouped_kernel<true> : &emit_keys_grouped_kernel<false>;
+        hipLaunchKernelGGL(kernel, dim3(bin_groups(P)), dim3(BIN_THREADS), (size_t)total_tiles(cam) * sizeof(uint32_t), stream,
+                           cam, P, bin_iters(P), radii, g, img, b.entries, capacity);
+    }
     else
         hipLaunchKernelGGL(emit_keys_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, cam, P, radii, g, img,
                            b.entries, capacity);

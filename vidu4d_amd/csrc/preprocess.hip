@@ -126,6 +126,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         // (staged path: the colour kernel, which ran before this one, left q4 in a compact array)
         if (stage) rec[4] = reinterpret_cast<const float4*>(a.geom.colour)[idx];
     }
+    // (staged path: the compact slot now carries what emit_keys_grouped_kernel reads -- centre, depth bits, radius -- in one
+    // lane-contiguous 16-byte load instead of three strided ones)
+    if (stage) reinterpret_cast<float4*>(a.geom.colour)[idx] =
+        make_float4(o.center[0], o.center[1], o.depth, __int_as_float(radius));
     a.radii[idx] = radius;
     a.geom.tiles_touched[idx] = tiles;
     return tiles;
@@ -250,6 +254,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void surfel_color_kernel(PreprocessArgs 
     }
 }
 
+static bool stage_records_enabled();
+bool preprocess_stages_records(int num_tiles)
+{
+    static int big_lds = -1;  // (one attribute call; benign if raced)
+    if (big_lds < 0)
+        big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&preprocess_fwd_grouped_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    const size_t hist = (size_t)((num_tiles + 3) & ~3) * sizeof(uint32_t);
+    const size_t staged = hist + (size_t)(BIN_THREADS / 64) * 64 * REC_FLOATS * sizeof(float);
+    return use_grouped_binning(num_tiles) && big_lds == 1 && staged <= 160 * 1024 && stage_records_enabled();
+}
+
 // VIDU4D_STAGE_RECORDS=0: the projection kernel stores its records directly (A/B of the LDS staging)
 static bool stage_records_enabled()
 {
@@ -275,13 +291,7 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
     g.stage_records = 0;
     const size_t hist = (size_t)((num_tiles + 3) & ~3) * sizeof(uint32_t);
     const size_t staged = hist + (size_t)(BIN_THREADS / 64) * 64 * REC_FLOATS * sizeof(float);
-    if (use_grouped_binning(num_tiles)) {
-        static int big_lds = -1;  // (one attribute call; benign if raced)
-        if (big_lds < 0)
-            big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&preprocess_fwd_grouped_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        g.stage_records = (big_lds == 1 && staged <= 160 * 1024 && stage_records_enabled()) ? 1 : 0;
-    }
+    g.stage_records = preprocess_stages_records(num_tiles) ? 1 : 0;
     if (sh_lds)
         hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(color_blocks), dim3(PRE_BLOCK),
                            (size_t)PRE_BLOCK * SH_STRIDE * sizeof(float), stream, g);

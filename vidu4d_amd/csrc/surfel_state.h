@@ -268,6 +268,8 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
 //   msd_split     -- every list beyond 1024 entries is split on its leading differing depth bits, the buckets sorted in LDS;
 //   one_workgroup -- a 16-wave workgroup per long list through global memory, the rest in LDS.
 enum class LongListSort { in_lds_only, msd_split, one_workgroup };
+// true when launch_preprocess_fwd stages its records (and leaves centre / depth / radius per surfel in GeomState::colour)
+bool preprocess_stages_records(int num_tiles);
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
                       int64_t capacity, LongListSort mode, hipStream_t stream);
 // split: blend tiles longer than SPLIT_MIN segment-parallel (three launches instead of one)
