@@ -112,6 +112,19 @@ def test_general_view_matrix(gpu_device):
     _check_backward(sc, st, d, shs, cols, out, gpu_device)
 
 
+def test_many_tiles_take_the_unstaged_projection_path(gpu_device):
+    """12 800 tiles (2048 x 1600): the tile histogram and the per-wave record staging of the projection kernel no longer
+    fit the workgroup's 160 KiB of LDS together, so the records are stored directly, the colour kernel writes its quarter of
+    the record itself and emit_keys reads the records (the path every image took before round 3; smaller images stage).
+    Same parity as everywhere else."""
+    sc = make_scene(2500, 2048, 1600, seed=57, sigma_px=6.0)
+    assert ((sc.width + 15) // 16) * ((sc.height + 15) // 16) * 4 + 16 * 64 * 28 * 4 > 160 * 1024
+    st = oracle_forward(sc)
+    d, shs, cols, out = _native_forward(sc, gpu_device)
+    _check_forward(sc, st, out)
+    _check_backward(sc, st, d, shs, cols, out, gpu_device)
+
+
 def test_colors_precomp_path(gpu_device):
     sc = make_case("small")
     g = torch.Generator().manual_seed(3)
