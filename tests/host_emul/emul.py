@@ -65,3 +65,20 @@ def run(st, dL_dcolor, dL_dothers, cull=True, lite=False):
                           _p(g["dL_drotations"]))
     out["grads"] = g
     return out
+
+
+def footprint_scan(st):
+    """Per (visible surfel, 8x8 quadrant): the rectangle form of the footprint test the blend kernels run against the exact
+    pair test and the per-pixel form, over the whole image -> counts (see host_emul.cpp: emul_footprint_scan)."""
+    L = lib()
+    inp = st["_inputs"]
+    P, D, M, W, H = st["P"], st["D"], st["M"], st["W"], st["H"]
+    radii, tiles, rec = np.zeros(P, np.int32), np.zeros(P, np.uint32), np.zeros((P, 28), np.float32)
+    L.emul_preprocess(C.c_int(P), C.c_int(D), C.c_int(M), _p(inp["means3D"]), _p(inp["scales"]), _p(inp["rotations"]),
+                      _p(inp["opacities"]), _p(inp["shs"]), _p(inp["colors_precomp"]), _p(inp["viewmatrix"]),
+                      _p(inp["campos"]), C.c_int(W), C.c_int(H), C.c_float(st["tanfovx"]), C.c_float(st["tanfovy"]),
+                      _p(radii), _p(tiles), _p(rec))
+    counts = np.zeros(5, np.int64)
+    L.emul_footprint_scan(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(rec), _p(counts))
+    return dict(kept=int(counts[0]), contributing=int(counts[1]), dropped_contributing=int(counts[2]),
+                kept_between_pixel_centres=int(counts[3]), box_would_keep=int(counts[4]))

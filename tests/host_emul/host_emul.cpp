@@ -2,6 +2,7 @@
 // (vidu4d_amd/csrc/surfel_math.h) for the host and runs it through sequential loops that stand in
 // for the kernels' thread grids, so that the formulas can be checked against the oracle on a box
 // without a GPU.  It is never loaded by the product package; it is not a fallback.
+#include <algorithm>
 #include <stdint.h>
 #include <string.h>
 #include <vector>
@@ -46,6 +47,49 @@ extern "C" void emul_preprocess(int P, int D, int M, const float* means3D, const
         memcpy(&r[R_CLAMP], &mask, 4);
         contribution_footprint(o.T, o.center[0], o.center[1], opacities[i], r + R_FOOT);
         radii[i] = o.radius; tiles[i] = o.tiles;
+    }
+}
+
+// For every visible surfel and every 8x8 quadrant of the image: does footprint_hits say the quadrant's rectangle of pixel
+// centres can be reached, and does some pixel of it pass the exact pair test (eval_pair) / the per-pixel footprint test?
+// counts[0] quadrants the rectangle test keeps, [1] quadrants with a pixel that passes eval_pair, [2] quadrants with such a
+// pixel that the rectangle test DROPS (must be 0: not conservative), [3] quadrants the rectangle test keeps although no
+// pixel centre passes even the per-pixel footprint test (slack of the rectangle test over its own per-pixel form: the
+// footprint passing between pixel centres), [4] quadrants the bounding box of the footprint's per-pixel hits reaches
+// (what a box test keeps at best).
+extern "C" void emul_footprint_scan(int P, int W, int H, const int32_t* radii, const float* rec, long long* counts)
+{
+    for (int k = 0; k < 5; k++) counts[k] = 0;
+    const int qx = (W + 7) / 8, qy = (H + 7) / 8;
+    std::vector<unsigned char> pass(qx * qy), foot(qx * qy);
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        const float* r = rec + (size_t)i * REC_FLOATS;
+        const FootprintTest ft = footprint_test(r + R_FOOT, r[R_CX], r[R_CY]);
+        std::fill(pass.begin(), pass.end(), 0);
+        std::fill(foot.begin(), foot.end(), 0);
+        int bx0 = qx, bx1 = -1, by0 = qy, by1 = -1;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float pixx = (float)x + 0.5f, pixy = (float)y + 0.5f;
+                PairEval e;
+                if (eval_pair(r + R_TU, r + R_TV, r + R_TW, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e)) pass[(y / 8) * qx + x / 8] = 1;
+                if (footprint_hits(ft, pixx, pixx, pixy, pixy)) {
+                    foot[(y / 8) * qx + x / 8] = 1;
+                    bx0 = std::min(bx0, x / 8); bx1 = std::max(bx1, x / 8);
+                    by0 = std::min(by0, y / 8); by1 = std::max(by1, y / 8);
+                }
+            }
+        for (int b = 0; b < qy; b++)
+            for (int a = 0; a < qx; a++) {
+                const float x0 = (float)(a * 8) + 0.5f, y0 = (float)(b * 8) + 0.5f;
+                const bool hit = footprint_hits(ft, x0, x0 + 7.0f, y0, y0 + 7.0f);
+                counts[0] += hit;
+                counts[1] += pass[b * qx + a];
+                counts[2] += pass[b * qx + a] && !hit;
+                counts[3] += hit && !foot[b * qx + a];
+                counts[4] += a >= bx0 && a <= bx1 && b >= by0 && b <= by1;
+            }
     }
 }
 

@@ -63,6 +63,28 @@ def test_contribution_footprint_is_conservative(seed):
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("seed,sigma", [(1, 1.5), (2, 4.0), (3, 12.0)])
+def test_quadrant_form_of_the_footprint_test(seed, sigma):
+    """footprint_hits on the 8x8 quadrants' rectangles of pixel centres (the form the blend kernels' staging runs: the
+    conic's quadratic form minimised over the rectangle, edge by edge), host-compiled, for every visible surfel and every
+    quadrant of the image: never drops a quadrant with a contributing pixel, keeps next to nothing beyond the quadrants its
+    own per-pixel form reaches (the footprint passing between pixel centres), and keeps clearly fewer quadrants than the
+    footprint's bounding box would."""
+    import torch
+    from vidu4d_amd.synthetic import make_scene
+    sc = make_scene(400, 96, 80, seed=200 + seed, sigma_px=sigma)
+    g = torch.Generator().manual_seed(seed)
+    sc.scales[::3, 1] *= 0.15                       # elongated footprints: where a box has the most slack
+    q = torch.randn(sc.rotations.shape, generator=g)
+    sc.rotations = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    st = oracle_forward(sc)
+    c = emul.footprint_scan(st)
+    assert c["contributing"] > 300 and c["dropped_contributing"] == 0, c
+    assert c["kept"] >= c["contributing"]
+    assert c["kept_between_pixel_centres"] <= 0.08 * c["kept"], c
+    assert c["kept"] <= 0.95 * c["box_would_keep"], c
+
+
 @pytest.mark.parametrize("case", ["ragged", "deg2", "huge", "init_opacity"])
 def test_alpha_only_instances_equal_the_full_math_on_zero_planes(case):
     """The LITE instances of the blend arithmetic (fwd_accumulate<true>, bwd_pair_core<true>, bwd_pair_geometry<true>:
