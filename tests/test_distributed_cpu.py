@@ -93,6 +93,79 @@ def test_frame_parallel_two_ranks_gloo():
     assert out[0][4] == out[1][4]
 
 
+def _net_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+        from vidu4d_amd.lab4d.stage3 import Stage3Trainer
+        rng = np.random.default_rng(0)
+        torch.manual_seed(0)
+        m = DeformableSurfels(dict(fg_motion="gs-bob", gs_optim_warp=True, num_rounds=2, iters_per_round=3,
+                                   optim_warp_neus_iters=4), num_frames=8, device="cpu")
+        m.init_from_points(rng.normal(size=(150, 3)).astype(np.float32) * 0.1, rng.uniform(size=(150, 3)).astype(np.float32))
+        tr = Stage3Trainer(m)
+        assert tr.optim_warp and len(tr._net_params) > 0
+        m.active_sh_degree = 3                       # all rest rows live: nothing is packed
+        tr.begin_gradients()
+        nets = {id(p) for p in tr._net_params}
+        untouched = tr._net_params[-1]               # a network parameter no loss reaches this step: grad stays None
+
+        def frame_grads(r):
+            gg = torch.Generator().manual_seed(300 + r)
+            return [torch.randn(q.shape, generator=gg) * 1e-3 for q in tr.exchanged_params()]
+        for p, gr in zip(tr.exchanged_params(), frame_grads(rank)):
+            if p is untouched:
+                continue
+            if id(p) in nets:
+                p.grad = gr.clone()
+            else:
+                p.grad.copy_(gr)                     # (the surfel gradients are views of the flat buffer)
+        tr.allreduce_gradients()
+        # three collectives' worth of layout: [small tensors][f_rest][networks]
+        assert 0 < tr._chunk_split < tr._net_split < tr._flat.numel()
+        all_g = [frame_grads(r) for r in range(world)]
+        ok = True
+        for i, p in enumerate(tr.exchanged_params()):
+            if p is untouched:
+                ok = ok and p.grad is None
+                continue
+            want = sum(all_g[r][i] for r in range(world)) / world
+            ok = ok and torch.allclose(p.grad, want, atol=1e-7)
+        # a second step of the round: the networks' gradients ADD up (upstream never zeroes them inside a round), the
+        # surfels' are fresh
+        tr.current_steps += 1                        # (step 1 of a round of 3: no zero_grad of the networks)
+        tr.begin_gradients()
+        for p, gr in zip(tr.exchanged_params(), frame_grads(rank)):
+            if p is untouched:
+                continue
+            if id(p) in nets:
+                p.grad = gr.clone()
+            else:
+                p.grad.copy_(gr)
+        tr.allreduce_gradients()
+        for i, p in enumerate(tr.exchanged_params()):
+            if p is untouched:
+                continue
+            want = sum(all_g[r][i] for r in range(world)) / world
+            ok = ok and torch.allclose(p.grad, (2.0 if id(p) in nets else 1.0) * want, atol=2e-7)
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_with_trainable_networks_two_ranks_gloo():
+    """--gs_optim_warp=True: the networks' per-step gradients travel as a third chunk of the flat buffer behind the small
+    surfel tensors and the SH rest bands, come back as the mean over the ranks, are ADDED to the round's accumulated
+    gradient (upstream's never-zeroed .grad), and a parameter no loss reached keeps grad None on every rank."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_net_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world and all(out[r] for r in range(world))
+
+
 # ---------------------------------------------------------------------------------------------
 class _TorchRasterizer(torch.nn.Module):
     """CPU stand-in for the HIP rasterizer in THIS TEST ONLY: the pure-PyTorch oracle render
