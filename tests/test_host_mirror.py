@@ -406,3 +406,34 @@ def test_relative_segment_blend_algorithm_in_numpy():
         assert repaired == expect_repair, (n, a_max, T0)
         assert last1 == last0 and (repaired or last0 == n)
         assert abs(T1 - T0) <= 2e-6 * T0 and np.abs(C1 - C0).max() <= 2e-6 * np.abs(C0).max()
+
+
+def test_modelled_scaling_arithmetic():
+    """bench.py's MODELLED multi-GPU figures (no node to measure them on): the all-reduce cost model and the two ways a step
+    pays for it -- plain arithmetic, pinned here so that the numbers on the bench line mean what BASELINE.md says."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    S = 200_000 * 58 * 4
+    assert b.exchange_model_ms(S, 1) == {"ring_one_link": 0.0, "ring_all_links": 0.0, "direct_rs_ag": 0.0}
+    e8 = b.exchange_model_ms(S, 8)
+    # ring over one link per hop: 2 (n-1)/n S bytes at 153 GB/s + two 20 us phases
+    assert abs(e8["ring_one_link"] - (2 * 7 / 8 * S / 153e9 * 1e3 + 0.04)) < 1e-9
+    assert e8["direct_rs_ag"] < e8["ring_all_links"] < e8["ring_one_link"]
+    # two GPUs have one link between them: the "all links" ring is the one-link ring
+    e2 = b.exchange_model_ms(S, 2)
+    assert abs(e2["ring_all_links"] - e2["ring_one_link"]) < 1e-12
+    serial = b.scaling_model(1.5, S, overlapped=False)["8"]
+    over = b.scaling_model(1.5, S, overlapped=True)["8"]
+    assert over["ring_all_links"] == 8.0 and 6.0 < serial["ring_all_links"] < 8.0
+    assert abs(serial["ring_all_links"] - round(8 * 1.5 / (1.5 + e8["ring_all_links"]), 2)) < 1e-9
+    # the fitting step as Stage3Trainer issues its exchange: only what of the SH bands' collective outlasts the warp's backward,
+    # plus the small tensors' collective, is serial -- never worse than everything serial, never better than free
+    fit = b.fit_scaling_model(1.5, 200_000)["8"]
+    for k in ("ring_one_link", "ring_all_links", "direct_rs_ag"):
+        assert serial[k] <= fit[k] <= 8.0
+    small = b.exchange_model_ms(200_000 * 13 * 4 + 12, 8)["ring_all_links"]
+    rest = b.exchange_model_ms(200_000 * 45 * 4, 8)["ring_all_links"]
+    assert abs(fit["serial_exchange_ms"]["ring_all_links"] - round(max(0.0, rest - b.WARP_BACKWARD_MS) + small, 3)) < 1e-9
