@@ -93,6 +93,28 @@ extern "C" void emul_footprint_scan(int P, int W, int H, const int32_t* radii, c
     }
 }
 
+// (debug aid of the fuzz tool) the first `cap` (surfel, x, y) whose pixel passes eval_pair but not the per-pixel footprint test
+extern "C" int emul_footprint_misses(int P, int W, int H, const int32_t* radii, const float* rec, int cap, int32_t* out)
+{
+    int n = 0;
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        const float* r = rec + (size_t)i * REC_FLOATS;
+        const FootprintTest ft = footprint_test(r + R_FOOT, r[R_CX], r[R_CY]);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float pixx = (float)x + 0.5f, pixy = (float)y + 0.5f;
+                PairEval e;
+                if (eval_pair(r + R_TU, r + R_TV, r + R_TW, r[R_CX], r[R_CY], r[R_OPAC], pixx, pixy, e) &&
+                    !footprint_hits(ft, pixx, pixx, pixy, pixy)) {
+                    if (n < cap) { out[3 * n] = i; out[3 * n + 1] = x; out[3 * n + 2] = y; }
+                    n++;
+                }
+            }
+    }
+    return n;
+}
+
 extern "C" void emul_render_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec,
                                 const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                                 float* out_others, int cull, int lite)

@@ -494,15 +494,65 @@ SURFEL_HD bool eval_pair_flat(const float Tu[3], const float Tv[3], const float 
 #endif
 constexpr float BOX_MARGIN_PX = SURFEL_BOX_MARGIN_PX;
 
+// Conservative pixel-space box of the same region (rounds 1-2's cull; round 3: the fallback where fp32 cannot hold the
+// conic to the margin): {rho2d <= rc} is a disc around the projected centre, {rho3d <= rc} the projection of the
+// splat-space disc of radius sqrt(rc), whose exact screen AABB follows from the homography like the reference's 1-sigma
+// box (forward.cu:133-163) with the first two columns scaled by sqrt(rc) -- evaluated relative to the projected centre.
+// If that conic is not an ellipse in front of the camera plane the box is unbounded.
+SURFEL_HD void contribution_box(const float T[9], float cx, float cy, float opacity, float box[4])
+{
+    const float BIG = 3.0e38f;
+    const float oa = opacity * 255.0f;
+    if (!(oa >= 1.0f)) {  // can never reach alpha >= 1/255 (also catches NaN)
+        box[0] = box[1] = BIG;
+        box[2] = box[3] = -BIG;
+        return;
+    }
+    const float rc = 2.0f * logf(oa) * 1.0001f + 1e-4f;
+    const float r2 = sqrtf(0.5f * rc);
+    float x0 = cx - r2, x1 = cx + r2, y0 = cy - r2, y1 = cy + r2;
+    // centred homography rows: screen coordinates relative to (cx, cy)
+    const float Tw0 = T[6], Tw1 = T[7], Tw2 = T[8];
+    const float Ux = T[0] - cx * Tw0, Uy = T[1] - cx * Tw1, Uz = T[2] - cx * Tw2;
+    const float Vx = T[3] - cy * Tw0, Vy = T[4] - cy * Tw1, Vz = T[5] - cy * Tw2;
+    const float d = rc * (Tw0 * Tw0 + Tw1 * Tw1) - Tw2 * Tw2;
+    if (d < -1e-3f * Tw2 * Tw2) {
+        const float f = 1.0f / d;
+        const float ex = f * (rc * (Ux * Tw0 + Uy * Tw1) - Uz * Tw2);
+        const float ey = f * (rc * (Vx * Tw0 + Vy * Tw1) - Vz * Tw2);
+        const float hx2 = ex * ex - f * (rc * (Ux * Ux + Uy * Uy) - Uz * Uz);
+        const float hy2 = ey * ey - f * (rc * (Vx * Vx + Vy * Vy) - Vz * Vz);
+        const float hx = sqrtf(fmaxf(hx2, 0.f)), hy = sqrtf(fmaxf(hy2, 0.f));
+        if (hx == hx && hy == hy && ex == ex && ey == ey) {
+            x0 = fminf(x0, cx + ex - hx);
+            x1 = fmaxf(x1, cx + ex + hx);
+            y0 = fminf(y0, cy + ey - hy);
+            y1 = fmaxf(y1, cy + ey + hy);
+        } else {
+            x0 = y0 = -BIG;
+            x1 = y1 = BIG;
+        }
+    } else {
+        x0 = y0 = -BIG;
+        x1 = y1 = BIG;
+    }
+    const float mx = BOX_MARGIN_PX + 2e-3f * (x1 - x0), my = BOX_MARGIN_PX + 2e-3f * (y1 - y0);
+    box[0] = x0 - mx;
+    box[1] = y0 - my;
+    box[2] = x1 + mx;
+    box[3] = y1 + my;
+}
+
 // The footprint for the blend kernels' per-quadrant culls (round 3; rounds 1-2 used its bounding box).
 // rho3d <= rc is a conic in the pixel plane: with k = x Tw - Tu, l = y Tw - Tv the intersection is s = (n_x, n_y) / n_z,
 // n = k x l = Tu x Tv + x (Tv x Tw) + y (Tw x Tu) -- LINEAR in the pixel -- so rho3d <= rc <=> n_x^2 + n_y^2 - rc n_z^2 <= 0,
 // a quadratic Q(x, y).  Where that is an ellipse it is stored by its centre and its form in offsets from the centre,
 // scaled so that the inside is q(du, dv) = A du^2 + 2 B du dv + C dv^2 <= 1:
 //   f[0..2] = A, B, C   f[3] = squared radius of the rho2d disc around the projected centre (with the margin)
-//   f[4], f[5] = conic centre minus projected centre   f[6] = limit q is compared with: 1 + margin; 3e38 where the
-//   conic is not a (numerically clear) ellipse: every rectangle hits; -1 (and f[3] = -1) where alpha >= 1/255 is
-//   out of reach: nothing hits.
+//   f[4], f[5] = conic centre minus projected centre   f[6] = limit q is compared with: 1 + margin; -1 (and
+//   f[3] = -1) where alpha >= 1/255 is out of reach: nothing hits; -2 where the conic is not an ellipse that fp32 holds
+//   to the margin (thin, far away, or not an ellipse at all): f[0..3] are then the contribution box x0 y0 x1 y1 above
+//   (absolute pixel coordinates; it covers the disc too).
 // Everything is evaluated relative to the projected centre (fp32 cancellation far below the margins: 1 % on q, i.e.
 // 0.5 % on the axes, and BOX_MARGIN_PX on the rectangle).  This only prunes work, like the box.
 SURFEL_HD void contribution_footprint(const float T[9], float cx, float cy, float opacity, float f[8])
@@ -518,7 +568,15 @@ SURFEL_HD void contribution_footprint(const float T[9], float cx, float cy, floa
     const float rc = 2.0f * logf(oa) * 1.0001f + 1e-4f;
     const float rd = sqrtf(0.5f * rc) + BOX_MARGIN_PX;
     f[3] = rd * rd;
-    f[6] = BIG;
+    {   // until the ellipse below is accepted: the box
+        float box[4];
+        contribution_box(T, cx, cy, opacity, box);
+        f[0] = box[0];
+        f[1] = box[1];
+        f[2] = box[2];
+        f[3] = box[3];
+        f[6] = -2.0f;
+    }
     const float* Tu = T;
     const float* Tv = T + 3;
     const float* Tw = T + 6;
@@ -534,17 +592,30 @@ SURFEL_HD void contribution_footprint(const float T[9], float cx, float cy, floa
     const float E = m0[0] * c2[0] + m0[1] * c2[1] - rc * m0[2] * c2[2];
     const float F = m0[0] * m0[0] + m0[1] * m0[1] - rc * m0[2] * m0[2];
     const float det = A * C - B * B;
-    if (!(A > 0.f && C > 0.f && det > 1e-5f * A * C)) return;  // not an ellipse, or too thin to trust: every rectangle hits
+    if (!(A > 0.f && C > 0.f && det > 1e-5f * A * C)) return;  // not an ellipse: the box
     const float uc = (E * B - D * C) / det, vc = (D * B - E * A) / det;
-    const float K = -(F + D * uc + E * vc);  // -Q at the centre: > 0 inside
+    // -Q at the centre (> 0 inside), from n(centre) itself: F + D uc + E vc is the same number, but with a conic centre
+    // thousands of pixels from the projected centre (huge, strongly foreshortened surfels) its terms are 1e5 times their
+    // sum and fp32 left K 7 % off -- found by tools/fuzz_footprint_cpu.py, two scenes in sixty
+    const float nc[3] = {m0[0] + uc * c1[0] + vc * c2[0], m0[1] + uc * c1[1] + vc * c2[1], m0[2] + uc * c1[2] + vc * c2[2]};
+    const float K = rc * nc[2] * nc[2] - (nc[0] * nc[0] + nc[1] * nc[1]);
+    (void)F;
     const float ik = 1.0f / K;
     const float a = A * ik, b = B * ik, c = C * ik;
-    if (!(K > 0.f) || !(a == a && b == b && c == c && uc == uc && vc == vc) || !(a < BIG && c < BIG) ||
-        !(fabsf(uc) < 1e6f && fabsf(vc) < 1e6f))
-        return;
+    if (!(K > 0.f) || !(a == a && b == b && c == c && uc == uc && vc == vc) || !(a < BIG && c < BIG)) return;
+    // can fp32 hold the 1 % margin?  b2: squared minor semi-axis (>= 1 / trace of the form).  The centre comes out of a
+    // system with condition A C / det, so it is off by ~ 2e-7 cond |centre| px, which moves q at the boundary by twice that
+    // over the minor semi-axis; and where q ~ 1 along the length of a rotated ellipse its three terms are ~ (a / b)^2 =
+    // trace^2 / det of the form each.  Thin or far-away ellipses (a third fuzz scene: axes 370 : 1, centre 3e5 px away) fail
+    // these: the box
+    const float b2 = 1.0f / (a + c);
+    const float cdist = fmaxf(fabsf(uc), fabsf(vc));
+    const float centre_err = 2e-7f * (A * C / det) * (cdist + 1.0f);
+    if (!(centre_err * centre_err < 4e-6f * b2) || !((a + c) * (a + c) < 1.5e4f * (a * c - b * b))) return;
     f[0] = a;
     f[1] = b;
     f[2] = c;
+    f[3] = rd * rd;
     f[4] = uc;
     f[5] = vc;
     f[6] = 1.01f;
@@ -577,6 +648,7 @@ SURFEL_HD FootprintTest footprint_test(const float f[8], float cx, float cy)
 
 SURFEL_HD bool footprint_hits(const FootprintTest& t, float x0, float x1, float y0, float y1)
 {
+    if (t.lim == -2.0f) return !(t.C < x0 || t.A > x1 || t.rd2 < y0 || t.B > y1);  // box mode: A B C rd2 = x0 y0 x1 y1
     const float ddx = fmaxf(fmaxf(x0 - t.cx, t.cx - x1), 0.f), ddy = fmaxf(fmaxf(y0 - t.cy, t.cy - y1), 0.f);
     const float u0 = x0 - t.ecx - BOX_MARGIN_PX, u1 = x1 - t.ecx + BOX_MARGIN_PX;
     const float v0 = y0 - t.ecy - BOX_MARGIN_PX, v1 = y1 - t.ecy + BOX_MARGIN_PX;
