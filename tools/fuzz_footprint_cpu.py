@@ -1,7 +1,7 @@
 """CPU fuzz of the blend culls' footprint test (no GPU): the product's arithmetic header compiled for the host
 (tests/host_emul) renders random scenes with the test applied PER PIXEL and without it; images, contributor counts and
 gradient accumulators must be bit-identical, and the quadrant form must never drop a contributing quadrant.
-Usage: python tools/fuzz_footprint_cpu.py [scenes] [seed]"""
+Usage: python tools/fuzz_footprint_cpu.py [scenes] [seed] [large]"""
 import os, sys
 import numpy as np
 import torch
@@ -12,10 +12,15 @@ from tests.util import oracle_forward
 from vidu4d_amd.synthetic import make_object_scene, make_scene, make_upstream_grads
 
 
-def random_scene(rng):
-    """One fuzz scene: size, footprint scale, orientation, near-plane fraction and opacity drawn from wide ranges."""
-    W, H = int(rng.choice([48, 80, 112, 160])), int(rng.choice([48, 64, 96]))
-    N = int(rng.choice([300, 800, 2000]))
+def random_scene(rng, large=False):
+    """One fuzz scene: size, footprint scale, orientation, near-plane fraction and opacity drawn from wide ranges.
+    large: image sizes up to 1920 x 1080 (pixel coordinates in the thousands), fewer surfels."""
+    if large:
+        W, H = [(512, 384), (1024, 512), (1920, 1080)][int(rng.integers(3))]
+        N = int(rng.choice([100, 250]))
+    else:
+        W, H = int(rng.choice([48, 80, 112, 160])), int(rng.choice([48, 64, 96]))
+        N = int(rng.choice([300, 800, 2000]))
     sp = float(rng.choice([0.15, 0.7, 1.5, 4.0, 12.0, 40.0]))
     seed = int(rng.integers(1 << 30))
     sc = (make_object_scene(N, W, H, radius=float(rng.choice([0.2, 0.6])), seed=seed, sigma_px=sp) if rng.random() < 0.4
@@ -48,8 +53,9 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     bad = 0
     tot = dict(kept=0, contributing=0, dropped_contributing=0, box_would_keep=0)
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     for i in range(n_scenes):
-        sc, what = random_scene(rng)
+        sc, what = random_scene(rng, large)
         same, c = check_scene(sc)
         for k in tot:
             tot[k] += c[k]
