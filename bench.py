@@ -111,20 +111,26 @@ def cpu_baseline(scene, n_images: int):
             "fwd_only_images_per_s": n_images / t_fwd}
 
 
-def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: int = 0, seed: int = 0, barrier=None):
+def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: int = 0, seed: int = 0, barrier=None,
+                  densify: bool = False):
     """Second figure of SURVEY.md 8(d): images/s of the FULL Stage-3 fitting step (bob LBS warp with frozen,
     randomly initialised warp / camera networks -> rasterize 2 frames -> losses -> backward -> gradient clip ->
     densification statistics -> Adam) on an object-centric synthetic sequence of the same size.
     start_step > 8000: the regularised regime of the second third of a Stage-3 run (lambda_normal on: all 8 planes
     through the blend kernels, depth / normal post-processing + normal-consistency term inside the loss kernels;
-    BASELINE.json configs[4] "depth/normal reg on")."""
+    BASELINE.json configs[4] "depth/normal reg on").
+    densify: BASELINE.json configs[2] as written -- "densify+prune on": the schedule's densify_and_prune every 100 steps
+    from step 500 on (lab4d/engine/trainer.py:549-572, gs/scene/gaussian_model.py:434-448) runs INSIDE the timed region
+    (start_step 501 and >= 300 steps: three events), on the device (csrc/optim.hip); the surfel count before / after is
+    reported."""
     import numpy as np
     from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
     from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     frames = 120
-    m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0), num_frames=frames, device=dev)
+    m = DeformableSurfels(dict(fg_motion="gs-bob") | ({} if densify else dict(densify_until_iter=0)), num_frames=frames,
+                          device=dev)
     d = rng.normal(size=(n_surfels, 3)).astype(np.float32)
     pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(n_surfels, 1)).astype(np.float32) ** (1 / 3)
     m.init_from_points(pts.astype(np.float32), rng.uniform(size=(n_surfels, 3)).astype(np.float32))
@@ -133,24 +139,40 @@ def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: i
         m.active_sh_degree = m.max_sh_degree   # (reached at step 3000)
         tr.current_steps = start_step
     batches = [synthetic_batch(m, [(2 * i) % frames, (2 * i + 1) % frames], H, W, seed=i) for i in range(8)]
-    for i in range(6):
+    warm = 20   # (capacity / segment-depth hints and the allocator settle over the first ~10 steps: with 6 warm-up steps
+    #             and 30 timed ones round 3's figure sat 18 % below what the same loop gives over 100 steps, tools/fit_profile.py)
+    for i in range(warm):
         tr.train_step(batches[i % 8])
+    if densify:
+        tr.current_steps = start_step   # (the warm-up steps do not count towards the cadence)
     torch.cuda.synchronize(dev)
     if barrier is not None:
         barrier()
+    n_before, events = int(m._xyz.shape[0]), []
     t0 = time.perf_counter()
     for i in range(steps):
+        n0 = int(m._xyz.shape[0])
         tr.train_step(batches[i % 8])
+        if densify and int(m._xyz.shape[0]) != n0:
+            events.append((tr.current_steps - 1, n0, int(m._xyz.shape[0])))
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
     regime = ("losses as the reference's --rgb_loss_only run before step 8000 (colour + silhouette, lambda_dist = 0), so the "
               "blend kernels run their colour + alpha-plane instances (aux_planes); the op-level `value` above drives all 8 planes"
               if start_step <= 8000 else
-              f"steps {start_step}.. of the schedule: normal-consistency regulariser on (lambda_normal = 0.05, model.py:817-842), "
-              "all 8 planes through the blend kernels, depth / normal post-processing inside the loss kernels")
-    return {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps, "seconds": dt * steps,
-            "config": f"{n_surfels} surfels in a unit ball 3 units from the camera, {W}x{H}, 25 bones, 120 frames, "
-                      "warp / camera networks frozen (--gs_optim_warp=False), densify off; " + regime}
+              f"steps {start_step}.. of the schedule: normal-consistency regulariser on (lambda_normal = 0.05, model.py:817-842) "
+              "with the upstream defaults lambda_dist = 0 and depth_ratio = 0, so only planes 0-4 (depth, alpha, normal) are read: "
+              "the blend kernels run their colour + planes-0-4 instances (aux_planes = AUX_GEOM; no median sample, no distortion "
+              "moments, no transmittance pre-pass), depth / normal post-processing inside the loss kernels")
+    out = {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps, "warmup_steps": warm,
+           "seconds": dt * steps,
+           "config": f"{n_surfels} surfels in a unit ball 3 units from the camera, {W}x{H}, 25 bones, 120 frames, "
+                     "warp / camera networks frozen (--gs_optim_warp=False), densify " + ("+ prune ON; " if densify else "off; ") + regime}
+    if densify:
+        out["surfels_before"], out["surfels_after"] = n_before, int(m._xyz.shape[0])
+        out["densification_events"] = [{"step": s, "surfels": [a, b]} for s, a, b in events]
+        out["steps_of_the_schedule"] = [start_step, start_step + steps]
+    return out
 
 
 # xGMI: 7 links per GPU, ~153 GB/s each (task statement / MI355X guide); one kernel-boundary-sized latency per collective phase
@@ -305,8 +327,10 @@ def main():
                                                             "(dsr.rasterize_frames, frame || tile keys); 0: one call per "
                                                             "frame, on separate HIP streams with --frame-streams 1")
     ap.add_argument("--repeats", type=int, default=5, help="further timed regions of --steps steps (median / p10 / p90)")
-    ap.add_argument("--fit-steps", type=int, default=30, help="steps of the full Stage-3 fitting loop timed for "
+    ap.add_argument("--fit-steps", type=int, default=60, help="steps of the full Stage-3 fitting loop timed for "
                                                               "\"fit_step\" and \"fit_step_geometry\" (0 = skip)")
+    ap.add_argument("--fit-densify-steps", type=int, default=320, help="steps of the fitting loop timed with densify + prune "
+                    "ON from step 501 of the schedule (three densification events; BASELINE.json configs[2] verbatim; 0 = skip)")
     ap.add_argument("--exchange", choices=["overlapped", "serial"], default="overlapped",
                     help="N > 1: overlapped = the step's all-reduce runs beside the next step's kernels (two gradient "
                          "buffers, joined before its buffer is reused: the op-level loop has no optimizer between steps); "
@@ -617,11 +641,11 @@ def main():
     lib = _lib.load()
     cnt = torch.zeros(16, dtype=torch.int64, device=dev)
     if rank == 0:
-        lib.vidu4d_surfel_blend_stats(cnt.data_ptr())
+        from vidu4d_amd import _C as _Cmod
+        _Cmod.count_next_walk(cnt)   # (per call: the step's first backward carries the counters)
     step()          # (every rank: the step carries the collective)
     sync()
     if rank == 0:
-        lib.vidu4d_surfel_blend_stats(None)
         c = [int(x) for x in cnt.tolist()]
         if c[1]:
             walk = {"list_entries_staged": c[0], "pair_evaluations": c[1], "evaluations_with_a_contributor": c[2],
@@ -727,6 +751,8 @@ def main():
         if world == 1 and args.fit_steps > 0:
             out["fit_step"] = fit_step_rate(dev, N, W, H, args.fit_steps)
             out["fit_step_geometry"] = fit_step_rate(dev, N, W, H, args.fit_steps, start_step=8001)
+            if args.fit_densify_steps > 0:
+                out["fit_step_densify"] = fit_step_rate(dev, N, W, H, args.fit_densify_steps, start_step=501, densify=True)
         if world == 1:
             # MODELLED multi-GPU figures (no multi-GPU node is reachable from the build box; the driver
             # measures the real curve when it has one): measured 1-GPU step + the all-reduce cost model above

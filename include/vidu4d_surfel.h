@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 16
+#define VIDU4D_SURFEL_ABI 17
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -133,10 +133,15 @@ typedef struct Vidu4dSurfelForwardArgs {
      * until its regularisers switch on, lab4d/engine/model.py:895-1012 with lambda_dist = lambda_normal = 0) the blend
      * carries colour, transmittance and the contributor count only: out_color and plane 1 are what the full blend
      * gives, bit for bit; the other planes come out as zeros, and the state kept for the backward holds no distortion
-     * moments and no median contributor.  Any other value: everything is computed. */
+     * moments and no median contributor.  When only planes 0-4 are named (any non-empty subset of VIDU4D_AUX_GEOM other
+     * than the alpha plane alone: depth, alpha, normal -- what the Stage-3 loop reads after step 8000 with the upstream
+     * defaults lambda_dist = 0 and depth_ratio = 0, lab4d/config.py:181, gs/arguments/__init__.py:68,
+     * lab4d/engine/model.py:817-842) the median sample and the distortion moments are not carried: out_color and planes
+     * 0-4 are the full blend's bit for bit, planes 5-7 come out as zeros.  Any other value: everything is computed. */
     int aux_planes;
     /* ---- segment-parallel blend without its transmittance pre-pass (extension; only with segment_split != 0 and
-     * aux_planes == VIDU4D_AUX_ALPHA, ignored otherwise).  != 0: every segment is blended from T = 1 and scaled by the
+     * aux_planes naming nothing beyond planes 0-4, ignored otherwise: the full blend's median sample depends on the exact
+     * start transmittance).  != 0: every segment is blended from T = 1 and scaled by the
      * product of its predecessors in the combine pass (colour is linear in the start transmittance; while a pixel stays
      * clear of the saturation threshold no decision depends on it), and the combine pass blends the one segment in which a
      * pixel comes within 0.1 % of the threshold (transmittance 1e-4) again, in list order, from the exact start: the
@@ -151,8 +156,20 @@ typedef struct Vidu4dSurfelForwardArgs {
      * memory (two launches: cheaper while the longest lists hold a few thousand entries).  Callers decide from word 2 of the
      * geometry buffer (the longest list of earlier frames). */
     int long_list_sort;
+    /* ---- debugging switches (ABI 17), bit mask, 0 in production:
+     * VIDU4D_DEBUG_NO_CULL: the blend kernels' footprint culls are off -- every list entry of a tile is evaluated for every
+     *   pixel of the tile, which is the reference's walk (forward.cu:359-405, backward.cu:282-323).  The culls only prune
+     *   work: outputs are bit-identical with and without (tests/test_gpu_cull_ab.py); hand the same flag to the backward.
+     * VIDU4D_DEBUG_WHOLE_TILE_BACKWARD (read by the backward only): after a forward with segment_split == 0 the backward
+     *   walks every tile with one workgroup, as the reference does (backward.cu:143-449).  Otherwise it walks the tiles
+     *   longer than 320 entries in 256-entry segments on separate workgroups, each starting from the per-pixel sums the
+     *   forward's own walk stored at the segment boundaries: same gradients up to fp32 re-association of those sums. */
+    int debug_flags;
 } Vidu4dSurfelForwardArgs;
 #define VIDU4D_AUX_ALPHA 0x02
+#define VIDU4D_AUX_GEOM 0x1F   /* planes 0-4: depth, alpha, normal */
+#define VIDU4D_DEBUG_NO_CULL 1
+#define VIDU4D_DEBUG_WHOLE_TILE_BACKWARD 2
 #define VIDU4D_SURFEL_MAX_FRAMES 8
 size_t vidu4d_surfel_image_bytes_frames(int width, int height, int frames);
 
@@ -221,8 +238,12 @@ typedef struct Vidu4dSurfelBackwardArgs {
     /* ---- planes of dL_dout_others that may be non-zero (0 = all).  VIDU4D_AUX_ALPHA: only dL_dout_color and plane 1 are
      * read -- the other planes are TAKEN as zero, whatever they hold -- and the depth / normal / median / distortion
      * chains they would multiply are skipped.  Must name every plane the forward's aux_planes did not compute: after a
-     * forward with VIDU4D_AUX_ALPHA the backward must be given VIDU4D_AUX_ALPHA too. */
+     * forward with VIDU4D_AUX_ALPHA the backward must be given VIDU4D_AUX_ALPHA too.  Planes 0-4 only (see the forward):
+     * planes 5-7 are taken as zero and the median / distortion chains are skipped; the gradients are the full backward's
+     * for such an input, bit for bit. */
     int aux_planes;
+    int debug_flags;                 /* as in the forward (same value there and here) */
+    void* diag_walk_counters;        /* NULL in production; see vidu4d_surfel_diag.h */
 } Vidu4dSurfelBackwardArgs;
 
 int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* args, void* stream);
@@ -247,22 +268,7 @@ enum Vidu4dSurfelStateArray {
 int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* args, const void* binning_buffer, int64_t capacity,
                              int what, void* dst, size_t dst_bytes, int64_t* count, void* stream);
 
-/* ---- per-stage timing with HIP events recorded on the launch stream (off by default).  Used by
- *      bench.py to measure each kernel's average launch duration inside the timed region; the
- *      reference has no equivalent (its only timing aid is torch.profiler around whole steps,
- *      lab4d/utils/profile_utils.py:113-161). ---- */
-int vidu4d_surfel_profile_enable(int on);
-/* Diagnostic: while device_counters (VIDU4D_BLEND_STATS u64, zeroed by the caller) is not NULL, every
- * vidu4d_surfel_backward call also counts what its tile walk looks like: [0] list entries staged, [1] (entry, wave)
- * pair evaluations, [2] those with a contributing lane, [3] contributing lanes, [4] 16-lane rows with a contributing
- * lane, [5..9] evaluations of [2] with <= 4 / 8 / 16 / 32 / 64 contributing lanes, [10] evaluations of [1] in which no
- * lane passes the pair test (the contribution box reaches the quadrant, the footprint does not).  [3] / (64 [1]) is the
- * lane utilisation bench.py's roofline note quotes. */
-#define VIDU4D_BLEND_STATS 11
-int vidu4d_surfel_blend_stats(unsigned long long* device_counters);
-int vidu4d_surfel_profile_stage_count(void);
-const char* vidu4d_surfel_profile_stage_name(int stage);
-int vidu4d_surfel_profile_read(double* total_ms /*[stage_count]*/, long long* count /*[stage_count]*/, int reset);
+/* (Diagnostics -- per-stage HIP-event timers, tile-walk counters -- are declared in vidu4d_surfel_diag.h.) */
 
 /* ---- quaternion ops: replace lab4d/third_party/quaternion/src/quaternion.cu
  *      (quaternion_mul :28-63 / :324-335, backward :66-140, backward-backward :143-214,

@@ -6,7 +6,10 @@ entries allowed beyond 1e-4 of the tensor's scale, largest error allowed on such
 profiles/r02_ref_parity.json), rounded up to two digits, with floors of 1e-4 and 5e-2.  They are threshold flips
 (alpha >= 1/255, T < 1e-4, T > 0.5, rho3d <= rho2d decided on an ill-conditioned cross product), not noise: the
 reference's two builds differ from each other by more than either differs from the oracle.  A kernel change that
-needs a number in here raised is a parity regression until proven otherwise; re-measuring does NOT move these."""
+needs a number in here raised is a parity regression until proven otherwise; re-measuring does NOT move these.
+"cfgE_full" (BASELINE.json configs[4] at its full size, 1 M surfels at 1920 x 1080) was first measured in round 4
+(profiles/r04_ref_parity.json) and frozen by the same rule; there the oracle and the product differ from the reference by
+the SAME amounts (each pixel blends four times the samples of the 250k slice: four times the threshold flips)."""
 
 # BUDGET[config][build][pair][tensor] = (outlier fraction, worst error of an outlier / scale)
 BUDGET = {
@@ -384,6 +387,40 @@ BUDGET = {
             },
         },
     },
+    "cfgE_full": {
+        "strict": {
+            "oracle_vs_ref": {
+                "color": (0.00013, 0.05), "others0": (0.00011, 0.05), "others1": (0.0001, 0.05),
+                "others2": (0.00066, 0.05), "others3": (0.00047, 0.05), "others4": (0.0004, 0.05),
+                "others5": (0.0001, 0.15), "others6": (0.95, 0.05), "others7": (0.00035, 1.4),
+                "dL_dmeans3D": (0.00028, 0.053), "dL_dmeans2D": (0.00021, 0.053), "dL_dopacity": (0.00029, 0.05),
+                "dL_dscales": (0.0007, 0.36), "dL_drotations": (0.00023, 0.05), "dL_dsh": (0.0001, 0.05),
+            },
+            "product_vs_ref": {
+                "color": (0.00013, 0.05), "others0": (0.00011, 0.05), "others1": (0.0001, 0.05),
+                "others2": (0.00066, 0.05), "others3": (0.00047, 0.05), "others4": (0.0004, 0.05),
+                "others5": (0.0001, 0.15), "others6": (0.93, 0.05), "others7": (0.00035, 1.4),
+                "dL_dmeans3D": (0.00028, 0.053), "dL_dmeans2D": (0.00021, 0.053), "dL_dopacity": (0.00029, 0.05),
+                "dL_dscales": (0.0007, 0.36), "dL_drotations": (0.00023, 0.05), "dL_dsh": (0.0001, 0.05),
+            },
+        },
+        "default": {
+            "oracle_vs_ref": {
+                "color": (0.0011, 0.05), "others0": (0.0011, 0.05), "others1": (0.0007, 0.05),
+                "others2": (0.0029, 0.059), "others3": (0.0022, 0.05), "others4": (0.0019, 0.05),
+                "others5": (0.0001, 0.15), "others6": (0.9, 0.05), "others7": (0.0011, 1.6),
+                "dL_dmeans3D": (0.00032, 0.052), "dL_dmeans2D": (0.00026, 0.053), "dL_dopacity": (0.00074, 0.05),
+                "dL_dscales": (0.0025, 0.36), "dL_drotations": (0.00029, 0.05), "dL_dsh": (0.0001, 0.05),
+            },
+            "product_vs_ref": {
+                "color": (0.0011, 0.05), "others0": (0.0011, 0.05), "others1": (0.0007, 0.05),
+                "others2": (0.0029, 0.059), "others3": (0.0022, 0.05), "others4": (0.0019, 0.05),
+                "others5": (0.0001, 0.15), "others6": (0.88, 0.05), "others7": (0.0011, 1.6),
+                "dL_dmeans3D": (0.00032, 0.052), "dL_dmeans2D": (0.00026, 0.053), "dL_dopacity": (0.00074, 0.05),
+                "dL_dscales": (0.0025, 0.36), "dL_drotations": (0.00029, 0.05), "dL_dsh": (0.0001, 0.05),
+            },
+        },
+    },
 }
 
 # A camera that is not Stage-3's (rigid view matrix off the identity, off-centre KCamera frustum; 60 k surfels, 384 x 288):
@@ -453,5 +490,12 @@ INTEGER = {
         "strict": {"oracle_vs_ref": (0.0002, 0.002), "product_vs_ref": (0.0002, 0.002)},
         "default": {"oracle_vs_ref": (0.39, 0.073), "product_vs_ref": (0.39, 0.073)},
     },
+    "cfgE_full": {   # (round 4: 95 of 4.1 M n_contrib entries in the strict build, 31.6 % / 3.6 % of the radii in the default one)
+        "strict": {"oracle_vs_ref": (0.0002, 0.002), "product_vs_ref": (0.0002, 0.002)},
+        "default": {"oracle_vs_ref": (0.64, 0.073), "product_vs_ref": (0.64, 0.073)},
+    },
 }
+# largest |radius difference| the default build shows (ceil(3 * extent) on a differently rounded extent): 1 everywhere but
+# at the full largest configuration, where one surfel in a million lands two apart -- for the oracle as for the product
+RADIUS_MAX_DELTA = {"cfgE_full": 2}
 INTEGER["world_kcam"] = {"strict": {"product_vs_ref": (0.0002, 0.002)}, "default": {"product_vs_ref": (0.11, 0.004)}}

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_header_symbols_exported():
     hdr = open(os.path.join(ROOT, "include", "vidu4d_surfel.h")).read()
-    declared = set(re.findall(r"\b(vidu4d_[a-z0-9_]+)\s*\(", hdr))
+    diag = open(os.path.join(ROOT, "include", "vidu4d_surfel_diag.h")).read()  # (diagnostics: not the drop-in boundary)
+    assert not re.findall(r"\b(vidu4d_surfel_profile_[a-z_]+)\s*\(", hdr), "diagnostics belong in vidu4d_surfel_diag.h"
+    declared = set(re.findall(r"\b(vidu4d_[a-z0-9_]+)\s*\(", hdr + diag))
     assert declared, "no declarations parsed"
     lib = _lib.load()
     for name in sorted(declared):

@@ -79,6 +79,48 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _partial_worker(rank, world, port, out):
+    """Some gradients already live in the flat buffer (views), others were handed over as tensors of their own: the
+    fallback of allreduce_gradients re-binds (zero-filling the buffer) and must not lose the former."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+        from vidu4d_amd.lab4d.stage3 import Stage3Trainer
+        rng = np.random.default_rng(0)
+        m = DeformableSurfels(dict(fg_motion="gs-bob"), num_frames=8, device="cpu")
+        torch.manual_seed(0)
+        m.init_from_points(rng.normal(size=(120, 3)).astype(np.float32) * 0.1, rng.uniform(size=(120, 3)).astype(np.float32))
+        tr = Stage3Trainer(m)
+        m.active_sh_degree = 3
+        tr.bind_flat_gradients()   # every .grad a view of the buffer
+        ps = tr.exchanged_params()
+
+        def frame_grads(r):
+            gg = torch.Generator().manual_seed(500 + r)
+            return [torch.randn(q.shape, generator=gg) * 1e-3 for q in ps]
+        own = {id(m._opacity), id(m._scaling), id(m._features_dc)}   # what a backward that was not adopted would leave
+        for p, gr in zip(ps, frame_grads(rank)):
+            if id(p) in own:
+                p.grad = gr.clone()          # a tensor of its own
+            else:
+                p.grad.copy_(gr)             # lives in the flat buffer
+        assert not all(tr._bound(p) for p in ps) and any(tr._bound(p) for p in ps)
+        tr.allreduce_gradients()
+        all_g = [frame_grads(r) for r in range(world)]
+        want = [sum(all_g[r][i] for r in range(world)) / world for i in range(len(ps))]
+        out[rank] = all(torch.allclose(p.grad, w, atol=1e-7) for p, w in zip(ps, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_from_a_partially_bound_gradient_state():
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_partial_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world and all(out[r] for r in range(world)), "gradients living in the flat buffer were lost"
+
+
 def test_frame_parallel_two_ranks_gloo():
     world = 2
     port = _free_port()

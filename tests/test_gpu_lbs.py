@@ -221,3 +221,32 @@ def test_lbs_skin_with_the_bone_map_equals_precomputed_coordinates(gpu_device, M
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max())), (what, float((a - b).abs().max()))
     with pytest.raises(RuntimeError, match="bone coordinates xbT OR the bone map"):
         lbs_skin_apply(None, None, (qr, qd), xyz, rot, cq, ct)
+
+
+@pytest.mark.parametrize("M,N,B", [(2, 700, 40), (1, 300, 64), (2, 500, 33)])
+def test_lbs_skin_more_than_32_bones_against_torch(gpu_device, M, N, B):
+    """lbs_skin_apply with a delta-skin term and MORE than 32 bones against the torch statement of the same chain
+    (softmax of -(|x_bone|^2 + 0.1 relu(raw)), blend, apply, camera): values and every gradient, g_raw of the bones
+    32..63 included -- the relu mask of the backward is one bit per bone (round 3 kept it in a 32-bit word; comparing two
+    instances of the kernel with each other, as the bone-map test does, could not see that)."""
+    from vidu4d_amd.lab4d.lbs_fused import lbs_skin_apply
+    dev = gpu_device
+    qr, qd, _, xyz, rot, cq, ct = _inputs(dev, M, N, B, seed=17 + B)
+    g = torch.Generator().manual_seed(3)
+    xbT0 = (0.7 * torch.randn(3 * B, N, generator=g)).to(dev)
+    raw0 = (3.0 * torch.randn(B, N, generator=g)).to(dev)     # about half of the logits positive, for every bone
+    gx, gr = torch.randn(M, N, 3, generator=g).to(dev), torch.randn(M, N, 4, generator=g).to(dev)
+    res = {}
+    for fused in (True, False):
+        xb, raw, x, r = (t.clone().requires_grad_(True) for t in (xbT0, raw0, xyz, rot))
+        if fused:
+            ox, orot = lbs_skin_apply(xb, raw, (qr, qd), x, r, cq, ct)
+        else:
+            logits = -((xb.view(B, 3, N) ** 2).sum(1) + 0.1 * torch.relu(raw)).t()
+            ox, orot = _composite((qr, qd), logits, x, r, cq, ct)
+        ((ox * gx).sum() + (orot * gr).sum()).backward()
+        res[fused] = [t.detach() for t in (ox, orot, xb.grad, raw.grad, x.grad, r.grad)]
+    for a, b, what in zip(res[True], res[False], ("xyz_cam", "rot_cam", "g_xbT", "g_raw", "g_xyz", "g_rot")):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max())), (what, float((a - b).abs().max()))
+    if B > 32:
+        assert float(res[False][3][32:].abs().max()) > 0, "the bones beyond 32 must carry a gradient for this to test anything"

@@ -1,14 +1,19 @@
 """GPU parity tests proper: the HIP path (through the C ABI, vidu4d_amd._C) against the CPU oracle on
 the same seeded inputs, stage by stage.  Integer / index outputs (radii, tile counts, sort keys,
 sorted surfel lists, tile ranges, contributor counts) must match bit-for-bit; floating-point
-outputs within 1e-4 of the output's scale (tests/util.py)."""
+outputs within 1e-5 of the output's scale (tests/util.py ORACLE_RTOL; north_star's 1e-4 is the bar against the reference)."""
 import numpy as np
 import pytest
 import torch
 
+import functools
+
 from oracle import surfel_oracle as so
-from tests.util import CASES, DIST_ATOL, assert_close, look_at_view, make_case, oracle_forward, to_np
+from tests.util import CASES, DIST_ATOL, ORACLE_RTOL, look_at_view, make_case, oracle_forward, to_np
+from tests.util import assert_close as _assert_close
 from vidu4d_amd.synthetic import make_scene, make_upstream_grads
+
+assert_close = functools.partial(_assert_close, rtol=ORACLE_RTOL)   # every comparison in this file is product vs oracle
 
 pytestmark = pytest.mark.gpu
 

@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Where does a blend_bwd launch spend its time?  (TEST / MEASUREMENT INFRASTRUCTURE; GPU box.)
+Needs the trace variant of the library -- tools/make_full_variant.sh trace "-DSURFEL_BWD_TRACE" -- swapped in for the
+product (tools/run_variants.sh does the same): every workgroup of blend_bwd then stores its start, end-of-prologue and
+end time (s_memrealtime, 10 ns), its CU / XCD and the list entries it walked.  Prints, for the headline step (two stacked
+frames) with recorded segments and with the whole-tile backward: workgroup counts and durations, prologue times, how many
+workgroups a CU holds over time, and how much of the launch runs with fewer than four.
+    python tools/bwd_trace.py [surfels] [res]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import diff_surfel_rasterization as dsr  # noqa: E402
+from vidu4d_amd import _C, _lib  # noqa: E402
+from vidu4d_amd.synthetic import frame_motion, make_scene, make_upstream_grads  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+F = 2
+dev = torch.device("cuda:0")
+scene = make_scene(N, W, None, seed=1234).to(dev)
+H = scene.height
+dc, do = (t.to(dev) for t in make_upstream_grads(W, H))
+frames = [frame_motion(scene, f, 120) for f in range(8)]
+rs = dsr.GaussianRasterizationSettings(H, W, scene.tanfovx, scene.tanfovy, scene.bg, 1.0, scene.viewmatrix, scene.projmatrix,
+                                       scene.sh_degree, scene.campos, False, False)
+dcs, dos = torch.stack([dc] * F, 1).contiguous(), torch.stack([do] * F, 1).contiguous()
+MAXWG = 1 << 16
+
+
+def step(k, trace=None):
+    ids = [(k * F + i) % 8 for i in range(F)]
+    m = torch.stack([frames[i].means3D for i in ids]).requires_grad_(True)
+    r = torch.stack([frames[i].rotations for i in ids]).requires_grad_(True)
+    leaves = [scene.shs.clone().requires_grad_(True), scene.opacities.clone().requires_grad_(True),
+              scene.scales.clone().requires_grad_(True)]
+    color, radii, allmap = dsr.rasterize_frames(m, torch.zeros_like(m, requires_grad=True), leaves[0], leaves[1], leaves[2], r,
+                                                [rs] * F)
+    if trace is not None:
+        _C.count_next_walk(trace)
+    torch.autograd.backward([color, allmap], [dcs, dos])
+
+
+for name, flags in (("recorded segments", 0), ("whole-tile backward", _lib.DEBUG_WHOLE_TILE_BACKWARD)):
+    with _C.debug_flags(flags):
+        for k in range(5):
+            step(k)
+        torch.cuda.synchronize()
+        trace = torch.zeros(4 * MAXWG, dtype=torch.int64, device=dev)
+        step(5, trace)
+        torch.cuda.synchronize()
+    t = trace.cpu().numpy().reshape(-1, 4)
+    t = t[t[:, 0] != 0]
+    t0, t1, t2 = (t[:, i].astype(np.float64) * 0.01 for i in range(3))   # microseconds
+    start = t0.min()
+    t0, t1, t2 = t0 - start, t1 - start, t2 - start
+    hw = t[:, 3]
+    cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (((hw >> 32) & 0xf) << 8)   # cu, sh, se, xcc
+    entries = (hw >> 40) & 0xffff
+    real = entries > 0
+    print(f"== {name}: {len(t)} workgroups ran ({int(real.sum())} with work), launch span {t2.max():.1f} us, "
+          f"{int(len(np.unique(cu)))} distinct CUs")
+    dur = t2 - t0
+    print(f"   empty workgroups: lifetime median {np.median(dur[~real]) if (~real).any() else 0:.2f} us, "
+          f"started between {t0[~real].min() if (~real).any() else 0:.1f} and {t0[~real].max() if (~real).any() else 0:.1f} us")
+    print(f"   working workgroups: prologue median {np.median((t1 - t0)[real]):.2f} us (p90 {np.percentile((t1 - t0)[real], 90):.2f}), "
+          f"lifetime median {np.median(dur[real]):.1f} us, max {dur[real].max():.1f}; us per list entry (lifetime / entries) median "
+          f"{np.median(dur[real] / entries[real]):.3f}")
+    # lifetime per entry by start time: how the sharing changes over the launch
+    order = np.argsort(t0[real])
+    q = np.array_split(order, 8)
+    print("   by start-time octile: start us, entries, us/entry:", [(round(float(np.median(t0[real][i])), 0), int(np.median(entries[real][i])),
+                                                                       round(float(np.median((dur[real] / entries[real])[i])), 3)) for i in q])
+    # residency per CU over time (working workgroups only)
+    grid = np.linspace(0, t2.max(), 200)
+    cus = np.unique(cu[real])
+    res = np.zeros((len(cus), len(grid)))
+    idx = {c: i for i, c in enumerate(cus)}
+    for a, b, c in zip(t0[real], t2[real], cu[real]):
+        res[idx[c], (grid >= a) & (grid < b)] += 1
+    mean_res = res.mean(0)
+    print("   mean working workgroups per CU over time (10 samples):", [round(float(x), 2) for x in mean_res[::20]])
+    frac_low = (res < 4).mean(0)
+    print("   fraction of CUs holding fewer than 4 working workgroups (10 samples):", [round(float(x), 2) for x in frac_low[::20]])
+    print(f"   time-averaged over the launch: {mean_res.mean():.2f} workgroups per CU; CU-time with < 4: {(res < 4).mean():.2%}, with < 2: {(res < 2).mean():.2%}")
+    last = np.array([t2[real][cu[real] == c].max() for c in cus])
+    print(f"   last workgroup of a CU ends at: min {last.min():.0f}, median {np.median(last):.0f}, max {last.max():.0f} us")

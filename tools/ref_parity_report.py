@@ -35,6 +35,7 @@ CONFIGS = {
     # BASELINE.json configs[4] is 1M surfels at 1920x1080; the CPU oracle walks it in ~1 min, so the report
     # uses a 250k-surfel slice of it at the full resolution (partial tiles: 1080 is not a multiple of 16)
     "cfgE_slice": dict(n=250_000, width=1920, height=1080, seed=1234),
+    "cfgE_full": dict(n=1_000_000, width=1920, height=1080, seed=1234),   # configs[4] itself (round 4)
 }
 from tests.util import CASES as SMALL_CASES  # noqa: E402
 for _n in ("tiny", "ragged", "small", "deg1", "subpixel", "huge", "init_opacity"):
@@ -99,9 +100,52 @@ def run_product(d, dc, do, W, Hh):
     return color2.detach(), allmap.detach(), grads, ints
 
 
+def budget_consumed(report, previous_path):
+    """Per configuration / build / pair: the largest fraction of a frozen budget (tests/ref_budgets.py) any tensor consumes
+    now -- outlier fraction over allowed fraction, worst error over allowed worst error -- next to the same number of an
+    earlier report.  (Budgets floor at 1e-4 / 5e-2, so small fractions are the rule.)"""
+    from tests.ref_budgets import BUDGET
+    prev = {}
+    if previous_path and os.path.exists(previous_path):
+        prev = json.load(open(previous_path))
+    out = {}
+
+    def consumed(rep, name, budget_name):
+        res = {}
+        for variant in ("strict", "default"):
+            if not isinstance(rep.get(name, {}).get(variant), dict):
+                continue
+            for pair in ("oracle_vs_ref", "product_vs_ref"):
+                fl = rep[name][variant][pair]["floats"]
+                bud = BUDGET.get(budget_name, {}).get(variant, {}).get(pair)
+                if not bud:
+                    continue
+                worst_t, worst_v = None, -1.0
+                for t, (bf, bw) in bud.items():
+                    if t not in fl:
+                        continue
+                    v = max(fl[t]["outlier_frac"] / bf, (fl[t]["worst_rel"] / bw) if fl[t]["outlier_frac"] > 0 else 0.0)
+                    if v > worst_v:
+                        worst_t, worst_v = t, v
+                res[f"{variant}/{pair}"] = {"max_fraction_of_budget": round(worst_v, 4), "tensor": worst_t}
+        return res
+
+    for name in report:
+        if name.startswith("_"):
+            continue
+        budget_name = name
+        now = consumed(report, name, budget_name)
+        before = consumed(prev, name, budget_name) if name in prev else {}
+        out[name] = {k: dict(v, previous=before.get(k, {}).get("max_fraction_of_budget")) for k, v in now.items()}
+        print("budget", name, json.dumps(out[name]), flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="tiny,ragged,small,deg1,subpixel,huge,init_opacity,mid,cfgA,cfgB,cfgE_slice")
+    ap.add_argument("--configs", default="tiny,ragged,small,deg1,subpixel,huge,init_opacity,mid,cfgA,cfgB,cfgE_slice,cfgE_full")
+    ap.add_argument("--previous", default=os.path.join(ROOT, "profiles", "r02_ref_parity.json"),
+                    help="an earlier report to print next to this one")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_parity.json"))
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -162,6 +206,7 @@ def main():
             "floats": compare_images(pc, po, pg, {"color": st["color"], "others": st["others"]}, og)}
         report[name] = entry
         print(name, json.dumps(entry)[:2000], flush=True)
+    report["_budget_consumed"] = budget_consumed(report, args.previous)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(report, open(args.out, "w"), indent=1)
     print("written", args.out)

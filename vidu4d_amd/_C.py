@@ -52,7 +52,37 @@ _unlimited: dict = {}
 # saturates in again from the exact start (round 3; until then a saturating frame raised Header::truncated and was
 # replayed with the pre-pass, so only callers that could replay speculated, and only on frames known not to saturate).
 _SPEC = os.environ.get("VIDU4D_SURFEL_SPEC", "1") == "1"
+# The same for the colour + planes-0-4 blend (AUX_GEOM): supported and tested, but OFF by default -- on the dense Stage-3
+# ball (200 k surfels, lists of ~5 k entries, every covered pixel saturates) the combine pass's serial repair of the
+# saturating segments costs more than the transmittance pre-pass it saves (blend_fwd + combine 250 + 311 us against
+# seg_T + blend_fwd + combine 148 + 255 + 50, profiles/r04_fit_step_geometry_kernel_stats*.csv).
+_SPEC_GEOM = os.environ.get("VIDU4D_SURFEL_SPEC_GEOM", "0") == "1"
 _pinned: dict = {}
+# Debugging switches (Vidu4dSurfel*Args::debug_flags).  VIDU4D_SURFEL_NO_CULL=1: the blend kernels' footprint culls are off
+# (every list entry is evaluated for every pixel of its tile, as the reference does); VIDU4D_SURFEL_WHOLE_TILE_BWD=1: the
+# backward of an unsplit forward walks every tile with one workgroup (no recorded segments).  Module attributes, so that a
+# test can A/B them inside one process.
+DEBUG_FLAGS = ((_lib.DEBUG_NO_CULL if os.environ.get("VIDU4D_SURFEL_NO_CULL", "0") == "1" else 0) |
+               (_lib.DEBUG_WHOLE_TILE_BACKWARD if os.environ.get("VIDU4D_SURFEL_WHOLE_TILE_BWD", "0") == "1" else 0))
+_walk_counters = None   # (device int64 tensor, one-shot): the next backward also counts its tile walk (vidu4d_surfel_diag.h)
+
+
+@contextlib.contextmanager
+def debug_flags(flags: int):
+    """with debug_flags(_lib.DEBUG_NO_CULL): ... -- forward AND backward inside run with these switches."""
+    global DEBUG_FLAGS
+    old, DEBUG_FLAGS = DEBUG_FLAGS, int(flags)
+    try:
+        yield
+    finally:
+        DEBUG_FLAGS = old
+
+
+def count_next_walk(counters):
+    """Diagnostic: the next rasterize_gaussians_backward call adds its tile-walk statistics to `counters`
+    (int64, >= _lib.BLEND_STATS entries, on the device, zeroed by the caller)."""
+    global _walk_counters
+    _walk_counters = counters
 
 
 def _ptr(t):
@@ -251,7 +281,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.background, a.means3D, a.shs, a.colors_precomp = _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors)
     if sh_rest is not None:
         a.shs, a.sh_dc, a.sh_rest = None, _ptr(sh), _ptr(sh_rest)
-    a.raw_params, a.aux_planes = int(bool(raw_params)), int(aux_planes)
+    a.raw_params, a.aux_planes, a.debug_flags = int(bool(raw_params)), int(aux_planes), int(DEBUG_FLAGS)
     a.opacities, a.scales, a.rotations = _ptr(opacity), _ptr(scales), _ptr(rotations)
     a.transMat_precomp = _ptr(transMat_precomp)
     a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
@@ -282,8 +312,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # long lists: the MSD split + bucket sorts from ~10 k entries per list on, one workgroup per list through global memory
     # below (dense Stage-3 ball, 5 k-entry lists: 81 us against 109; 3 %-coverage object, 25 k: 171 against 78)
     a.long_list_sort = 0 if _len_hint.get(key, 1 << 30) >= MSD_SORT_FROM else 1
-    if a.segment_split and int(aux_planes) == _lib.AUX_ALPHA and _SPEC:
-        a.assume_unsaturated = 1
+    if a.segment_split and ((int(aux_planes) == _lib.AUX_ALPHA and _SPEC) or
+                            (int(aux_planes) != _lib.AUX_ALPHA and int(aux_planes) and not (int(aux_planes) & ~_lib.AUX_GEOM)
+                             and _SPEC_GEOM)):
+        a.assume_unsaturated = 1   # (planes 0-4 at most: no median sample, nothing depends on the start transmittance)
 
     if P == 0:  # rasterize_points.cu:105: nothing is launched, outputs are zeros
         out_color.zero_()
@@ -467,7 +499,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         b.dL_dsh, b.dL_dsh_dc, b.dL_dsh_rest = None, dL_dsh[0].data_ptr(), dL_dsh[1].data_ptr()
     else:
         b.dL_dsh = _ptr(dL_dsh)
-    b.raw_params, b.aux_planes = int(bool(raw_params)), int(aux_planes)
+    b.raw_params, b.aux_planes, b.debug_flags = int(bool(raw_params)), int(aux_planes), int(DEBUG_FLAGS)
+    global _walk_counters
+    if _walk_counters is not None:
+        b.diag_walk_counters, keep_counters, _walk_counters = _walk_counters.data_ptr(), _walk_counters, None  # noqa: F841
     b.dL_dscales, b.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
     _lib.check(lib.vidu4d_surfel_backward(C.byref(b), _stream(dev)), "surfel backward")
     global _grad_written

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class ForwardArgs(C.Structure):
@@ -29,7 +29,7 @@ class ForwardArgs(C.Structure):
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
         ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("raw_params", C.c_int), ("aux_planes", C.c_int),
-        ("assume_unsaturated", C.c_int), ("long_list_sort", C.c_int),
+        ("assume_unsaturated", C.c_int), ("long_list_sort", C.c_int), ("debug_flags", C.c_int),
     ]
 
 
@@ -76,6 +76,9 @@ class Stage3LossGrads(C.Structure):
 
 SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
 AUX_ALPHA = 0x02  # VIDU4D_AUX_ALPHA
+AUX_GEOM = 0x1F   # VIDU4D_AUX_GEOM: planes 0-4 (depth, alpha, normal)
+DEBUG_NO_CULL, DEBUG_WHOLE_TILE_BACKWARD = 1, 2   # VIDU4D_DEBUG_*
+BLEND_STATS = 11  # VIDU4D_BLEND_STATS (vidu4d_surfel_diag.h)
 ADAM_MAX_TENSORS = 8
 CLIP_MAX_TENSORS = 16
 CLIP_WORKSPACE_FLOATS = 1056
@@ -99,7 +102,7 @@ class BackwardArgs(C.Structure):
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
         ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("dL_dsh_dc", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
-        ("raw_params", C.c_int), ("aux_planes", C.c_int),
+        ("raw_params", C.c_int), ("aux_planes", C.c_int), ("debug_flags", C.c_int), ("diag_walk_counters", C.c_void_p),
     ]
 
 
@@ -107,7 +110,6 @@ class BackwardArgs(C.Structure):
 _P = C.c_void_p
 SYMBOLS = {
     "vidu4d_surfel_abi_version": (C.c_int, []),
-    "vidu4d_surfel_blend_stats": (C.c_int, [_P]),
     "vidu4d_last_error": (C.c_char_p, []),
     "vidu4d_surfel_geom_bytes": (C.c_size_t, [C.c_int]),
     "vidu4d_surfel_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),

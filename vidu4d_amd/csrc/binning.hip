@@ -133,7 +133,11 @@ struct TileOrderShared {
     uint32_t any;
 };
 
-__device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_tiles, TileOrderShared& sh)
+// by_class (recorded segments): a tile is split iff its length CLASS lies above the class of split_min -- the split tiles
+// are then exactly the schedule positions [0, num_split_pos), which is what lets blend_bwd number the full segments and the
+// remainders separately (blend.hip find_work_recorded); every split tile is longer than split_min.
+__device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_tiles, TileOrderShared& sh, int seg_len,
+                                           int split_min, int by_class)
 {
     uint32_t* s_bin = sh.bin;
     uint32_t* s_scan = sh.scan;
@@ -172,18 +176,21 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
     for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tile_order[atomicAdd(&s_bin[bucket(t)], 1u)] = (uint32_t)t;
     __syncthreads();  // tile_order is read back below (same workgroup: the barrier orders the global accesses)
 
-    // Segment table for the tiles longer than SPLIT_MIN (blend.hip): exclusive prefix of their segment
+    // Segment table for the tiles longer than split_min (blend.hip; SPLIT_MIN for a segment-parallel forward, REC_MIN for
+    // the recorded segments of a whole-tile forward): exclusive prefix of their segment
     // counts by schedule position.  The long tiles sit at the front of the schedule, so the walk stops
     // at the first chunk of 1024 positions that holds none (a length class may straddle SPLIT_MIN,
     // hence "none in a whole chunk" and not "the first short tile").
     uint32_t carry = 0, split_pos = 0;
+    const uint32_t cls_min = 1023u - (uint32_t)(((uint64_t)min((uint32_t)split_min, max_len) << 10) / denom);
     for (int base = 0; base < num_tiles; base += 1024) {
         const int pos = base + threadIdx.x;
         uint32_t nseg = 0, tile = 0;
         if (pos < num_tiles) {
             tile = img.tile_order[pos];
             const uint32_t len = img.ranges[2 * tile + 1] - img.ranges[2 * tile];
-            if (len > (uint32_t)SPLIT_MIN) nseg = (len + SEG_LEN - 1) / SEG_LEN;
+            const bool split = by_class ? (1023u - (uint32_t)(((uint64_t)len << 10) / denom)) < cls_min : len > (uint32_t)split_min;
+            if (split) nseg = (len + (uint32_t)seg_len - 1) / (uint32_t)seg_len;
         }
         if (threadIdx.x == 0) s_any = 0;
         __syncthreads();
@@ -209,20 +216,50 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
         __syncthreads();
         if (!any) break;
     }
+    if (by_class) {
+        // Tails, largest first (blend.hip find_work_recorded): the remainder segment of a split tile or a whole unsplit
+        // tile.  They are dispatched behind the full segments, so the launch drains on ever smaller units.  Same bucket
+        // sort as above, on the tail's size.
+        __syncthreads();  // (seg_first of every tile is final)
+        s_bin[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t denom2 = (uint64_t)max(max_len, (uint32_t)seg_len) + 1;
+        auto tail_bucket = [&](int t) {
+            const uint32_t len = img.ranges[2 * t + 1] - img.ranges[2 * t];
+            const uint32_t tail = img.seg_first[t] == SEG_NONE ? len : len - ((len - 1u) / (uint32_t)seg_len) * (uint32_t)seg_len;
+            return 1023u - (uint32_t)(((uint64_t)tail << 10) / denom2);
+        };
+        for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&s_bin[tail_bucket(t)], 1u);
+        __syncthreads();
+        const uint32_t c2 = s_bin[threadIdx.x];
+        const uint32_t inc2 = wave_inclusive_scan(c2, lane);
+        if (lane == 63) s_scan[wave] = inc2;
+        __syncthreads();
+        uint32_t wbase2 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            if (w < wave) wbase2 += s_scan[w];
+        s_bin[threadIdx.x] = wbase2 + inc2 - c2;
+        __syncthreads();
+        for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tail_order[atomicAdd(&s_bin[tail_bucket(t)], 1u)] = (uint32_t)t;
+    }
     if (threadIdx.x == 0) {
         img.seg_prefix[split_pos] = carry;  // closes the last split tile's interval
         g.hdr->max_tile_len = max_len;
         g.hdr->num_segments = carry;
         g.hdr->num_split_pos = split_pos;
+        g.hdr->seg_len = (uint32_t)seg_len;
+        g.hdr->split_min = (uint32_t)split_min;
         g.hdr->split_used = 0;
         g.hdr->truncated = 0;
     }
 }
 
-__global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageState img, int num_tiles)
+__global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageState img, int num_tiles, int seg_len, int split_min,
+                                                          int by_class)
 {
     __shared__ TileOrderShared sh;
-    tile_order(g, img, num_tiles, sh);
+    tile_order(g, img, num_tiles, sh, seg_len, split_min, by_class);
 }
 
 // Grouped path, ONE launch (round 1 used three dependent ones, 22 us of mostly launch latency for ~1 MB):
@@ -241,7 +278,6 @@ __global__ __launch_bounds__(1024) void tile_scan_fused_kernel(GeomState g, Imag
     __shared__ uint32_t s_part[16][SCAN_TILES];
     __shared__ uint32_t s_scan16[16];
     __shared__ uint32_t s_last;
-    __shared__ TileOrderShared s_order;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * SCAN_TILES + lane;
     const int per = (groups + 15) / 16;
@@ -282,8 +318,8 @@ __global__ __launch_bounds__(1024) void tile_scan_fused_kernel(GeomState g, Imag
     __syncthreads();
     if (!s_last) return;
     tile_totals_scan(g, img, num_tiles, s_scan16);
-    __syncthreads();  // ranges are read back by the same workgroup (the barrier orders its global accesses)
-    tile_order(g, img, num_tiles, s_order);
+    // (round 4: the longest-first schedule and the segment tables -- 20 us of single-workgroup work that only the sort and
+    // the blend read -- are built by an extra workgroup of the key emit that follows, beside it: launch_emit_keys)
     if (threadIdx.x == 0) g.hdr->scan_arrivals = 0;
 }
 
@@ -295,7 +331,11 @@ void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, 
         return;
     }
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles);
+}
+
+void launch_tile_order(const GeomState& g, const ImageState& img, int num_tiles, const ScheduleParams& sp, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles, sp.seg_len, sp.split_min, sp.by_class);
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, int P, const int32_t* radii,
@@ -329,13 +369,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, 
 // Grouped path: the same 1024-thread groups as the projection; each group owns, in every tile's
 // segment, the sub-range [ranges[t].x + prefix[group][t], +count[group][t]) and hands out its slots
 // with LDS atomics.
+// The LAST workgroup of the launch emits nothing: it builds the longest-first schedule and the segment tables
+// (tile_order), which only the sort and the blend kernels behind this launch read -- beside the emit instead of in front of it.
 template <bool COMPACT>
 __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraParams cam, int P, int iters,
                                                                        const int32_t* radii, GeomState g,
                                                                        ImageState img, uint64_t* entries,
-                                                                       int64_t capacity)
+                                                                       int64_t capacity, ScheduleParams sp)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cur[];
+    if (blockIdx.x == gridDim.x - 1) {
+        tile_order(g, img, cam.grid_x * cam.grid_y * cam.frames, *reinterpret_cast<TileOrderShared*>(s_cur), sp.seg_len,
+                   sp.split_min, sp.by_class);
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) g.hdr->num_buckets = 0;  // (work list of the long-list sort that follows)
     if ((int64_t)g.hdr->num_rendered > capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) g.hdr->overflow = 1;
@@ -374,17 +421,22 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraPa
 }
 
 void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
-                      const BinState& b, int64_t capacity, bool grouped, hipStream_t stream)
+                      const BinState& b, int64_t capacity, bool grouped, const ScheduleParams& sp, hipStream_t stream)
 {
-    if (P <= 0) return;
+    if (P <= 0 || capacity <= 0) {   // nothing to emit: the schedule on its own (the blend kernels read it whatever happens)
+        launch_tile_order(g, img, total_tiles(cam), sp, stream);
+        return;
+    }
     if (grouped) {
         auto kernel = preprocess_stages_records(total_tiles(cam)) ? &emit_keys_grouped_kernel<true> : &emit_keys_grouped_kernel<false>;
-        hipLaunchKernelGGL(kernel, dim3(bin_groups(P)), dim3(BIN_THREADS), (size_t)total_tiles(cam) * sizeof(uint32_t), stream,
-                           cam, P, bin_iters(P), radii, g, img, b.entries, capacity);
-    }
-    else
+        const size_t lds = std::max((size_t)total_tiles(cam) * sizeof(uint32_t), sizeof(TileOrderShared));
+        hipLaunchKernelGGL(kernel, dim3(bin_groups(P) + 1), dim3(BIN_THREADS), lds, stream,
+                           cam, P, bin_iters(P), radii, g, img, b.entries, capacity, sp);
+    } else {
+        launch_tile_order(g, img, total_tiles(cam), sp, stream);
         hipLaunchKernelGGL(emit_keys_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, cam, P, radii, g, img,
                            b.entries, capacity);
+    }
 }
 
 // One workgroup per tile.  Stable LSD radix sort of the tile's segment on the bytes of

@@ -88,13 +88,17 @@ __device__ __forceinline__ FootprintTest no_footprint()
 // of the 64 entries this wave staged can reach a pixel centre of that quadrant.  s_mask[q][w] = entries 64w..64w+63
 // relevant to quadrant q.  Afterwards wave q walks only the set bits: entries that cannot
 // contribute to its pixels cost nothing.
+//
+// no_cull (Vidu4dSurfel*Args::debug_flags, VIDU4D_DEBUG_NO_CULL): every staged entry is handed to all four waves -- the
+// reference's walk (forward.cu:359-405 evaluates every list entry for every pixel of the tile).  The culls only prune work;
+// tests/test_gpu_cull_ab.py holds the kernels to "bit-identical with and without".
 __device__ __forceinline__ void publish_cull_masks(unsigned long long (*s_mask)[4], bool valid, const FootprintTest& foot,
-                                                   int tile_x0, int tile_y0, int wave, int lane)
+                                                   int tile_x0, int tile_y0, int wave, int lane, bool no_cull)
 {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float rx0 = (float)(tile_x0 + (q & 1) * 8) + 0.5f, ry0 = (float)(tile_y0 + (q >> 1) * 8) + 0.5f;
-        const bool hit = valid && footprint_hits(foot, rx0, rx0 + 7.0f, ry0, ry0 + 7.0f);
+        const bool hit = valid && (no_cull || footprint_hits(foot, rx0, rx0 + 7.0f, ry0, ry0 + 7.0f));
         const unsigned long long m = __ballot(hit);
         if (lane == 0) s_mask[q][wave] = m;
     }
@@ -163,6 +167,62 @@ __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageStat
     return w;
 }
 
+// Recorded segments (Header::split_used == 2; surfel_state.h): where a workgroup of blend_bwd works.  The split tiles are
+// exactly the schedule positions [0, S) (tile_order: split by length class), tile at position p has n_p = its segment
+// count, of which n_p - 1 are FULL segments (REC_SEG_LEN entries) and the last one the remainder.  Workgroups
+//   [0, F)        F = num_segments - S: the full segments, position by position -- equal units, dispatched first;
+//   [F, F + T)    one "tail" per tile, largest first (ImageState::tail_order): the remainder segment of a split tile, or
+//                 a whole unsplit tile -- the launch drains on its smallest units;
+//   beyond        nothing (the host's grid is an upper bound) -- at the END of the dispatch order, where they delay nobody.
+// A full segment finds its position by a search over the exclusive prefix key(p) = seg_prefix[p] - p with 64 keys per
+// step (one load round trip per step instead of one per bisection step: 2 steps for 2048 tiles instead of 11).
+__device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const ImageState& img, int grid_x, int grid_y)
+{
+    WorkItem w;
+    w.seg = -1;
+    w.slot = 0;
+    w.valid = true;
+    const uint32_t S = hdr->num_split_pos, F = hdr->num_segments - S;
+    const uint32_t idx = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    int tile;
+    if (idx < F) {
+        uint32_t lo = 0, n = S;   // the answer lies in [lo, lo + n): the largest p with key(p) <= idx
+        while (n > 1) {
+            const uint32_t step = (n + 63u) / 64u;
+            const uint32_t p = lo + (uint32_t)lane * step;
+            const bool in = (uint32_t)lane * step < n;
+            const uint32_t key = in ? img.seg_prefix[p] - p : 0xffffffffu;
+            const int cnt = __builtin_popcountll(__ballot(in && key <= idx));   // (keys ascend: a prefix of the lanes)
+            const uint32_t first = (uint32_t)(cnt - 1) * step;
+            lo += first;
+            n = min(step, n - first);
+        }
+        lo = __builtin_amdgcn_readfirstlane(lo);
+        tile = (int)img.tile_order[lo];
+        w.seg = (int)(idx - (img.seg_prefix[lo] - lo));
+        w.slot = img.seg_first[tile] + (uint32_t)w.seg;
+    } else {
+        const uint32_t j = idx - F;
+        if (j >= (uint32_t)(grid_x * grid_y)) {
+            w.valid = false;
+            return w;
+        }
+        tile = (int)img.tail_order[j];
+        const uint32_t first = img.seg_first[tile];
+        if (first != SEG_NONE) {   // the remainder of a split tile: its last segment
+            const uint32_t len = img.ranges[2 * tile + 1] - img.ranges[2 * tile];
+            w.seg = (int)((len + hdr->seg_len - 1u) / hdr->seg_len) - 1;
+            w.slot = first + (uint32_t)w.seg;
+        }
+    }
+    w.tc.tile = tile;
+    w.tc.valid = true;
+    w.tc.tx = tile % grid_x;
+    w.tc.ty = tile / grid_x;
+    return w;
+}
+
 // Deepest list position blended by any pixel of this workgroup -> frame-wide maximum (a hint for the
 // caller's split decision; the longest tiles run first, so most workgroups only read).
 __device__ __forceinline__ void report_depth(uint32_t* depth_used, uint32_t last_contributor)
@@ -213,7 +273,7 @@ __device__ __forceinline__ void write_pixel(const FwdPixel& s, size_t HW, size_t
 __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                          ImageState img, const uint32_t* __restrict__ point_list,
                                                          int64_t capacity, int max_seg, const float* __restrict__ rec,
-                                                         float* __restrict__ seg_data)
+                                                         float* __restrict__ seg_data, int flags)
 {
     __shared__ float4 s_rec[FWD_BATCH * 5];
     __shared__ unsigned long long s_mask[4][4];
@@ -238,7 +298,7 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
         const bool have = (int)threadIdx.x < todo;
         FootprintTest foot = no_footprint();
         if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
-        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
         __syncthreads();
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
@@ -256,32 +316,67 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
     seg_data[((size_t)wk.slot * SEG_FLOATS + SG_TSEG) * 256 + threadIdx.x] = T;
 }
 
-// The blend (pass 2 of the segment-parallel forward when SPLIT).  LITE: colour + alpha plane only (surfel_math.h,
-// fwd_accumulate<true>); the other auxiliary planes, the distortion moments and the median contributor come out as zeros.
+// One record of the recorded segments (surfel_state.h RecordedSlot): the sums of the segment the walk is leaving; the
+// next segment's sums start from zero (the totals are put together from the records when the walk ends: the registers of
+// seven more running sums would cost the kernel two of its seven waves per SIMD).
+template <int MODE>
+__device__ __forceinline__ void store_record(float* __restrict__ seg_data, uint32_t slot, FwdPixel& s, float first)
+{
+    float* d = seg_data + (size_t)slot * REC_REC_FLOATS * 256 + threadIdx.x;
+    d[RS_T * 256] = first;
+    for (int ch = 0; ch < 3; ch++) {
+        d[(RS_C + ch) * 256] = s.C[ch];
+        s.C[ch] = 0.f;
+    }
+    if (MODE != BLEND_LITE) {
+        d[RS_D * 256] = s.D;
+        s.D = 0.f;
+        for (int ch = 0; ch < 3; ch++) {
+            d[(RS_N + ch) * 256] = s.N[ch];
+            s.N[ch] = 0.f;
+        }
+    }
+    if (MODE == BLEND_FULL) {
+        d[RS_M1 * 256] = s.seg1;
+        d[RS_M2 * 256] = s.seg2;
+        s.seg1 = s.seg2 = 0.f;
+    }
+}
+
+// The blend (pass 2 of the segment-parallel forward when SPLIT).  MODE (surfel_math.h): BLEND_LITE carries colour + alpha
+// plane only, BLEND_GEOM colour + planes 0-4 (fwd_accumulate<MODE>); what an instance does not carry comes out as zeros.
 //
-// spec (SPLIT && LITE only; Vidu4dSurfelForwardArgs::assume_unsaturated): no transmittance pre-pass ran.  A segment is
-// blended from T = 1 -- colour is linear in the start transmittance and, as long as the pixel does not saturate, no
-// decision depends on it -- and stores its colour and its transmittance PRODUCT; blend_combine_kernel scales by the
-// product of the predecessors and blends the ONE segment in which a pixel comes near the saturation threshold again,
-// in order, from the exact start (round 3: until then such a frame was reported and blended again with the pre-pass).
-#ifdef SURFEL_FWD_WAVES_PER_EU
-#define SURFEL_FWD_OCC __attribute__((amdgpu_waves_per_eu(SURFEL_FWD_WAVES_PER_EU, SURFEL_FWD_WAVES_PER_EU)))
-#else
-#define SURFEL_FWD_OCC
+// spec (SPLIT && MODE != BLEND_FULL only; Vidu4dSurfelForwardArgs::assume_unsaturated): no transmittance pre-pass ran.  A
+// segment is blended from T = 1 -- colour, depth and normal sums are linear in the start transmittance and, as long as the
+// pixel does not saturate, no decision depends on it (the full instance's median sample does: T > 0.5) -- and stores its sums
+// and its transmittance PRODUCT; blend_combine_kernel scales by the product of the predecessors and blends the ONE segment
+// in which a pixel comes near the saturation threshold again, in order, from the exact start.
+//
+// rec_len (!SPLIT only; 0: off): the walk leaves recorded segments for the backward (surfel_state.h): a prefix record after
+// every rec_len-th entry of a tile the segment table lists, the final sums in the tile's last slot.
+// Register budget: the whole-tile full instance is held to 72 VGPRs = 7 waves per SIMD (the LDS limit; the allocator takes
+// 74 = 6 waves when left alone since the segment-local distortion moments joined the pixel state).
+#ifndef SURFEL_FWD_WAVES_PER_EU
+#define SURFEL_FWD_WAVES_PER_EU 7
 #endif
-template <bool SPLIT, bool LITE>
-__global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
+template <bool SPLIT, int MODE>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu((!SPLIT && MODE == BLEND_FULL) ? SURFEL_FWD_WAVES_PER_EU : 1, (!SPLIT && MODE == BLEND_FULL) ? SURFEL_FWD_WAVES_PER_EU : 8)))
+void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        int64_t capacity, int max_seg, const float* __restrict__ rec,
                                                        const float* __restrict__ bg, float* __restrict__ seg_data,
                                                        float* __restrict__ out_color, float* __restrict__ out_others,
-                                                       uint32_t* depth_used, int spec)
+                                                       uint32_t* depth_used, int spec, int flags, int rec_len)
 {
+    constexpr bool SPEC_OK = MODE != BLEND_FULL;
     __shared__ float4 s_rec[FWD_BATCH * 5];
     __shared__ unsigned long long s_mask[4][4];
     const bool overflow = (int64_t)hdr->num_rendered > capacity;
-    if (SPLIT && LITE && spec && blockIdx.x == 0 && threadIdx.x == 0)  // (what blend_seg_T_kernel does when it runs)
+    if (SPLIT && SPEC_OK && spec && blockIdx.x == 0 && threadIdx.x == 0)  // (what blend_seg_T_kernel does when it runs)
         hdr->split_used = !overflow && hdr->num_segments > 0;
+    if (!SPLIT && rec_len && blockIdx.x == 0 && threadIdx.x == 0)
+        hdr->split_used = (!overflow && hdr->num_segments > 0) ? 2u : 0u;
     const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     TileCoord tc = wk.tc;
@@ -297,6 +392,10 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
     // caller re-runs with a larger buffer)
     int todo = overflow ? 0 : (int)(r1 - r0);
     int begin = 0;
+    // recorded segments: first slot of this tile (SEG_NONE: the table does not list it) and where the next record is due
+    const uint32_t rec_first = (!SPLIT && rec_len && !overflow) ? img.seg_first[tc.tile] : SEG_NONE;
+    int rec_next = rec_len;
+    uint32_t rec_stop = 0;  // segment of the batch the walk is in
 
     FwdPixel s;
     bool done = !inside;
@@ -306,7 +405,7 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
         todo = min(todo - begin, SEG_LEN);
         // transmittance left by the earlier segments of this tile; below T_EPS the pixel saturated
         // inside one of them (the running product only decreases), and this segment adds nothing
-        if (!(LITE && spec)) {
+        if (!(SPEC_OK && spec)) {
             const uint32_t first = wk.slot - (uint32_t)wk.seg;
             for (int q = 0; q < wk.seg; q++)
                 s.T = s.T * seg_data[((size_t)(first + q) * SEG_FLOATS + SG_TSEG) * 256 + threadIdx.x];
@@ -316,11 +415,16 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
     }
     bool sat_local = false;  // (spec: a sample was refused for saturation although the walk started from T = 1)
     for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
+        if (!SPLIT && rec_first != SEG_NONE && base == rec_next) {  // (wave-uniform) entries [0, base) are behind us
+            rec_stop = (uint32_t)(base / rec_len);
+            store_record<MODE>(seg_data, rec_first + rec_stop - 1u, s, s.T);
+            rec_next += rec_len;
+        }
         if (__syncthreads_count(done) == 256) break;
         const bool have = (int)threadIdx.x < todo;
         FootprintTest foot = no_footprint();
         if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
-        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
         __syncthreads();
         if (__all(done)) continue;  // this wave's 64 pixels are saturated; it keeps helping to stage
 #pragma unroll 1
@@ -348,7 +452,7 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
                     if (okA) {
                         const float4 q3 = s_rec[ja * 5 + 3], q4 = s_rec[ja * 5 + 4];
                         const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate<LITE>(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = sat_local = true;
+                        if (!fwd_accumulate<MODE>(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = sat_local = true;
                     }
                 }
                 okB = okB && !done;
@@ -356,7 +460,7 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
                     if (okB) {
                         const float4 q3 = s_rec[jb * 5 + 3], q4 = s_rec[jb * 5 + 4];
                         const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate<LITE>(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = sat_local = true;
+                        if (!fwd_accumulate<MODE>(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = sat_local = true;
                     }
                 }
             }
@@ -368,10 +472,12 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
         for (int ch = 0; ch < 3; ch++) d[(SG_C + ch) * 256] = s.C[ch];
         d[SG_TEND * 256] = dead ? -1.0f : s.T;
         d[SG_LAST * 256] = __uint_as_float(s.last_contributor);
-        if (LITE && spec) d[SG_TSEG * 256] = sat_local ? 0.f : s.T;  // the segment's own product (0: must not be trusted)
-        if (!LITE) {  // (LITE: nobody reads the other fields -- blend_combine_kernel<true>, blend_bwd_kernel<true, true>)
+        if (SPEC_OK && spec) d[SG_TSEG * 256] = sat_local ? 0.f : s.T;  // the segment's own product (0: must not be trusted)
+        if (MODE != BLEND_LITE) {  // (LITE: nobody reads the other fields -- blend_combine_kernel, blend_bwd_kernel of that mode)
             for (int ch = 0; ch < 3; ch++) d[(SG_N + ch) * 256] = s.N[ch];
             d[SG_D * 256] = s.D;
+        }
+        if (MODE == BLEND_FULL) {
             d[SG_M1 * 256] = s.dist1;
             d[SG_M2 * 256] = s.dist2;
             d[SG_DIST * 256] = s.distortion;
@@ -380,6 +486,24 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
             d[SG_MED_C * 256] = __uint_as_float(s.median_contributor);
         }
         return;
+    }
+    if (!SPLIT && rec_first != SEG_NONE) {  // the final sums, in the slot of the tile's last segment (which has nothing behind it)
+        const uint32_t nseg = (r1 - r0 + (uint32_t)rec_len - 1u) / (uint32_t)rec_len;
+        // (an early end -- every pixel saturated -- leaves the prefix records [rec_stop, nseg - 1) unwritten; nobody reads them:
+        // no pixel's walk enters from behind them, and the distortion sums stop at rec_stop)
+        seg_data[((size_t)(rec_first + nseg - 1u) * REC_REC_FLOATS + RS_STOP) * 256 + threadIdx.x] = __uint_as_float(rec_stop);
+        store_record<MODE>(seg_data, rec_first + nseg - 1u, s, s.median_weight);
+        // the totals the images get: the finished segments' sums in list order, then the last one (this thread's own
+        // stores, read back: store_record has zeroed the running sums)
+        for (uint32_t k = 0; k <= rec_stop; k++) {
+            const uint32_t q = k < rec_stop ? k : nseg - 1u;
+            const float* e = seg_data + (size_t)(rec_first + q) * REC_REC_FLOATS * 256 + threadIdx.x;
+            for (int ch = 0; ch < 3; ch++) s.C[ch] += e[(RS_C + ch) * 256];
+            if (MODE != BLEND_LITE) {
+                for (int ch = 0; ch < 3; ch++) s.N[ch] += e[(RS_N + ch) * 256];
+                s.D += e[RS_D * 256];
+            }
+        }
     }
     if (inside)
         write_pixel(s, plane, frame_base + (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
@@ -394,16 +518,20 @@ __global__ __launch_bounds__(256) SURFEL_FWD_OCC void blend_fwd_kernel(int W, in
 // where _p is the state at the segment start and a_i, m1_i, m2_i run inside the segment.  Pass 2 used
 // the global accumulated alpha (1 - T) and segment-local moments, which leaves
 //   M2_p * (sum w_i) - 2 M1_p * (sum w_i m_i)      with sum w_i = T_start - T_end.
-// LITE (colour + alpha plane only): the segments hold colour, end transmittance and last contributor, nothing else.
-template <bool LITE>
+// BLEND_LITE (colour + alpha plane only): the segments hold colour, end transmittance and last contributor, nothing else;
+// BLEND_GEOM: depth and normal sums as well.
+template <int MODE>
 __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                            ImageState img, const uint32_t* __restrict__ point_list,
                                                            const float* __restrict__ rec, int64_t capacity, int max_seg,
                                                            const float* __restrict__ bg,
                                                            float* __restrict__ seg_data,
                                                            float* __restrict__ out_color,
-                                                           float* __restrict__ out_others, uint32_t* depth_used, int spec)
+                                                           float* __restrict__ out_others, uint32_t* depth_used, int spec,
+                                                           int flags)
 {
+    constexpr bool SPEC_OK = MODE != BLEND_FULL;
+    constexpr bool GEOM = MODE == BLEND_GEOM;
     if ((int64_t)hdr->num_rendered > capacity || blockIdx.x >= hdr->num_split_pos) return;
     const int tile = (int)img.tile_order[blockIdx.x];
     const uint32_t first = img.seg_first[tile];
@@ -427,7 +555,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     for (int q = 0; q < nseg; q++) {
         float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
         const float T_start = T_raw;
-        if (LITE && spec) {
+        if (SPEC_OK && spec) {
             // the segment was blended from T = 1: scale by what its predecessors leave.  A pixel that stays clear of the
             // saturation threshold to the segment's end never met it inside (the running product only decreases); one that
             // does not (or saturated inside a segment even from T = 1: product stored as 0) has this segment blended again
@@ -443,6 +571,10 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
                 continue;
             }
             for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(T_start, d[(SG_C + ch) * 256], s.C[ch]);
+            if (GEOM) {
+                for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(T_start, d[(SG_N + ch) * 256], s.N[ch]);
+                s.D = fmaf(T_start, d[SG_D * 256], s.D);
+            }
             d[SG_TEND * 256] = T_end;
             T_raw = s.T = T_end;
             const uint32_t last = __float_as_uint(d[SG_LAST * 256]);
@@ -456,11 +588,12 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
         s.T = T_end;
         const uint32_t last = __float_as_uint(d[SG_LAST * 256]);
         if (last) s.last_contributor = last;
-        if (LITE) continue;
-        const float m1 = d[SG_M1 * 256], m2 = d[SG_M2 * 256];
-        s.distortion += d[SG_DIST * 256] + (s.dist2 * (T_start - T_end) - 2.0f * s.dist1 * m1);
+        if (MODE == BLEND_LITE) continue;
         for (int ch = 0; ch < 3; ch++) s.N[ch] += d[(SG_N + ch) * 256];
         s.D += d[SG_D * 256];
+        if (GEOM) continue;
+        const float m1 = d[SG_M1 * 256], m2 = d[SG_M2 * 256];
+        s.distortion += d[SG_DIST * 256] + (s.dist2 * (T_start - T_end) - 2.0f * s.dist1 * m1);
         s.dist1 += m1;
         s.dist2 += m2;
         const uint32_t med = __float_as_uint(d[SG_MED_C * 256]);
@@ -470,7 +603,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
             s.median_weight = d[SG_MED_W * 256];
         }
     }
-    if constexpr (LITE) if (spec) {
+    if constexpr (SPEC_OK) if (spec) {
         // ---- the saturating segments, blended again for the pixels that saturate in them: the loop of blend_fwd_kernel,
         // restricted to the segment and to those pixels, from the exact transmittance (the product of the predecessors'
         // products in list order: what blend_seg_T_kernel + blend_fwd_kernel use for their start)
@@ -492,7 +625,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
                 const bool have = (int)threadIdx.x < todo;
                 FootprintTest foot = no_footprint();
                 if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
-                publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
+                publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
                 __syncthreads();
                 if (__all(done)) continue;
 #pragma unroll 1
@@ -509,7 +642,7 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
                         if (ok) {
                             const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                             const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                            if (!fwd_accumulate<true>(t, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
+                            if (!fwd_accumulate<MODE>(t, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
                         }
                     }
                 }
@@ -520,6 +653,14 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
                 for (int ch = 0; ch < 3; ch++) {
                     d[(SG_C + ch) * 256] = t.C[ch];  // (absolute, unlike the speculated segments': SG_TSEG says so)
                     s.C[ch] += t.C[ch];
+                }
+                if (GEOM) {
+                    for (int ch = 0; ch < 3; ch++) {
+                        d[(SG_N + ch) * 256] = t.N[ch];
+                        s.N[ch] += t.N[ch];
+                    }
+                    d[SG_D * 256] = t.D;
+                    s.D += t.D;
                 }
                 d[SG_TSEG * 256] = -2.0f;
                 d[SG_TEND * 256] = t.T;
@@ -546,16 +687,27 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     for (int q = nseg - 1; q >= 0; q--) {
         float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
         if (d[SG_TEND * 256] < 0.f) continue;
-        if (LITE) {
+        if (SPEC_OK) {
             float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
-            if (spec && d[SG_TSEG * 256] != -2.0f) {  // (the stored colours are relative to the segment's start transmittance)
+            float n0 = 0, n1 = 0, n2 = 0, dd = 0;
+            if (GEOM) n0 = d[(SG_N + 0) * 256], n1 = d[(SG_N + 1) * 256], n2 = d[(SG_N + 2) * 256], dd = d[SG_D * 256];
+            if (spec && d[SG_TSEG * 256] != -2.0f) {  // (the stored sums are relative to the segment's start transmittance)
                 const float T_start = q > 0 ? seg_data[((size_t)(first + q - 1) * SEG_FLOATS + SG_TEND) * 256 + threadIdx.x] : 1.0f;
                 c0 *= T_start, c1 *= T_start, c2 *= T_start;
+                n0 *= T_start, n1 *= T_start, n2 *= T_start, dd *= T_start;
             }
             d[(SG_C + 0) * 256] = sufC[0];
             d[(SG_C + 1) * 256] = sufC[1];
             d[(SG_C + 2) * 256] = sufC[2];
             sufC[0] += c0, sufC[1] += c1, sufC[2] += c2;
+            if (GEOM) {
+                d[(SG_N + 0) * 256] = sufN[0];
+                d[(SG_N + 1) * 256] = sufN[1];
+                d[(SG_N + 2) * 256] = sufN[2];
+                d[SG_D * 256] = sufD;
+                sufN[0] += n0, sufN[1] += n1, sufN[2] += n2;
+                sufD += dd;
+            }
             continue;
         }
         const float c0 = d[(SG_C + 0) * 256], c1 = d[(SG_C + 1) * 256], c2 = d[(SG_C + 2) * 256];
@@ -581,17 +733,27 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     }
 }
 
+template <bool SPLIT>
+static auto pick_fwd(int mode)
+{
+    return mode == BLEND_LITE ? &blend_fwd_kernel<SPLIT, BLEND_LITE>
+           : mode == BLEND_GEOM ? &blend_fwd_kernel<SPLIT, BLEND_GEOM>
+                                : &blend_fwd_kernel<SPLIT, BLEND_FULL>;
+}
+
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
-                      float* out_others, uint32_t* depth_used, bool lite, bool assume_unsaturated, hipStream_t stream)
+                      float* out_others, uint32_t* depth_used, int mode, bool assume_unsaturated, int flags, bool record,
+                      hipStream_t stream)
 {
-    const int spec = (assume_unsaturated && lite && split && capacity > 0) ? 1 : 0;
+    const int spec = (assume_unsaturated && mode != BLEND_FULL && split && capacity > 0) ? 1 : 0;
     const int tiles = total_tiles(cam), grid_y = cam.grid_y * cam.frames;  // (stacked frames: a taller tile grid)
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
-        auto kernel = lite ? &blend_fwd_kernel<false, true> : &blend_fwd_kernel<false, false>;
-        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
-                           point_list, capacity, 0, g.rec, background, b.seg_data, out_color, out_others, depth_used, 0);
+        const int rec_len = (record && capacity > 0) ? REC_SEG_LEN : 0;
+        hipLaunchKernelGGL(pick_fwd<false>(mode), dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
+                           point_list, capacity, 0, g.rec, background, b.seg_data, out_color, out_others, depth_used, 0, flags,
+                           rec_len);
         return;
     }
     // upper bounds; the device knows the exact counts.  The combine runs over ALL schedule positions: the
@@ -601,13 +763,16 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     const int split_tiles = tiles;
     if (!spec)
         hipLaunchKernelGGL(blend_seg_T_kernel, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y,
-                           g.hdr, img, point_list, capacity, max_seg, g.rec, b.seg_data);
-    auto kernel = lite ? &blend_fwd_kernel<true, true> : &blend_fwd_kernel<true, false>;
-    hipLaunchKernelGGL(kernel, dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
-                       point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used, spec);
-    auto combine = lite ? &blend_combine_kernel<true> : &blend_combine_kernel<false>;
+                           g.hdr, img, point_list, capacity, max_seg, g.rec, b.seg_data, flags);
+    hipLaunchKernelGGL(pick_fwd<true>(mode), dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr,
+                       img, point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used, spec,
+                       flags, 0);
+    auto combine = mode == BLEND_LITE ? &blend_combine_kernel<BLEND_LITE>
+                   : mode == BLEND_GEOM ? &blend_combine_kernel<BLEND_GEOM>
+                                        : &blend_combine_kernel<BLEND_FULL>;
     hipLaunchKernelGGL(combine, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
-                       point_list, g.rec, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used, spec);
+                       point_list, g.rec, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used, spec,
+                       flags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -691,11 +856,14 @@ __device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
     return v;
 }
 
-// SPLIT: the tiles the forward blended segment-parallel are walked segment-parallel here too.  The
-// back-to-front recurrences of a segment start from what the segments behind it add up to (stored by
-// blend_combine_kernel); everything else is the single-workgroup loop restricted to the segment.
-// LITE: only dL/dcolour and dL/d(alpha plane) are read (the caller promised zeros elsewhere, aux_planes); the forward
-// that filled the state may itself have run LITE (no distortion moments, no median contributor: never read here).
+// SPLIT: the tiles the segment table lists are walked segment-parallel.  The back-to-front recurrences of a segment start
+// from what the segments behind it add up to -- stored by blend_combine_kernel after a segment-parallel forward
+// (Header::split_used == 1), or final - prefix of the records a whole-tile forward left (== 2: recorded segments,
+// surfel_state.h); everything else is the single-workgroup loop restricted to the segment.  The segment length is the one
+// the table was built with (Header::seg_len).
+// MODE: BLEND_LITE reads only dL/dcolour and dL/d(alpha plane), BLEND_GEOM those and the planes 0, 2-4 (the caller promised
+// zeros elsewhere, aux_planes); the forward that filled the state may itself have run in that mode (no distortion moments,
+// no median contributor: never read here).
 // Register budget of the full instances: 80 VGPRs = 6 waves per SIMD (the allocator takes 88 = 5 waves when left alone;
 // no spills at 80, 10-13 spilled registers at 72).  Round 3, stacked launch at the headline size: 509 -> 497 us; 4 waves
 // per SIMD measure the same as 5 -- the kernel is bound by VALU issue, not by latency, the sixth wave only fills bubbles.
@@ -703,15 +871,37 @@ __device__ __forceinline__ float row_reduce_scatter2(float a, float b, int lane)
 #ifndef SURFEL_BWD_WAVES_PER_EU
 #define SURFEL_BWD_WAVES_PER_EU 6
 #endif
-template <bool SPLIT, bool LITE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LITE ? 1 : SURFEL_BWD_WAVES_PER_EU, LITE ? 8 : SURFEL_BWD_WAVES_PER_EU)))
+template <bool SPLIT, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == BLEND_LITE ? 1 : SURFEL_BWD_WAVES_PER_EU, MODE == BLEND_LITE ? 8 : SURFEL_BWD_WAVES_PER_EU)))
 void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        const float* __restrict__ rec, const float* __restrict__ bg,
                                                        const float* __restrict__ seg_data, int max_seg,
                                                        const float* __restrict__ dL_dcolor,
-                                                       const float* __restrict__ dL_dothers, float* __restrict__ acc)
+                                                       const float* __restrict__ dL_dothers, float* __restrict__ acc, int flags
+#ifdef SURFEL_BWD_TRACE   // (tools/bwd_trace.py: a variant build that timestamps every workgroup; never in the product)
+                                                       , unsigned long long* __restrict__ trace
+#endif
+                                                       )
 {
+    constexpr bool LITE = MODE == BLEND_LITE, FULL = MODE == BLEND_FULL;
+#ifdef SURFEL_BWD_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    unsigned long long trace_t1 = trace_t0;
+    struct TraceEnd {
+        unsigned long long* p; unsigned long long t0; const unsigned long long* t1; int entries;
+        __device__ ~TraceEnd() {
+            if (p && threadIdx.x == 0) {
+                p[4 * blockIdx.x + 0] = t0;
+                p[4 * blockIdx.x + 1] = *t1;
+                p[4 * blockIdx.x + 2] = wall_clock64();
+                p[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |
+                                        ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 0xf) << 32) |
+                                        ((unsigned long long)(entries & 0xffff) << 40);
+            }
+        }
+    } trace_end{trace, trace_t0, &trace_t1, 0};
+#endif
     const uint32_t* __restrict__ ranges = img.ranges;
     const float* __restrict__ final_T = img.final_T;
     const uint32_t* __restrict__ n_contrib = img.n_contrib;
@@ -720,8 +910,10 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     __shared__ uint32_t s_id[BWD_BATCH];
     __shared__ unsigned long long s_mask[4][4];
     __shared__ uint32_t s_max;
-    // (a forward that ran unsplit left no segment state: every tile is then walked whole)
-    const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, SPLIT && !hdr->split_used);
+    // (a forward that left no segment state: every tile is then walked whole)
+    const uint32_t split_used = SPLIT ? hdr->split_used : 0u;
+    const WorkItem wk = (SPLIT && split_used == 2u) ? find_work_recorded(hdr, img, grid_x, grid_y)
+                                                    : find_work<SPLIT>(hdr, img, grid_x, grid_y, SPLIT && !split_used);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     TileCoord tc = wk.tc;
     size_t HW;  // (distance between planes: frames * H * W)
@@ -733,7 +925,8 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
     const uint32_t r0 = ranges[2 * tc.tile];
     const size_t pid = frame_base + (size_t)py * W + px;
-    const int seg_begin = (SPLIT && wk.seg >= 0) ? wk.seg * SEG_LEN : 0;
+    const int seg_len = SPLIT ? (int)hdr->seg_len : 0;
+    const int seg_begin = (SPLIT && wk.seg >= 0) ? wk.seg * seg_len : 0;
 
     BwdPixel s;
     s.last_contributor = 0;
@@ -748,11 +941,13 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
         for (int c = 0; c < 3; c++) s.dL_dpixel[c] = dL_dcolor[c * HW + pid];
         s.dL_daccum = dL_dothers[pid + HW];
         if (!LITE) {
+            s.dL_ddepth = dL_dothers[pid];
+            for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = dL_dothers[pid + (2 + c) * HW];
+        }
+        if (FULL) {
             s.final_D = final_T[pid + HW];
             s.final_D2 = final_T[pid + 2 * HW];
             s.median_contributor = n_contrib[pid + HW];
-            s.dL_ddepth = dL_dothers[pid];
-            for (int c = 0; c < 3; c++) s.dL_dnormal2D[c] = dL_dothers[pid + (2 + c) * HW];
             s.dL_dmedian_depth = dL_dothers[pid + 5 * HW];
             s.dL_dreg = dL_dothers[pid + 6 * HW];
             s.dL_dmax_dweight = dL_dothers[pid + 7 * HW];
@@ -762,23 +957,67 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     s.final_A = 1.0f - s.T_final;
     s.bg_dot_dpixel = bg[0] * s.dL_dpixel[0] + bg[1] * s.dL_dpixel[1] + bg[2] * s.dL_dpixel[2];
     if (SPLIT && wk.seg >= 0) {
-        const float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
-        const float T_end = d[SG_TEND * 256];
-        // the entries of this segment lie in [seg_begin, seg_begin + SEG_LEN): clip the pixel's range
-        const uint32_t seg_end = (uint32_t)(seg_begin + SEG_LEN);
+        // the entries of this segment lie in [seg_begin, seg_begin + seg_len): clip the pixel's range
+        const uint32_t seg_end = (uint32_t)(seg_begin + seg_len);
         if (s.last_contributor > seg_end) {
             // the walk enters from the segments behind: start from what they add up to
+            float T_end, sufC[3], sufN[3] = {0.f, 0.f, 0.f}, sufD = 0.f, sufM1 = 0.f, sufM2 = 0.f, med_w = 0.f;
+            if (split_used == 2u) {
+                // recorded segments: what lies behind = the later segments' own sums, up to the one the forward's walk
+                // stopped in (whose sums the final record, in the tile's last slot, holds) -- each summed from zero
+                const uint32_t len = ranges[2 * tc.tile + 1] - r0;
+                const uint32_t nseg = (len + (uint32_t)seg_len - 1u) / (uint32_t)seg_len;
+                const float* d = seg_data + (size_t)wk.slot * REC_REC_FLOATS * 256 + threadIdx.x;
+                const float* f = seg_data + (size_t)(wk.slot - (uint32_t)wk.seg + nseg - 1u) * REC_REC_FLOATS * 256 + threadIdx.x;
+                T_end = d[RS_T * 256];
+                const uint32_t stop = __builtin_amdgcn_readfirstlane(__float_as_uint(f[RS_STOP * 256]));
+                for (int ch = 0; ch < 3; ch++) sufC[ch] = f[(RS_C + ch) * 256];
+                if (!LITE) {
+                    for (int ch = 0; ch < 3; ch++) sufN[ch] = f[(RS_N + ch) * 256];
+                    sufD = f[RS_D * 256];
+                }
+                if (FULL) {
+                    sufM1 = f[RS_M1 * 256];
+                    sufM2 = f[RS_M2 * 256];
+                    med_w = s.median_contributor > seg_end ? f[RS_T * 256] : 0.f;  // (the median sample lies behind)
+                }
+                for (uint32_t q = (uint32_t)wk.seg + 1u; q < stop; q++) {
+                    const float* e = seg_data + (size_t)(wk.slot - (uint32_t)wk.seg + q) * REC_REC_FLOATS * 256 + threadIdx.x;
+                    for (int ch = 0; ch < 3; ch++) sufC[ch] += e[(RS_C + ch) * 256];
+                    if (!LITE) {
+                        for (int ch = 0; ch < 3; ch++) sufN[ch] += e[(RS_N + ch) * 256];
+                        sufD += e[RS_D * 256];
+                    }
+                    if (FULL) {
+                        sufM1 += e[RS_M1 * 256];
+                        sufM2 += e[RS_M2 * 256];
+                    }
+                }
+            } else {
+                const float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
+                T_end = d[SG_TEND * 256];
+                for (int ch = 0; ch < 3; ch++) sufC[ch] = d[(SG_C + ch) * 256];
+                if (!LITE) {
+                    for (int ch = 0; ch < 3; ch++) sufN[ch] = d[(SG_N + ch) * 256];
+                    sufD = d[SG_D * 256];
+                }
+                if (FULL) {
+                    sufM1 = d[SG_M1 * 256];
+                    sufM2 = d[SG_M2 * 256];
+                    med_w = d[SG_MED_W * 256];
+                }
+            }
             const float inv = 1.0f / T_end;
             const float behind = T_end - s.T_final;  // sum of their blend weights
-            for (int ch = 0; ch < 3; ch++) s.accum_rec[ch] = d[(SG_C + ch) * 256] * inv;
+            for (int ch = 0; ch < 3; ch++) s.accum_rec[ch] = sufC[ch] * inv;
             s.accum_alpha_rec = behind * inv;
             if (!LITE) {
-                for (int ch = 0; ch < 3; ch++) s.accum_normal_rec[ch] = d[(SG_N + ch) * 256] * inv;
-                s.accum_depth_rec = d[SG_D * 256] * inv;
-                s.last_dL_dT = inv * (s.dL_dmax_dweight * d[SG_MED_W * 256] +
-                                      s.dL_dreg * (s.final_D2 * behind + s.final_A * d[SG_M2 * 256] -
-                                                   2.0f * s.final_D * d[SG_M1 * 256]));
+                for (int ch = 0; ch < 3; ch++) s.accum_normal_rec[ch] = sufN[ch] * inv;
+                s.accum_depth_rec = sufD * inv;
             }
+            if (FULL)
+                s.last_dL_dT = inv * (s.dL_dmax_dweight * med_w +
+                                      s.dL_dreg * (s.final_D2 * behind + s.final_A * sufM2 - 2.0f * s.final_D * sufM1));
             s.T = T_end;
             s.last_contributor = seg_end;
         }
@@ -799,6 +1038,10 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     if (lane == 0) atomicMax(&s_max, wave_last);
     __syncthreads();
     const int n_used = (int)s_max;
+#ifdef SURFEL_BWD_TRACE
+    trace_t1 = wall_clock64();
+    trace_end.entries = n_used > seg_begin ? n_used - seg_begin : 0;
+#endif
 
     // accumulator slot handled by this lane after the row reduce-scatter
     // (after wave_reduce_scatter16 every lane of quad q in row r holds value q + 4r; lane 0 of the quad adds it)
@@ -819,7 +1062,8 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                 s_id[threadIdx.x] = id;
                 foot = stage_record(s_rec, threadIdx.x, rec, id);
             }
-            if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
+            if (wave < BWD_BATCH / 64)
+                publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
             for (int i = threadIdx.x; i < BWD_BATCH * ACC_FLOATS / 4; i += 256)
                 reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -846,11 +1090,11 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                 if (ok) {
                     const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                     const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                    pg = bwd_pair_core<LITE>(s, e, nrm, rgb, contributor + 1 == s.median_contributor);
+                    pg = bwd_pair_core<MODE>(s, e, nrm, rgb, contributor + 1 == s.median_contributor);
                 }
                 e.sanitise(ok);
                 float g[ACC_FLOATS];
-                bwd_pair_geometry<LITE>(s, e, pg, Tw, q2.w, pixx, pixy, g);
+                bwd_pair_geometry<MODE>(s, e, pg, Tw, q2.w, pixx, pixy, g);
                 float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
                                g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
                 const float r16 = wave_reduce_scatter16(v, lane);
@@ -884,7 +1128,7 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
 __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int grid_x, int grid_y, ImageState img,
                                                              const uint32_t* __restrict__ point_list,
                                                              const float* __restrict__ rec,
-                                                             unsigned long long* __restrict__ out)
+                                                             unsigned long long* __restrict__ out, int flags)
 {
     __shared__ float4 s_rec[BWD_BATCH * 5];
     __shared__ unsigned long long s_mask[4][4];
@@ -921,7 +1165,8 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
         const bool have = (int)threadIdx.x < cnt;
         FootprintTest foot = no_footprint();
         if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)]);
-        if (wave < BWD_BATCH / 64) publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane);
+        if (wave < BWD_BATCH / 64)
+            publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
         __syncthreads();
         if (wave == 0) c_staged += (unsigned long long)cnt;
         for (int k = 0; k < BWD_BATCH / 64; k++) {
@@ -964,7 +1209,7 @@ void launch_blend_bwd_stats(const BackwardArgs& a, unsigned long long* counters,
 {
     const int tiles = total_tiles(a.cam), grid_y = a.cam.grid_y * a.cam.frames;
     hipLaunchKernelGGL(blend_bwd_stats_kernel, dim3(tiles), dim3(256), 0, stream, a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.img,
-                       a.point_list, a.geom.rec, counters);
+                       a.point_list, a.geom.rec, counters, a.flags);
 }
 
 // (experiments, tools/occ_probe.sh: VIDU4D_BWD_PAD_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups
@@ -979,19 +1224,37 @@ static int bwd_pad_lds()
     return v;
 }
 
+template <bool SPLIT>
+static auto pick_bwd(int mode)
+{
+    return mode == BLEND_LITE ? &blend_bwd_kernel<SPLIT, BLEND_LITE>
+           : mode == BLEND_GEOM ? &blend_bwd_kernel<SPLIT, BLEND_GEOM>
+                                : &blend_bwd_kernel<SPLIT, BLEND_FULL>;
+}
+
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
 {
     const int tiles = total_tiles(a.cam), grid_y = a.cam.grid_y * a.cam.frames;
     const int pad = bwd_pad_lds();
     if (a.split && a.seg_data) {
-        auto kernel = a.lite ? &blend_bwd_kernel<true, true> : &blend_bwd_kernel<true, false>;
-        hipLaunchKernelGGL(kernel, dim3((int)seg_capacity(a.capacity) + tiles), dim3(256), pad, stream, a.cam.W, a.cam.H,
+        // upper bound of the segment count (the device knows the exact one; the workgroups beyond it leave at once).
+        // Recorded segments (find_work_recorded): the FULL segments, at most capacity / REC_SEG_LEN, then one tail per tile.
+        const int64_t segs = a.recorded ? a.capacity / REC_SEG_LEN + 1 : seg_capacity(a.capacity);
+        hipLaunchKernelGGL(pick_bwd<true>(a.mode), dim3((int)segs + tiles), dim3(256), pad, stream, a.cam.W, a.cam.H,
                            a.cam.grid_x, grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data,
-                           a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc);
+                           a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc, a.flags
+#ifdef SURFEL_BWD_TRACE
+                           , a.trace
+#endif
+                           );
     } else {
-        auto kernel = a.lite ? &blend_bwd_kernel<false, true> : &blend_bwd_kernel<false, false>;
-        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), pad, stream, a.cam.W, a.cam.H, a.cam.grid_x, grid_y, a.geom.hdr,
-                           a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0, a.dL_dcolor, a.dL_dothers, a.acc);
+        hipLaunchKernelGGL(pick_bwd<false>(a.mode), dim3(tiles), dim3(256), pad, stream, a.cam.W, a.cam.H, a.cam.grid_x, grid_y,
+                           a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data, 0, a.dL_dcolor, a.dL_dothers,
+                           a.acc, a.flags
+#ifdef SURFEL_BWD_TRACE
+                           , a.trace
+#endif
+                           );
     }
 }
 

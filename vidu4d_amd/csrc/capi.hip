@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/vidu4d_surfel.h"
+#include "../../include/vidu4d_surfel_diag.h"
 #include "surfel_state.h"
 
 using namespace surfel;
@@ -43,7 +44,6 @@ struct StageSpan {
     int stage;
 };
 static bool g_prof_on = false;
-static unsigned long long* g_blend_stats = nullptr;  // vidu4d_surfel_blend_stats: device counters, or NULL (off)
 static std::vector<StageSpan> g_spans;      // recorded, not yet harvested
 static std::vector<StageSpan> g_span_pool;  // reusable event pairs
 static double g_stage_ms[ST_COUNT];
@@ -77,11 +77,6 @@ struct StageTimer {
 extern "C" int vidu4d_surfel_profile_enable(int on)
 {
     g_prof_on = on != 0;
-    return VIDU4D_OK;
-}
-extern "C" int vidu4d_surfel_blend_stats(unsigned long long* device_counters)
-{
-    g_blend_stats = device_counters;
     return VIDU4D_OK;
 }
 extern "C" int vidu4d_surfel_profile_stage_count(void) { return ST_COUNT; }
@@ -188,6 +183,15 @@ static int check_canonical_sh(const Args* a)
         return fail(VIDU4D_E_INVALID, "sh_dc / sh_rest must be 16-byte aligned");
     return VIDU4D_OK;
 }
+
+// aux_planes -> the blend instance that carries exactly what the caller reads (surfel_math.h)
+static int blend_mode(int aux_planes)
+{
+    if (aux_planes == VIDU4D_AUX_ALPHA) return BLEND_LITE;
+    if (aux_planes != 0 && (aux_planes & ~VIDU4D_AUX_GEOM) == 0) return BLEND_GEOM;  // some of the planes 0-4, nothing else
+    return BLEND_FULL;
+}
+static int kernel_flags(int debug_flags) { return (debug_flags & VIDU4D_DEBUG_NO_CULL) ? FLAG_NO_CULL : 0; }
 
 static int check_forward(const Vidu4dSurfelForwardArgs* a)
 {
@@ -318,12 +322,15 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     carve_image((char*)a->image_buffer, a->width, a->height, img, F);
     carve_binning((char*)binning, capacity, b);
     const CameraParams cam = camera_of(a);
+    // the segment table: for a segment-parallel forward, or (whole-tile forward) for the recorded segments of its backward
+    const bool record = a->segment_split == 0;
+    const ScheduleParams sp = {record ? REC_SEG_LEN : SEG_LEN, record ? REC_MIN : SPLIT_MIN, record ? 1 : 0};
+    {
+        StageTimer t(ST_EMIT, stream);
+        launch_emit_keys(cam, P, a->radii, g, img, b, capacity, use_grouped_binning(total_tiles(cam)), sp, stream);
+    }
+    STAGE_CHECK(a->debug, stream, "emit_keys");
     if (capacity > 0) {
-        {
-            StageTimer t(ST_EMIT, stream);
-            launch_emit_keys(cam, P, a->radii, g, img, b, capacity, use_grouped_binning(total_tiles(cam)), stream);
-        }
-        STAGE_CHECK(a->debug, stream, "emit_keys");
         {
             StageTimer t(ST_SORT, stream);
             launch_tile_sort(g, img, b, total_tiles(cam), P, capacity,
@@ -339,7 +346,8 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
         // segment_split: 0 off, 1 on, k > 1: on, at most k segments per tile (Header::truncated reports a miss)
         const int max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
         launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, max_seg, a->background, a->out_color, a->out_others,
-                         a->depth_used, a->aux_planes == VIDU4D_AUX_ALPHA, a->assume_unsaturated != 0, stream);
+                         a->depth_used, blend_mode(a->aux_planes), a->assume_unsaturated != 0, kernel_flags(a->debug_flags),
+                         a->segment_split == 0, stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
     return VIDU4D_OK;
@@ -376,7 +384,9 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     ba.point_list = a->binning_capacity > 0 ? b.point_list : nullptr;
     ba.seg_data = a->binning_capacity > 0 ? b.seg_data : nullptr;
     ba.capacity = a->binning_capacity;
-    ba.split = a->segment_split != 0 && a->binning_capacity > 0;
+    // segment_split == 0: the forward walked whole tiles and (unless told not to) left recorded segments
+    ba.recorded = a->segment_split == 0;
+    ba.split = a->binning_capacity > 0 && (a->segment_split != 0 || !(a->debug_flags & VIDU4D_DEBUG_WHOLE_TILE_BACKWARD));
     ba.max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
     ba.P = P;
     ba.background = a->background;
@@ -403,7 +413,8 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     ba.dL_dsh_dc = a->sh_dc ? a->dL_dsh_dc : nullptr;
     ba.dL_dsh_rest = a->sh_dc ? a->dL_dsh_rest : nullptr;
     ba.raw_params = a->raw_params;
-    ba.lite = a->aux_planes == VIDU4D_AUX_ALPHA;
+    ba.mode = blend_mode(a->aux_planes);
+    ba.flags = kernel_flags(a->debug_flags);
 
     {
         StageTimer t(ST_BWD_ZERO, stream);
@@ -418,9 +429,15 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     }
     {
         StageTimer t(ST_BLEND_BWD, stream);
+#ifdef SURFEL_BWD_TRACE   // (variant build for tools/bwd_trace.py: diag_walk_counters is blend_bwd's own trace buffer)
+        ba.trace = (unsigned long long*)a->diag_walk_counters;
+#endif
         launch_blend_bwd(ba, stream);
     }
-    if (g_blend_stats && ba.point_list) launch_blend_bwd_stats(ba, g_blend_stats, stream);
+#ifndef SURFEL_BWD_TRACE
+    if (a->diag_walk_counters && ba.point_list)
+        launch_blend_bwd_stats(ba, (unsigned long long*)a->diag_walk_counters, stream);  // (vidu4d_surfel_diag.h)
+#endif
     STAGE_CHECK(a->debug, stream, "blend_backward");
     {
         StageTimer t(ST_PREPROCESS_BWD, stream);

@@ -18,6 +18,7 @@
 // parameters are treated as constants (--gs_optim_warp=False, the README's Stage-3 setting).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/vidu4d_surfel.h"
 
@@ -257,7 +258,10 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
     };
     constexpr int NB = BX ? BX : BCAP;
     float w[BCAP];
-    uint32_t raw_pos = 0;  // bit b: the delta-skin logit of bone b is positive (the relu of the forward)
+    // bit b: the delta-skin logit of bone b is positive (the relu of the forward).  One word per 32 bones: the 64-bone
+    // instance needs two (a 32-bit shift by b >= 32 is undefined and aliases bit b - 32 on this hardware)
+    using RawMask = typename std::conditional<(NB > 32), uint64_t, uint32_t>::type;
+    RawMask raw_pos = 0;
     int anchor = 0;
     float best = -3.0e38f;
     float rawv[BX ? BX : 1];
@@ -268,7 +272,7 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
         if (!BX && b >= B) break;
         const float x0 = bone_coord(3 * b), x1 = bone_coord(3 * b + 1), x2 = bone_coord(3 * b + 2);
         const float raw = BX ? rawv[BX ? b : 0] : (rawT ? rawT[(uint32_t)b * (uint32_t)N + (uint32_t)n] : 0.f);
-        raw_pos |= raw > 0.f ? (1u << b) : 0u;
+        raw_pos |= raw > 0.f ? (RawMask(1) << b) : RawMask(0);
         w[b] = -((x0 * x0 + x1 * x1 + x2 * x2) + 0.1f * fmaxf(raw, 0.f));
         if (w[b] > best) {  // first maximum, like torch.argmax (the softmax keeps the order)
             best = w[b];
@@ -392,7 +396,7 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
             g_xbT[(uint32_t)(3 * b + 1) * Ns + (uint32_t)n] = g1;
             g_xbT[(uint32_t)(3 * b + 2) * Ns + (uint32_t)n] = g2;
         }
-        if (g_rawT) g_rawT[(uint32_t)b * Ns + (uint32_t)n] = ((raw_pos >> b) & 1u) ? -0.1f * g_logit : 0.f;
+        if (g_rawT) g_rawT[(uint32_t)b * Ns + (uint32_t)n] = ((raw_pos >> b) & RawMask(1)) ? -0.1f * g_logit : 0.f;
         PIN3(acc_p.x, acc_p.y, acc_p.z);
     }
     g_xyz[3 * n] = acc_p.x;
@@ -428,6 +432,8 @@ void launch_lbs_skin(int M, int N, int B, bool from_xyz, hipStream_t stream, Arg
 int check(int M, int N, int B)
 {
     if (M < 0 || N < 0 || B <= 0 || B > MAX_BONES) return VIDU4D_E_INVALID;
+    // feature-major rows are addressed as (uint32_t)k * N + n with k < 3 B: must stay inside 32 bits
+    if ((int64_t)3 * B * (int64_t)N > 0xffffffffll) return VIDU4D_E_INVALID;
     return VIDU4D_OK;
 }
 

@@ -140,14 +140,22 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
 __device__ __forceinline__ void flush_staged_records(const float4* stage, float* rec, int idx0, unsigned long long visible,
                                                      int lane)
 {
-    if (!visible) return;
-    float4* dst = reinterpret_cast<float4*>(rec + (size_t)idx0 * REC_FLOATS);
-    constexpr int PARTS = REC_FLOATS / 4;
+    // the lanes read each other's records: the per-lane LDS stores above must be complete (and not sunk below by the
+    // compiler) before, and the reads done before the next batch's stores -- wave-level fences, as bucket_sort_small_kernel has
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (visible) {
+        float4* dst = reinterpret_cast<float4*>(rec + (size_t)idx0 * REC_FLOATS);
+        constexpr int PARTS = REC_FLOATS / 4;
 #pragma unroll
-    for (int i0 = 0; i0 < 64 * PARTS; i0 += 64) {
-        const int i = i0 + lane, r = i / PARTS;
-        if ((visible >> r) & 1ull) dst[i] = stage[i];
+        for (int i0 = 0; i0 < 64 * PARTS; i0 += 64) {
+            const int i = i0 + lane, r = i / PARTS;
+            if ((visible >> r) & 1ull) dst[i] = stage[i];
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Atomic path (more than BIN_MAX_TILES tiles): per-tile pair counts with global atomics.

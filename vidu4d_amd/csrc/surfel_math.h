@@ -673,15 +673,27 @@ struct FwdPixel {
     float dist1 = 0, dist2 = 0, distortion = 0;
     float median_depth = 0, median_weight = 0;
     uint32_t last_contributor = 0, median_contributor = 0;
+    // the distortion moments once more, summed from zero since the last segment boundary (recorded segments, blend.hip:
+    // the backward's distortion chain needs "what lies behind a segment" to the precision of THAT sum, not of the total's)
+    float seg1 = 0, seg2 = 0;
 };
 
 // One accepted sample (forward.cu:400-438).  Returns false (and leaves the state untouched) when
 // the pixel saturates on this sample.
 //
-// LITE (aux_planes names only the alpha plane: colour + silhouette losses, Stage-3 before the regularisers switch on):
-// depth, normal, median and distortion accumulations are not carried; their planes come out as zeros.  Colour,
-// transmittance and the contributor count are the same operations on the same operands as in the full version.
-template <bool LITE = false>
+// Which planes a blend instance carries (Vidu4dSurfelForwardArgs::aux_planes):
+//   BLEND_FULL  everything the reference computes;
+//   BLEND_LITE  colour + alpha plane (aux_planes names only the alpha plane: colour + silhouette losses, Stage-3 before the
+//               regularisers switch on): depth, normal, median and distortion accumulations are not carried, their planes
+//               come out as zeros;
+//   BLEND_GEOM  colour + planes 0-4 (depth, alpha, normal: Stage-3 after step 8000 with the upstream defaults lambda_dist = 0,
+//               depth_ratio = 0 -- lab4d/config.py:181, gs/arguments/__init__.py:68 -- where only these planes are read,
+//               lab4d/engine/model.py:817-842): the median sample and the distortion moments are not carried, planes 5-7
+//               come out as zeros.
+// What an instance does carry is the same operations on the same operands as in the full version: bit-identical planes.
+constexpr int BLEND_FULL = 0, BLEND_LITE = 1, BLEND_GEOM = 2;
+
+template <int MODE = BLEND_FULL>
 SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal[3], const float rgb[3],
                               uint32_t contributor)
 {
@@ -689,7 +701,7 @@ SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal
     const float test_T = s.T * (1.0f - e.alpha);  // THRESHOLD-EXACT (same two roundings as the oracle)
     if (test_T < T_EPS) return false;
     const float w = e.alpha * s.T;
-    if (!LITE) {
+    if (MODE == BLEND_FULL) {
         const float A = 1.0f - s.T;
         const float m = map_depth(e.depth);
         const float error = fmaf(m * m, A, fmaf(-2.0f * m, s.dist1, s.dist2));
@@ -699,10 +711,14 @@ SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal
             s.median_weight = w;
             s.median_contributor = contributor;
         }
-        for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(normal[ch], w, s.N[ch]);
-        s.D = fmaf(e.depth, w, s.D);
         s.dist1 = fmaf(m, w, s.dist1);
         s.dist2 = fmaf(m * m, w, s.dist2);
+        s.seg1 = fmaf(m, w, s.seg1);
+        s.seg2 = fmaf(m * m, w, s.seg2);
+    }
+    if (MODE != BLEND_LITE) {
+        for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(normal[ch], w, s.N[ch]);
+        s.D = fmaf(e.depth, w, s.D);
     }
     for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(rgb[ch], w, s.C[ch]);
     s.T = test_T;
@@ -734,9 +750,11 @@ struct PairGrad {
     float w, dL_dalpha, dL_dz;
 };
 
-// LITE: only dL/dcolour and dL/dalpha-plane are live (every other upstream gradient plane is zero by the caller's
+// BLEND_LITE: only dL/dcolour and dL/dalpha-plane are live (every other upstream gradient plane is zero by the caller's
 // promise, aux_planes): the depth / normal / median / distortion chains, which would multiply by those zeros, are left out.
-template <bool LITE = false>
+// BLEND_GEOM: the planes 5-7 are zero by the caller's promise: the median and distortion chains are left out; what remains
+// is what the full version computes with those zeros (x + 0 and 0 * finite are exact: the same bits).
+template <int MODE = BLEND_FULL>
 SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float normal[3], const float rgb[3],
                                  bool is_median)
 {
@@ -747,7 +765,7 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
     const float w = alpha * s.T;
     float dL_dalpha = 0.0f;
     for (int ch = 0; ch < 3; ch++) dL_dalpha += (rgb[ch] - s.accum_rec[ch]) * s.dL_dpixel[ch];
-    if (LITE) {
+    if (MODE == BLEND_LITE) {
         dL_dalpha += (1.0f - s.accum_alpha_rec) * s.dL_daccum;
         dL_dalpha *= s.T;
         dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot_dpixel;
@@ -759,20 +777,23 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
         r.dL_dz = 0.f;
         return r;
     }
-    float dL_dz = 0.0f, dL_dweight = 0.0f;
-    // m_d = far (d - near) / ((far - near) d) and its derivative far near / ((far - near) d^2) from ONE reciprocal
-    const float inv_d = fast_rcp((FAR_PLANE - NEAR_PLANE) * c_d);
-    const float m_d = (FAR_PLANE * c_d - FAR_PLANE * NEAR_PLANE) * inv_d;
-    const float dmd_dd = (FAR_PLANE * NEAR_PLANE * (FAR_PLANE - NEAR_PLANE)) * inv_d * inv_d;
-    if (is_median) {
-        dL_dz += s.dL_dmedian_depth;
-        dL_dweight += s.dL_dmax_dweight;
+    float dL_dz = 0.0f;
+    if (MODE == BLEND_FULL) {
+        float dL_dweight = 0.0f;
+        // m_d = far (d - near) / ((far - near) d) and its derivative far near / ((far - near) d^2) from ONE reciprocal
+        const float inv_d = fast_rcp((FAR_PLANE - NEAR_PLANE) * c_d);
+        const float m_d = (FAR_PLANE * c_d - FAR_PLANE * NEAR_PLANE) * inv_d;
+        const float dmd_dd = (FAR_PLANE * NEAR_PLANE * (FAR_PLANE - NEAR_PLANE)) * inv_d * inv_d;
+        if (is_median) {
+            dL_dz += s.dL_dmedian_depth;
+            dL_dweight += s.dL_dmax_dweight;
+        }
+        dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2.0f * m_d * s.final_D) * s.dL_dreg;
+        dL_dalpha += dL_dweight - s.last_dL_dT;
+        s.last_dL_dT = dL_dweight * alpha + one_m_alpha * s.last_dL_dT;
+        const float dL_dmd = 2.0f * w * (m_d * s.final_A - s.final_D) * s.dL_dreg;
+        dL_dz += dL_dmd * dmd_dd;
     }
-    dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2.0f * m_d * s.final_D) * s.dL_dreg;
-    dL_dalpha += dL_dweight - s.last_dL_dT;
-    s.last_dL_dT = dL_dweight * alpha + one_m_alpha * s.last_dL_dT;
-    const float dL_dmd = 2.0f * w * (m_d * s.final_A - s.final_D) * s.dL_dreg;
-    dL_dz += dL_dmd * dmd_dd;
 
     dL_dalpha += (c_d - s.accum_depth_rec) * s.dL_ddepth;
     dL_dalpha += (1.0f - s.accum_alpha_rec) * s.dL_daccum;
@@ -803,10 +824,11 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
 // contribute passes pg = 0 and `e` with finite sx, sy, ipz, G (PairEval::sanitise) and gets exact zeros without
 // a branch.  The six dL/dTu, dL/dTv sums are accumulated with the OPPOSITE sign (+dk, +dl: the negations are
 // seven VALU instructions per pair); surfel_backward flips them back (exact).
-template <bool LITE = false>
+template <int MODE = BLEND_FULL>
 SURFEL_HD void bwd_pair_geometry(const BwdPixel& s, const PairEval& e, const PairGrad& pg, const float Tw[3],
                                  float opacity, float pixx, float pixy, float g[ACC_FLOATS])
 {
+    constexpr bool LITE = MODE == BLEND_LITE;
     const float G = e.G, dL_dz = LITE ? 0.f : pg.dL_dz;
     for (int ch = 0; ch < 3; ch++) {
         g[A_RGB + ch] = pg.w * s.dL_dpixel[ch];

@@ -58,18 +58,61 @@ constexpr uint32_t SEG_NONE = 0xFFFFFFFFu;
 // segments of all split tiles: sum ceil(len / SEG_LEN) <= R / SEG_LEN + (#tiles longer than SPLIT_MIN)
 inline int64_t seg_capacity(int64_t capacity) { return capacity / SEG_LEN + capacity / SPLIT_MIN + 2; }
 
+// Recorded segments (round 4): the backward of a frame whose forward walked every tile WHOLE still runs segment-parallel.
+// The forward is a sequential walk anyway; at every REC_SEG_LEN-th list entry of a tile longer than REC_MIN it stores, per
+// pixel, the transmittance and the sums of the segment it has just finished (a record: REC_REC_FLOATS x 256 floats) and
+// starts the next segment's sums from zero (its totals are base + running segment: a two-level sum); at the end it stores
+// the sums of the segment it stopped in.  The backward's back-to-front recurrences of a segment start from "what lies
+// behind the segment" = the sum of the later segments' records -- what blend_combine_kernel hands the backward of a
+// segment-parallel forward -- each summed from zero, i.e. to the precision of the recurrence they replace (the first
+// version stored running totals and took final - prefix: 5e-6 of the gradients' scale instead of 1e-6).  The serial
+// chain of a backward workgroup drops from the tile's list to REC_SEG_LEN entries, and the units become small enough for
+// the dispatcher to balance the CUs: the whole-tile launch spends a third of its CU-time with fewer than four workgroups
+// per CU (tools/bwd_trace.py), this one a tenth.
+#ifndef SURFEL_REC_SEG_LEN
+#define SURFEL_REC_SEG_LEN 256
+#endif
+#ifndef SURFEL_REC_MIN
+#define SURFEL_REC_MIN 320
+#endif
+constexpr int REC_SEG_LEN = SURFEL_REC_SEG_LEN;  // (a multiple of the forward's batch, 256 entries)
+constexpr int REC_MIN = SURFEL_REC_MIN;
+constexpr int REC_REC_FLOATS = 11;  // per (segment, pixel) values of a record: seg_data[(slot * 11 + k) * 256 + pixel]
+enum RecordedSlot {
+    RS_T = 0,     // record of segment q (slot first + q, written at its end): transmittance after its last entry;
+                  // FINAL record (the tile's last slot, written when the walk ends): the median weight
+    RS_C = 1,     // sums over THIS segment only -- final record: over the segment the walk stopped in --: colour (3)
+    RS_D = 4,     // depth
+    RS_N = 5,     // normal (3)
+    RS_M1 = 8,    // w m, w m^2 (distortion moments)
+    RS_M2 = 9,
+    RS_STOP = 10  // final record: index of the segment the walk stopped in (bits of a uint32)
+};
+inline int64_t rec_seg_capacity(int64_t capacity) { return capacity / REC_SEG_LEN + capacity / REC_MIN + 2; }
+// floats of seg_data: the larger of the two uses
+inline size_t seg_data_floats(int64_t capacity)
+{
+    const size_t a = (size_t)seg_capacity(capacity) * SEG_FLOATS * 256, b = (size_t)rec_seg_capacity(capacity) * REC_REC_FLOATS * 256;
+    return a > b ? a : b;
+}
+// debug_flags of the ABI as the kernels see them
+constexpr int FLAG_NO_CULL = 1;
+
 struct Header {           // first 256 bytes of the geometry buffer
     uint32_t num_rendered;  // R, written by the tile scan
     uint32_t overflow;      // set by emit when R > capacity
     uint32_t max_tile_len;  // longest tile list (tile_order_kernel)
     uint32_t num_segments;  // segments over all tiles longer than SPLIT_MIN
     uint32_t num_split_pos; // schedule positions [0, num_split_pos) hold every split tile
-    uint32_t split_used;    // the forward blended long tiles segment-parallel (seg_data is valid)
+    uint32_t split_used;    // 1: the forward blended long tiles segment-parallel (seg_data holds what the combine left);
+                            // 2: it walked them whole and recorded prefix / final records per segment
     uint32_t truncated;     // a pixel was still unsaturated after the last segment the caller allowed (max_seg)
     uint32_t scan_arrivals; // workgroups of tile_scan_fused_kernel that have finished their columns (reset per forward)
     uint32_t min_T_bits;    // bits of the smallest final transmittance of the frame (atomic min; reset per forward)
     uint32_t num_buckets;   // buckets the MSD split of the long lists queued for bucket_sort_kernel (reset by the schedule)
-    uint32_t pad[54];
+    uint32_t seg_len;       // what the segment table was built with: entries per segment ...
+    uint32_t split_min;     // ... of the tiles longer than this (SEG_LEN / SPLIT_MIN, or REC_SEG_LEN / REC_MIN: recorded segments)
+    uint32_t pad[52];
 };
 
 struct GeomState {
@@ -90,13 +133,16 @@ struct ImageState {
     uint32_t* tile_order;  // [tiles] tile ids, longest list first: workgroup b of the blend kernels takes tile_order[b]
     uint32_t* seg_first;   // [tiles] first segment slot of a split tile, SEG_NONE otherwise
     uint32_t* seg_prefix;  // [tiles + 1] by schedule position: exclusive prefix of the segment counts
+    uint32_t* tail_order;  // [tiles] recorded segments: tile ids by the size of their tail unit (remainder segment of a
+                           // split tile, or the whole unsplit tile), largest first
 };
 
 struct BinState {
     uint64_t* entries;     // [cap] (depth bits << 32 | surfel id), grouped by tile, sorted per tile
     uint64_t* scratch;     // [cap] ping-pong space for tiles too long for LDS
     uint32_t* point_list;  // [cap] sorted surfel ids == the reference's binningState.point_list
-    float* seg_data;       // [seg_capacity(cap)][SEG_FLOATS][256] per-segment, per-pixel partial results
+    float* seg_data;       // [seg_capacity(cap)][SEG_FLOATS][256] per-segment, per-pixel partial results, or
+                           // [rec_seg_capacity(cap)][REC_REC_FLOATS][256] recorded segments
 };
 
 template <typename T>
@@ -142,6 +188,7 @@ inline size_t carve_image(char* base, int W, int H, ImageState& s, int frames = 
     carve(p, s.tile_order, tiles);
     carve(p, s.seg_first, tiles);
     carve(p, s.seg_prefix, tiles + 1);
+    carve(p, s.tail_order, tiles);
     return (size_t)(p - base) + 256;
 }
 
@@ -152,7 +199,7 @@ inline size_t carve_binning(char* base, int64_t capacity, BinState& b)
     carve(p, b.entries, cap);
     carve(p, b.scratch, cap);
     carve(p, b.point_list, cap);
-    carve(p, b.seg_data, cap ? (size_t)seg_capacity(capacity) * SEG_FLOATS * 256 : 0);
+    carve(p, b.seg_data, cap ? seg_data_floats(capacity) : 0);
     return (size_t)(p - base) + 256;
 }
 
@@ -260,8 +307,15 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
 // counts -> ranges (exclusive scan over tiles), total -> header; atomic path: counts reset to 0 (they
 // become cursors); grouped path (groups > 0): per-(group, tile) counts become prefixes over the groups
 void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, int groups, hipStream_t stream);
+// The longest-first schedule and the segment table (binning.hip tile_order): the table is built for tiles longer than
+// split_min, in segments of seg_len entries; by_class: split by length class (recorded segments: the split tiles then lead
+// the schedule without exception).  Built by launch_emit_keys -- by an extra workgroup of the emit launch where it can.
+struct ScheduleParams {
+    int seg_len, split_min, by_class;
+};
+void launch_tile_order(const GeomState& g, const ImageState& img, int num_tiles, const ScheduleParams& sp, hipStream_t stream);
 void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
-                      const BinState& b, int64_t capacity, bool grouped, hipStream_t stream);
+                      const BinState& b, int64_t capacity, bool grouped, const ScheduleParams& sp, hipStream_t stream);
 // per-tile stable radix sort of the (depth, id) entries; fills point_list
 // How lists longer than the LDS capacity (TILE_SORT_CAP) are sorted (Vidu4dSurfelForwardArgs::long_list_sort):
 //   in_lds_only   -- the long-tile machinery is off (segment_split == 0): the 4-wave kernel runs them through global memory;
@@ -275,9 +329,11 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
 // split: blend tiles longer than SPLIT_MIN segment-parallel (three launches instead of one)
 // max_seg: only the first max_seg segments of a split tile are blended (a caller that knows how deep the
 // previous frames went saves the rest of pass 1); Header::truncated is set if that was not enough
+// mode: BLEND_FULL / BLEND_LITE / BLEND_GEOM (surfel_math.h); flags: FLAG_*; record: an unsplit walk leaves recorded segments
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
-                      float* out_others, uint32_t* depth_used, bool lite, bool assume_unsaturated, hipStream_t stream);
+                      float* out_others, uint32_t* depth_used, int mode, bool assume_unsaturated, int flags, bool record,
+                      hipStream_t stream);
 
 struct BackwardArgs {
     CameraParams cam;
@@ -312,7 +368,13 @@ struct BackwardArgs {
     float* dL_dsh_dc;
     float* dL_dsh_rest;
     int raw_params;       // scales are log-scales; dL_dscales / dL_dopacity are w.r.t. log-scales / logits
-    bool lite;            // only dL_dcolor and plane 1 of dL_dothers are live (aux_planes == alpha only)
+    int mode;             // BLEND_LITE: only dL_dcolor and plane 1 of dL_dothers are live (aux_planes == alpha only);
+                          // BLEND_GEOM: planes 5-7 are taken as zero; BLEND_FULL: everything
+    int flags;            // FLAG_*
+    bool recorded;        // (with split) the forward walked whole tiles and may have left recorded segments
+#ifdef SURFEL_BWD_TRACE
+    unsigned long long* trace;  // (variant build for tools/bwd_trace.py) 4 words per workgroup of blend_bwd, or NULL
+#endif
 };
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream);
 void launch_blend_bwd_stats(const BackwardArgs& a, unsigned long long* counters, hipStream_t stream);  // diagnostic

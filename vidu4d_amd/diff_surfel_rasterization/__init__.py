@@ -166,6 +166,8 @@ def rasterize_frames(means3D, means2D, sh, opacities, scales, rotations, setting
 
 
 AUX_ALPHA = 0x02  # (VIDU4D_AUX_ALPHA)
+AUX_GEOM = 0x1F   # (VIDU4D_AUX_GEOM) planes 0-4: depth, alpha, normal -- colour and these planes bit-identical to the full
+                  # call's, planes 5-7 (median depth, distortion, median weight) zeros, their gradients TAKEN as zero
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -329,7 +329,12 @@ class Stage3Trainer:
             # gradients that were not produced into the flat buffer (a caller that set them by hand): gather them
             ps = self.exchanged_params()
             nets = {id(p) for p in self._net_params} if self.optim_warp else set()
-            grads = [p.grad for p in ps]
+            # (a PARTIALLY bound state is reachable: with direct gradient outputs some parameters' .grad are views of the
+            # buffers while autograd handed others a tensor of its own -- re-binding zero-fills the buffers, so whatever
+            # lives in them is copied out first)
+            homes = {t.untyped_storage().data_ptr() for t in (self._flat, self.__dict__.get("_rest_full")) if t is not None}
+            grads = [(p.grad.clone() if p.grad is not None and p.grad.untyped_storage().data_ptr() in homes else p.grad)
+                     for p in ps]
             self.bind_flat_gradients()
             for p, g_ in zip(ps, grads):
                 if id(p) in nets:
@@ -469,10 +474,20 @@ class Stage3Trainer:
             from .loss_fused import stage3_loss
             # colour and silhouette terms read the colour and the alpha plane; the distortion term (plane 6) only counts
             # once lambda_dist does, the normal term reads planes 0-5: until then the blend kernels carry nothing else
-            # (aux_planes, csrc/blend.hip LITE)
-            from ..diff_surfel_rasterization import AUX_ALPHA
+            # (aux_planes, csrc/blend.hip BLEND_LITE).  With the normal term on but the upstream defaults lambda_dist = 0
+            # (lab4d/config.py:181) and depth_ratio = 0 (gs/arguments/__init__.py:68; gs/gaussian_renderer/__init__.py:146:
+            # the surface depth is the EXPECTED depth) only planes 0-4 -- depth, alpha, normal -- carry gradient
+            # (lab4d/engine/model.py:817-842): the blend kernels then leave the median sample and the distortion moments out
+            # (BLEND_GEOM) and, where they run segment-parallel, need no transmittance pre-pass.
+            from ..diff_surfel_rasterization import AUX_ALPHA, AUX_GEOM
             lam_d = float(self.cfg.lambda_dist) if step > 8000 else 0.0
-            aux = AUX_ALPHA if (lam_d == 0.0 and not need_geometry and m.opts.get("alpha_only_blend", True)) else 0
+            depth_ratio = float(getattr(m.pipeline, "depth_ratio", 0.0))
+            if lam_d == 0.0 and not need_geometry and m.opts.get("alpha_only_blend", True):
+                aux = AUX_ALPHA
+            elif lam_d == 0.0 and depth_ratio == 0.0 and m.opts.get("geom_blend", True):
+                aux = AUX_GEOM
+            else:
+                aux = 0
             rendered = m.render_frames(batch["frameid"], batch["Kinv"], batch["H"], batch["W"], outputs=("raw",),
                                        aux_planes=aux)
             if "raw_stacked" in rendered:   # the frames came out of one stacked launch set: (3,M,H,W), (8,M,H,W)
