@@ -165,6 +165,11 @@ typedef struct Vidu4dSurfelForwardArgs {
      *   longer than 320 entries in 256-entry segments on separate workgroups, each starting from the per-pixel sums the
      *   forward's own walk stored at the segment boundaries: same gradients up to fp32 re-association of those sums. */
     int debug_flags;
+    /* ---- longest tile list the caller expects (extension, ABI 17; 0 = unknown): e.g. word 2 of the geometry buffer after
+     * an earlier frame of the same view.  With segment_split == 0 and 0 < max_list_hint <= 900 the in-LDS sort of the
+     * lists up to 1024 entries is the only sort launch (a longer list, should one appear after all, is sorted by that
+     * launch through global memory: the result never depends on the hint). */
+    int max_list_hint;
 } Vidu4dSurfelForwardArgs;
 #define VIDU4D_AUX_ALPHA 0x02
 #define VIDU4D_AUX_GEOM 0x1F   /* planes 0-4: depth, alpha, normal */
@@ -262,7 +267,7 @@ enum Vidu4dSurfelStateArray {
     VIDU4D_STATE_POINT_LIST = 3,    /* uint32[num_rendered] sorted surfel ids (binning.point_list) */
     VIDU4D_STATE_SORTED_KEYS = 4,   /* uint64[num_rendered] (tile << 32 | depth bits); dst must be HOST memory */
     VIDU4D_STATE_RANGES = 5,        /* uint32[tiles][2] */
-    VIDU4D_STATE_FINAL_T = 6,       /* float[3][H*W]: T, dist1, dist2 */
+    VIDU4D_STATE_FINAL_T = 6,       /* float[3][H*W]: T, dist1, dist2 (the distortion moments about a per-tile reference depth) */
     VIDU4D_STATE_N_CONTRIB = 7      /* uint32[2][H*W]: last, median */
 };
 int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* args, const void* binning_buffer, int64_t capacity,

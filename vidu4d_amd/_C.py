@@ -312,6 +312,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # long lists: the MSD split + bucket sorts from ~10 k entries per list on, one workgroup per list through global memory
     # below (dense Stage-3 ball, 5 k-entry lists: 81 us against 109; 3 %-coverage object, 25 k: 171 against 78)
     a.long_list_sort = 0 if _len_hint.get(key, 1 << 30) >= MSD_SORT_FROM else 1
+    a.max_list_hint = int(_len_hint.get(key, 0))   # (0: unknown.  Short lists only: one sort launch instead of two)
     if a.segment_split and ((int(aux_planes) == _lib.AUX_ALPHA and _SPEC) or
                             (int(aux_planes) != _lib.AUX_ALPHA and int(aux_planes) and not (int(aux_planes) & ~_lib.AUX_GEOM)
                              and _SPEC_GEOM)):

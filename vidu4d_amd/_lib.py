@@ -30,6 +30,7 @@ class ForwardArgs(C.Structure):
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
         ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("raw_params", C.c_int), ("aux_planes", C.c_int),
         ("assume_unsaturated", C.c_int), ("long_list_sort", C.c_int), ("debug_flags", C.c_int),
+        ("max_list_hint", C.c_int),
     ]
 
 
@@ -102,7 +103,8 @@ class BackwardArgs(C.Structure):
         ("frames", C.c_int), ("frame_viewmatrix", C.c_void_p * 8), ("frame_campos", C.c_void_p * 8),
         ("frame_tan_fovx", C.c_float * 8), ("frame_tan_fovy", C.c_float * 8),
         ("sh_dc", C.c_void_p), ("sh_rest", C.c_void_p), ("dL_dsh_dc", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
-        ("raw_params", C.c_int), ("aux_planes", C.c_int), ("debug_flags", C.c_int), ("diag_walk_counters", C.c_void_p),
+        ("raw_params", C.c_int), ("aux_planes", C.c_int), ("debug_flags", C.c_int),
+        ("diag_walk_counters", C.c_void_p),
     ]
 
 

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
                                                               const uint32_t* num_ptr, int64_t capacity,
                                                               uint64_t* entries, uint64_t* scratch,
                                                               uint32_t* __restrict__ point_list, int id_bytes,
-                                                              int skip_long, int min_len)
+                                                              int skip_long, int min_len, int take_long)
 {
     __shared__ uint64_t s_buf[IN_LDS ? 2 : 1][IN_LDS ? CAP : 1];
     __shared__ uint32_t s_cnt[WAVES][256];  // per-wave digit counts, then per-wave destination cursors
@@ -585,7 +585,8 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
     const uint32_t start = ranges[2 * tile];
     const int n = (int)(ranges[2 * tile + 1] - start);
     if (n == 0 || n < min_len) return;
-    if (IN_LDS ? ((skip_long || CAP < TILE_SORT_CAP) && n > CAP) : n <= TILE_SORT_CAP) return;
+    // (take_long: this is the only sort launch -- a list beyond CAP goes through global memory here)
+    if (IN_LDS ? ((skip_long || (CAP < TILE_SORT_CAP && !take_long)) && n > CAP) : n <= TILE_SORT_CAP) return;
     sort_one_list<WAVES, IN_LDS, CAP>(entries + start, start, n, 32, entries, scratch, point_list, id_bytes, s_buf, s_cnt,
                                       s_scan, &s_long_run);
 }
@@ -786,13 +787,16 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
     } else {
         if (mode == LongListSort::one_workgroup)  // lists beyond the LDS capacity: 16 waves each, through global memory
             hipLaunchKernelGGL((tile_sort_kernel<16, false, 1>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order,
-                               img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0, 0);
-        hipLaunchKernelGGL((tile_sort_kernel<4, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
-                           img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes,
-                           mode == LongListSort::one_workgroup ? 1 : 0, SMALL_CAP + 1);
+                               img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0, 0, 0);
+        if (mode != LongListSort::short_lists_expected)
+            hipLaunchKernelGGL((tile_sort_kernel<4, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
+                               img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes,
+                               mode == LongListSort::one_workgroup ? 1 : 0, SMALL_CAP + 1, 0);
     }
+    const int only = mode == LongListSort::short_lists_expected ? 1 : 0;
     hipLaunchKernelGGL((tile_sort_kernel<4, true, SMALL_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
-                       img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 1, 0);
+                       img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, only ? 0 : 1, 0,
+                       only);
 }
 
 }  // namespace surfel

@@ -337,9 +337,8 @@ __device__ __forceinline__ void store_record(float* __restrict__ seg_data, uint3
         }
     }
     if (MODE == BLEND_FULL) {
-        d[RS_M1 * 256] = s.seg1;
-        d[RS_M2 * 256] = s.seg2;
-        s.seg1 = s.seg2 = 0.f;
+        d[RS_M1 * 256] = s.dist1;
+        d[RS_M2 * 256] = s.dist2;
     }
 }
 
@@ -398,6 +397,12 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
     uint32_t rec_stop = 0;  // segment of the batch the walk is in
 
     FwdPixel s;
+    if (MODE == BLEND_FULL && todo > 0) {
+        // reference of the tile's distortion moments (surfel_math.h FwdPixel::m0): its first list entry's mapped depth
+        // (every workgroup of a split tile computes the same value)
+        s.m0 = map_depth(rec[(size_t)point_list[r0] * REC_FLOATS + R_DEPTH]);
+        if (threadIdx.x == 0) img.tile_m0[tc.tile] = s.m0;
+    }
     bool done = !inside;
     bool dead = false;
     if (SPLIT && wk.seg >= 0) {
@@ -953,6 +958,7 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
             s.dL_dmax_dweight = dL_dothers[pid + 7 * HW];
         }
     }
+    if (FULL) s.m0 = img.tile_m0[tc.tile];
     s.T = s.T_final;
     s.final_A = 1.0f - s.T_final;
     s.bg_dot_dpixel = bg[0] * s.dL_dpixel[0] + bg[1] * s.dL_dpixel[1] + bg[2] * s.dL_dpixel[2];
@@ -976,11 +982,6 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                     for (int ch = 0; ch < 3; ch++) sufN[ch] = f[(RS_N + ch) * 256];
                     sufD = f[RS_D * 256];
                 }
-                if (FULL) {
-                    sufM1 = f[RS_M1 * 256];
-                    sufM2 = f[RS_M2 * 256];
-                    med_w = s.median_contributor > seg_end ? f[RS_T * 256] : 0.f;  // (the median sample lies behind)
-                }
                 for (uint32_t q = (uint32_t)wk.seg + 1u; q < stop; q++) {
                     const float* e = seg_data + (size_t)(wk.slot - (uint32_t)wk.seg + q) * REC_REC_FLOATS * 256 + threadIdx.x;
                     for (int ch = 0; ch < 3; ch++) sufC[ch] += e[(RS_C + ch) * 256];
@@ -988,10 +989,13 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                         for (int ch = 0; ch < 3; ch++) sufN[ch] += e[(RS_N + ch) * 256];
                         sufD += e[RS_D * 256];
                     }
-                    if (FULL) {
-                        sufM1 += e[RS_M1 * 256];
-                        sufM2 += e[RS_M2 * 256];
-                    }
+                }
+                if (FULL) {
+                    // (the distortion moments: totals minus this segment's running totals -- about the tile's reference
+                    // depth they are small numbers, and so is what the subtraction loses)
+                    sufM1 = s.final_D - d[RS_M1 * 256];
+                    sufM2 = s.final_D2 - d[RS_M2 * 256];
+                    med_w = s.median_contributor > seg_end ? f[RS_T * 256] : 0.f;  // (the median sample lies behind)
                 }
             } else {
                 const float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
@@ -1015,6 +1019,8 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                 for (int ch = 0; ch < 3; ch++) s.accum_normal_rec[ch] = sufN[ch] * inv;
                 s.accum_depth_rec = sufD * inv;
             }
+            // (distortion chain: sum over the samples behind of w (D2 + m^2 A - 2 m D); all moments about the tile's
+            // reference depth, so the three terms are of the size of their sum)
             if (FULL)
                 s.last_dL_dT = inv * (s.dL_dmax_dweight * med_w +
                                       s.dL_dreg * (s.final_D2 * behind + s.final_A * sufM2 - 2.0f * s.final_D * sufM1));

@@ -334,7 +334,8 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
         {
             StageTimer t(ST_SORT, stream);
             launch_tile_sort(g, img, b, total_tiles(cam), P, capacity,
-                             a->segment_split == 0 ? LongListSort::in_lds_only
+                             a->segment_split == 0 ? (a->max_list_hint > 0 && a->max_list_hint <= SHORT_LIST_HINT_MAX
+                                                          ? LongListSort::short_lists_expected : LongListSort::in_lds_only)
                              : a->long_list_sort    ? LongListSort::one_workgroup
                                                     : LongListSort::msd_split,
                              stream);

@@ -673,9 +673,13 @@ struct FwdPixel {
     float dist1 = 0, dist2 = 0, distortion = 0;
     float median_depth = 0, median_weight = 0;
     uint32_t last_contributor = 0, median_contributor = 0;
-    // the distortion moments once more, summed from zero since the last segment boundary (recorded segments, blend.hip:
-    // the backward's distortion chain needs "what lies behind a segment" to the precision of THAT sum, not of the total's)
-    float seg1 = 0, seg2 = 0;
+    // Reference mapped depth of the tile (wave-uniform; the blend kernels set it to the mapped depth of the tile's first
+    // list entry, 0 elsewhere): dist1, dist2 are the moments of m - m0.  Every use of them -- the distortion
+    // sum_{j<i} w_j (m_i - m_j)^2 here, dL/dweight and dL/dm in the backward -- is a function of DIFFERENCES of mapped
+    // depths, written by the reference (forward.cu:400-407, backward.cu:343-362) as m^2 A + M2 - 2 m M1 with
+    // A = sum w, M1 = sum w m, M2 = sum w m^2: three terms of size m^2 ~ 0.9 that cancel to (depth spread)^2 ~ 1e-4.  About
+    // a reference inside the tile's depth range the same three terms are of the size of the result.
+    float m0 = 0;
 };
 
 // One accepted sample (forward.cu:400-438).  Returns false (and leaves the state untouched) when
@@ -703,7 +707,7 @@ SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal
     const float w = e.alpha * s.T;
     if (MODE == BLEND_FULL) {
         const float A = 1.0f - s.T;
-        const float m = map_depth(e.depth);
+        const float m = map_depth(e.depth) - s.m0;
         const float error = fmaf(m * m, A, fmaf(-2.0f * m, s.dist1, s.dist2));
         s.distortion = fmaf(error, w, s.distortion);
         if (s.T > 0.5f) {
@@ -713,8 +717,6 @@ SURFEL_HD bool fwd_accumulate(FwdPixel& s, const PairEval& e, const float normal
         }
         s.dist1 = fmaf(m, w, s.dist1);
         s.dist2 = fmaf(m * m, w, s.dist2);
-        s.seg1 = fmaf(m, w, s.seg1);
-        s.seg2 = fmaf(m * m, w, s.seg2);
     }
     if (MODE != BLEND_LITE) {
         for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(normal[ch], w, s.N[ch]);
@@ -741,6 +743,7 @@ struct BwdPixel {
     float accum_depth_rec = 0, accum_alpha_rec = 0, accum_normal_rec[3] = {0, 0, 0};
     float last_dL_dT = 0;
     uint32_t last_contributor, median_contributor;
+    float m0 = 0;  // the tile's reference mapped depth (FwdPixel): final_D, final_D2 are moments of m - m0
 };
 
 // The part of one (pixel, surfel) pair's backward that runs through the pixel's back-to-front recurrences
@@ -782,7 +785,7 @@ SURFEL_HD PairGrad bwd_pair_core(BwdPixel& s, const PairEval& e, const float nor
         float dL_dweight = 0.0f;
         // m_d = far (d - near) / ((far - near) d) and its derivative far near / ((far - near) d^2) from ONE reciprocal
         const float inv_d = fast_rcp((FAR_PLANE - NEAR_PLANE) * c_d);
-        const float m_d = (FAR_PLANE * c_d - FAR_PLANE * NEAR_PLANE) * inv_d;
+        const float m_d = (FAR_PLANE * c_d - FAR_PLANE * NEAR_PLANE) * inv_d - s.m0;
         const float dmd_dd = (FAR_PLANE * NEAR_PLANE * (FAR_PLANE - NEAR_PLANE)) * inv_d * inv_d;
         if (is_median) {
             dL_dz += s.dL_dmedian_depth;

@@ -84,8 +84,8 @@ enum RecordedSlot {
     RS_C = 1,     // sums over THIS segment only -- final record: over the segment the walk stopped in --: colour (3)
     RS_D = 4,     // depth
     RS_N = 5,     // normal (3)
-    RS_M1 = 8,    // w m, w m^2 (distortion moments)
-    RS_M2 = 9,
+    RS_M1 = 8,    // distortion moments sum w (m - m0), sum w (m - m0)^2 about the tile's reference (ImageState::tile_m0): the
+    RS_M2 = 9,    // RUNNING TOTALS at the segment's end (the finals are ImageState::final_T planes 1, 2)
     RS_STOP = 10  // final record: index of the segment the walk stopped in (bits of a uint32)
 };
 inline int64_t rec_seg_capacity(int64_t capacity) { return capacity / REC_SEG_LEN + capacity / REC_MIN + 2; }
@@ -123,7 +123,7 @@ struct GeomState {
 };
 
 struct ImageState {
-    float* final_T;        // [3][H*W]  T, dist1, dist2
+    float* final_T;        // [3][H*W]  T, dist1, dist2 (the distortion moments about ImageState::tile_m0)
     uint32_t* n_contrib;   // [2][H*W]  last contributor, median contributor
     uint32_t* ranges;      // [tiles][2]
     uint32_t* tile_count;  // [tiles][TILE_SLICES] pair counts (preprocess), then emit cursors (atomic path);
@@ -135,6 +135,8 @@ struct ImageState {
     uint32_t* seg_prefix;  // [tiles + 1] by schedule position: exclusive prefix of the segment counts
     uint32_t* tail_order;  // [tiles] recorded segments: tile ids by the size of their tail unit (remainder segment of a
                            // split tile, or the whole unsplit tile), largest first
+    float* tile_m0;        // [tiles] reference mapped depth of the tile's distortion moments (surfel_math.h FwdPixel::m0):
+                           // written by the full blend's forward, read by its backward
 };
 
 struct BinState {
@@ -189,6 +191,7 @@ inline size_t carve_image(char* base, int W, int H, ImageState& s, int frames = 
     carve(p, s.seg_first, tiles);
     carve(p, s.seg_prefix, tiles + 1);
     carve(p, s.tail_order, tiles);
+    carve(p, s.tile_m0, tiles);
     return (size_t)(p - base) + 256;
 }
 
@@ -321,7 +324,12 @@ void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, cons
 //   in_lds_only   -- the long-tile machinery is off (segment_split == 0): the 4-wave kernel runs them through global memory;
 //   msd_split     -- every list beyond 1024 entries is split on its leading differing depth bits, the buckets sorted in LDS;
 //   one_workgroup -- a 16-wave workgroup per long list through global memory, the rest in LDS.
-enum class LongListSort { in_lds_only, msd_split, one_workgroup };
+//   short_lists_expected -- as in_lds_only, but the caller expects no list beyond 1024 entries (max_list_hint): ONE launch,
+//                   the in-LDS sort of the short lists, which sorts a longer list -- should one appear after all -- through
+//                   global memory itself (correct whatever the hint; the launch of the 56 KiB instance, whose workgroups
+//                   would all leave at once, is saved).
+enum class LongListSort { in_lds_only, msd_split, one_workgroup, short_lists_expected };
+constexpr int SHORT_LIST_HINT_MAX = 900;  // (an eighth of headroom below the 1024 entries of the small in-LDS sort)
 // true when launch_preprocess_fwd stages its records (and leaves centre / depth / radius per surfel in GeomState::colour)
 bool preprocess_stages_records(int num_tiles);
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
