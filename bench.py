@@ -365,7 +365,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under torchrun: start the ranks ourselves (one process per GPU over RCCL) and relay rank 0's line
         import subprocess
-        if torch.cuda.device_count() < args.gpus:
+        # VIDU4D_BENCH_BACKEND=gloo (CI on one GPU): the ranks may share a device -- gloo stages device tensors through the
+        # host, RCCL refuses two ranks on one GPU.  Not a performance configuration: it runs the N > 1 code path.
+        if torch.cuda.device_count() < args.gpus and os.environ.get("VIDU4D_BENCH_BACKEND", "nccl") != "gloo":
             raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
         port = 29500 + os.getpid() % 2000
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -378,6 +380,9 @@ def main():
             raise SystemExit(f"spawning {args.gpus} ranks failed (rc {r.returncode})")
         print(lines[-1], flush=True)
         return
+    backend = os.environ.get("VIDU4D_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -387,7 +392,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import diff_surfel_rasterization as dsr
     from vidu4d_amd import _lib
@@ -667,7 +675,9 @@ def main():
                                f"{W}x{H}, SH degree 3, {args.frames} frames sharded one-frame-per-GPU, "
                                f"{FRAMES_PER_STEP} frames per step per GPU",
                    "scene": args.scene, "surfels": N, "width": W, "height": H, "frames": args.frames, "frames_per_step": FRAMES_PER_STEP,
-                   "parallelism": f"frame-parallel x{world}" + (" + RCCL all-reduce of surfel grads" if world > 1 else ""),
+                   "parallelism": f"frame-parallel x{world}" + ((" + RCCL" if backend != "gloo" else " + gloo") +
+                                                                " all-reduce of surfel grads" if world > 1 else ""),
+                   "frames_of_rank0": my_frames[:4] + ["..."],
                    "frames_of_a_step": "one stacked launch set" if args.stacked else
                                        ("one call per frame, separate HIP streams" if args.frame_streams else "one call per frame")},
     }

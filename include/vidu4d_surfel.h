@@ -104,7 +104,9 @@ typedef struct Vidu4dSurfelForwardArgs {
                                         set: blend it again with segment_split = 1. */
     uint32_t* depth_used;            /* optional device counter (or NULL): atomic max of the deepest list position
                                         any pixel of the frame blended, i.e. the serial chain length of the
-                                        unsplit blend.  Callers use it to decide segment_split for later frames. */
+                                        unsplit blend.  Callers use it to decide segment_split for later frames.  Word 12 of
+                                        the geometry buffer is zeroed by every forward for this purpose: a caller that reads
+                                        the buffer's first words back anyway may pass geom_buffer + 48. */
     /* ---- stacked frames (the reference renders the frames of a step one after the other,
      * lab4d/nnutils/deformable_gaussian.py:1175-1228).  frames > 1: ONE launch set rasterizes `frames` frames that
      * share opacities / scales / shs (P rows) but have their own centres and orientations -- means3D (frames,P,3),
@@ -312,16 +314,19 @@ int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_q
  * them, gs/scene/gaussian_model.py:57 / gs/gaussian_renderer/__init__.py:73) and the backward goes through it.
  * bone_A (3B, 3) / bone_c (3B) with xbT == NULL: the bone coordinates are evaluated inside the kernels, x_bone = A xyz + c
  * (the rest pose's bone map, as vidu4d_skin_field_* takes it), and the backward adds A^T (d/d x_bone) to g_xyz instead of
- * writing g_xbT (which may be NULL): three quarters of the kernels' traffic.  Otherwise pass bone_A = bone_c = NULL. */
+ * writing g_xbT (which may be NULL): three quarters of the kernels' traffic.  Otherwise pass bone_A = bone_c = NULL.
+ * frame_index (M device int64, or NULL; ABI 17): se3_qr / se3_qd / cam_q / cam_t are then TABLES over all frames of the
+ * sequence ((frames,B,4), (frames,4), (frames,3): what frozen networks give once per run) and frame m of the call is their
+ * row frame_index[m] -- the per-step row gathers happen inside the kernels. */
 int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                             const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                             const float* cam_t, float* out_xyz, float* out_rot, int unit_rot, const float* bone_A,
-                            const float* bone_c, void* stream);
+                            const float* bone_c, const int64_t* frame_index, void* stream);
 int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                              const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                              const float* cam_t, const float* g_out_xyz, const float* g_out_rot, float* g_xbT,
                              float* g_rawT, float* g_xyz, float* g_rot, int unit_rot, const float* bone_A,
-                             const float* bone_c, void* stream);
+                             const float* bone_c, const int64_t* frame_index, void* stream);
 
 /* ---- the per-surfel part of the bob skinning field, once per optimizer step: Gaussian-bone coordinates of the rest
  *      pose and the delta-skin MLP on them (replaces gauss_mlp_skinning's bone transform and SkinningField.delta_field,

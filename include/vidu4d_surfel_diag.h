@@ -28,6 +28,11 @@ int vidu4d_surfel_profile_stage_count(void);
 const char* vidu4d_surfel_profile_stage_name(int stage);
 int vidu4d_surfel_profile_read(double* total_ms /*[stage_count]*/, long long* count /*[stage_count]*/, int reset);
 
+/* A device-to-device copy of `bytes` (16-byte aligned pointers), `repeat` times over, by `workgroups` workgroups of 512
+ * threads: the footprint of a collective's kernel, for measuring what such a co-tenant costs the blend kernels
+ * (tools/contention_probe.py -> profiles/r04_contention.json, read by bench.py's scaling model). */
+int vidu4d_diag_copy(void* dst, const void* src, size_t bytes, int workgroups, int repeat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,3 +95,28 @@ def test_two_ranks_on_one_gpu_keep_identical_surfels(gpu_device):
     assert a.shape == b.shape
     differing = float(np.mean(np.abs(a - b) > 1e-4 * (1.0 + np.abs(b))))
     assert differing < 2e-3, f"early and late exchange disagree in {differing:.2e} of the parameters"
+
+
+def test_bench_two_ranks_on_one_gpu(gpu_device):
+    """`bench.py --gpus 2` end to end, as the driver launches it -- self-spawn through torch.distributed.run, rank-strided
+    frames, alternating exchange buffers, barrier + synchronize around the timed region, MAX over the ranks' clocks, ONE
+    JSON line from rank 0 -- with the two ranks sharing this GPU over gloo (VIDU4D_BENCH_BACKEND=gloo: RCCL refuses two
+    ranks on one device).  Small workload: this is about the N > 1 code path not dying on its first real 8-GPU run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIDU4D_BENCH_BACKEND="gloo", MASTER_PORT=str(_free_port()))
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--surfels", "20000",
+           "--res", "128", "--cpu-images", "0", "--torch-cpu-images", "0", "--fit-steps", "0", "--repeats", "1",
+           "--per-frame-surface", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"].startswith("frame-parallel x2") and d["config"]["frames_of_rank0"][:3] == [0, 2, 4]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]   # both ranks' images
+    assert "exchange" in d["config"] and "roofline" in d

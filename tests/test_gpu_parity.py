@@ -525,7 +525,7 @@ def test_segment_limit_reports_truncation_and_replay_is_exact(gpu_device, monkey
     dev = gpu_device
     sc = _concentrated(30_000, seed=98)
     sc.opacities[:] = 0.05
-    key = (sc.width, sc.height, str(dev))
+    key = (sc.width, sc.height, str(dev), 1, None)   # (image shape, device, frames of a stacked call, hint scope)
     monkeypatch.setattr(_C, "_SPLIT", "1")
     _native_forward(sc, dev)
     ref = _native_forward(sc, dev)[3]          # split on, unlimited

@@ -32,7 +32,12 @@ SHORT = {"blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd", "emit
          "preprocess_fwd": "preprocess_fwd", "surfel_color": "surfel_color", "preprocess_bwd": "preprocess_bwd",
          "tile_sort_kernel": "tile_sort", "tile_scan": "tile_scan", "tile_order": "tile_scan",
          "blend_seg_T": "blend_seg_T", "blend_combine": "blend_combine"}
-STREAMING = {"preprocess_fwd", "surfel_color", "preprocess_bwd"}  # wide coalesced streaming reads: FETCH_SIZE counts 1/2 (guide, HBM section)
+# FETCH_SIZE counts every 128-byte read request as 64 bytes: x2 for every kernel.  The guide (MI355X_MICROARCH.md, HBM)
+# establishes this for wide coalesced streaming reads and calls other patterns uncalibrated; tools/ubench/fetch_calib.hip
+# (profiles/r04_fetch_calib.txt) measured the blend kernels' own pattern -- a gather of records with seven / eight 16-byte
+# loads per lane: 128-byte-aligned records read exactly once report 1/2 of their bytes like the stream does; the product's
+# 112-byte records report ~1.0x their bytes, i.e. 2x counted = the ~1.9 LINES a record straddling line boundaries pulls.
+# (Round 3 used 1.0 for the blend kernels and said so: its traffic figure was a lower bound.)
 per = defaultdict(lambda: defaultdict(list))
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     path = find(counter, "*counter_collection.csv")
@@ -53,7 +58,7 @@ with open(os.path.join(summ, f"{tag}_pmc_fetch_write.csv"), "w") as f:
     for k, d in per.items():
         fe = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
         wr = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
-        corr = 2.0 if k in STREAMING else 1.0
+        corr = 2.0
         traffic[k] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "fetch_correction": corr,
                       "hbm_bytes_per_launch": (fe * corr + wr) * 1024.0}
         f.write(f"surfel::{k},{fe:.1f},{wr:.1f},{len(d['FETCH_SIZE'])}\n")

@@ -67,6 +67,21 @@ DEBUG_FLAGS = ((_lib.DEBUG_NO_CULL if os.environ.get("VIDU4D_SURFEL_NO_CULL", "0
 _walk_counters = None   # (device int64 tensor, one-shot): the next backward also counts its tile walk (vidu4d_surfel_diag.h)
 
 
+_hint_scope = None
+
+
+@contextlib.contextmanager
+def hint_scope(scope):
+    """The capacity / split-depth / longest-list hints of the rasterizer calls inside are kept per `scope` (any hashable:
+    DeformableSurfels passes id(self)) instead of per image shape alone."""
+    global _hint_scope
+    old, _hint_scope = _hint_scope, scope
+    try:
+        yield
+    finally:
+        _hint_scope = old
+
+
 @contextlib.contextmanager
 def debug_flags(flags: int):
     """with debug_flags(_lib.DEBUG_NO_CULL): ... -- forward AND backward inside run with these switches."""
@@ -145,6 +160,14 @@ class graph_capture_mode:
         return False
 
 
+HEADER_DEPTH_WORD = 12   # surfel_state.h Header::depth_used
+
+
+def _depth_of(stat, slot) -> int:
+    """deepest list position the frame blended: from the header copy (this frame's) or the counter pair (the one before)"""
+    return int(slot[HEADER_DEPTH_WORD]) if stat == "header" else int(stat[1][0])
+
+
 def _note_longest_list(slot, key):
     _len_hint[key] = max(int(slot[2]), int(0.9 * _len_hint.get(key, 0)))
 
@@ -155,7 +178,7 @@ def check_slots(frames) -> bool:
         n = int(slot[0])
         _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
         if stat is not None:
-            _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
+            _depth_hint[key] = max(_depth_of(stat, slot), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
         _note_longest_list(slot, key)
         if int(slot[6]):
             _unlimited[key] = 4
@@ -176,7 +199,7 @@ def check_deferred() -> bool:
         # (a slowly decaying maximum: the buffers shrink again after a prune)
         _capacity_hint[key] = max(int(n * 1.25) + 4096, int(0.98 * _capacity_hint.get(key, 0)))
         if stat is not None:
-            _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
+            _depth_hint[key] = max(_depth_of(stat, slot), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
         _note_longest_list(slot, key)
         if int(slot[6]):  # the segment limit cut a tile short: this frame is incomplete,
             _unlimited[key] = 4   # the next ones run unlimited
@@ -289,11 +312,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.geom_buffer, a.geom_bytes = geom.data_ptr(), geom.numel()
     a.image_buffer, a.image_bytes = img.data_ptr(), img.numel()
     stream = _stream(dev)
+    hint = None
     # Hints are keyed on the image shape and device only: the surfel count changes with every densify / prune,
     # and the pair count, split depth and per-stream counters of the previous frames stay good guesses across it
     # (keying on P leaked one entry -- with a device tensor and a pinned buffer -- per surfel count).
-    key = (W, H, str(dev)) if F == 1 else (W, H, str(dev), F)
+    # ... and, where the caller names one, on its scope (hint_scope: a model instance) -- two models that render the same image
+    # size no longer feed each other's guesses.  (key[2] stays the device: _pinned_slot reads it.)
+    key = (W, H, str(dev), F, _hint_scope)
     stat = None
+    hint = _capacity_hint.get(key)
     if _SPLIT == "auto":
         depth = _depth_hint.get(key, 0)
         a.segment_split = int(depth > SPLIT_AUTO_LEN)
@@ -302,11 +329,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _unlimited[key] -= 1
             else:
                 a.segment_split = max(2, (int(depth * 1.25) + 511) // 512 + 1)
-        stat = _depth_stat.get((key, stream))
-        if stat is None:
-            stat = _depth_stat[(key, stream)] = (torch.zeros(1, dtype=torch.int32, device=dev),
-                                                 torch.zeros(1, dtype=torch.int32).pin_memory())
-        a.depth_used = stat[0].data_ptr()
+        if _deferred and not debug and hint is not None and not _EXACT:
+            # (the header is read back after the blend anyway: the depth counter lives in it -- word 12, zeroed by the
+            # projection kernel -- instead of in a tensor of its own that wants a reset and a copy per frame)
+            stat = "header"
+            a.depth_used = geom.data_ptr() + 4 * HEADER_DEPTH_WORD
+        else:
+            stat = _depth_stat.get((key, stream))
+            if stat is None:
+                stat = _depth_stat[(key, stream)] = (torch.zeros(1, dtype=torch.int32, device=dev),
+                                                     torch.zeros(1, dtype=torch.int32).pin_memory())
+            a.depth_used = stat[0].data_ptr()
     else:
         a.segment_split = int(_SPLIT == "1")
     # long lists: the MSD split + bucket sorts from ~10 k entries per list on, one workgroup per list through global memory
@@ -325,7 +358,6 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         return 0, out_color, out_others, radii, geom, binning, img
 
     _lib.check(lib.vidu4d_surfel_forward_plan(C.byref(a), stream), "surfel forward (plan)")
-    hint = _capacity_hint.get(key)
     R = C.c_int64(0)
     if _EXACT or hint is None or debug:
         _lib.check(lib.vidu4d_surfel_num_rendered(C.byref(a), stream, C.byref(R)), "surfel forward (count)")
@@ -338,7 +370,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         cap = hint
         binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
         slot = _pinned_slot(dev)
-        if stat is not None:  # depth reached by the previous frame on this stream; then reset for this one
+        if stat is not None and stat != "header":  # depth reached by the previous frame on this stream; then reset for this one
             stat[1].copy_(stat[0], non_blocking=True)
             stat[0].zero_()
         if _deferred and not debug:

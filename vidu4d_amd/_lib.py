@@ -125,6 +125,7 @@ SYMBOLS = {
     "vidu4d_surfel_mark_visible": (C.c_int, [C.c_int, _P, _P, _P, _P, _P]),
     "vidu4d_surfel_state_read": (C.c_int, [C.POINTER(ForwardArgs), _P, C.c_int64, C.c_int, _P, C.c_size_t,
                                            C.POINTER(C.c_int64), _P]),
+    "vidu4d_diag_copy": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "vidu4d_surfel_profile_enable": (C.c_int, [C.c_int]),
     "vidu4d_surfel_profile_stage_count": (C.c_int, []),
     "vidu4d_surfel_profile_stage_name": (C.c_char_p, [C.c_int]),
@@ -136,8 +137,8 @@ SYMBOLS = {
     "vidu4d_quaternion_conjugate": (C.c_int, [C.c_int64, _P, _P, _P]),
     "vidu4d_lbs_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 10),
     "vidu4d_lbs_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 13),
-    "vidu4d_lbs_skin_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 10 + [C.c_int, _P, _P, _P]),
-    "vidu4d_lbs_skin_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 14 + [C.c_int, _P, _P, _P]),
+    "vidu4d_lbs_skin_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 10 + [C.c_int, _P, _P, _P, _P]),
+    "vidu4d_lbs_skin_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 14 + [C.c_int, _P, _P, _P, _P]),
     "vidu4d_knn_mean_dist2": (C.c_int, [C.c_int, _P, _P, _P]),
     "vidu4d_radius_count": (C.c_int, [C.c_int, _P, C.c_float, _P, _P]),
     "vidu4d_post_forward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),

@@ -79,6 +79,22 @@ extern "C" int vidu4d_surfel_profile_enable(int on)
     g_prof_on = on != 0;
     return VIDU4D_OK;
 }
+// Diagnostic (vidu4d_surfel_diag.h): a device-to-device copy held to `workgroups` workgroups of 512 threads -- the footprint
+// of a collective's kernel (RCCL runs a fixed number of channels, one workgroup each) -- for measuring what such a tenant
+// costs a compute kernel it shares the GPU with (tools/contention_probe.py).
+__global__ __launch_bounds__(512) void diag_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, int repeat)
+{
+    for (int r = 0; r < repeat; r++)
+        for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 512) dst[i] = src[i];
+}
+extern "C" int vidu4d_diag_copy(void* dst, const void* src, size_t bytes, int workgroups, int repeat, void* stream)
+{
+    if (!dst || !src || workgroups <= 0 || repeat <= 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return fail(VIDU4D_E_INVALID, "diag_copy: bad arguments");
+    hipLaunchKernelGGL(diag_copy_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src,
+                       bytes / 16, repeat);
+    return VIDU4D_OK;
+}
 extern "C" int vidu4d_surfel_profile_stage_count(void) { return ST_COUNT; }
 extern "C" const char* vidu4d_surfel_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 // Waits for the recorded events, adds them to the per-stage totals and returns the totals
@@ -192,6 +208,11 @@ static int blend_mode(int aux_planes)
     return BLEND_FULL;
 }
 static int kernel_flags(int debug_flags) { return (debug_flags & VIDU4D_DEBUG_NO_CULL) ? FLAG_NO_CULL : 0; }
+// Does a whole-tile forward leave recorded segments for its backward (surfel_state.h)?  They pay by letting the dispatcher
+// balance the CUs when a launch has about as many tiles as the chip has workgroup slots (256 CUs x 6: the headline's 2048
+// tiles drain for a third of the launch); with several tiles per slot the whole-tile launch balances by itself and the
+// records only cost (1080p, 16 320 tiles in two frames: blend_fwd +4 %, blend_bwd +1 %).
+static bool records_segments(int segment_split, int tiles) { return segment_split == 0 && tiles <= REC_MAX_TILES; }
 
 static int check_forward(const Vidu4dSurfelForwardArgs* a)
 {
@@ -323,7 +344,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     carve_binning((char*)binning, capacity, b);
     const CameraParams cam = camera_of(a);
     // the segment table: for a segment-parallel forward, or (whole-tile forward) for the recorded segments of its backward
-    const bool record = a->segment_split == 0;
+    const bool record = records_segments(a->segment_split, total_tiles(cam));
     const ScheduleParams sp = {record ? REC_SEG_LEN : SEG_LEN, record ? REC_MIN : SPLIT_MIN, record ? 1 : 0};
     {
         StageTimer t(ST_EMIT, stream);
@@ -348,7 +369,7 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
         const int max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
         launch_blend_fwd(cam, g, img, b, capacity, a->segment_split != 0, max_seg, a->background, a->out_color, a->out_others,
                          a->depth_used, blend_mode(a->aux_planes), a->assume_unsaturated != 0, kernel_flags(a->debug_flags),
-                         a->segment_split == 0, stream);
+                         record, stream);
     }
     STAGE_CHECK(a->debug, stream, "blend_forward");
     return VIDU4D_OK;
@@ -386,8 +407,9 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
     ba.seg_data = a->binning_capacity > 0 ? b.seg_data : nullptr;
     ba.capacity = a->binning_capacity;
     // segment_split == 0: the forward walked whole tiles and (unless told not to) left recorded segments
-    ba.recorded = a->segment_split == 0;
-    ba.split = a->binning_capacity > 0 && (a->segment_split != 0 || !(a->debug_flags & VIDU4D_DEBUG_WHOLE_TILE_BACKWARD));
+    ba.recorded = records_segments(a->segment_split, total_tiles(ba.cam));
+    ba.split = a->binning_capacity > 0 && (a->segment_split != 0 ||
+                                           (ba.recorded && !(a->debug_flags & VIDU4D_DEBUG_WHOLE_TILE_BACKWARD)));
     ba.max_seg = a->segment_split > 1 ? a->segment_split : 0x7fffffff;
     ba.P = P;
     ba.background = a->background;

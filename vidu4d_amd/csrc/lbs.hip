@@ -235,7 +235,8 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
                                                        float* __restrict__ g_xbT, float* __restrict__ g_rawT,
                                                        float* __restrict__ g_xyz, float* __restrict__ g_rot,
                                                        int unit_rot, const float* __restrict__ bone_A,
-                                                       const float* __restrict__ bone_c)
+                                                       const float* __restrict__ bone_c,
+                                                       const int64_t* __restrict__ frame_index)
 {
     __shared__ float s_q[MAX_FRAMES][2 * MAX_BONES * 4];
     __shared__ unsigned long long s_sign[MAX_FRAMES][MAX_BONES];
@@ -243,7 +244,9 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
     if (XB_FROM_XYZ)
         for (int k = threadIdx.x; k < 3 * B; k += 256)
             s_map[k] = make_float4(bone_A[3 * k], bone_A[3 * k + 1], bone_A[3 * k + 2], bone_c[k]);
-    for (int m = 0; m < M; m++) stage_frame(se3_qr, se3_qd, m, B, s_q[m], s_sign[m]);
+    // frame_index: se3_* / cam_* are TABLES over all frames of the sequence, frame m of this call is their row frame_index[m]
+    // (the per-step row gathers of the frozen-network tables -- four launches -- happen here instead)
+    for (int m = 0; m < M; m++) stage_frame(se3_qr, se3_qd, frame_index ? (int)frame_index[m] : m, B, s_q[m], s_sign[m]);
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
 
@@ -316,8 +319,9 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
         rotate(q, p, p1, px);
         const Q xt = qvec(px.x + tq.x, px.y + tq.y, px.z + tq.z);
         const Q rt = qmul(q, r);
-        const Q cq = ldq(cam_q + 4 * m);
-        const float* ct = cam_t + 3 * m;
+        const int mf = frame_index ? (int)frame_index[m] : m;
+        const Q cq = ldq(cam_q + 4 * mf);
+        const float* ct = cam_t + 3 * mf;
         Q c1, cx;
         rotate(cq, xt, c1, cx);
         const size_t o = (size_t)m * N + n;
@@ -471,7 +475,7 @@ extern "C" int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const f
 extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                                        const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                                        const float* cam_t, float* out_xyz, float* out_rot, int unit_rot,
-                                       const float* bone_A, const float* bone_c, void* stream)
+                                       const float* bone_A, const float* bone_c, const int64_t* frame_index, void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
@@ -480,7 +484,7 @@ extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, co
     (void)hipGetLastError();
     launch_lbs_skin<false>(M, N, B, bone_A != nullptr, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t,
                            out_xyz, out_rot, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (float*)nullptr, (float*)nullptr, unit_rot, bone_A, bone_c);
+                           (float*)nullptr, (float*)nullptr, unit_rot, bone_A, bone_c, frame_index);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
@@ -489,7 +493,7 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
                                         const float* cam_t, const float* g_out_xyz, const float* g_out_rot,
                                         float* g_xbT /*(3B,N)*/, float* g_rawT /*(B,N) or NULL*/, float* g_xyz /*(N,3)*/,
                                         float* g_rot /*(N,4)*/, int unit_rot, const float* bone_A, const float* bone_c,
-                                        void* stream)
+                                        const int64_t* frame_index, void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
@@ -500,6 +504,6 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
     (void)hipGetLastError();
     launch_lbs_skin<true>(M, N, B, bone_A != nullptr, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t,
                           (float*)nullptr, (float*)nullptr, g_out_xyz, g_out_rot, g_xbT, g_rawT, g_xyz, g_rot, unit_rot, bone_A,
-                          bone_c);
+                          bone_c, frame_index);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }

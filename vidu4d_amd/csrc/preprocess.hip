@@ -147,11 +147,11 @@ __device__ __forceinline__ void flush_staged_records(const float4* stage, float*
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (visible) {
         float4* dst = reinterpret_cast<float4*>(rec + (size_t)idx0 * REC_FLOATS);
-        constexpr int PARTS = REC_FLOATS / 4;
+        constexpr int PARTS = REC_USED_FLOATS / 4, STRIDE = REC_FLOATS / 4;  // (staged densely; a padded record keeps its gap)
 #pragma unroll
         for (int i0 = 0; i0 < 64 * PARTS; i0 += 64) {
             const int i = i0 + lane, r = i / PARTS;
-            if ((visible >> r) & 1ull) dst[i] = stage[i];
+            if ((visible >> r) & 1ull) dst[PARTS == STRIDE ? i : r * STRIDE + (i - r * PARTS)] = stage[i];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -162,7 +162,10 @@ __device__ __forceinline__ void flush_staged_records(const float4* stage, float*
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    if (idx == 0) a.geom.hdr->min_T_bits = 0x3f800000u;  // 1.0f (the header is fresh memory)
+    if (idx == 0) {  // (the header is fresh memory)
+        a.geom.hdr->min_T_bits = 0x3f800000u;  // 1.0f
+        a.geom.hdr->depth_used = 0;
+    }
     if (idx >= a.P) return;
     const FrameIndex fi = frame_index(a.cam, idx);
     const Camera cam = load_camera(a.cam, fi.frame);
@@ -187,12 +190,13 @@ __global__ __launch_bounds__(BIN_THREADS) void preprocess_fwd_grouped_kernel(Pre
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // (the header is fresh memory)
         a.geom.hdr->scan_arrivals = 0;
         a.geom.hdr->min_T_bits = 0x3f800000u;  // 1.0f
+        a.geom.hdr->depth_used = 0;
     }
     __syncthreads();
     const int first = blockIdx.x * BIN_THREADS * a.iters;
     // (optional: per-wave staging of the records behind the histogram, launch_preprocess_fwd)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int PARTS = REC_FLOATS / 4;
+    constexpr int PARTS = REC_USED_FLOATS / 4;
     float4* stage = a.stage_records
                         ? reinterpret_cast<float4*>(s_hist + ((num_tiles + 3) & ~3)) + (size_t)wave * 64 * PARTS
                         : nullptr;
@@ -270,7 +274,7 @@ bool preprocess_stages_records(int num_tiles)
         big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&preprocess_fwd_grouped_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     const size_t hist = (size_t)((num_tiles + 3) & ~3) * sizeof(uint32_t);
-    const size_t staged = hist + (size_t)(BIN_THREADS / 64) * 64 * REC_FLOATS * sizeof(float);
+    const size_t staged = hist + (size_t)(BIN_THREADS / 64) * 64 * REC_USED_FLOATS * sizeof(float);
     return use_grouped_binning(num_tiles) && big_lds == 1 && staged <= 160 * 1024 && stage_records_enabled();
 }
 
@@ -298,7 +302,7 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream)
     PreprocessArgs g = a;
     g.stage_records = 0;
     const size_t hist = (size_t)((num_tiles + 3) & ~3) * sizeof(uint32_t);
-    const size_t staged = hist + (size_t)(BIN_THREADS / 64) * 64 * REC_FLOATS * sizeof(float);
+    const size_t staged = hist + (size_t)(BIN_THREADS / 64) * 64 * REC_USED_FLOATS * sizeof(float);
     g.stage_records = preprocess_stages_records(num_tiles) ? 1 : 0;
     if (sh_lds)
         hipLaunchKernelGGL(surfel_color_kernel<true>, dim3(color_blocks), dim3(PRE_BLOCK),

@@ -35,7 +35,11 @@ constexpr float T_EPS = 0.0001f;
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z cx cy opacity
 //   q3 = n.x n.y n.z depth   | q4 = r g b clampmask(bits)
 //   q5, q6 = the footprint outside which the surfel cannot contribute (contribution_footprint below)
-constexpr int REC_FLOATS = 28;
+#ifndef SURFEL_REC_FLOATS
+#define SURFEL_REC_FLOATS 28
+#endif
+constexpr int REC_FLOATS = SURFEL_REC_FLOATS;  // (28 used; 32 = one record per 128-byte line, the rest padding)
+constexpr int REC_USED_FLOATS = 28;
 constexpr int REC_LDS_FLOATS = 20;  // q0..q4 are staged in LDS; q5, q6 only feed the per-wave cull masks
 enum RecSlot {
     R_TU = 0, R_TV = 3, R_TW = 6, R_CX = 9, R_CY = 10, R_OPAC = 11, R_NX = 12, R_DEPTH = 15, R_RGB = 16, R_CLAMP = 19,

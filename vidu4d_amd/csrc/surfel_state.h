@@ -75,6 +75,10 @@ inline int64_t seg_capacity(int64_t capacity) { return capacity / SEG_LEN + capa
 #ifndef SURFEL_REC_MIN
 #define SURFEL_REC_MIN 320
 #endif
+#ifndef SURFEL_REC_MAX_TILES
+#define SURFEL_REC_MAX_TILES 4096
+#endif
+constexpr int REC_MAX_TILES = SURFEL_REC_MAX_TILES;  // launches with more tiles (stacked frames counted) walk whole tiles in both directions
 constexpr int REC_SEG_LEN = SURFEL_REC_SEG_LEN;  // (a multiple of the forward's batch, 256 entries)
 constexpr int REC_MIN = SURFEL_REC_MIN;
 constexpr int REC_REC_FLOATS = 11;  // per (segment, pixel) values of a record: seg_data[(slot * 11 + k) * 256 + pixel]
@@ -112,7 +116,10 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t num_buckets;   // buckets the MSD split of the long lists queued for bucket_sort_kernel (reset by the schedule)
     uint32_t seg_len;       // what the segment table was built with: entries per segment ...
     uint32_t split_min;     // ... of the tiles longer than this (SEG_LEN / SPLIT_MIN, or REC_SEG_LEN / REC_MIN: recorded segments)
-    uint32_t pad[52];
+    uint32_t depth_used;    // a home for Vidu4dSurfelForwardArgs::depth_used inside the buffer (word 12, zeroed by the projection
+                            // kernel): a caller that reads the header back anyway points depth_used here and saves a counter
+                            // tensor, its reset and its copy
+    uint32_t pad[51];
 };
 
 struct GeomState {

@@ -249,6 +249,7 @@ class DeformableSurfels(GaussianModel):
         direction (csrc/lbs.hip).  -> xyz_cam (M,N,3), rot_cam (M,N,4)."""
         samples_dict = samples_dict or {}
         w = self.warp
+        table_rows = None   # (frame ids when se3 / cq / ct below are whole tables)
         self.__dict__["_warp_rot_is_unit"] = False
         overrides = any(k in samples_dict for k in ("rest_articulation", "t_articulation", "field2cam"))
         if overrides:
@@ -263,9 +264,15 @@ class DeformableSurfels(GaussianModel):
             # frozen networks: bone transforms and cameras of ALL frames are constants of the run; they are
             # evaluated once (and again whenever a parameter is written) and indexed per step
             tab = self._frozen_warp_table()
-            se3 = (tab["se3_qr"][frame_id], tab["se3_qd"][frame_id])
             rest1 = tab["rest1"]
-            cq, ct = tab["cam_q"][frame_id], tab["cam_t"][frame_id]
+            # (the fused skinning kernel below indexes the tables itself -- `frame_index` -- instead of four row gathers per step)
+            in_kernel = (frame_id.dtype == torch.int64 and frame_id.shape[0] <= 8 and self.opts.get("fused_skin", True)
+                         and self.opts.get("table_index_in_kernel", True))
+            if in_kernel:
+                se3, (cq, ct), table_rows = (tab["se3_qr"], tab["se3_qd"]), (tab["cam_q"], tab["cam_t"]), frame_id
+            else:
+                se3 = (tab["se3_qr"][frame_id], tab["se3_qd"][frame_id])
+                cq, ct = tab["cam_q"][frame_id], tab["cam_t"][frame_id]
         sm = w.skinning_model
         M = frame_id.shape[0]
         iid = None if inst_id is None else inst_id[:1]
@@ -304,10 +311,12 @@ class DeformableSurfels(GaussianModel):
             # applied inside the kernel: render_frames hands these orientations on as already activated)
             unit = bool(self.opts.get("fused_rot_activation", True))
             xyz_cam, rot_cam = lbs_skin_apply(xbT, rawT, se3, self._xyz, self._rotation, cq, ct, unit_rot=unit,
-                                              bone_map=bone_map)
+                                              bone_map=bone_map, frame_index=table_rows)
             self.__dict__["_warp_rot_is_unit"] = unit
             skin = delta = None
         else:
+            if table_rows is not None:   # (this path takes per-frame rows)
+                se3, cq, ct = (se3[0][table_rows], se3[1][table_rows]), cq[table_rows], ct[table_rows]
             frames = None if overrides else tab["bone_frames"]
             skin, delta = sm(self._xyz[None], rest1, None, iid, bone_frames=frames)
             xyz_cam, rot_cam = lbs_apply(skin[0].softmax(-1), se3, self._xyz, self._rotation, cq, ct)
@@ -411,6 +420,15 @@ class DeformableSurfels(GaussianModel):
         keeps the per-frame screen-space tensors the densification statistics need.
         aux_planes (stacked raw output only): bit mask of the allmap planes the caller reads, 0 = all
         (diff_surfel_rasterization.rasterize_frames)."""
+        if self._xyz.is_cuda and not self.__dict__.get("_in_hint_scope", False):
+            # the rasterizer's capacity / split hints are this model's own (two models of one image size do not share them)
+            from .. import _C
+            self.__dict__["_in_hint_scope"] = True
+            try:
+                with _C.hint_scope(id(self)):
+                    return self.render_frames(frame_id, Kinv, H, W, inst_id, samples_dict, outputs, aux_planes)
+            finally:
+                self.__dict__["_in_hint_scope"] = False
         M = frame_id.shape[0]
         if self.fused_warp_ok(inst_id):
             xyz_cam, rot_cam = self.forward_warp_fused(frame_id, inst_id, samples_dict)  # (M,N,3), (M,N,4)

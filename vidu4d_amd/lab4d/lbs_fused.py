@@ -68,7 +68,8 @@ class _LbsSkinApply(Function):
     -> blend -> apply -> camera, for all frames, one kernel per direction (csrc/lbs.hip lbs_skin_kernel)."""
 
     @staticmethod
-    def forward(ctx, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, unit_rot=False, bone_A=None, bone_c=None):
+    def forward(ctx, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t, unit_rot=False, bone_A=None, bone_c=None,
+                frame_index=None):
         if not xyz.is_cuda:
             raise RuntimeError("lbs_skin_apply: HIP tensors required")
         consts = [(se3_qr, "se3"), (se3_qd, "se3"), (cam_q, "field2cam"), (cam_t, "field2cam")]
@@ -78,6 +79,11 @@ class _LbsSkinApply(Function):
             if t.requires_grad:
                 raise RuntimeError(f"lbs_skin_apply: {name} requires grad; the fused path treats it as constant")
         M, B = se3_qr.shape[:2]
+        if frame_index is not None:   # se3 / cam are tables over all frames; this call's frames are their rows frame_index
+            if frame_index.dtype != torch.int64 or not frame_index.is_cuda or frame_index.ndim != 1:
+                raise RuntimeError("lbs_skin_apply: frame_index must be a 1-d int64 tensor on the device")
+            M = frame_index.shape[0]
+            frame_index = frame_index.contiguous()
         N = xyz.shape[0]
         if (xbT is None) == (bone_A is None):
             raise RuntimeError("lbs_skin_apply: pass the bone coordinates xbT OR the bone map (bone_A, bone_c)")
@@ -94,7 +100,9 @@ class _LbsSkinApply(Function):
         ptr = [None if a is None else a.data_ptr() for a in args]
         bptr = [None if a is None else a.data_ptr() for a in bmap]
         _lib.check(lib.vidu4d_lbs_skin_forward(M, N, B, *ptr, out_xyz.data_ptr(), out_rot.data_ptr(), int(unit_rot), *bptr,
+                                               None if frame_index is None else frame_index.data_ptr(),
                                                torch.cuda.current_stream(xyz.device).cuda_stream), "lbs skin forward")
+        ctx.frame_index = frame_index
         ctx.present = [a is not None for a in args + bmap]
         ctx.unit_rot = bool(unit_rot)
         ctx.save_for_backward(*[a for a in args + bmap if a is not None])
@@ -122,19 +130,20 @@ class _LbsSkinApply(Function):
                                                 None if g_xbT is None else g_xbT.data_ptr(),
                                                 None if g_rawT is None else g_rawT.data_ptr(), g_xyz.data_ptr(),
                                                 g_rot.data_ptr(), int(ctx.unit_rot), *bptr,
+                                                None if ctx.frame_index is None else ctx.frame_index.data_ptr(),
                                                 torch.cuda.current_stream(dev).cuda_stream),
                    "lbs skin backward")
-        return g_xbT, g_rawT, None, None, g_xyz, g_rot, None, None, None, None, None
+        return g_xbT, g_rawT, None, None, g_xyz, g_rot, None, None, None, None, None, None
 
 
-def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False, bone_map=None):
+def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False, bone_map=None, frame_index=None):
     """xbT (3B,N) Gaussian-bone coordinates; rawT (B,N) raw output of the delta-skin MLP or None; se3 = (qr, qd)
     each (M,B,4), M <= 8; xyz (N,3); rot (N,4); cam_q (M,4), cam_t (M,3).  -> xyz_cam (M,N,3), rot_cam (M,N,4);
     unit_rot: rot_cam comes out normalised (F.normalize, the renderer's rotation activation, fused in).
     bone_map = (A (3B,3), c (3B)) with xbT = None (frozen bones): the kernels evaluate x_bone = A xyz + c themselves and
     the gradient w.r.t. xyz includes that path -- the (3B,N) coordinates and their gradient never cross HBM."""
     bone_A, bone_c = (None, None) if bone_map is None else bone_map
-    return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot, bone_A, bone_c)
+    return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot, bone_A, bone_c, frame_index)
 
 
 # ---------------------------------------------------------------------------------------------------------------
