@@ -198,7 +198,7 @@ def exchange_model_ms(payload_bytes: float, n: int) -> dict:
             "direct_rs_ag": 2.0 * (s / n) / (XGMI_LINK_GBPS * 1e9) * 1e3 + 2 * lat}
 
 
-def scaling_model(ms_per_step_1gpu: float, payload_bytes: float, overlapped: bool) -> dict:
+def scaling_model(ms_per_step_1gpu: float, payload_bytes: float, overlapped: bool, contention: float = 1.0) -> dict:
     """MODELLED weak scaling (images/s at N GPUs / images/s at 1 GPU) from the MEASURED 1-GPU step and the exchange
     model above.  serial: the exchange sits between backward and optimizer (the fitting loop: Adam needs the reduced
     gradient); overlapped: it runs beside the next step's kernels (bench.py's op-level loop, double-buffered gradient
@@ -206,8 +206,9 @@ def scaling_model(ms_per_step_1gpu: float, payload_bytes: float, overlapped: boo
     out = {}
     for n in (2, 4, 8):
         ex = exchange_model_ms(payload_bytes, n)
-        out[str(n)] = {k: round(n * ms_per_step_1gpu / (max(ms_per_step_1gpu, v) if overlapped else ms_per_step_1gpu + v), 2)
-                       for k, v in ex.items()}
+        # (overlapped: the step runs `contention` times slower while a collective shares the GPU with it)
+        out[str(n)] = {k: round(n * ms_per_step_1gpu / (max(ms_per_step_1gpu * contention, v) if overlapped
+                                                        else ms_per_step_1gpu + v), 2) for k, v in ex.items()}
         out[str(n)]["exchange_ms"] = {k: round(v, 3) for k, v in ex.items()}
     return out
 
@@ -217,16 +218,32 @@ def scaling_model(ms_per_step_1gpu: float, payload_bytes: float, overlapped: boo
 WARP_BACKWARD_MS = 0.15
 
 
-def fit_scaling_model(ms_per_step_1gpu: float, n_surfels: int) -> dict:
+def measured_contention() -> dict:
+    """What a collective's kernel costs the kernels it shares the GPU with, MEASURED on one GPU (tools/contention_probe.py ->
+    profiles/r04_contention.json): the step's 46.4 MB copied device-to-device by 16 / 32 / 64 workgroups on a side stream
+    while the headline backward runs.  {"factor": slowdown of the overlapped compute, ...}; factor 1.0 if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r04_contention.json")
+    try:
+        d = json.load(open(path))
+        f = max(v for k, v in d["backward_slowdown"].items() if not k.startswith("0"))
+        return {"factor": round(float(f), 4), "source": "profiles/r04_contention.json (tools/contention_probe.py)",
+                "what": "backward of the headline step (blend_bwd + preprocess_bwd) with a 46.4 MB device-to-device copy "
+                        "looping on 16-64 workgroups of a side stream / without: the worst of the three tenant sizes"}
+    except Exception:
+        return {"factor": 1.0, "source": "not measured (profiles/r04_contention.json absent)"}
+
+
+def fit_scaling_model(ms_per_step_1gpu: float, n_surfels: int, contention: float = 1.0) -> dict:
     """MODELLED weak scaling of the fitting step as Stage3Trainer exchanges: the SH rest bands (45 of the 58 floats per
     surfel) go on the wire behind the rasterizer's backward and ride beside the warp's backward (WARP_BACKWARD_MS of
-    compute that does not touch them); the 13 small floats per surfel (+ background) follow behind the whole backward.
+    compute that does not touch them, slowed by the MEASURED co-tenant factor `contention`); the 13 small floats per
+    surfel (+ background) follow behind the whole backward.
     Serial cost = what of the first collective outlasts the warp's backward + the second collective."""
     out = {}
     rest, small = n_surfels * 45 * 4, n_surfels * 13 * 4 + 12
     for n in (2, 4, 8):
         e_rest, e_small = exchange_model_ms(rest, n), exchange_model_ms(small, n)
-        serial = {k: max(0.0, e_rest[k] - WARP_BACKWARD_MS) + e_small[k] for k in e_rest}
+        serial = {k: max(0.0, e_rest[k] - WARP_BACKWARD_MS) + e_small[k] + (contention - 1.0) * WARP_BACKWARD_MS for k in e_rest}
         out[str(n)] = {k: round(n * ms_per_step_1gpu / (ms_per_step_1gpu + v), 2) for k, v in serial.items()}
         out[str(n)]["serial_exchange_ms"] = {k: round(v, 3) for k, v in serial.items()}
     return out
@@ -767,12 +784,22 @@ def main():
             # MODELLED multi-GPU figures (no multi-GPU node is reachable from the build box; the driver
             # measures the real curve when it has one): measured 1-GPU step + the all-reduce cost model above
             payload = N * GRAD_FLOATS_PER_SURFEL * 4
-            sm = {"label": "MODELLED, not measured: measured 1-GPU step + cost model of one all-reduce per step",
+            cont = measured_contention()
+            sm = {"label": "MODELLED, not measured: measured 1-GPU step + cost model of one all-reduce per step; the only "
+                           "measured multi-tenant term is `contention`",
+                  "north_star_row": "fit_step.speedup_exchange_serial (a fitting step cannot start before its gradients are "
+                                    "reduced; the op-level rows below have no optimizer between steps)",
                   "assumptions": {"xgmi_links_per_gpu": XGMI_LINKS, "GBps_per_link": XGMI_LINK_GBPS,
                                   "latency_ms_per_collective_phase": COLLECTIVE_LATENCY_MS,
-                                  "ring_all_links_efficiency": 0.7, "weak_scaling": "per-GPU work fixed (2 frames per step)"},
+                                  "ring_all_links_efficiency": "0.7 -- a guess, not a measurement",
+                                  "weak_scaling": "per-GPU work fixed (2 frames per step)"},
+                  "contention": cont,
                   "op_level": {"ms_per_step_1gpu": out["ms_per_step"], "payload_bytes": payload,
-                               "speedup_exchange_overlapped": scaling_model(out["ms_per_step"], payload, True),
+                               # the exchange of step i beside the kernels of step i + 1 (double-buffered gradients): the
+                               # compute slows down by the measured co-tenant factor while a collective is in flight, and
+                               # a collective longer than the (slowed) step bounds the rate -- an UPPER BOUND on what
+                               # overlapping can give, not a prediction (RCCL's own kernels were never run here)
+                               "upper_bound_exchange_hidden": scaling_model(out["ms_per_step"], payload, True, cont["factor"]),
                                "speedup_exchange_serial": scaling_model(out["ms_per_step"], payload, False)}}
             for key in ("fit_step", "fit_step_geometry"):
                 if key in out:
@@ -783,7 +810,8 @@ def main():
                                "speedup_exchange_serial": scaling_model(out[key]["ms_per_step"], pay, False),
                                # as Stage3Trainer issues it: the SH rest bands' collective behind the rasterizer's
                                # backward, beside the warp's backward (allreduce_gradients)
-                               "speedup_rest_bands_beside_the_warp_backward": fit_scaling_model(out[key]["ms_per_step"], N),
+                               "speedup_rest_bands_beside_the_warp_backward": fit_scaling_model(out[key]["ms_per_step"], N,
+                                                                                                cont["factor"]),
                                "warp_backward_ms_assumed": WARP_BACKWARD_MS}
             out["scaling_modelled"] = sm
         if world == 1 and args.cpu_images > 0:

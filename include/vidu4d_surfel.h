@@ -264,7 +264,7 @@ int vidu4d_surfel_mark_visible(int P, const float* means3D, const float* viewmat
  *      (device or host pointer, any hipMemcpy-able) and the element count is returned in *count. */
 enum Vidu4dSurfelStateArray {
     VIDU4D_STATE_NUM_RENDERED = 0,  /* uint32[1] */
-    VIDU4D_STATE_RECORDS = 1,       /* float[P][24]  (layout: vidu4d_amd/csrc/surfel_math.h) */
+    VIDU4D_STATE_RECORDS = 1,       /* float[P][32], 28 used  (layout: vidu4d_amd/csrc/surfel_math.h) */
     VIDU4D_STATE_TILES_TOUCHED = 2, /* uint32[P] */
     VIDU4D_STATE_POINT_LIST = 3,    /* uint32[num_rendered] sorted surfel ids (binning.point_list) */
     VIDU4D_STATE_SORTED_KEYS = 4,   /* uint64[num_rendered] (tile << 32 | depth bits); dst must be HOST memory */

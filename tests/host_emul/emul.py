@@ -34,7 +34,7 @@ def run(st, dL_dcolor, dL_dothers, cull=True, lite=False):
     out = {}
     out["radii"] = np.zeros(P, np.int32)
     out["tiles"] = np.zeros(P, np.uint32)
-    out["rec"] = np.zeros((P, 28), np.float32)
+    out["rec"] = np.zeros((P, 32), np.float32)
     L.emul_preprocess(C.c_int(P), C.c_int(D), C.c_int(M), _p(inp["means3D"]), _p(inp["scales"]), _p(inp["rotations"]),
                       _p(inp["opacities"]), _p(inp["shs"]), _p(inp["colors_precomp"]), _p(inp["viewmatrix"]),
                       _p(inp["campos"]), C.c_int(W), C.c_int(H), C.c_float(st["tanfovx"]), C.c_float(st["tanfovy"]),
@@ -73,7 +73,7 @@ def footprint_scan(st):
     L = lib()
     inp = st["_inputs"]
     P, D, M, W, H = st["P"], st["D"], st["M"], st["W"], st["H"]
-    radii, tiles, rec = np.zeros(P, np.int32), np.zeros(P, np.uint32), np.zeros((P, 28), np.float32)
+    radii, tiles, rec = np.zeros(P, np.int32), np.zeros(P, np.uint32), np.zeros((P, 32), np.float32)
     L.emul_preprocess(C.c_int(P), C.c_int(D), C.c_int(M), _p(inp["means3D"]), _p(inp["scales"]), _p(inp["rotations"]),
                       _p(inp["opacities"]), _p(inp["shs"]), _p(inp["colors_precomp"]), _p(inp["viewmatrix"]),
                       _p(inp["campos"]), C.c_int(W), C.c_int(H), C.c_float(st["tanfovx"]), C.c_float(st["tanfovy"]),

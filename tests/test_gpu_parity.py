@@ -53,7 +53,7 @@ def _check_forward(sc, st, out, colors=None):
     assert R == st["num_rendered"]
     assert np.array_equal(to_np(radii), st["radii"])
     assert np.array_equal(_state("tiles_touched", out, sc, torch.int32, P).astype(np.uint32), st["tiles_touched"])
-    rec = _state("records", out, sc, torch.float32, P * 28).reshape(P, 28)
+    rec = _state("records", out, sc, torch.float32, P * 32).reshape(P, 32)   # (28 floats used, one 128-byte line each)
     vis = st["radii"] > 0
     assert np.array_equal(rec[vis, 0:9], st["transMat"][vis]), "homography must be bit-exact (feeds the binning)"
     assert np.array_equal(rec[vis, 9:11], st["means2D"][vis])

@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out; export TMPDIR=/tmp
+P='import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); s=d["stage_ms_avg"]; print(sys.argv[1], round(d["value"]), round(d["repeats"]["median"]), "fwd", s["blend_fwd"], "bwd", s["blend_bwd"], "pre", s["preprocess_fwd"], "prebwd", s["preprocess_bwd"], "sum", round(sum(s.values()),4))'
+cp vidu4d_amd/csrc/libvidu4d_surfel.so /tmp/product.so
+for i in 1 2 3; do
+  cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so
+  timeout 600 python bench.py --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 3 --per-frame-surface 0 2>/dev/null | python -c "$P" product
+  cp variants/rec128B.so vidu4d_amd/csrc/libvidu4d_surfel.so
+  timeout 600 python bench.py --cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --repeats 3 --per-frame-surface 0 2>/dev/null | python -c "$P" rec128B
+done
+cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so

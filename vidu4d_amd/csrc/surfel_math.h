@@ -31,14 +31,18 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_EPS = 0.0001f;
 
-// Per-surfel record written by preprocess and gathered by the blend kernels (7 x float4 = 112 B).
+// Per-surfel record written by preprocess and gathered by the blend kernels (7 x float4 = 112 B, at a 128-byte stride).
 //   q0 = Tu.x Tu.y Tu.z Tv.x | q1 = Tv.y Tv.z Tw.x Tw.y | q2 = Tw.z cx cy opacity
 //   q3 = n.x n.y n.z depth   | q4 = r g b clampmask(bits)
 //   q5, q6 = the footprint outside which the surfel cannot contribute (contribution_footprint below)
+// Stride of a record: 32 floats = ONE 128-byte cache line (round 4; the first 28 are used, the rest is never written).
+// With the dense 112-byte stride of round 3 a record straddled line boundaries three times in four and the blend kernels'
+// gathers pulled ~1.9 lines per record (tools/ubench/fetch_calib.hip, profiles/r04_fetch_calib.txt); a line per record
+// takes a fifth off their HBM traffic and costs the projection kernel 2 us of extra stores: a wash on the clock.
 #ifndef SURFEL_REC_FLOATS
-#define SURFEL_REC_FLOATS 28
+#define SURFEL_REC_FLOATS 32
 #endif
-constexpr int REC_FLOATS = SURFEL_REC_FLOATS;  // (28 used; 32 = one record per 128-byte line, the rest padding)
+constexpr int REC_FLOATS = SURFEL_REC_FLOATS;
 constexpr int REC_USED_FLOATS = 28;
 constexpr int REC_LDS_FLOATS = 20;  // q0..q4 are staged in LDS; q5, q6 only feed the per-wave cull masks
 enum RecSlot {
