@@ -168,7 +168,21 @@ def backward(st, dL_dcolor, dL_dothers):
         dL_dcolors=acc_c.astype(np.float32))
     g["dL_dmeans2D_filter"] = g["dL_dmeans2D"].copy()  # before the densification "hack" overwrites it
     g["dL_dtransMat_render"] = g["dL_dtransMat"].copy()
+    g.update(backward_chain(st, g["dL_dtransMat_render"], g["dL_dmeans2D_filter"], g["dL_dnormal"], g["dL_dcolors"]))
+    return g
 
+
+def backward_chain(st, dL_dtransMat_render, dL_dmeans2D_filter, dL_dnormal, dL_dcolors):
+    """The per-surfel chain rule behind the blend (BACKWARD::preprocess, backward.cu:601-668: the AABB's share of
+    dL_dtransMat / dL_dmeans2D, then transMat -> mean / scale / rotation and colour -> SH) from the blend's accumulators.
+    Split out of backward() so a test can push a perturbed accumulator through it (how much of a rounding difference in
+    the sums the chain amplifies: tools/fuzz_footprint_gpu.py)."""
+    L = lib()
+    P, M, D, W, H = st["P"], st["M"], st["D"], st["W"], st["H"]
+    inp = st["_inputs"]
+    g = dict(dL_dtransMat=_f32(dL_dtransMat_render, (P, 9)).copy(), dL_dmeans2D=_f32(dL_dmeans2D_filter, (P, 3)).copy())
+    dL_dnormal = _f32(dL_dnormal, (P, 3))
+    dL_dcolors = _f32(dL_dcolors, (P, 3))
     focal_y = np.float32(H) / (np.float32(2.0) * np.float32(st["tanfovy"]))
     focal_x = np.float32(W) / (np.float32(2.0) * np.float32(st["tanfovx"]))
     Wh = np.float32(focal_x * np.float32(st["tanfovx"]))
@@ -184,7 +198,7 @@ def backward(st, dL_dcolor, dL_dothers):
         C.c_int(P), C.c_int(D), C.c_int(M), _p(inp["means3D"]), _p(st["radii"]), _p(inp["shs"]), _p(st["clamped"]),
         _p(inp["scales"]), _p(inp["rotations"]), _p(inp["viewmatrix"]), C.c_float(float(focal_x)),
         C.c_float(float(focal_y)), C.c_float(st["tanfovx"]), C.c_float(st["tanfovy"]), _p(inp["campos"]),
-        _p(g["dL_dtransMat"]), _p(g["dL_dnormal"]), _p(g["dL_dcolors"]), _p(g["dL_dsh"]), _p(g["dL_dmeans3D"]),
+        _p(g["dL_dtransMat"]), _p(dL_dnormal), _p(dL_dcolors), _p(g["dL_dsh"]), _p(g["dL_dmeans3D"]),
         _p(g["dL_dscales"]), _p(g["dL_drotations"]))
     return g
 

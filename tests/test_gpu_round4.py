@@ -39,10 +39,16 @@ def _run(sc, dev, dc, do, aux=0, flags=None, frames=None):
                 header=header, R=R)
 
 
-def _grad_error(a, b):
+# what the blend kernel itself accumulates (float atomics); the other tensors are preprocess_bwd's deterministic chain rule
+# applied to these, which can amplify a rounding difference when its terms cancel (dL_dscales of a near-degenerate
+# surfel: tools/fuzz_footprint_gpu.py prices that separately)
+BLEND_GRADS = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dtransMat")
+
+
+def _grad_error(a, b, names=GRAD_NAMES):
     """largest |a - b| / max|b| over the gradient tensors"""
     worst = 0.0
-    for k in GRAD_NAMES:
+    for k in names:
         x, y = a["grads"][k], b["grads"][k]
         assert torch.isfinite(x).all(), k
         worst = max(worst, float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30))
@@ -70,7 +76,7 @@ def test_footprint_cull_ab_on_the_device(gpu_device, seed, large, n):
     """Forward planes, final_T, n_contrib bit-identical with and without the culls.  The gradient sums are float atomics
     whose order differs from run to run (screen-filling surfels add thousands of terms of both signs: the same kernel run
     twice differs by up to ~5e-6 of the tensor's scale on these scenes), so they are held to 1e-6 of scale plus four times
-    the noise floor measured on the spot (culls on, twice).  seed 3: the scenes whose footprints round 3's first conic test
+    the noise floor measured on the spot (culls on, twice) -- on the sums the blend kernel makes (BLEND_GRADS).  seed 3: the scenes whose footprints round 3's first conic test
     cut (huge, strongly foreshortened, near-plane surfels); `large`: image sizes up to 1920 x 1080."""
     from vidu4d_amd import _lib
     dev = gpu_device
@@ -81,8 +87,9 @@ def test_footprint_cull_ab_on_the_device(gpu_device, seed, large, n):
         b = _run(sc, dev, dc, do, flags=_lib.DEBUG_NO_CULL)
         for k in ("color", "others", "radii", "n_contrib", "final_T"):
             assert torch.equal(a[k], b[k]), (what, k, int((a[k] != b[k]).sum()))
-        noise = _grad_error(a2, a)
-        assert _grad_error(a, b) <= 1e-6 + 4.0 * noise, (what, _grad_error(a, b), noise)
+        noise = _grad_error(a2, a, BLEND_GRADS)
+        assert _grad_error(a, b, BLEND_GRADS) <= 1e-6 + 4.0 * noise, (what, _grad_error(a, b, BLEND_GRADS), noise)
+        assert _grad_error(a, b) <= 1e-4, (what, _grad_error(a, b))   # the chain-rule tensors: the north star's tolerance
 
 
 @pytest.mark.parametrize("mode", ["full", "lite", "geom"])
