@@ -172,23 +172,28 @@ def backward(st, dL_dcolor, dL_dothers):
     return g
 
 
-def backward_chain(st, dL_dtransMat_render, dL_dmeans2D_filter, dL_dnormal, dL_dcolors):
+def backward_chain(st, dL_dtransMat_render, dL_dmeans2D_filter, dL_dnormal, dL_dcolors, after_aabb=False):
     """The per-surfel chain rule behind the blend (BACKWARD::preprocess, backward.cu:601-668: the AABB's share of
     dL_dtransMat / dL_dmeans2D, then transMat -> mean / scale / rotation and colour -> SH) from the blend's accumulators.
-    Split out of backward() so a test can push a perturbed accumulator through it (how much of a rounding difference in
-    the sums the chain amplifies: tools/fuzz_footprint_gpu.py)."""
+    Split out of backward() so a test can push ANOTHER implementation's blend sums through it and compare that
+    implementation's chain with this one on equal inputs (tools/fuzz_footprint_gpu.py: the chain amplifies rounding
+    differences of the sums by two orders of magnitude).  after_aabb: dL_dtransMat already holds the AABB's share (the
+    tensor RasterizeGaussiansBackwardCUDA returns); dL_dmeans2D_filter may then be None."""
     L = lib()
     P, M, D, W, H = st["P"], st["M"], st["D"], st["W"], st["H"]
     inp = st["_inputs"]
-    g = dict(dL_dtransMat=_f32(dL_dtransMat_render, (P, 9)).copy(), dL_dmeans2D=_f32(dL_dmeans2D_filter, (P, 3)).copy())
+    g = dict(dL_dtransMat=_f32(dL_dtransMat_render, (P, 9)).copy())
+    if not after_aabb:
+        g["dL_dmeans2D"] = _f32(dL_dmeans2D_filter, (P, 3)).copy()
     dL_dnormal = _f32(dL_dnormal, (P, 3))
     dL_dcolors = _f32(dL_dcolors, (P, 3))
     focal_y = np.float32(H) / (np.float32(2.0) * np.float32(st["tanfovy"]))
     focal_x = np.float32(W) / (np.float32(2.0) * np.float32(st["tanfovx"]))
     Wh = np.float32(focal_x * np.float32(st["tanfovx"]))
     Hh = np.float32(focal_y * np.float32(st["tanfovy"]))
-    L.oracle_aabb_backward(C.c_int(P), _p(st["radii"]), C.c_float(float(Wh)), C.c_float(float(Hh)),
-                           _p(st["transMat"]), _p(g["dL_dmeans2D"]), _p(g["dL_dtransMat"]))
+    if not after_aabb:
+        L.oracle_aabb_backward(C.c_int(P), _p(st["radii"]), C.c_float(float(Wh)), C.c_float(float(Hh)),
+                               _p(st["transMat"]), _p(g["dL_dmeans2D"]), _p(g["dL_dtransMat"]))
 
     g["dL_dsh"] = np.zeros((P, M, 3), np.float32)
     g["dL_dmeans3D"] = np.zeros((P, 3), np.float32)

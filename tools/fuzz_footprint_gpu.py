@@ -10,12 +10,12 @@ run through the PRODUCT kernels.  Per scene:
       (tests/util.py::assert_close at ORACLE_RTOL = 1e-5 of scale decides; a pixel whose contributor counts differ from
       the oracle's is a threshold flip -- T > 0.5, T < 1e-4 on a transmittance within an ulp -- and moves the gradient rows
       of TWO surfels, the one that loses the sample and the one that gains it: that many rows are allowed per flip).
-      The chain-rule tensors (dL_dmeans3D / dL_dscales / dL_drotations) get, on top of 1e-5 of their own scale, what the
-      chain makes of a 1e-6-of-scale difference in the blend's sums (a tenth of what those sums are themselves allowed;
-      their measured worst is ~1.5e-6) -- measured by pushing such a perturbation through the oracle's chain
-      (oracle backward_chain).  Seed 0's scene 29 is why: 300 screen-filling surfels whose dL_dscales (scale 6e-6) is a
-      difference of dL_dtransMat terms (scale 5e-2) -- a 1e-6 perturbation of those moves it by 60 % of its scale, so
-      "1e-5 of its scale" is below the fp32 rounding of its inputs; such scenes are counted ("ill-conditioned chain").
+      The chain-rule tensors (dL_dmeans3D / dL_dscales / dL_drotations; preprocess_bwd) are held to the north star's 1e-4
+      against the oracle directly, and to 1e-5 against the oracle's chain applied to the PRODUCT's own blend sums
+      (oracle backward_chain on the returned dL_dtransMat / dL_dcolors): the chain multiplies a rounding difference of
+      those sums by two orders of magnitude (a 1e-6 perturbation of them moves dL_dscales by 1e-4..1e-2 of its scale on
+      these scenes; seed 0's scene 29 -- 300 screen-filling surfels, dL_dscales of scale 6e-6 from dL_dtransMat of scale
+      5e-2 -- by half of it), so the direct comparison cannot be tighter than the sums' own 1e-5 times that factor.
 Usage: python tools/fuzz_footprint_gpu.py [scenes=200] [seed=0] [large] > profiles/r04_fuzz_footprint_gpu.txt"""
 import os
 import sys
@@ -29,7 +29,7 @@ from oracle import surfel_oracle as so  # noqa: E402
 from tests.test_gpu_round4 import BLEND_GRADS, GRAD_NAMES, _grad_error, _run  # noqa: E402
 import functools  # noqa: E402
 
-from tests.util import DIST_ATOL, ORACLE_RTOL, oracle_forward  # noqa: E402
+from tests.util import DIST_ATOL, ORACLE_RTOL, RTOL, oracle_forward  # noqa: E402
 from tests.util import assert_close as _assert_close  # noqa: E402
 
 assert_close = functools.partial(_assert_close, rtol=ORACLE_RTOL)
@@ -41,18 +41,6 @@ from vidu4d_amd.synthetic import make_upstream_grads  # noqa: E402
 CHAIN = ("dL_dmeans3D", "dL_dscales", "dL_drotations")
 
 
-def chain_tolerance(st, g, rel, rng, draws=3):
-    """largest change of each chain-rule tensor when the blend's sums move by `rel` of their scale (random signs)"""
-    tol = {k: 0.0 for k in CHAIN}
-    src = {k: g[k] for k in ("dL_dtransMat_render", "dL_dmeans2D_filter", "dL_dnormal")}
-    for _ in range(draws):
-        pert = {k: v + (rel * np.abs(v).max() * rng.choice((-1.0, 1.0), size=v.shape)).astype(np.float32) for k, v in src.items()}
-        h = so.backward_chain(st, pert["dL_dtransMat_render"], pert["dL_dmeans2D_filter"], pert["dL_dnormal"], g["dL_dcolors"])
-        for k in CHAIN:
-            tol[k] = max(tol[k], float(np.abs(h[k].astype(np.float64) - g[k]).max()))
-    return tol
-
-
 def main():
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -62,7 +50,6 @@ def main():
     so.set_threads(min(64, os.cpu_count() or 1))
     bad_ab = bad_oracle = flips_total = 0
     worst_noise = worst_ab = worst_chain = 0.0
-    ill = 0
     worst = {}
     pairs = 0
     for i in range(n_scenes):
@@ -83,8 +70,7 @@ def main():
         # ---- product vs oracle
         st = oracle_forward(sc)
         g = so.backward(st, dc, do)
-        chain_atol = chain_tolerance(st, g, 0.1 * ORACLE_RTOL, np.random.default_rng(i))
-        ill += any(chain_atol[k] > ORACLE_RTOL * np.abs(g[k]).max() for k in CHAIN)
+        own = so.backward_chain(st, a["grads"]["dL_dtransMat"], None, g["dL_dnormal"], a["grads"]["dL_dcolors"], after_aabb=True)
         fails = []
         W, H = sc.width, sc.height
         if not np.array_equal(a["radii"].cpu().numpy(), st["radii"]):
@@ -102,8 +88,8 @@ def main():
                 kw["min_outliers"] = 2 * flips * int(np.prod(np.shape(want)[1:]))
             elif flips:
                 kw["min_outliers"] = flips * (3 if name == "color" else 1)
-            if name in chain_atol:
-                kw["atol"] = chain_atol[name]
+            if name in CHAIN:
+                kw["rtol"] = RTOL
             try:
                 w = assert_close(name, got, want, **kw)
             except AssertionError as e:
@@ -118,14 +104,15 @@ def main():
         for k in GRAD_NAMES:
             if k in g:
                 cmp(k, a["grads"][k], g[k])
+        for k in CHAIN:
+            cmp(k + " | oracle chain of the product's sums", a["grads"][k], own[k])
         if fails:
             bad_oracle += 1
             print(f"PRODUCT != ORACLE scene {i}: {what}: {fails}", flush=True)
     print(f"{n_scenes} scenes (seed {seed}{', large' if large else ''}), {pairs} (surfel, tile) pairs: "
           f"{bad_ab} cull A/B mismatches (forward planes / final_T / n_contrib bit-identical in the others; gradients: worst "
           f"A/B difference {worst_ab:.2e} of scale, worst run-to-run noise {worst_noise:.2e}, chain-rule tensors {worst_chain:.2e}), "
-          f"{bad_oracle} scenes outside 1e-5 of scale vs the oracle ({flips_total} pixels with a threshold flip in all; "
-          f"{ill} scenes with an ill-conditioned chain)")
+          f"{bad_oracle} scenes outside 1e-5 of scale vs the oracle ({flips_total} pixels with a threshold flip in all)")
     print("worst error / scale vs the oracle over all scenes:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
     sys.exit(1 if (bad_ab or bad_oracle) else 0)
 

@@ -77,6 +77,15 @@ __device__ __forceinline__ FootprintTest stage_record(float4* s_rec, int slot, c
     return footprint_test(f, c.y, c.z);
 }
 
+// The footprint alone (a thread that tests an entry somebody else stages).
+__device__ __forceinline__ FootprintTest load_footprint(const float* rec, uint32_t id)
+{
+    const float4* src = reinterpret_cast<const float4*>(rec + (size_t)id * REC_FLOATS);
+    const float4 c = src[2], f0 = src[5], f1 = src[6];
+    const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    return footprint_test(f, c.y, c.z);
+}
+
 __device__ __forceinline__ FootprintTest no_footprint()
 {
     const float f[8] = {0.f, 0.f, 0.f, -1.f, 0.f, 0.f, -1.f, 0.f};
@@ -101,6 +110,23 @@ __device__ __forceinline__ void publish_cull_masks(unsigned long long (*s_mask)[
         const bool hit = valid && (no_cull || footprint_hits(foot, rx0, rx0 + 7.0f, ry0, ry0 + 7.0f));
         const unsigned long long m = __ballot(hit);
         if (lane == 0) s_mask[q][wave] = m;
+    }
+}
+
+// The finer version: eight 8x4 pixel blocks (block 2q + h = rows 4h..4h+3 of quadrant q: the pixels of lanes
+// 32h..32h+31 of wave q).  The calling wave holds the 64 staged entries of mask word `word` and tests them against blocks
+// first..first+COUNT-1: s_mask8[b][word] = which of them can reach a pixel centre of block b.
+template <int WORDS, int COUNT>
+__device__ __forceinline__ void publish_block_masks(unsigned long long (*s_mask8)[WORDS], bool valid, const FootprintTest& foot,
+                                                    int tile_x0, int tile_y0, int word, int first, int lane, bool no_cull)
+{
+#pragma unroll
+    for (int i = 0; i < COUNT; i++) {
+        const int b = first + i, q = b >> 1, h = b & 1;
+        const float rx0 = (float)(tile_x0 + (q & 1) * 8) + 0.5f, ry0 = (float)(tile_y0 + (q >> 1) * 8 + 4 * h) + 0.5f;
+        const bool hit = valid && (no_cull || footprint_hits(foot, rx0, rx0 + 7.0f, ry0, ry0 + 3.0f));
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_mask8[b][word] = m;
     }
 }
 
@@ -369,8 +395,9 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                        uint32_t* depth_used, int spec, int flags, int rec_len)
 {
     constexpr bool SPEC_OK = MODE != BLEND_FULL;
-    __shared__ float4 s_rec[FWD_BATCH * 5];
-    __shared__ unsigned long long s_mask[4][4];
+    __shared__ float4 s_rec[(FWD_BATCH + 1) * 5];  // (+ an all-zero record: what an idle half of a wave evaluates)
+    __shared__ unsigned long long s_mask8[8][FWD_BATCH / 64];
+    if (threadIdx.x < 5) s_rec[FWD_BATCH * 5 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool overflow = (int64_t)hdr->num_rendered > capacity;
     if (SPLIT && SPEC_OK && spec && blockIdx.x == 0 && threadIdx.x == 0)  // (what blend_seg_T_kernel does when it runs)
         hdr->split_used = !overflow && hdr->num_segments > 0;
@@ -429,29 +456,31 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
         const bool have = (int)threadIdx.x < todo;
         FootprintTest foot = no_footprint();
         if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
-        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
+        publish_block_masks<FWD_BATCH / 64, 8>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave, 0, lane, flags & FLAG_NO_CULL);
         __syncthreads();
         if (__all(done)) continue;  // this wave's 64 pixels are saturated; it keeps helping to stage
+        // Half walk (see blend_bwd_kernel): lanes 0-31 / 32-63 follow the cull masks of their own 8x4 block, two list
+        // entries of each per trip; the accumulation stays in list order per pixel.
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            unsigned long long m = uniform_u64(s_mask[wave][k]);
-            // two list entries per trip: their evaluations are independent, so the scheduler interleaves
-            // the two dependency chains (LDS read -> cross product -> rcp -> exp); the accumulation stays
-            // in list order.  This is what hides latency when a SIMD has only one or two resident waves
-            // (small images, object-centric scenes).
-            while (m) {
-                const int ja = k * 64 + __builtin_ctzll(m);
-                m &= m - 1;
-                const bool two = m != 0;
-                const int jb = two ? k * 64 + __builtin_ctzll(m) : ja;
-                if (two) m &= m - 1;
+        for (int k = 0; k < FWD_BATCH / 64; k++) {
+            unsigned long long mA = uniform_u64(s_mask8[2 * wave][k]), mB = uniform_u64(s_mask8[2 * wave + 1][k]);
+            while (mA | mB) {
+                const int jaA = mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH;
+                mA &= mA - 1;
+                const int jbA = mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH;
+                mA &= mA - 1;
+                const int jaB = mB ? k * 64 + __builtin_ctzll(mB) : FWD_BATCH;
+                mB &= mB - 1;
+                const int jbB = mB ? k * 64 + __builtin_ctzll(mB) : FWD_BATCH;
+                mB &= mB - 1;
+                const int ja = lane < 32 ? jaA : jaB, jb = lane < 32 ? jbA : jbB;
                 const float4 a0 = s_rec[ja * 5 + 0], a1 = s_rec[ja * 5 + 1], a2 = s_rec[ja * 5 + 2];
                 const float4 b0 = s_rec[jb * 5 + 0], b1 = s_rec[jb * 5 + 1], b2 = s_rec[jb * 5 + 2];
                 const float TuA[3] = {a0.x, a0.y, a0.z}, TvA[3] = {a0.w, a1.x, a1.y}, TwA[3] = {a1.z, a1.w, a2.x};
                 const float TuB[3] = {b0.x, b0.y, b0.z}, TvB[3] = {b0.w, b1.x, b1.y}, TwB[3] = {b1.z, b1.w, b2.x};
                 PairEval ea, eb;
                 bool okA = eval_pair_flat(TuA, TvA, TwA, a2.y, a2.z, a2.w, pixx, pixy, ea);
-                bool okB = eval_pair_flat(TuB, TvB, TwB, b2.y, b2.z, b2.w, pixx, pixy, eb) && two;
+                bool okB = eval_pair_flat(TuB, TvB, TwB, b2.y, b2.z, b2.w, pixx, pixy, eb);
                 okA = okA && !done;
                 if (__any(okA)) {
                     if (okA) {
@@ -806,46 +835,25 @@ __device__ __forceinline__ void halve(float (&v)[16], bool hi)
     }
 }
 
-// Sums 16 per-lane values over each row of 16 lanes; on return lane L holds the row total of
-// component (L & 15).
-__device__ __forceinline__ float row_reduce_scatter16(float (&v)[16], int lane)
-{
-    halve<DPP_ROW_MIRROR, 16>(v, (lane & 8) != 0);
-    halve<DPP_ROW_HALF_MIRROR, 8>(v, (lane & 4) != 0);
-    halve<DPP_QUAD_XOR2, 4>(v, (lane & 2) != 0);
-    halve<DPP_QUAD_XOR1, 2>(v, (lane & 1) != 0);
-    return v[0];
-}
-
-// Wave-wide reduce-scatter of 16 values with the gfx950 lane-swap instructions.  v_permlane32_swap
-// exchanges the upper 32 lanes of one register with the lower 32 lanes of another, v_permlane16_swap
-// the odd 16-lane rows of one with the even rows of the other: after "swap, add" on register pairs
-// (k, k+8) and then (k, k+4) the 16 inputs have become 4 registers in which row r holds, per column,
-// the sum over the four rows of value k + 4r -- the two steps that cross the rows need no select at
-// all (8+8 and 4+4 instructions).  Two select-and-add DPP steps and two plain quad adds finish the
-// columns: every lane of quad q in row r then holds the wave total of value q + 4r.
-// 35 VALU instructions instead of the 45 selects/adds (+ register shuffling) of four row-local
-// halvings, and the LDS accumulation that follows has 16 distinct addresses instead of 4 lanes each.
-__device__ __forceinline__ void swap_add32(float& a, float b)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+// Reduce-scatter of 16 per-lane values over each HALF of the wave (32 lanes = two 16-lane rows = the pixels of one 8x4
+// block) with the gfx950 lane-swap instruction: v_permlane16_swap exchanges the odd rows of one register with the even rows
+// of another, so "swap, add" on the register pairs (k, k + 8) folds the two rows AND halves the values per lane without a
+// select (even rows: values 0-7, odd rows: 8-15).  Three select-and-add DPP steps and a quad add finish the columns.
+// Lane L then holds its half's total of value 8 ((L >> 4) & 1) + ((L >> 1) & 7) -- both lanes of a pair the same one.
+// (Rounds 2-3 reduced over the whole wave, with a v_permlane32_swap step in front: same cost per trip, one entry per trip.)
 __device__ __forceinline__ void swap_add16(float& a, float b)
 {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float wave_reduce_scatter16(float (&v)[16], int lane)
+__device__ __forceinline__ float half_reduce_scatter16(float (&v)[16], int lane)
 {
 #pragma unroll
-    for (int k = 0; k < 8; k++) swap_add32(v[k], v[k + 8]);  // lanes 0-31: value k, lanes 32-63: value k + 8
-#pragma unroll
-    for (int k = 0; k < 4; k++) swap_add16(v[k], v[k + 4]);  // row r: value k + 4r
-    halve<DPP_ROW_MIRROR, 4>(v, (lane & 8) != 0);            // columns 0-7: k = 0,1   columns 8-15: k = 2,3
-    halve<DPP_ROW_HALF_MIRROR, 2>(v, (lane & 4) != 0);       // quad q: k = q
+    for (int k = 0; k < 8; k++) swap_add16(v[k], v[k + 8]);
+    halve<DPP_ROW_MIRROR, 8>(v, (lane & 8) != 0);
+    halve<DPP_ROW_HALF_MIRROR, 4>(v, (lane & 4) != 0);
+    halve<DPP_QUAD_XOR2, 2>(v, (lane & 2) != 0);
     float t = v[0];
-    t += dpp_xchg<DPP_QUAD_XOR2>(t);
     t += dpp_xchg<DPP_QUAD_XOR1>(t);
     return t;
 }
@@ -910,10 +918,10 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     const uint32_t* __restrict__ ranges = img.ranges;
     const float* __restrict__ final_T = img.final_T;
     const uint32_t* __restrict__ n_contrib = img.n_contrib;
-    __shared__ float4 s_rec[BWD_BATCH * 5];
+    __shared__ float4 s_rec[(BWD_BATCH + 1) * 5];  // (+ an all-zero record: what an idle half of a wave evaluates)
     __shared__ float s_acc[BWD_BATCH * ACC_FLOATS];
     __shared__ uint32_t s_id[BWD_BATCH];
-    __shared__ unsigned long long s_mask[4][4];
+    __shared__ unsigned long long s_mask8[8][BWD_BATCH / 64];
     __shared__ uint32_t s_max;
     // (a forward that left no segment state: every tile is then walked whole)
     const uint32_t split_used = SPLIT ? hdr->split_used : 0u;
@@ -1033,14 +1041,16 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     // entries at or beyond every pixel's last contributor never matter: skip them wholesale
     // (per wave for the inner loop, per workgroup for the staging)
     if (threadIdx.x == 0) s_max = 0;
+    if (threadIdx.x < 5) s_rec[BWD_BATCH * 5 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     uint32_t wave_last = s.last_contributor;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
+    for (int d = 16; d > 0; d >>= 1) {
         const uint32_t o = (uint32_t)__shfl_xor((int)wave_last, d, 64);
         wave_last = o > wave_last ? o : wave_last;
     }
-    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+    const int half_last[2] = {(int)__builtin_amdgcn_readlane(wave_last, 0), (int)__builtin_amdgcn_readlane(wave_last, 32)};
+    wave_last = (uint32_t)(half_last[0] > half_last[1] ? half_last[0] : half_last[1]);
     if (lane == 0) atomicMax(&s_max, wave_last);
     __syncthreads();
     const int n_used = (int)s_max;
@@ -1050,10 +1060,10 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
 #endif
 
     // accumulator slot handled by this lane after the row reduce-scatter
-    // (after wave_reduce_scatter16 every lane of quad q in row r holds value q + 4r; lane 0 of the quad adds it)
-    const int c16 = ((lane & 15) >> 2) + 4 * (lane >> 4);
+    // (after half_reduce_scatter16 the lane pair p of row r holds, for its half, value p + 8 (r & 1); the even lane adds it)
+    const int c16 = ((lane >> 1) & 7) + 8 * ((lane >> 4) & 1);
+    const bool adds16 = (lane & 1) == 0;
     const int slot16 = c16 < 9 ? c16 : (c16 == 9 ? A_OPAC : (c16 < 13 ? c16 + 2 : c16 + 3));
-    const bool adds16 = (lane & 3) == 0;
     const int slot2 = A_M2D + ((lane >> 3) & 1);
 
     for (int hi = n_used; hi > seg_begin; hi -= BWD_BATCH) {
@@ -1061,36 +1071,54 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
         __syncthreads();
         {
             // threads 0..127 stage (back to front: slot t <-> list entry hi-1-t), all zero the accumulators
-            const bool have = (int)threadIdx.x < cnt;
+            // (waves 2, 3 fetch the footprints of the same entries again and test the lower four blocks)
+            const int ent = (int)threadIdx.x & (BWD_BATCH - 1);
+            const bool have = ent < cnt;
             FootprintTest foot = no_footprint();
             if (have) {
-                const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)];
-                s_id[threadIdx.x] = id;
-                foot = stage_record(s_rec, threadIdx.x, rec, id);
+                const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - ent)];
+                if (wave < BWD_BATCH / 64) {
+                    s_id[ent] = id;
+                    foot = stage_record(s_rec, ent, rec, id);
+                } else {
+                    foot = load_footprint(rec, id);
+                }
             }
-            if (wave < BWD_BATCH / 64)
-                publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
+            publish_block_masks<BWD_BATCH / 64, 4>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave & 1, 4 * (wave >> 1), lane,
+                                                   flags & FLAG_NO_CULL);
             for (int i = threadIdx.x; i < BWD_BATCH * ACC_FLOATS / 4; i += 256)
                 reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
 
+        // Half walk: lanes 0-31 and 32-63 (the upper and lower 8x4 block of the quadrant) each follow their OWN cull mask --
+        // one trip evaluates the next entry of block A on the upper lanes and the next entry of block B on the lower ones,
+        // so a 64-entry word costs max(|A|, |B|) trips instead of |A u B|.  Both bit streams are scalar; only the entry's
+        // LDS address differs between the halves.
+        // (the halves re-align at every 64-entry mask word; letting them run on independently over the batch saves 2 % of the
+        // trips and costs more than that in scalar bookkeeping -- measured, round 4)
 #pragma unroll 1
         for (int k = 0; k < BWD_BATCH / 64; k++) {
-            unsigned long long m = uniform_u64(s_mask[wave][k]);
-            while (m) {
-                const int j = k * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+            unsigned long long mA = uniform_u64(s_mask8[2 * wave][k]), mB = uniform_u64(s_mask8[2 * wave + 1][k]);
+            {
+                // entries at or beyond a half's last contributor: slot j <-> list entry hi - 1 - j, i.e. the low bits
+                const int dA = hi - half_last[0] - k * 64, dB = hi - half_last[1] - k * 64;
+                mA = dA >= 64 ? 0ull : (dA > 0 ? mA & (~0ull << dA) : mA);
+                mB = dB >= 64 ? 0ull : (dB > 0 ? mB & (~0ull << dB) : mB);
+            }
+            while (mA | mB) {
+                // (a half whose word is exhausted evaluates the all-zero record in slot BWD_BATCH: no pixel passes its test)
+                const int jA = mA ? k * 64 + __builtin_ctzll(mA) : BWD_BATCH, jB = mB ? k * 64 + __builtin_ctzll(mB) : BWD_BATCH;
+                mA &= mA - 1;
+                mB &= mB - 1;
+                const int j = lane < 32 ? jA : jB;
                 const uint32_t contributor = (uint32_t)(hi - 1 - j);
-                if (contributor >= wave_last) continue;  // wave-uniform
                 const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
                 const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
                 PairEval e;
                 const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) &&
                                 contributor < s.last_contributor;  // (outside pixels have last_contributor 0)
                 if (!__any(ok)) continue;
-                // recurrences under the lane mask; the gradient products for every lane (zeros where !ok: no
-                // register zeroing, no second divergent region)
                 PairGrad pg;
                 pg.w = pg.dL_dalpha = pg.dL_dz = 0.f;
                 if (ok) {
@@ -1103,7 +1131,7 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                 bwd_pair_geometry<MODE>(s, e, pg, Tw, q2.w, pixx, pixy, g);
                 float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
                                g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
-                const float r16 = wave_reduce_scatter16(v, lane);
+                const float r16 = half_reduce_scatter16(v, lane);
                 if (adds16 && r16 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot16], r16);
                 if (__any(g[A_M2D] != 0.f || g[A_M2D + 1] != 0.f)) {
                     const float r2 = row_reduce_scatter2(g[A_M2D], g[A_M2D + 1], lane);
@@ -1126,7 +1154,7 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
 
 // Diagnostic (vidu4d_surfel_blend_stats): what the backward's walk looks like for the frame at hand, counted by walking
 // every tile whole with the backward's own staging, cull masks and skip rules (no recurrences, no gradients).
-//   [0] list entries staged (per workgroup batch, summed)          [1] (entry, wave) trips that evaluate the pair
+//   [0] list entries staged (per workgroup batch, summed)          [1] wave trips (one entry per half wave) that evaluate
 //   [2] trips in which some lane contributes                       [3] contributing lanes (pairs) in total
 //   [4] 16-lane rows with a contributing lane, summed over [2]     [5..9] trips of [2] with <= 4, 8, 16, 32, 64 lanes
 //   [10] trips of [1] in which no lane passes the pair test itself (the contribution box reaches the quadrant, the
@@ -1137,7 +1165,7 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
                                                              unsigned long long* __restrict__ out, int flags)
 {
     __shared__ float4 s_rec[BWD_BATCH * 5];
-    __shared__ unsigned long long s_mask[4][4];
+    __shared__ unsigned long long s_mask8[8][BWD_BATCH / 64];
     __shared__ uint32_t s_max;
     TileCoord tc;
     tc.tile = (int)img.tile_order[blockIdx.x];
@@ -1156,11 +1184,12 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
     __syncthreads();
     uint32_t wave_last = last;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
+    for (int d = 16; d > 0; d >>= 1) {
         const uint32_t o = (uint32_t)__shfl_xor((int)wave_last, d, 64);
         wave_last = o > wave_last ? o : wave_last;
     }
-    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+    const int half_last[2] = {(int)__builtin_amdgcn_readlane(wave_last, 0), (int)__builtin_amdgcn_readlane(wave_last, 32)};
+    wave_last = (uint32_t)(half_last[0] > half_last[1] ? half_last[0] : half_last[1]);
     if (lane == 0) atomicMax(&s_max, wave_last);
     __syncthreads();
     const int n_used = (int)s_max;
@@ -1168,24 +1197,34 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
     for (int hi = n_used; hi > 0; hi -= BWD_BATCH) {
         const int cnt = hi < BWD_BATCH ? hi : BWD_BATCH;
         __syncthreads();
-        const bool have = (int)threadIdx.x < cnt;
+        const int ent = (int)threadIdx.x & (BWD_BATCH - 1);
+        const bool have = ent < cnt;
         FootprintTest foot = no_footprint();
-        if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)]);
-        if (wave < BWD_BATCH / 64)
-            publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
+        if (have) {
+            const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - ent)];
+            foot = wave < BWD_BATCH / 64 ? stage_record(s_rec, ent, rec, id) : load_footprint(rec, id);
+        }
+        publish_block_masks<BWD_BATCH / 64, 4>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave & 1, 4 * (wave >> 1), lane,
+                                                   flags & FLAG_NO_CULL);
         __syncthreads();
         if (wave == 0) c_staged += (unsigned long long)cnt;
         for (int k = 0; k < BWD_BATCH / 64; k++) {
-            unsigned long long m = uniform_u64(s_mask[wave][k]);
-            while (m) {
-                const int j = k * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+            unsigned long long mA = uniform_u64(s_mask8[2 * wave][k]), mB = uniform_u64(s_mask8[2 * wave + 1][k]);
+            const int dA = hi - half_last[0] - k * 64, dB = hi - half_last[1] - k * 64;
+            mA = dA >= 64 ? 0ull : (dA > 0 ? mA & (~0ull << dA) : mA);
+            mB = dB >= 64 ? 0ull : (dB > 0 ? mB & (~0ull << dB) : mB);
+            while (mA | mB) {
+                const int jA = mA ? __builtin_ctzll(mA) : 0, jB = mB ? __builtin_ctzll(mB) : 0;
+                const bool liveA = mA != 0, liveB = mB != 0;
+                mA &= mA - 1;
+                mB &= mB - 1;
+                const int j = k * 64 + (lane < 32 ? jA : jB);
+                const bool live = lane < 32 ? liveA : liveB;
                 const uint32_t contributor = (uint32_t)(hi - 1 - j);
-                if (contributor >= wave_last) continue;
                 const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
                 const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
                 PairEval e;
-                const bool geo = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && inside;
+                const bool geo = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && inside && live;
                 const bool ok = geo && contributor < last;
                 const unsigned long long b = __ballot(ok);
                 c_trips++;
