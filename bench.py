@@ -673,11 +673,12 @@ def main():
     if rank == 0:
         c = [int(x) for x in cnt.tolist()]
         if c[1]:
-            walk = {"list_entries_staged": c[0], "pair_evaluations": c[1], "evaluations_with_a_contributor": c[2],
+            # (a trip = one pass of a wave through its loop body: one list entry per 32-lane half, the "half walk")
+            walk = {"list_entries_staged": c[0], "wave_trips": c[1], "trips_with_a_contributor": c[2],
                     "contributing_pairs": c[3], "lane_utilisation": c[3] / (64.0 * c[1]),
-                    "rows_touched_per_contributing_evaluation": c[4] / max(1, c[2]),
+                    "rows_touched_per_contributing_trip": c[4] / max(1, c[2]),
                     "contributing_lanes_histogram_le_4_8_16_32_64": c[5:10],
-                    "evaluations_whose_footprint_misses_the_quadrant": c[10], "per": "step (its frames, one or more launches)"}
+                    "trips_whose_footprints_miss_their_blocks": c[10], "per": "step (its frames, one or more launches)"}
 
     images = world * args.steps * FRAMES_PER_STEP
     value = images / elapsed

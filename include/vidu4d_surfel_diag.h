@@ -18,10 +18,11 @@ extern "C" {
 int vidu4d_surfel_profile_enable(int on);
 /* Tile-walk counters: a vidu4d_surfel_backward call whose args->diag_walk_counters points at VIDU4D_BLEND_STATS device
  * u64 counters (zeroed by the caller; per call, no library state) also counts what its tile walk looks like, by a
- * counting kernel queued behind the backward blend (outside the stage timers' blend_bwd span): [0] list entries staged, [1] (entry, wave)
- * pair evaluations, [2] those with a contributing lane, [3] contributing lanes, [4] 16-lane rows with a contributing
- * lane, [5..9] evaluations of [2] with <= 4 / 8 / 16 / 32 / 64 contributing lanes, [10] evaluations of [1] in which no
- * lane passes the pair test (the contribution box reaches the quadrant, the footprint does not).  [3] / (64 [1]) is the
+ * counting kernel queued behind the backward blend (outside the stage timers' blend_bwd span): [0] list entries staged, [1] wave
+ * trips (one pass of a wave through the walk's loop body: one list entry per 32-lane half), [2] those with a contributing
+ * lane, [3] contributing lanes = (pixel, entry) pairs, [4] 16-lane rows with a contributing lane, [5..9] trips of [2] with
+ * <= 4 / 8 / 16 / 32 / 64 contributing lanes, [10] trips of [1] in which no lane passes the pair test (the cull test's
+ * footprints reach the two 8x4 pixel blocks, the exact ones do not).  [3] / (64 [1]) is the
  * lane utilisation bench.py's roofline note quotes. */
 #define VIDU4D_BLEND_STATS 11
 int vidu4d_surfel_profile_stage_count(void);

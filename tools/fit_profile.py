@@ -25,6 +25,17 @@ t0 = time.perf_counter(); K = int(os.environ.get("FIT_K", "10"))
 for i in range(K): tr.train_step(batches[i % 4])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 print(f"FIT_STEP 200k/512^2 radius {RADIUS}, 2 frames/step: {dt*1e3:.2f} ms/step = {2/dt:.1f} images/s")
+if os.environ.get("FIT_PRINT_HINTS", "0") == "1":   # what the split decision sees
+    from vidu4d_amd import _C
+    print("FIT_HINTS deepest blended list position", dict(_C._depth_hint), "longest list", dict(_C._len_hint))
+if os.environ.get("FIT_WALK_STATS", "0") == "1":   # what the backward's walk of one step looks like (vidu4d_surfel_blend_stats)
+    from vidu4d_amd import _C
+    cnt = torch.zeros(16, dtype=torch.int64, device=dev)
+    _C.count_next_walk(cnt)
+    tr.train_step(batches[0]); torch.cuda.synchronize()
+    c = [int(x) for x in cnt.tolist()]
+    print(f"FIT_WALK entries staged {c[0]}, wave trips {c[1]} ({c[1] / max(1, c[0]):.2f} per entry), with a contributor {c[2]}, "
+          f"contributing pairs {c[3]} = {c[3] / (64.0 * max(1, c[1])):.1%} of the lanes, lanes <=4/8/16/32/64: {c[5:10]}")
 if os.environ.get("FIT_NO_TORCH_PROF", "0") == "1":
     sys.exit(0)
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:

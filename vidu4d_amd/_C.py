@@ -28,8 +28,17 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 # when, in an earlier frame of the same shape, some pixel blended deeper than SPLIT_AUTO_LEN list
 # entries (the serial chain of that tile then bounds the blend kernels; long lists that saturate
 # early do not count -- splitting them only adds work); "1" / "0" force it on / off.
+# Round 4: ... AND the frame had fewer long tiles than SPLIT_AUTO_TILES_PER_CU per compute unit.  Since the backward of a
+# whole-tile forward runs segment-parallel anyway (recorded segments), the only thing the split still buys is parallelism
+# for the FORWARD, and a frame with enough long tiles to fill the chip has it already -- while the segment-parallel forward
+# blends every segment up to the caller's limit, the whole-tile walk stops where the pixels saturate.  Stage-3 ball of
+# 200 k surfels at 512^2, two frames (tools/gpu_r4_z.sh): radius 1.0 = 720 long tiles, depth 4.5 k: 1.18 ms whole / 1.23
+# split (1.42 / 1.55 in the regularised regime); radius 0.7 = 350 tiles, 6.7 k: 1.30 / 1.19; 0.5: 1.59 / 1.21; 0.3: 2.78 / 2.00.
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = int(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_LEN", "2048"))
+SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU", "2.5"))
+_long_tiles_hint: dict = {}  # tiles longer than the schedule's split threshold (Header word 4), latest frame of a shape
+_cu_count: dict = {}
 _capacity_hint: dict = {}
 # Deferred capacity check (opt-in, for callers that can replay a step -- Stage3Trainer): the forward
 # does not wait for the pair count at all; it leaves (event, pinned slot, capacity) in `_pending`, and
@@ -170,6 +179,14 @@ def _depth_of(stat, slot) -> int:
 
 def _note_longest_list(slot, key):
     _len_hint[key] = max(int(slot[2]), int(0.9 * _len_hint.get(key, 0)))
+    _long_tiles_hint[key] = int(slot[4])
+
+
+def _compute_units(dev) -> int:
+    n = _cu_count.get(str(dev))
+    if n is None:
+        n = _cu_count[str(dev)] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    return n
 
 
 def check_slots(frames) -> bool:
@@ -323,7 +340,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     hint = _capacity_hint.get(key)
     if _SPLIT == "auto":
         depth = _depth_hint.get(key, 0)
-        a.segment_split = int(depth > SPLIT_AUTO_LEN)
+        a.segment_split = int(depth > SPLIT_AUTO_LEN and
+                              _long_tiles_hint.get(key, 0) < SPLIT_AUTO_TILES_PER_CU * _compute_units(dev))
         if a.segment_split and _deferred and not debug:
             if _unlimited.get(key, 0) > 0:
                 _unlimited[key] -= 1

@@ -92,15 +92,9 @@ __device__ __forceinline__ FootprintTest no_footprint()
     return footprint_test(f, 0.f, 0.f);
 }
 
-// Per-wave cull masks.  Thread t staged list entry t of the batch and knows its footprint (the conic rho3d <= rc and
-// the rho2d disc); for each of the four 8x8 pixel quadrants of the tile (one per wave) a wave64 ballot says which
-// of the 64 entries this wave staged can reach a pixel centre of that quadrant.  s_mask[q][w] = entries 64w..64w+63
-// relevant to quadrant q.  Afterwards wave q walks only the set bits: entries that cannot
-// contribute to its pixels cost nothing.
-//
-// no_cull (Vidu4dSurfel*Args::debug_flags, VIDU4D_DEBUG_NO_CULL): every staged entry is handed to all four waves -- the
-// reference's walk (forward.cu:359-405 evaluates every list entry for every pixel of the tile).  The culls only prune work;
-// tests/test_gpu_cull_ab.py holds the kernels to "bit-identical with and without".
+// The quadrant version of the cull masks below (four 8x8 quadrants, s_mask[q][w] = entries 64w..64w+63 relevant to quadrant
+// q): rounds 1-3's walk, still what blend_combine_kernel's repair uses -- on the frames that need a repair (dense, saturating)
+// the footprints cover whole quadrants and the half walk's bookkeeping buys nothing (measured, round 4: 148 -> 163 us).
 __device__ __forceinline__ void publish_cull_masks(unsigned long long (*s_mask)[4], bool valid, const FootprintTest& foot,
                                                    int tile_x0, int tile_y0, int wave, int lane, bool no_cull)
 {
@@ -113,9 +107,16 @@ __device__ __forceinline__ void publish_cull_masks(unsigned long long (*s_mask)[
     }
 }
 
-// The finer version: eight 8x4 pixel blocks (block 2q + h = rows 4h..4h+3 of quadrant q: the pixels of lanes
-// 32h..32h+31 of wave q).  The calling wave holds the 64 staged entries of mask word `word` and tests them against blocks
-// first..first+COUNT-1: s_mask8[b][word] = which of them can reach a pixel centre of block b.
+// Cull masks.  A thread that staged a list entry knows its footprint (the conic rho3d <= rc and the rho2d disc); for each
+// 8x4 pixel block of the tile -- block 2q + h = rows 4h..4h+3 of the 8x8 quadrant q, i.e. the pixels of lanes 32h..32h+31 of
+// wave q -- a wave64 ballot says which of the 64 entries the calling wave holds can reach a pixel centre of that block:
+// s_mask8[b][word] for the blocks first..first+COUNT-1 and the mask word `word` the wave's entries belong to.  Afterwards
+// each HALF of wave q walks only the set bits of its own block ("half walk", blend_bwd_kernel): entries that cannot
+// contribute to its 32 pixels cost nothing.  (Rounds 1-3 and most of round 4 culled per quadrant, one entry per wave trip.)
+//
+// no_cull (Vidu4dSurfel*Args::debug_flags, VIDU4D_DEBUG_NO_CULL): every staged entry is handed to every block -- the
+// reference's walk (forward.cu:359-405 evaluates every list entry for every pixel of the tile).  The culls only prune work;
+// tests/test_gpu_round4.py holds the kernels to "bit-identical with and without".
 template <int WORDS, int COUNT>
 __device__ __forceinline__ void publish_block_masks(unsigned long long (*s_mask8)[WORDS], bool valid, const FootprintTest& foot,
                                                     int tile_x0, int tile_y0, int word, int first, int lane, bool no_cull)
@@ -149,6 +150,27 @@ struct WorkItem {
     bool valid;
 };
 
+// The largest schedule position p in [0, n) with key(p) <= idx, key(p) = prefix[p] (- p: EXCLUSIVE_OF_TAILS, the recorded
+// segments' numbering below) ascending with key(0) = 0: a search with 64 keys per step, one per lane -- one load round trip
+// per step instead of one per bisection step (2 steps for 2048 positions instead of 11; the bisection cost every workgroup
+// of a segment-parallel launch 10-20 us before its first useful instruction).
+template <bool EXCLUSIVE_OF_TAILS>
+__device__ __forceinline__ uint32_t search_positions(const uint32_t* __restrict__ prefix, uint32_t n, uint32_t idx, int lane)
+{
+    uint32_t lo = 0;  // the answer lies in [lo, lo + n)
+    while (n > 1) {
+        const uint32_t step = (n + 63u) / 64u;
+        const uint32_t p = lo + (uint32_t)lane * step;
+        const bool in = (uint32_t)lane * step < n;
+        const uint32_t key = in ? prefix[p] - (EXCLUSIVE_OF_TAILS ? p : 0u) : 0xffffffffu;
+        const int cnt = __builtin_popcountll(__ballot(in && key <= idx));   // (keys ascend: a prefix of the lanes)
+        const uint32_t first = (uint32_t)(cnt - 1) * step;
+        lo += first;
+        n = min(step, n - first);
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
 template <bool SPLIT>
 __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageState& img, int grid_x, int grid_y,
                                               bool overflow)
@@ -165,12 +187,8 @@ __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageStat
                 w.valid = false;
                 return w;
             }
-            int lo = 0, hi = (int)hdr->num_split_pos - 1;
-            while (lo < hi) {  // largest position whose prefix is <= blockIdx.x
-                const int mid = (lo + hi + 1) >> 1;
-                if (img.seg_prefix[mid] <= blockIdx.x) lo = mid;
-                else hi = mid - 1;
-            }
+            // largest position whose prefix is <= blockIdx.x
+            const uint32_t lo = search_positions<false>(img.seg_prefix, hdr->num_split_pos, blockIdx.x, threadIdx.x & 63);
             tile = (int)img.tile_order[lo];
             w.seg = (int)(blockIdx.x - img.seg_prefix[lo]);
             w.slot = blockIdx.x;
@@ -200,8 +218,7 @@ __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageStat
 //   [F, F + T)    one "tail" per tile, largest first (ImageState::tail_order): the remainder segment of a split tile, or
 //                 a whole unsplit tile -- the launch drains on its smallest units;
 //   beyond        nothing (the host's grid is an upper bound) -- at the END of the dispatch order, where they delay nobody.
-// A full segment finds its position by a search over the exclusive prefix key(p) = seg_prefix[p] - p with 64 keys per
-// step (one load round trip per step instead of one per bisection step: 2 steps for 2048 tiles instead of 11).
+// A full segment finds its position by search_positions over the exclusive prefix key(p) = seg_prefix[p] - p.
 __device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const ImageState& img, int grid_x, int grid_y)
 {
     WorkItem w;
@@ -213,18 +230,7 @@ __device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const 
     const int lane = threadIdx.x & 63;
     int tile;
     if (idx < F) {
-        uint32_t lo = 0, n = S;   // the answer lies in [lo, lo + n): the largest p with key(p) <= idx
-        while (n > 1) {
-            const uint32_t step = (n + 63u) / 64u;
-            const uint32_t p = lo + (uint32_t)lane * step;
-            const bool in = (uint32_t)lane * step < n;
-            const uint32_t key = in ? img.seg_prefix[p] - p : 0xffffffffu;
-            const int cnt = __builtin_popcountll(__ballot(in && key <= idx));   // (keys ascend: a prefix of the lanes)
-            const uint32_t first = (uint32_t)(cnt - 1) * step;
-            lo += first;
-            n = min(step, n - first);
-        }
-        lo = __builtin_amdgcn_readfirstlane(lo);
+        const uint32_t lo = search_positions<true>(img.seg_prefix, S, idx, lane);
         tile = (int)img.tile_order[lo];
         w.seg = (int)(idx - (img.seg_prefix[lo] - lo));
         w.slot = img.seg_first[tile] + (uint32_t)w.seg;
@@ -301,8 +307,9 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
                                                          int64_t capacity, int max_seg, const float* __restrict__ rec,
                                                          float* __restrict__ seg_data, int flags)
 {
-    __shared__ float4 s_rec[FWD_BATCH * 5];
-    __shared__ unsigned long long s_mask[4][4];
+    __shared__ float4 s_rec[(FWD_BATCH + 1) * 5];  // (+ the all-zero record of an idle half, see blend_bwd_kernel)
+    __shared__ unsigned long long s_mask8[8][FWD_BATCH / 64];
+    if (threadIdx.x < 5) s_rec[FWD_BATCH * 5 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool overflow = (int64_t)hdr->num_rendered > capacity;
     if (blockIdx.x == 0 && threadIdx.x == 0) hdr->split_used = !overflow && hdr->num_segments > 0;  // for backward
     if (overflow || blockIdx.x >= hdr->num_segments) return;
@@ -324,14 +331,16 @@ __global__ __launch_bounds__(256) void blend_seg_T_kernel(int W, int H, int grid
         const bool have = (int)threadIdx.x < todo;
         FootprintTest foot = no_footprint();
         if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
-        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
+        publish_block_masks<FWD_BATCH / 64, 8>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave, 0, lane, flags & FLAG_NO_CULL);
         __syncthreads();
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            unsigned long long m = uniform_u64(s_mask[wave][k]);
-            while (m) {
-                const int j = k * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+        for (int k = 0; k < FWD_BATCH / 64; k++) {  // (half walk, as in blend_fwd_kernel)
+            unsigned long long mA = uniform_u64(s_mask8[2 * wave][k]), mB = uniform_u64(s_mask8[2 * wave + 1][k]);
+            while (mA | mB) {
+                const int jA = mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH, jB = mB ? k * 64 + __builtin_ctzll(mB) : FWD_BATCH;
+                mA &= mA - 1;
+                mB &= mB - 1;
+                const int j = lane < 32 ? jA : jB;
                 const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
                 const float Tu[3] = {a0.x, a0.y, a0.z}, Tv[3] = {a0.w, a1.x, a1.y}, Tw[3] = {a1.z, a1.w, a2.x};
                 PairEval e;
@@ -463,7 +472,9 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
         // entries of each per trip; the accumulation stays in list order per pixel.
 #pragma unroll 1
         for (int k = 0; k < FWD_BATCH / 64; k++) {
-            unsigned long long mA = uniform_u64(s_mask8[2 * wave][k]), mB = uniform_u64(s_mask8[2 * wave + 1][k]);
+            const unsigned long long alive = __ballot(!done);  // a half whose pixels are all finished walks nothing
+            unsigned long long mA = (uint32_t)alive ? uniform_u64(s_mask8[2 * wave][k]) : 0ull;
+            unsigned long long mB = (alive >> 32) ? uniform_u64(s_mask8[2 * wave + 1][k]) : 0ull;
             while (mA | mB) {
                 const int jaA = mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH;
                 mA &= mA - 1;
@@ -1157,8 +1168,8 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
 //   [0] list entries staged (per workgroup batch, summed)          [1] wave trips (one entry per half wave) that evaluate
 //   [2] trips in which some lane contributes                       [3] contributing lanes (pairs) in total
 //   [4] 16-lane rows with a contributing lane, summed over [2]     [5..9] trips of [2] with <= 4, 8, 16, 32, 64 lanes
-//   [10] trips of [1] in which no lane passes the pair test itself (the contribution box reaches the quadrant, the
-//        footprint does not; the rest of [1] - [2] found every pixel it reaches finished)
+//   [10] trips of [1] in which no lane passes the pair test itself (the cull test's footprints reach the two 8x4 blocks,
+//        the exact ones do not; the rest of [1] - [2] found every pixel they reach finished)
 __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int grid_x, int grid_y, ImageState img,
                                                              const uint32_t* __restrict__ point_list,
                                                              const float* __restrict__ rec,
