@@ -331,6 +331,32 @@ def test_long_list_sort_mode_follows_the_longest_list_of_earlier_frames():
         d.pop(key, None)
 
 
+def test_auto_split_wants_deep_blending_and_too_few_long_tiles():
+    """_C's host-side policy for Vidu4dSurfelForwardArgs::segment_split under VIDU4D_SURFEL_SPLIT=auto (no GPU involved): the
+    forward is segment-parallel only when a pixel of the earlier frames blended deeper than SPLIT_AUTO_LEN AND those frames
+    had fewer long tiles (header word 4) than SPLIT_AUTO_TILES_PER_CU per compute unit -- a frame with enough long tiles
+    fills the chip with whole-tile walks, which stop at saturation, and its backward is segment-parallel anyway."""
+    import torch
+    from vidu4d_amd import _C
+    cu = 256
+    few, many = int(_C.SPLIT_AUTO_TILES_PER_CU * cu) - 1, int(_C.SPLIT_AUTO_TILES_PER_CU * cu)
+    assert not _C.auto_split(_C.SPLIT_AUTO_LEN, few, cu)          # shallow: never
+    assert _C.auto_split(_C.SPLIT_AUTO_LEN + 1, few, cu)          # deep, few long tiles: split
+    assert not _C.auto_split(10 * _C.SPLIT_AUTO_LEN, many, cu)    # deep, but the chip is full of long tiles already
+    assert _C.auto_split(_C.SPLIT_AUTO_LEN + 1, 0, cu)            # nothing known about the tiles yet: the depth decides
+    key = ("test-shape-split",)
+    _C._long_tiles_hint.pop(key, None)
+    slot = torch.zeros(16, dtype=torch.int32)
+    slot[0], slot[2], slot[4] = 1000, 5000, 720
+    _C.check_slots([(slot, None, 2000, key)])
+    assert _C._long_tiles_hint[key] == 720                          # the latest frame's count, no smoothing
+    slot[4] = 350
+    _C.check_slots([(slot, None, 2000, key)])
+    assert _C._long_tiles_hint[key] == 350
+    for d in (_C._long_tiles_hint, _C._len_hint, _C._unlimited, _C._capacity_hint):
+        d.pop(key, None)
+
+
 def test_depth_only_sort_with_tie_fix_up_is_the_reference_order():
     """The tile sort's algorithm (csrc/binning.hip), restated in numpy: LSD passes on the four depth bytes of keys that
     arrive in ARBITRARY order (the emission order inside a group is not deterministic), then every run of equal depths

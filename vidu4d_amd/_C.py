@@ -182,6 +182,12 @@ def _note_longest_list(slot, key):
     _long_tiles_hint[key] = int(slot[4])
 
 
+def auto_split(depth: int, long_tiles: int, compute_units: int) -> bool:
+    """VIDU4D_SURFEL_SPLIT=auto: blend this frame's long tiles segment-parallel?  depth: deepest list position a pixel of
+    the earlier frames blended; long_tiles: their tiles longer than the schedule's split threshold (0: not known yet)."""
+    return depth > SPLIT_AUTO_LEN and long_tiles < SPLIT_AUTO_TILES_PER_CU * compute_units
+
+
 def _compute_units(dev) -> int:
     n = _cu_count.get(str(dev))
     if n is None:
@@ -340,8 +346,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     hint = _capacity_hint.get(key)
     if _SPLIT == "auto":
         depth = _depth_hint.get(key, 0)
-        a.segment_split = int(depth > SPLIT_AUTO_LEN and
-                              _long_tiles_hint.get(key, 0) < SPLIT_AUTO_TILES_PER_CU * _compute_units(dev))
+        a.segment_split = int(auto_split(depth, _long_tiles_hint.get(key, 0), _compute_units(dev)))
         if a.segment_split and _deferred and not debug:
             if _unlimited.get(key, 0) > 0:
                 _unlimited[key] -= 1

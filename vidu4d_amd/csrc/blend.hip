@@ -77,15 +77,6 @@ __device__ __forceinline__ FootprintTest stage_record(float4* s_rec, int slot, c
     return footprint_test(f, c.y, c.z);
 }
 
-// The footprint alone (a thread that tests an entry somebody else stages).
-__device__ __forceinline__ FootprintTest load_footprint(const float* rec, uint32_t id)
-{
-    const float4* src = reinterpret_cast<const float4*>(rec + (size_t)id * REC_FLOATS);
-    const float4 c = src[2], f0 = src[5], f1 = src[6];
-    const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-    return footprint_test(f, c.y, c.z);
-}
-
 __device__ __forceinline__ FootprintTest no_footprint()
 {
     const float f[8] = {0.f, 0.f, 0.f, -1.f, 0.f, 0.f, -1.f, 0.f};
@@ -1081,22 +1072,19 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
         const int cnt = hi - seg_begin < BWD_BATCH ? hi - seg_begin : BWD_BATCH;
         __syncthreads();
         {
-            // threads 0..127 stage (back to front: slot t <-> list entry hi-1-t), all zero the accumulators
-            // (waves 2, 3 fetch the footprints of the same entries again and test the lower four blocks)
-            const int ent = (int)threadIdx.x & (BWD_BATCH - 1);
-            const bool have = ent < cnt;
-            FootprintTest foot = no_footprint();
-            if (have) {
-                const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - ent)];
-                if (wave < BWD_BATCH / 64) {
-                    s_id[ent] = id;
-                    foot = stage_record(s_rec, ent, rec, id);
-                } else {
-                    foot = load_footprint(rec, id);
+            // threads 0..127 stage (back to front: slot t <-> list entry hi-1-t) and test their entry against all eight
+            // blocks; all threads zero the accumulators
+            const bool have = (int)threadIdx.x < cnt;
+            if (wave < BWD_BATCH / 64) {
+                FootprintTest foot = no_footprint();
+                if (have) {
+                    const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)];
+                    s_id[threadIdx.x] = id;
+                    foot = stage_record(s_rec, threadIdx.x, rec, id);
                 }
+                publish_block_masks<BWD_BATCH / 64, 8>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave, 0, lane,
+                                                       flags & FLAG_NO_CULL);
             }
-            publish_block_masks<BWD_BATCH / 64, 4>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave & 1, 4 * (wave >> 1), lane,
-                                                   flags & FLAG_NO_CULL);
             for (int i = threadIdx.x; i < BWD_BATCH * ACC_FLOATS / 4; i += 256)
                 reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -1208,15 +1196,12 @@ __global__ __launch_bounds__(256) void blend_bwd_stats_kernel(int W, int H, int 
     for (int hi = n_used; hi > 0; hi -= BWD_BATCH) {
         const int cnt = hi < BWD_BATCH ? hi : BWD_BATCH;
         __syncthreads();
-        const int ent = (int)threadIdx.x & (BWD_BATCH - 1);
-        const bool have = ent < cnt;
-        FootprintTest foot = no_footprint();
-        if (have) {
-            const uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - ent)];
-            foot = wave < BWD_BATCH / 64 ? stage_record(s_rec, ent, rec, id) : load_footprint(rec, id);
+        const bool have = (int)threadIdx.x < cnt;
+        if (wave < BWD_BATCH / 64) {
+            FootprintTest foot = no_footprint();
+            if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + (uint32_t)(hi - 1 - (int)threadIdx.x)]);
+            publish_block_masks<BWD_BATCH / 64, 8>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave, 0, lane, flags & FLAG_NO_CULL);
         }
-        publish_block_masks<BWD_BATCH / 64, 4>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave & 1, 4 * (wave >> 1), lane,
-                                                   flags & FLAG_NO_CULL);
         __syncthreads();
         if (wave == 0) c_staged += (unsigned long long)cnt;
         for (int k = 0; k < BWD_BATCH / 64; k++) {
