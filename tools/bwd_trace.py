@@ -5,7 +5,9 @@ product (tools/run_variants.sh does the same): every workgroup of blend_bwd then
 end time (s_memrealtime, 10 ns), its CU / XCD and the list entries it walked.  Prints, for the headline step (two stacked
 frames) with recorded segments and with the whole-tile backward: workgroup counts and durations, prologue times, how many
 workgroups a CU holds over time, and how much of the launch runs with fewer than four.
-    python tools/bwd_trace.py [surfels] [res]"""
+    python tools/bwd_trace.py [surfels] [res]
+TRACE_OBJECT_RADIUS=r: the object-centric scene (long lists); TRACE_SPLIT=1: the segment-parallel forward's backward
+(split_used == 1) instead of the recorded segments."""
 import os
 import sys
 
@@ -15,13 +17,19 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import diff_surfel_rasterization as dsr  # noqa: E402
 from vidu4d_amd import _C, _lib  # noqa: E402
-from vidu4d_amd.synthetic import frame_motion, make_scene, make_upstream_grads  # noqa: E402
+from vidu4d_amd.synthetic import frame_motion, make_object_scene, make_scene, make_upstream_grads  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 F = 2
 dev = torch.device("cuda:0")
-scene = make_scene(N, W, None, seed=1234).to(dev)
+if os.environ.get("TRACE_OBJECT_RADIUS"):
+    kw = {"sigma_px": float(os.environ["TRACE_SIGMA_PX"])} if os.environ.get("TRACE_SIGMA_PX") else {}
+    scene = make_object_scene(N, W, None, radius=float(os.environ["TRACE_OBJECT_RADIUS"]), seed=1234, **kw).to(dev)
+else:
+    scene = make_scene(N, W, None, seed=1234).to(dev)
+if os.environ.get("TRACE_SPLIT"):
+    _C._SPLIT = os.environ["TRACE_SPLIT"]
 H = scene.height
 dc, do = (t.to(dev) for t in make_upstream_grads(W, H))
 frames = [frame_motion(scene, f, 120) for f in range(8)]
@@ -44,7 +52,9 @@ def step(k, trace=None):
     torch.autograd.backward([color, allmap], [dcs, dos])
 
 
-for name, flags in (("recorded segments", 0), ("whole-tile backward", _lib.DEBUG_WHOLE_TILE_BACKWARD)):
+MODES = ((("segment-parallel forward's backward", 0),) if os.environ.get("TRACE_SPLIT") == "1" else
+         (("recorded segments", 0), ("whole-tile backward", _lib.DEBUG_WHOLE_TILE_BACKWARD)))
+for name, flags in MODES:
     with _C.debug_flags(flags):
         for k in range(5):
             step(k)

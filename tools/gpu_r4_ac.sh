@@ -1,0 +1,13 @@
+#!/bin/bash
+# live-segment compaction of the recorded backward: tests, then A/B against variants/prev.so (headline bench, dense fit step)
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+O=gpurun_out/ac; mkdir -p $O; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -x > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+grep -E "^(FAILED|ERROR)|passed|failed|Error" $O/pytest.log | tail -10
+bash tools/gpu_r4_q.sh prev
+cp vidu4d_amd/csrc/libvidu4d_surfel.so /tmp/product.so
+for i in 1 2; do for v in product prev; do
+  if [ $v = product ]; then cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so; else cp variants/$v.so vidu4d_amd/csrc/libvidu4d_surfel.so; fi
+  for regime in 0 8001; do echo -n "$v step0=$regime: "; FIT_STEP0=$regime FIT_K=60 FIT_NO_TORCH_PROF=1 python tools/fit_profile.py 2>&1 | grep "FIT_STEP" | cut -c40-120; done
+done; done
+cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so

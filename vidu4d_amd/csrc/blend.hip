@@ -141,11 +141,9 @@ struct WorkItem {
     bool valid;
 };
 
-// The largest schedule position p in [0, n) with key(p) <= idx, key(p) = prefix[p] (- p: EXCLUSIVE_OF_TAILS, the recorded
-// segments' numbering below) ascending with key(0) = 0: a search with 64 keys per step, one per lane -- one load round trip
-// per step instead of one per bisection step (2 steps for 2048 positions instead of 11; the bisection cost every workgroup
-// of a segment-parallel launch 10-20 us before its first useful instruction).
-template <bool EXCLUSIVE_OF_TAILS>
+// The largest schedule position p in [0, n) with prefix[p] <= idx (prefix non-decreasing, prefix[0] = 0): a search with 64
+// keys per step, one per lane -- one load round trip per step instead of one per bisection step (2 steps for 2048 positions
+// instead of 11; the bisection cost every workgroup of a segment-parallel launch 10-20 us before its first useful instruction).
 __device__ __forceinline__ uint32_t search_positions(const uint32_t* __restrict__ prefix, uint32_t n, uint32_t idx, int lane)
 {
     uint32_t lo = 0;  // the answer lies in [lo, lo + n)
@@ -153,7 +151,7 @@ __device__ __forceinline__ uint32_t search_positions(const uint32_t* __restrict_
         const uint32_t step = (n + 63u) / 64u;
         const uint32_t p = lo + (uint32_t)lane * step;
         const bool in = (uint32_t)lane * step < n;
-        const uint32_t key = in ? prefix[p] - (EXCLUSIVE_OF_TAILS ? p : 0u) : 0xffffffffu;
+        const uint32_t key = in ? prefix[p] : 0xffffffffu;
         const int cnt = __builtin_popcountll(__ballot(in && key <= idx));   // (keys ascend: a prefix of the lanes)
         const uint32_t first = (uint32_t)(cnt - 1) * step;
         lo += first;
@@ -179,7 +177,7 @@ __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageStat
                 return w;
             }
             // largest position whose prefix is <= blockIdx.x
-            const uint32_t lo = search_positions<false>(img.seg_prefix, hdr->num_split_pos, blockIdx.x, threadIdx.x & 63);
+            const uint32_t lo = search_positions(img.seg_prefix, hdr->num_split_pos, blockIdx.x, threadIdx.x & 63);
             tile = (int)img.tile_order[lo];
             w.seg = (int)(blockIdx.x - img.seg_prefix[lo]);
             w.slot = blockIdx.x;
@@ -204,26 +202,29 @@ __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageStat
 
 // Recorded segments (Header::split_used == 2; surfel_state.h): where a workgroup of blend_bwd works.  The split tiles are
 // exactly the schedule positions [0, S) (tile_order: split by length class), tile at position p has n_p = its segment
-// count, of which n_p - 1 are FULL segments (REC_SEG_LEN entries) and the last one the remainder.  Workgroups
-//   [0, F)        F = num_segments - S: the full segments, position by position -- equal units, dispatched first;
-//   [F, F + T)    one "tail" per tile, largest first (ImageState::tail_order): the remainder segment of a split tile, or
-//                 a whole unsplit tile -- the launch drains on its smallest units;
+// count, of which n_p - 1 are FULL segments (REC_SEG_LEN entries) and the last one the remainder; the forward's walk of
+// the tile reached the first live_p of the full ones (ImageState::live_prefix: nothing behind them holds a contributor).
+//   [0, F)        F = Header::num_live_full: the LIVE full segments, position by position -- equal units, dispatched first;
+//   [F, F + T)    one "tail" per tile, largest first (ImageState::tail_order): the remainder segment of a split tile (if
+//                 the walk got that far), or a whole unsplit tile -- the launch drains on its smallest units;
 //   beyond        nothing (the host's grid is an upper bound) -- at the END of the dispatch order, where they delay nobody.
-// A full segment finds its position by search_positions over the exclusive prefix key(p) = seg_prefix[p] - p.
-__device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const ImageState& img, int grid_x, int grid_y)
+// A full segment finds its position by search_positions over live_prefix.
+__device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const ImageState& img, int grid_x, int grid_y,
+                                                       const float* __restrict__ seg_data)
 {
     WorkItem w;
     w.seg = -1;
     w.slot = 0;
     w.valid = true;
-    const uint32_t S = hdr->num_split_pos, F = hdr->num_segments - S;
+    const uint32_t S = hdr->num_split_pos, F = hdr->num_live_full;
     const uint32_t idx = blockIdx.x;
     const int lane = threadIdx.x & 63;
     int tile;
     if (idx < F) {
-        const uint32_t lo = search_positions<true>(img.seg_prefix, S, idx, lane);
+        // (positions without a live full segment repeat their neighbour's key: the search takes the last of equal keys)
+        const uint32_t lo = search_positions(img.live_prefix, S, idx, lane);
         tile = (int)img.tile_order[lo];
-        w.seg = (int)(idx - (img.seg_prefix[lo] - lo));
+        w.seg = (int)(idx - img.live_prefix[lo]);
         w.slot = img.seg_first[tile] + (uint32_t)w.seg;
     } else {
         const uint32_t j = idx - F;
@@ -237,6 +238,9 @@ __device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const 
             const uint32_t len = img.ranges[2 * tile + 1] - img.ranges[2 * tile];
             w.seg = (int)((len + hdr->seg_len - 1u) / hdr->seg_len) - 1;
             w.slot = first + (uint32_t)w.seg;
+            // (the segment the forward's walk stopped in, as its final record says: short of this one, nothing to do here)
+            const uint32_t stop = __float_as_uint(seg_data[((size_t)w.slot * REC_REC_FLOATS + RS_STOP) * 256]);
+            if (stop < (uint32_t)w.seg) w.valid = false;
         }
     }
     w.tc.tile = tile;
@@ -545,6 +549,16 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
         write_pixel(s, plane, frame_base + (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
     report_depth(depth_used, s.last_contributor);
     report_min_T(hdr, s.T, inside);
+    if (!SPLIT && rec_len && threadIdx.x == 0) {
+        // Recorded segments: how many FULL segments of this tile the walk reached (nothing behind them holds a contributor:
+        // the backward gives them no workgroup -- launch_bwd_prepare), by schedule position
+        uint32_t live = 0;
+        if (rec_first != SEG_NONE) {
+            const uint32_t nseg = (r1 - r0 + (uint32_t)rec_len - 1u) / (uint32_t)rec_len;
+            live = rec_stop + 1u < nseg - 1u ? rec_stop + 1u : nseg - 1u;
+        }
+        img.live_count[blockIdx.x] = live;
+    }
 }
 
 // Pass 3: adds the segments of a split tile up in list order.  The colour / depth / normal / moment
@@ -927,7 +941,7 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     __shared__ uint32_t s_max;
     // (a forward that left no segment state: every tile is then walked whole)
     const uint32_t split_used = SPLIT ? hdr->split_used : 0u;
-    const WorkItem wk = (SPLIT && split_used == 2u) ? find_work_recorded(hdr, img, grid_x, grid_y)
+    const WorkItem wk = (SPLIT && split_used == 2u) ? find_work_recorded(hdr, img, grid_x, grid_y, seg_data)
                                                     : find_work<SPLIT>(hdr, img, grid_x, grid_y, SPLIT && !split_used);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     TileCoord tc = wk.tc;
@@ -1271,6 +1285,51 @@ static auto pick_bwd(int mode)
     return mode == BLEND_LITE ? &blend_bwd_kernel<SPLIT, BLEND_LITE>
            : mode == BLEND_GEOM ? &blend_bwd_kernel<SPLIT, BLEND_GEOM>
                                 : &blend_bwd_kernel<SPLIT, BLEND_FULL>;
+}
+
+// What runs in front of blend_bwd, as one launch: the gradient accumulator is zeroed (workgroups [0, gridDim.x - 1)), and --
+// recorded segments -- the last workgroup turns the forward's per-tile counts of live full segments (ImageState::live_count)
+// into their exclusive prefix over the schedule positions and the total (live_prefix, Header::num_live_full), which is what
+// blend_bwd's workgroups find their segment with.  On frames whose long lists saturate early most segments are dead: a
+// workgroup per dead segment (3 us each until it had found that out, interleaved with the live ones in dispatch order)
+// delayed the live ones by a quarter of the launch (tools/bwd_trace.py on a dense ball: 30 k dead against 4 k live).
+__global__ __launch_bounds__(256) void bwd_prepare_kernel(uint4* __restrict__ acc, size_t n16, Header* hdr, ImageState img, int tiles)
+{
+    if (blockIdx.x + 1 < gridDim.x) {
+        const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (i < n16) acc[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    if (hdr->split_used != 2u) return;
+    __shared__ uint32_t s_part[256];
+    const uint32_t S = min(hdr->num_split_pos, (uint32_t)tiles);
+    const uint32_t per = (S + 255u) / 256u, lo = min(threadIdx.x * per, S), hi = min(lo + per, S);
+    uint32_t sum = 0;
+    for (uint32_t p = lo; p < hi; p++) sum += img.live_count[p];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; t++) {
+            const uint32_t v = s_part[t];
+            s_part[t] = run;
+            run += v;
+        }
+        hdr->num_live_full = run;
+    }
+    __syncthreads();
+    uint32_t run = s_part[threadIdx.x];
+    for (uint32_t p = lo; p < hi; p++) {
+        img.live_prefix[p] = run;
+        run += img.live_count[p];
+    }
+}
+
+void launch_bwd_prepare(const BackwardArgs& a, size_t acc_bytes, hipStream_t stream)
+{
+    const size_t n16 = acc_bytes / 16;
+    hipLaunchKernelGGL(bwd_prepare_kernel, dim3((unsigned)((n16 + 255) / 256) + 1u), dim3(256), 0, stream, (uint4*)a.acc, n16,
+                       a.geom.hdr, a.img, total_tiles(a.cam));
 }
 
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)

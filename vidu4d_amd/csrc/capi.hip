@@ -441,7 +441,7 @@ extern "C" int vidu4d_surfel_backward(const Vidu4dSurfelBackwardArgs* a, void* s
 
     {
         StageTimer t(ST_BWD_ZERO, stream);
-        zero_fill(ba.acc, (size_t)P * ACC_FLOATS * sizeof(float), stream);
+        launch_bwd_prepare(ba, (size_t)P * ACC_FLOATS * sizeof(float), stream);  // (zeroes the accumulator)
         const bool sums_in_kernel = a->M == 16 && (a->sh_dc || (a->shs && a->dL_dsh && ((uintptr_t)a->shs & 15) == 0 &&
                                                                ((uintptr_t)a->dL_dsh & 15) == 0));  // (preprocess_bwd_stacked_kernel's condition)
         if (F > 1 && !sums_in_kernel) {  // the frames ADD their gradients of the shared parameters (preprocess_bwd_kernel)

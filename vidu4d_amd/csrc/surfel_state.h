@@ -119,7 +119,9 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t depth_used;    // a home for Vidu4dSurfelForwardArgs::depth_used inside the buffer (word 12, zeroed by the projection
                             // kernel): a caller that reads the header back anyway points depth_used here and saves a counter
                             // tensor, its reset and its copy
-    uint32_t pad[51];
+    uint32_t num_live_full; // recorded segments: FULL segments the forward's walks reached (ImageState::live_prefix; written by
+                            // the backward's preparation launch)
+    uint32_t pad[50];
 };
 
 struct GeomState {
@@ -144,6 +146,10 @@ struct ImageState {
                            // split tile, or the whole unsplit tile), largest first
     float* tile_m0;        // [tiles] reference mapped depth of the tile's distortion moments (surfel_math.h FwdPixel::m0):
                            // written by the full blend's forward, read by its backward
+    uint32_t* live_count;  // [tiles] recorded segments, by schedule position: full segments the forward's walk of the tile
+                           // reached (written by the tile's forward workgroup) ...
+    uint32_t* live_prefix; // [tiles + 1] ... and their exclusive prefix (bwd_prepare_kernel): blend_bwd runs a workgroup per
+                           // LIVE full segment
 };
 
 struct BinState {
@@ -199,6 +205,8 @@ inline size_t carve_image(char* base, int W, int H, ImageState& s, int frames = 
     carve(p, s.seg_prefix, tiles + 1);
     carve(p, s.tail_order, tiles);
     carve(p, s.tile_m0, tiles);
+    carve(p, s.live_count, tiles);
+    carve(p, s.live_prefix, tiles + 1);
     return (size_t)(p - base) + 256;
 }
 
@@ -391,6 +399,7 @@ struct BackwardArgs {
     unsigned long long* trace;  // (variant build for tools/bwd_trace.py) 4 words per workgroup of blend_bwd, or NULL
 #endif
 };
+void launch_bwd_prepare(const BackwardArgs& a, size_t acc_bytes, hipStream_t stream);  // zeroes acc (+ live-segment prefix)
 void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream);
 void launch_blend_bwd_stats(const BackwardArgs& a, unsigned long long* counters, hipStream_t stream);  // diagnostic
 void launch_preprocess_bwd(const BackwardArgs& a, hipStream_t stream);
