@@ -122,6 +122,14 @@ def test_recorded_segments_equal_the_whole_tile_backward(gpu_device, monkeypatch
     rec = _run(sc, dev, dc, do, aux=aux, flags=0)
     whole = _run(sc, dev, dc, do, aux=aux, flags=_lib.DEBUG_WHOLE_TILE_BACKWARD)
     assert int(rec["header"][5]) == 2 and int(rec["header"][3]) > 0, "no recorded segments"   # split_used, num_segments
+    # the backward's workgroups: one per full segment the forward's walk REACHED (Header::num_live_full, word 13) -- on the
+    # saturating scene far fewer than the full segments there are (num_segments - num_split_pos), elsewhere most of them
+    full, live = int(rec["header"][3]) - int(rec["header"][4]), int(rec["header"][13])
+    assert 0 < live <= full, (live, full)
+    if which == "saturating":
+        assert live < 0.6 * full, (live, full)
+    if which == "init_opacity":
+        assert live == full, (live, full)          # nothing saturates: every walk reaches the end of its list
     for k in ("color", "others", "radii", "n_contrib", "final_T"):
         assert torch.equal(rec[k], whole[k]), k
     _grads_close(rec, whole, 3e-6, which)
