@@ -25,6 +25,35 @@ t0 = time.perf_counter(); K = int(os.environ.get("FIT_K", "10"))
 for i in range(K): tr.train_step(batches[i % 4])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 print(f"FIT_STEP 200k/512^2 radius {RADIUS}, 2 frames/step: {dt*1e3:.2f} ms/step = {2/dt:.1f} images/s")
+if os.environ.get("FIT_TILE_STATS", "0") == "1":   # how far the forward's walk of each tile has to go (last contributor per tile)
+    from vidu4d_amd import _C
+    seen = {}
+    orig = _C.rasterize_gaussians
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        seen["out"], seen["P"], seen["F"] = out, a[1].shape[-2] if a[1].dim() == 3 else a[1].shape[0], (a[1].shape[0] if a[1].dim() == 3 else 1)
+        return out
+    _C.rasterize_gaussians = spy
+    tr.train_step(batches[0]); torch.cuda.synchronize()
+    _C.rasterize_gaussians = orig
+    R, color, others, radii, geom, binning, img = seen["out"]
+    F = seen["F"]
+    T = F * (H // 16) * (W // 16)
+    rng_ = _C.read_state("ranges", None, geom, binning, img, seen["P"], W, H, torch.int32, 2 * T, frames=F).numpy().reshape(-1, 2)
+    nc = _C.read_state("n_contrib", None, geom, binning, img, seen["P"], W, H, torch.int32, 2 * F * H * W, frames=F).numpy()
+    last = nc[: F * H * W].reshape(F, H // 16, 16, W // 16, 16).transpose(0, 1, 3, 2, 4).reshape(-1, 256)
+    lens = (rng_[:, 1] - rng_[:, 0]).astype(np.int64)
+    walk = last.max(axis=1).astype(np.int64)              # entries the tile's walk covers
+    alive_at = lambda k: (last > k).sum(axis=1)           # pixels still blending beyond entry k
+    long_ = lens > 320
+    print(f"FIT_TILES {T} tiles, {int(long_.sum())} longer than 320; list length median / max of those {int(np.median(lens[long_]))} / {int(lens.max())}; "
+          f"walk length (deepest pixel) median / p90 / max {int(np.median(walk[long_]))} / {int(np.percentile(walk[long_], 90))} / {int(walk.max())}; "
+          f"sum of walks {int(walk.sum())}")
+    for k in (1024, 1536, 2048, 3072):
+        u = walk > k
+        print(f"   beyond entry {k}: {int(u.sum())} tiles still walking, {int((walk[u] - k).sum())} entries left in total, "
+              f"alive pixels per such tile median {int(np.median(alive_at(k)[u])) if u.any() else 0}")
 if os.environ.get("FIT_PRINT_HINTS", "0") == "1":   # what the split decision sees
     from vidu4d_amd import _C
     print("FIT_HINTS deepest blended list position", dict(_C._depth_hint), "longest list", dict(_C._len_hint))
