@@ -35,6 +35,7 @@
 #include <cstdlib>
 
 #include "surfel_state.h"
+#include "wave_utils.h"
 
 namespace surfel {
 
@@ -1295,33 +1296,30 @@ static auto pick_bwd(int mode)
 // delayed the live ones by a quarter of the launch (tools/bwd_trace.py on a dense ball: 30 k dead against 4 k live).
 __global__ __launch_bounds__(256) void bwd_prepare_kernel(uint4* __restrict__ acc, size_t n16, Header* hdr, ImageState img, int tiles)
 {
-    if (blockIdx.x + 1 < gridDim.x) {
-        const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x > 0) {
+        const size_t i = (size_t)(blockIdx.x - 1) * 256 + threadIdx.x;
         if (i < n16) acc[i] = make_uint4(0, 0, 0, 0);
         return;
     }
+    // (workgroup 0, dispatched first: the scan runs under the zero fill)
     if (hdr->split_used != 2u) return;
-    __shared__ uint32_t s_part[256];
-    const uint32_t S = min(hdr->num_split_pos, (uint32_t)tiles);
-    const uint32_t per = (S + 255u) / 256u, lo = min(threadIdx.x * per, S), hi = min(lo + per, S);
-    uint32_t sum = 0;
-    for (uint32_t p = lo; p < hi; p++) sum += img.live_count[p];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < 256; t++) {
-            const uint32_t v = s_part[t];
-            s_part[t] = run;
-            run += v;
-        }
-        hdr->num_live_full = run;
+    constexpr int PER = REC_MAX_TILES / 256;  // positions per thread (recorded segments exist for at most REC_MAX_TILES tiles)
+    __shared__ uint32_t s_wave[4];
+    const uint32_t S = min(min(hdr->num_split_pos, (uint32_t)tiles), (uint32_t)REC_MAX_TILES);
+    const uint32_t lo = threadIdx.x * PER;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        v[i] = lo + i < S ? img.live_count[lo + i] : 0u;
+        sum += v[i];
     }
-    __syncthreads();
-    uint32_t run = s_part[threadIdx.x];
-    for (uint32_t p = lo; p < hi; p++) {
-        img.live_prefix[p] = run;
-        run += img.live_count[p];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, s_wave, total);
+    if (threadIdx.x == 0) hdr->num_live_full = total;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        if (lo + i < S) img.live_prefix[lo + i] = run;
+        run += v[i];
     }
 }
 
