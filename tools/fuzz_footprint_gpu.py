@@ -76,18 +76,22 @@ def main():
         if not np.array_equal(a["radii"].cpu().numpy(), st["radii"]):
             fails.append("radii")
         nc = a["n_contrib"].numpy().view(np.uint32).reshape(2, H, W)
-        flips = int(((nc[0] != st["n_contrib"][0]) | (nc[1] != st["n_contrib"][1])).sum())   # pixels with a flipped threshold
+        flipped = (nc[0] != st["n_contrib"][0]) | (nc[1] != st["n_contrib"][1])                # pixels with a flipped threshold
+        flips = int(flipped.sum())
+        rows = int(np.maximum(nc[0], st["n_contrib"][0])[flipped].sum())   # surfels those pixels blend (an upper bound)
         flips_total += flips
         if flips > max(2, int(2e-5 * W * H)):
             fails.append(f"n_contrib differs at {flips} pixels")
 
         def cmp(name, got, want, **kw):
-            if flips and np.ndim(want) == 2 and name.startswith("dL_"):   # per-surfel tensor: two rows per flipped pixel
-                kw["min_outliers"] = 2 * flips * int(np.prod(np.shape(want)[1:]))
+            if flips and np.ndim(want) == 2 and name.startswith("dL_"):   # per-surfel tensor: the rows of the surfels it blends
+                kw["min_outliers"] = max(2 * flips, rows) * int(np.prod(np.shape(want)[1:]))
             elif flips and name.startswith("dL_dsh"):
-                kw["min_outliers"] = 2 * flips * int(np.prod(np.shape(want)[1:]))
+                kw["min_outliers"] = max(2 * flips, rows) * int(np.prod(np.shape(want)[1:]))
             elif flips:
                 kw["min_outliers"] = flips * (3 if name == "color" else 1)
+            if flips and (name.startswith("dL_") or name in ("others5", "others7")):
+                kw["outlier_rtol"] = 1.0   # (a flipped median sample replaces the pixel's median depth / max weight outright)
             if name in CHAIN:
                 kw["rtol"] = RTOL
             try:
