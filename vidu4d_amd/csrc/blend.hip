@@ -386,6 +386,15 @@ __device__ __forceinline__ void store_record(float* __restrict__ seg_data, uint3
 // every rec_len-th entry of a tile the segment table lists, the final sums in the tile's last slot.
 // Register budget: the whole-tile full instance is held to 72 VGPRs = 7 waves per SIMD (the LDS limit; the allocator takes
 // 74 = 6 waves when left alone since the segment-local distortion moments joined the pixel state).
+#ifdef SURFEL_FWD_TRACE   // (tools/fwd_trace.py: a variant build that timestamps every workgroup of blend_fwd; never in the product)
+__device__ unsigned long long* g_fwd_trace = nullptr;
+}  // namespace surfel
+extern "C" int vidu4d_diag_set_forward_trace(void* buffer)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(surfel::g_fwd_trace), &buffer, sizeof(buffer));
+}
+namespace surfel {
+#endif
 #ifndef SURFEL_FWD_WAVES_PER_EU
 #define SURFEL_FWD_WAVES_PER_EU 7
 #endif
@@ -400,6 +409,21 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                        uint32_t* depth_used, int spec, int flags, int rec_len)
 {
     constexpr bool SPEC_OK = MODE != BLEND_FULL;
+#ifdef SURFEL_FWD_TRACE
+    struct TraceEnd {
+        unsigned long long* p; unsigned long long t0; int entries;
+        __device__ ~TraceEnd() {
+            if (p && threadIdx.x == 0) {
+                p[4 * blockIdx.x + 0] = t0;
+                p[4 * blockIdx.x + 1] = t0;
+                p[4 * blockIdx.x + 2] = wall_clock64();
+                p[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |
+                                        ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 0xf) << 32) |
+                                        ((unsigned long long)(entries & 0xffff) << 40);
+            }
+        }
+    } trace_end{g_fwd_trace, (unsigned long long)wall_clock64(), 0};
+#endif
     __shared__ float4 s_rec[(FWD_BATCH + 1) * 5];  // (+ an all-zero record: what an idle half of a wave evaluates)
     __shared__ unsigned long long s_mask8[8][FWD_BATCH / 64];
     if (threadIdx.x < 5) s_rec[FWD_BATCH * 5 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -458,6 +482,9 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
             rec_next += rec_len;
         }
         if (__syncthreads_count(done) == 256) break;
+#ifdef SURFEL_FWD_TRACE
+        trace_end.entries = base - begin + min(todo, FWD_BATCH);
+#endif
         const bool have = (int)threadIdx.x < todo;
         FootprintTest foot = no_footprint();
         if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
@@ -792,6 +819,18 @@ static auto pick_fwd(int mode)
                                 : &blend_fwd_kernel<SPLIT, BLEND_FULL>;
 }
 
+// (experiments: VIDU4D_FWD_PAD_LDS=<bytes> of unused dynamic LDS per workgroup of the whole-tile forward caps the workgroups
+// resident per CU)
+static int fwd_pad_lds()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VIDU4D_FWD_PAD_LDS");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageState& img, const BinState& b,
                       int64_t capacity, bool split, int max_seg, const float* background, float* out_color,
                       float* out_others, uint32_t* depth_used, int mode, bool assume_unsaturated, int flags, bool record,
@@ -802,7 +841,7 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
         const int rec_len = (record && capacity > 0) ? REC_SEG_LEN : 0;
-        hipLaunchKernelGGL(pick_fwd<false>(mode), dim3(tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
+        hipLaunchKernelGGL(pick_fwd<false>(mode), dim3(tiles), dim3(256), fwd_pad_lds(), stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
                            point_list, capacity, 0, g.rec, background, b.seg_data, out_color, out_others, depth_used, 0, flags,
                            rec_len);
         return;
