@@ -482,6 +482,13 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
             rec_next += rec_len;
         }
         if (__syncthreads_count(done) == 256) break;
+        // Issue priority by the fraction of the walk that is left.  A CU serves its oldest waves first, so of seven resident
+        // workgroups with like lists the first dispatched finished after 93 us and the last after 154 (tools/fwd_trace.py), and
+        // the last third of the launch ran on two or three workgroups per CU; with the ones that have most left in front they
+        // finish together: 168 -> 157 us at the headline size.
+        if (3 * todo > 2 * (int)(r1 - r0)) __builtin_amdgcn_s_setprio(3);
+        else if (3 * todo > (int)(r1 - r0)) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
 #ifdef SURFEL_FWD_TRACE
         trace_end.entries = base - begin + min(todo, FWD_BATCH);
 #endif
@@ -994,7 +1001,7 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
     const uint32_t r0 = ranges[2 * tc.tile];
     const size_t pid = frame_base + (size_t)py * W + px;
-    const int seg_len = SPLIT ? (int)hdr->seg_len : 0;
+    const int seg_len = SPLIT ? (int)hdr->seg_len : 1;   // (!SPLIT: unused; 1 keeps the divisions below defined)
     const int seg_begin = (SPLIT && wk.seg >= 0) ? wk.seg * seg_len : 0;
 
     BwdPixel s;
@@ -1124,6 +1131,9 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
 
     for (int hi = n_used; hi > seg_begin; hi -= BWD_BATCH) {
         const int cnt = hi - seg_begin < BWD_BATCH ? hi - seg_begin : BWD_BATCH;
+        // (issue priority by what is left of the unit, as in blend_fwd_kernel: 397 -> 381 us)
+        if (hi - seg_begin > BWD_BATCH) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
         __syncthreads();
         {
             // threads 0..127 stage (back to front: slot t <-> list entry hi-1-t) and test their entry against all eight
