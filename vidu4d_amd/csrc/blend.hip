@@ -486,8 +486,9 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
         // workgroups with like lists the first dispatched finished after 93 us and the last after 154 (tools/fwd_trace.py), and
         // the last third of the launch ran on two or three workgroups per CU; with the ones that have most left in front they
         // finish together: 168 -> 157 us at the headline size.
-        if (3 * todo > 2 * (int)(r1 - r0)) __builtin_amdgcn_s_setprio(3);
-        else if (3 * todo > (int)(r1 - r0)) __builtin_amdgcn_s_setprio(2);
+        const int prio_len = (int)(r1 - r0);   // (against the frame's longest list instead -- the long walks ahead -- is worse: 431 -> 448 us on the dense ball)
+        if (3 * todo > 2 * prio_len) __builtin_amdgcn_s_setprio(3);
+        else if (3 * todo > prio_len) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(1);
 #ifdef SURFEL_FWD_TRACE
         trace_end.entries = base - begin + min(todo, FWD_BATCH);
