@@ -71,6 +71,14 @@ def stage_bytes(stage: str, N: int, R: float, P: int, T: int, K: int) -> float:
     }[stage]
 
 
+def baseline_config_label(N: int, W: int, H: int) -> str:
+    """Which BASELINE.json configuration a size is (configs[1]: 50 k / 256^2, [2]: 200 k / 512^2 = the headline, [4]: 1 M / 1080p)."""
+    return {(50_000, 256, 256): "BASELINE.json configs[1] size (50 k surfels, 256^2)",
+            (200_000, 512, 512): "BASELINE.json configs[2] (the headline: 200 k surfels, 512^2)",
+            (1_000_000, 1920, 1080): "BASELINE.json configs[4] size (1 M surfels, 1920x1080)"}.get(
+                (N, W, H), "a size BASELINE.json does not list")
+
+
 def higher_msb(n: int) -> int:
     """Bits the reference sorts the tile id on (getHigherMsb, rasterizer_impl.cu:35-50)."""
     msb = step = 16
@@ -335,6 +343,9 @@ def main():
                     help="uniform: BASELINE.md scene (surfels spread over the frustum); object: the same surfels "
                          "inside a ball covering about a third of the image (uneven tile lists)")
     ap.add_argument("--object-radius", type=float, default=1.0)
+    ap.add_argument("--opacity", choices=["random", "init"], default="random",
+                    help="random: sigmoid(N(0, 2^2)) (BASELINE.md scene); init: every surfel 0.1, the Stage-3 initialisation "
+                         "(gs/scene/gaussian_model.py:143) -- nothing saturates, every list is walked to its end (SURVEY.md 8d)")
     ap.add_argument("--cpu-images", type=int, default=6, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--torch-cpu-images", type=int, default=1,
                     help="frames timed on the pure-PyTorch CPU render (0 = skip; ~10-20 s each at 200k/512^2)")
@@ -414,15 +425,18 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if use_dist and backend != "gloo" and torch.cuda.current_device() != local_rank:
+        raise SystemExit(f"rank {rank}: HIP device {torch.cuda.current_device()} is not LOCAL_RANK {local_rank}")
+
     import diff_surfel_rasterization as dsr
     from vidu4d_amd import _lib
     from vidu4d_amd.synthetic import frame_motion, make_object_scene, make_scene, make_upstream_grads
 
     N, W = args.surfels, args.res
     if args.scene == "object":
-        scene_cpu = make_object_scene(N, W, args.height or None, radius=args.object_radius, seed=1234)
+        scene_cpu = make_object_scene(N, W, args.height or None, radius=args.object_radius, seed=1234, opacity_mode=args.opacity)
     else:
-        scene_cpu = make_scene(N, W, args.height or None, seed=1234)
+        scene_cpu = make_scene(N, W, args.height or None, seed=1234, opacity_mode=args.opacity)
     scene = scene_cpu.to(dev)
     H = scene.height
     dc, do = (t.to(dev) for t in make_upstream_grads(W, H))
@@ -441,6 +455,12 @@ def main():
     # step i can still be on the wire while step i + 1 fills the other one (--exchange overlapped)
     flats = [torch.empty(N * GRAD_FLOATS_PER_SURFEL, device=dev) for _ in range(2)] if use_dist else None
     pending = [None, None]
+    # the first N > 1 launch validates itself before anything is timed (vidu4d_amd/lab4d/dist_check.py): every rank seen,
+    # device == LOCAL_RANK, the payload's standalone all-reduce time, which frames each rank renders
+    rccl_check = None
+    if use_dist:
+        from vidu4d_amd.lab4d.dist_check import collective_self_check
+        rccl_check = collective_self_check(dist, dev, local_rank, flats[0], my_frames, backend=backend)
     use_distributed_exchange = use_dist
     opac_f, scales_f, shs_f = opac, scales, shs
     counter = {"slot": 0, "R": 0.0, "n": 0, "buf": 0}
@@ -689,16 +709,19 @@ def main():
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "host_enqueue_ms_per_step": 1e3 * enqueued / args.steps, "settle_steps_before_warmup": settle, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[2] op-level: Stage-3 gs-bob rasterizer fwd+bwd, {N} surfels, "
+        "config": {"workload": f"{baseline_config_label(N, W, H)} op-level: Stage-3 gs-bob rasterizer fwd+bwd, {N} surfels, "
                                f"{W}x{H}, SH degree 3, {args.frames} frames sharded one-frame-per-GPU, "
-                               f"{FRAMES_PER_STEP} frames per step per GPU",
-                   "scene": args.scene, "surfels": N, "width": W, "height": H, "frames": args.frames, "frames_per_step": FRAMES_PER_STEP,
+                               f"{FRAMES_PER_STEP} frames per step per GPU" +
+                               (", opacity 0.1 everywhere (Stage-3 initialisation, gaussian_model.py:143)" if args.opacity == "init" else ""),
+                   "scene": args.scene, "opacity": args.opacity, "surfels": N, "width": W, "height": H, "frames": args.frames, "frames_per_step": FRAMES_PER_STEP,
                    "parallelism": f"frame-parallel x{world}" + ((" + RCCL" if backend != "gloo" else " + gloo") +
                                                                 " all-reduce of surfel grads" if world > 1 else ""),
                    "frames_of_rank0": my_frames[:4] + ["..."],
                    "frames_of_a_step": "one stacked launch set" if args.stacked else
                                        ("one call per frame, separate HIP streams" if args.frame_streams else "one call per frame")},
     }
+    if rccl_check is not None:
+        out["rccl"] = rccl_check
     if world > 1 or use_dist:
         out["config"]["exchange"] = ("all-reduce of the step's flat gradient buffer joined before its buffer is reused, two steps "
                                      "later (the op-level loop has no optimizer between steps)" if args.exchange == "overlapped"

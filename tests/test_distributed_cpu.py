@@ -332,3 +332,33 @@ def test_two_rank_step_equals_the_one_rank_step_over_the_same_frames(monkeypatch
     assert [tuple(a.shape) for a in got] == [tuple(b.shape) for b in want]
     for a, b in zip(got, want):
         assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(b.abs().max()) + 1e-9), float((a - b).abs().max())
+
+
+def _self_check_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vidu4d_amd.lab4d.dist_check import collective_self_check
+        payload = torch.full((1000,), float(rank + 1))
+        frames = list(range(rank, 16, world))
+        c = collective_self_check(dist, torch.device("cpu"), rank, payload, frames, backend="gloo", reps=3)
+        c["payload_zeroed"] = bool((payload == 0).all())
+        out[rank] = c
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_self_check_two_ranks_gloo():
+    """The block the first N > 1 launch puts on its JSON line (bench.py "rccl", train.py's first log line): both ranks seen,
+    the rank ids sum up, every rank's first frames, a standalone all-reduce time of the payload."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_self_check_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for r in range(world):
+        c = res[r]
+        assert c["world"] == 2 and c["ranks_seen"] == 2 and c["rank_sum_ok"] and c["backend"] == "gloo"
+        assert c["frames_of_each_rank_head"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+        assert c["payload_bytes"] == 4000 and c["allreduce_ms_p50"] > 0 and c["allreduce_reps"] == 3
+        assert c["payload_zeroed"] and c["device_of_each_rank"] == [-1, -1]

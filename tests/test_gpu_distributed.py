@@ -120,3 +120,9 @@ def test_bench_two_ranks_on_one_gpu(gpu_device):
     assert d["config"]["parallelism"].startswith("frame-parallel x2") and d["config"]["frames_of_rank0"][:3] == [0, 2, 4]
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]   # both ranks' images
     assert "exchange" in d["config"] and "roofline" in d
+    # the launch's self-validation block (vidu4d_amd/lab4d/dist_check.py): both ranks seen, their first frames, the payload's
+    # standalone all-reduce
+    c = d["rccl"]
+    assert c["world"] == 2 and c["ranks_seen"] == 2 and c["rank_sum_ok"] and c["backend"] == "gloo"
+    assert c["frames_of_each_rank_head"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert c["payload_bytes"] == 20000 * 58 * 4 and c["allreduce_ms_p50"] > 0

@@ -123,6 +123,10 @@ __device__ __forceinline__ void publish_block_masks(unsigned long long (*s_mask8
     }
 }
 
+// __any() on a predicate that is already a lane mask: hip's __any(int) widens the bool to an int per lane first (v_cndmask
+// 0 / 1, v_cmp_ne: two VALU instructions of the expensive kind per call in the blend loops); the ballot builtin takes the mask.
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -501,47 +505,54 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
         if (__all(done)) continue;  // this wave's 64 pixels are saturated; it keeps helping to stage
         // Half walk (see blend_bwd_kernel): lanes 0-31 / 32-63 follow the cull masks of their own 8x4 block, two list
         // entries of each per trip; the accumulation stays in list order per pixel.
+        const int key_base = (base + 1) * 80;   // (list positions stay below 2^31 / 80: the pair count is an int64 capacity, a tile's list a uint32 range)
 #pragma unroll 1
         for (int k = 0; k < FWD_BATCH / 64; k++) {
             const unsigned long long alive = __ballot(!done);  // a half whose pixels are all finished walks nothing
             unsigned long long mA = (uint32_t)alive ? uniform_u64(s_mask8[2 * wave][k]) : 0ull;
             unsigned long long mB = (alive >> 32) ? uniform_u64(s_mask8[2 * wave + 1][k]) : 0ull;
             while (mA | mB) {
-                const int jaA = mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH;
+                // The slots travel as BYTE OFFSETS into s_rec (80 j; the scalar unit multiplies): `ja * 5` of a per-lane j
+                // compiled to v_mul_lo_u32, a quarter-rate instruction, twice per trip.  An accepted sample's list position
+                // is kept as the key 80 (base + j + 1) = offset + key_base and divided back once per pixel after the walk.
+                const int oaA = (mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH) * 80;
                 mA &= mA - 1;
-                const int jbA = mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH;
+                const int obA = (mA ? k * 64 + __builtin_ctzll(mA) : FWD_BATCH) * 80;
                 mA &= mA - 1;
-                const int jaB = mB ? k * 64 + __builtin_ctzll(mB) : FWD_BATCH;
+                const int oaB = (mB ? k * 64 + __builtin_ctzll(mB) : FWD_BATCH) * 80;
                 mB &= mB - 1;
-                const int jbB = mB ? k * 64 + __builtin_ctzll(mB) : FWD_BATCH;
+                const int obB = (mB ? k * 64 + __builtin_ctzll(mB) : FWD_BATCH) * 80;
                 mB &= mB - 1;
-                const int ja = lane < 32 ? jaA : jaB, jb = lane < 32 ? jbA : jbB;
-                const float4 a0 = s_rec[ja * 5 + 0], a1 = s_rec[ja * 5 + 1], a2 = s_rec[ja * 5 + 2];
-                const float4 b0 = s_rec[jb * 5 + 0], b1 = s_rec[jb * 5 + 1], b2 = s_rec[jb * 5 + 2];
+                const int oa = lane < 32 ? oaA : oaB, ob = lane < 32 ? obA : obB;
+                const float4* ra = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + oa);
+                const float4* rb = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + ob);
+                const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2];
+                const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2];
                 const float TuA[3] = {a0.x, a0.y, a0.z}, TvA[3] = {a0.w, a1.x, a1.y}, TwA[3] = {a1.z, a1.w, a2.x};
                 const float TuB[3] = {b0.x, b0.y, b0.z}, TvB[3] = {b0.w, b1.x, b1.y}, TwB[3] = {b1.z, b1.w, b2.x};
                 PairEval ea, eb;
                 bool okA = eval_pair_flat(TuA, TvA, TwA, a2.y, a2.z, a2.w, pixx, pixy, ea);
                 bool okB = eval_pair_flat(TuB, TvB, TwB, b2.y, b2.z, b2.w, pixx, pixy, eb);
+                // (no __any() around the masked blocks: the compiler's own "skip if no lane is left" -- s_and_saveexec,
+                // s_cbranch_execz -- does that on the scalar unit; hip's __any(int) widened the predicate through a VGPR first,
+                // v_cndmask 0 / 1 + v_cmp_ne, four VALU instructions of the expensive kind per trip for nothing)
                 okA = okA && !done;
-                if (__any(okA)) {
-                    if (okA) {
-                        const float4 q3 = s_rec[ja * 5 + 3], q4 = s_rec[ja * 5 + 4];
-                        const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate<MODE>(s, ea, nrm, rgb, (uint32_t)(base + ja + 1))) done = sat_local = true;
-                    }
+                if (okA) {
+                    const float4 q3 = ra[3], q4 = ra[4];
+                    const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                    if (!fwd_accumulate<MODE>(s, ea, nrm, rgb, (uint32_t)(key_base + oa))) done = sat_local = true;
                 }
                 okB = okB && !done;
-                if (__any(okB)) {
-                    if (okB) {
-                        const float4 q3 = s_rec[jb * 5 + 3], q4 = s_rec[jb * 5 + 4];
-                        const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                        if (!fwd_accumulate<MODE>(s, eb, nrm, rgb, (uint32_t)(base + jb + 1))) done = sat_local = true;
-                    }
+                if (okB) {
+                    const float4 q3 = rb[3], q4 = rb[4];
+                    const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                    if (!fwd_accumulate<MODE>(s, eb, nrm, rgb, (uint32_t)(key_base + ob))) done = sat_local = true;
                 }
             }
         }
     }
+    s.last_contributor /= 80u;   // (keys -> list positions, see the walk)
+    s.median_contributor /= 80u;
     if (SPLIT && wk.seg >= 0) {
         // partial results of this segment; blend_combine_kernel adds the segments up in list order
         float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
@@ -910,12 +921,45 @@ __device__ __forceinline__ void swap_add16(float& a, float b)
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// Round 5: the two halving steps whose "upper" lanes are whole DPP banks (lane & 8: banks 2-3 of a row; lane & 4: banks 1
+// and 3) are written as bank-masked DPP adds -- "the lower lanes add their partner's copy of v[i] into v[i]; the upper lanes
+// put v[i + N/2] plus the partner's copy of it into v[i]" -- two instructions per kept value and NO select (the select
+// version: two v_cndmask on an SGPR-pair mask, 4.7 issue cycles each, and one DPP add).  Same additions on the same operands
+// (a + b against b + a): bit-identical.  Hand-scheduled: a DPP source must not have been written by the two instructions in
+// front of it, and the compiler's hazard recogniser does not look into inline assembly -- hence the s_nop at both ends.
+// SURFEL_ABLATE (timing experiments only, results are wrong): bit 0 replaces the reduce-scatter ladder by a per-lane sum,
+// bit 1 drops the LDS atomics, bit 2 the global flush atomics.
+#ifndef SURFEL_ABLATE
+#define SURFEL_ABLATE 0
+#endif
+#ifndef SURFEL_MASKED_DPP_LADDER
+#define SURFEL_MASKED_DPP_LADDER 1
+#endif
 __device__ __forceinline__ float half_reduce_scatter16(float (&v)[16], int lane)
 {
 #pragma unroll
     for (int k = 0; k < 8; k++) swap_add16(v[k], v[k + 8]);
+#if SURFEL_MASKED_DPP_LADDER
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])
+        : "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#else
     halve<DPP_ROW_MIRROR, 8>(v, (lane & 8) != 0);
     halve<DPP_ROW_HALF_MIRROR, 4>(v, (lane & 4) != 0);
+#endif
     halve<DPP_QUAD_XOR2, 2>(v, (lane & 2) != 0);
     float t = v[0];
     t += dpp_xchg<DPP_QUAD_XOR1>(t);
@@ -1129,9 +1173,21 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     const bool adds16 = (lane & 1) == 0;
     const int slot16 = c16 < 9 ? c16 : (c16 == 9 ? A_OPAC : (c16 < 13 ? c16 + 2 : c16 + 3));
     const int slot2 = A_M2D + ((lane >> 3) & 1);
+    // (this lane's two accumulator addresses of slot 0; a slot adds its byte offset)
+    char* const acc16 = reinterpret_cast<char*>(s_acc + slot16);
+    char* const acc2 = reinterpret_cast<char*>(s_acc + slot2);
 
+    // one slot of the batch in LDS: an 80-byte record in s_rec, an 80-byte accumulator row in s_acc
+    constexpr int SLOT_BYTES = 80;
+    static_assert(ACC_FLOATS * 4 == SLOT_BYTES && sizeof(float4) * 5 == SLOT_BYTES, "record and accumulator row share the slot offset");
     for (int hi = n_used; hi > seg_begin; hi -= BWD_BATCH) {
         const int cnt = hi - seg_begin < BWD_BATCH ? hi - seg_begin : BWD_BATCH;
+        // slot j of the batch <-> list entry hi - 1 - j.  This pixel's entries are those below its last contributor: slots
+        // j > hi - 1 - last_contributor; its median sample is entry median_contributor - 1: slot hi - median_contributor (no
+        // median: slot hi, which is not in the batch -- and whose offset no contributing lane holds: the idle slot BWD_BATCH
+        // fails the pair test).  As byte offsets:
+        const int off_last = (hi - 1 - (int)s.last_contributor) * SLOT_BYTES;
+        const int off_median = (hi - (int)s.median_contributor) * SLOT_BYTES;
         // (issue priority by what is left of the unit, as in blend_fwd_kernel: 397 -> 381 us)
         if (hi - seg_begin > BWD_BATCH) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(1);
@@ -1172,34 +1228,53 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
             }
             while (mA | mB) {
                 // (a half whose word is exhausted evaluates the all-zero record in slot BWD_BATCH: no pixel passes its test)
-                const int jA = mA ? k * 64 + __builtin_ctzll(mA) : BWD_BATCH, jB = mB ? k * 64 + __builtin_ctzll(mB) : BWD_BATCH;
+                // Round 5: the slot travels as its BYTE OFFSET, 80 j -- the same for the record (s_rec, 80 bytes) and for the
+                // accumulator row (s_acc, ACC_FLOATS floats) -- and the two tests on the entry's list position compare offsets
+                // (off_last, off_median: per batch), so the per-lane select is the only vector instruction the walk's
+                // bookkeeping costs a trip (it was select, multiply, subtract; the scalar unit does the multiplications)
+                const int oA = (mA ? k * 64 + __builtin_ctzll(mA) : BWD_BATCH) * SLOT_BYTES;
+                const int oB = (mB ? k * 64 + __builtin_ctzll(mB) : BWD_BATCH) * SLOT_BYTES;
                 mA &= mA - 1;
                 mB &= mB - 1;
-                const int j = lane < 32 ? jA : jB;
-                const uint32_t contributor = (uint32_t)(hi - 1 - j);
-                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+                const int off = lane < 32 ? oA : oB;
+                const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + off);
+                const float4 q0 = r[0], q1 = r[1], q2 = r[2];
                 const float Tu[3] = {q0.x, q0.y, q0.z}, Tv[3] = {q0.w, q1.x, q1.y}, Tw[3] = {q1.z, q1.w, q2.x};
                 PairEval e;
-                const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) &&
-                                contributor < s.last_contributor;  // (outside pixels have last_contributor 0)
+                // (contributor = hi - 1 - j < last_contributor  <=>  80 j > off_last; outside pixels have last_contributor 0)
+                const bool ok = eval_pair_flat(Tu, Tv, Tw, q2.y, q2.z, q2.w, pixx, pixy, e) && off > off_last;
                 if (!__any(ok)) continue;
+                // (a pair has centre-offset terms only where the low-pass disc won, rho2d < rho3d: the branch bwd_pair_geometry
+                // takes -- its compare, ANDed with `ok` on the scalar unit, replaces two compares of the products with zero.
+                // Taken here, as a wave-uniform flag: a lane mask carried across the masked blocks below travels through a VGPR)
+                const bool any2d = __builtin_amdgcn_ballot_w64(ok && !(e.rho3d <= e.rho2d)) != 0ull;   // (__any(int) widens the predicate in a VGPR)
                 PairGrad pg;
                 pg.w = pg.dL_dalpha = pg.dL_dz = 0.f;
                 if (ok) {
-                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                    const float4 q3 = r[3], q4 = r[4];
                     const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-                    pg = bwd_pair_core<MODE>(s, e, nrm, rgb, contributor + 1 == s.median_contributor);
+                    pg = bwd_pair_core<MODE>(s, e, nrm, rgb, off == off_median);
                 }
                 e.sanitise(ok);
                 float g[ACC_FLOATS];
                 bwd_pair_geometry<MODE>(s, e, pg, Tw, q2.w, pixx, pixy, g);
                 float v[16] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[A_OPAC],
                                g[A_NRM], g[A_NRM + 1], g[A_NRM + 2], g[A_RGB], g[A_RGB + 1], g[A_RGB + 2]};
+#if SURFEL_ABLATE & 1   // (tools/gpu_r5_b.sh: what the ladder costs -- the lanes' values go nowhere in particular)
+                float r16 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) r16 += v[i];
+#else
                 const float r16 = half_reduce_scatter16(v, lane);
-                if (adds16 && r16 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot16], r16);
-                if (__any(g[A_M2D] != 0.f || g[A_M2D + 1] != 0.f)) {
+#endif
+#if SURFEL_ABLATE & 2   // (... and the LDS float atomics)
+                if (r16 == 123.456f) s_acc[lane] = r16;
+#else
+                if (adds16 && r16 != 0.f) atomicAdd(reinterpret_cast<float*>(acc16 + off), r16);
+#endif
+                if (any2d) {
                     const float r2 = row_reduce_scatter2(g[A_M2D], g[A_M2D + 1], lane);
-                    if ((lane & 7) == 0 && r2 != 0.f) atomicAdd(&s_acc[j * ACC_FLOATS + slot2], r2);
+                    if ((lane & 7) == 0 && r2 != 0.f) atomicAdd(reinterpret_cast<float*>(acc2 + off), r2);
                 }
             }
         }
@@ -1208,7 +1283,11 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
         // fall into ~6 cache lines (3.2 records of 80 B) instead of 64
         for (int idx = threadIdx.x; idx < cnt * ACC_FLOATS; idx += 256) {
             const float val = s_acc[idx];
+#if SURFEL_ABLATE & 4   // (... and the global flush)
+            if (val == 123.456f) {
+#else
             if (val != 0.f) {
+#endif
                 const int ent = idx / ACC_FLOATS;
                 atomicAdd(acc + (size_t)s_id[ent] * ACC_FLOATS + (idx - ent * ACC_FLOATS), val);
             }

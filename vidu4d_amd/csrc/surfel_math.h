@@ -396,8 +396,10 @@ struct PairEval {
         sy = ok ? sy : 0.f;
         ipz = ok ? ipz : 0.f;
         G = ok ? G : 0.f;
-        rho3d = ok ? rho3d : 0.f;  // (takes the homography branch, whose entries are all products with the above)
-        rho2d = ok ? rho2d : 1.f;
+        // (takes the homography branch of bwd_pair_geometry, whose entries are all products with the above -- rho2d is a
+        // sum of squares of finite numbers, so 0 <= rho2d holds without touching it; the other branch would be just as
+        // safe, but a lane without a contribution must not be the reason a wave enters it)
+        rho3d = ok ? rho3d : 0.f;
     }
 };
 
@@ -490,7 +492,11 @@ SURFEL_HD bool eval_pair_flat(const float Tu[3], const float Tv[3], const float 
     const float power = -0.5f * rho;
     e.G = fast_exp(power);
     e.alpha = fminf(ALPHA_MAX, opacity * e.G);
-    return (pz != 0.0f) & !(e.depth < NEAR_PLANE) & !(power > 0.0f) & !(e.alpha < ALPHA_MIN);
+    // (`power > 0` -- forward.cu:390 -- can never hold: rho3d and rho2d are sums of squares, so rho = fminf(...) is >= +0 or
+    // NaN, and power = -0.5 rho is <= -0 or NaN, neither of which compares greater than zero.  eval_pair keeps the test as the
+    // reference writes it; here it was a VOPC compare and a scalar AND per pair evaluation for nothing.)
+    (void)power;
+    return (pz != 0.0f) & !(e.depth < NEAR_PLANE) & !(e.alpha < ALPHA_MIN);
 }
 
 // Which pixels a surfel can contribute to.  A pair contributes only if alpha = min(0.99, o*exp(-rho/2)) >= 1/255 with

@@ -19,6 +19,7 @@ evaluation are outside this build.  Flags of the reference that 
 accepted and listed as ignored, so the reference's command lines keep working."""
 from __future__ import annotations
 
+import json
 import os
 import sys
 import time
@@ -117,6 +118,15 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     say = print if rank == 0 else (lambda *a, **k: None)
+    if world > 1:
+        # the launch validates itself before the first step (dist_check.py): every rank seen, device == LOCAL_RANK, what one
+        # all-reduce of the canonical-surfel gradients costs standalone, which frames each rank starts on
+        from .dist_check import collective_self_check
+        per = 2 * opts["imgs_per_gpu"]
+        probe = torch.zeros(opts["num_surfels"] * 58 + 3, device=dev)
+        chk = collective_self_check(dist, dev, local_rank, probe, [(rank * per + k) % max(1, opts["num_frames"]) for k in range(per)])
+        say("rccl self-check: " + json.dumps(chk))
+        del probe
     if ignored:
         say("flags accepted but not used by the Stage-3 hot path:", " ".join(ignored))
 
