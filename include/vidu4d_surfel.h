@@ -139,7 +139,14 @@ typedef struct Vidu4dSurfelForwardArgs {
      * than the alpha plane alone: depth, alpha, normal -- what the Stage-3 loop reads after step 8000 with the upstream
      * defaults lambda_dist = 0 and depth_ratio = 0, lab4d/config.py:181, gs/arguments/__init__.py:68,
      * lab4d/engine/model.py:817-842) the median sample and the distortion moments are not carried: out_color and planes
-     * 0-4 are the full blend's bit for bit, planes 5-7 come out as zeros.  Any other value: everything is computed. */
+     * 0-4 are the full blend's bit for bit, planes 5-7 come out as zeros.  Any other value: everything is computed.
+     * ("Bit for bit" compares the instances of ONE call configuration: same library build, same segment_split, same image
+     * size and frame count.  A whole-tile forward that leaves recorded segments -- segment_split == 0 and at most 4096 tiles
+     * in the launch, stacked frames counted -- sums colour, depth and normal of a tile longer than 320 entries in two levels,
+     * per 256-entry segment and then across segments, in every instance alike; beyond 4096 tiles (-DSURFEL_REC_MAX_TILES, a
+     * multiple of 256: a build with 256 is the A/B switch for any real image) it keeps ONE running sum per pixel as the
+     * reference does, forward.cu:400-438.  The two differ in the last bits, so results do change in the last bits with the
+     * image size / the number of stacked frames across that boundary, and against releases before ABI 17.) */
     int aux_planes;
     /* ---- segment-parallel blend without its transmittance pre-pass (extension; only with segment_split != 0 and
      * aux_planes naming nothing beyond planes 0-4, ignored otherwise: the full blend's median sample depends on the exact
@@ -264,7 +271,8 @@ int vidu4d_surfel_mark_visible(int P, const float* means3D, const float* viewmat
  *      (device or host pointer, any hipMemcpy-able) and the element count is returned in *count. */
 enum Vidu4dSurfelStateArray {
     VIDU4D_STATE_NUM_RENDERED = 0,  /* uint32[1] */
-    VIDU4D_STATE_RECORDS = 1,       /* float[P][32], 28 used  (layout: vidu4d_amd/csrc/surfel_math.h) */
+    VIDU4D_STATE_RECORDS = 1,       /* float[P][32], 28 used  (layout: vidu4d_amd/csrc/surfel_math.h); floats 28..31 of a
+                                     * record are padding to the 128-byte line and come back as whatever the buffer held */
     VIDU4D_STATE_TILES_TOUCHED = 2, /* uint32[P] */
     VIDU4D_STATE_POINT_LIST = 3,    /* uint32[num_rendered] sorted surfel ids (binning.point_list) */
     VIDU4D_STATE_SORTED_KEYS = 4,   /* uint64[num_rendered] (tile << 32 | depth bits); dst must be HOST memory */

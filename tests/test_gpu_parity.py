@@ -209,10 +209,14 @@ def test_capacity_guess_too_small_is_recovered(gpu_device):
     from vidu4d_amd import _C
     sc = make_case("small")
     st = oracle_forward(sc)
-    key = (sc.width, sc.height, str(gpu_device))
+    key = (sc.width, sc.height, str(gpu_device), 1, None)   # (hints are keyed on shape, device, frames per call, hint scope)
     _C._capacity_hint[key] = 4096  # far below num_rendered
     d, shs, cols, out = _native_forward(sc, gpu_device)
     assert out[0] == st["num_rendered"] > 4096
+    # the re-run branch was taken: the planted hint was read (the binning buffer of the first attempt was carved for it)
+    # and has grown to the exact count's + 25 %
+    assert _C._capacity_hint[key] >= st["num_rendered"] > 4096, _C._capacity_hint[key]
+    assert getattr(out[5], "_vidu4d_capacity", 0) == st["num_rendered"], "the tail was queued again with an exact buffer"
     _check_forward(sc, st, out)
     # and the refreshed hint is used without a re-run on the next call
     d, shs, cols, out = _native_forward(sc, gpu_device)

@@ -64,6 +64,28 @@ def assert_close(name, got, want, rtol=RTOL, atol=0.0, outlier_fraction=OUTLIER_
     return worst
 
 
+def relative_error_stats(got, want, floor=1e-3):
+    """Beyond "a fraction of the tensor's max": (i) the relative L2 error ||got - want|| / ||want|| and (ii) the element-wise
+    relative error |got - want| / |want| over the entries whose reference magnitude is above `floor` of the tensor's
+    scale (median, 99th percentile, maximum) -- a uniformly small-magnitude region of a tensor cannot drift unseen behind
+    a max-normalised gate."""
+    got, want = to_np(got).astype(np.float64), to_np(want).astype(np.float64)
+    scale = np.abs(want).max() if want.size else 0.0
+    nrm = float(np.sqrt((want * want).sum()))
+    err = got - want
+    out = {"rel_l2": float(np.sqrt((err ** 2).sum()) / (nrm + 1e-300)) if want.size else 0.0}
+    # ... and without the entries a flipped threshold decision moved (those beyond 1e-4 of the scale: the set the outlier
+    # budgets of assert_close bound by count and size): what is left is rounding, and must be small in the L2 sense too
+    keep = np.abs(err) <= RTOL * scale
+    out["rel_l2_without_outliers"] = float(np.sqrt((err[keep] ** 2).sum()) / (nrm + 1e-300)) if want.size else 0.0
+    big = np.abs(want) > floor * scale
+    if big.any():
+        r = np.abs(got - want)[big] / np.abs(want)[big]
+        out.update(elem_rel_p50=float(np.percentile(r, 50)), elem_rel_p99=float(np.percentile(r, 99)), elem_rel_max=float(r.max()),
+                   elem_rel_entries=int(big.sum()), elem_rel_floor=floor)
+    return out
+
+
 def oracle_forward(sc: SurfelScene, colors_precomp=None, stats=False):
     kw = dict(shs=sc.shs) if colors_precomp is None else dict(colors_precomp=colors_precomp)
     return so.forward(sc.means3D, sc.opacities, sc.scales, sc.rotations, sc.viewmatrix, sc.projmatrix, sc.campos,

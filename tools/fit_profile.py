@@ -18,6 +18,16 @@ tr.current_steps = int(os.environ.get("FIT_STEP0", "0"))  # > 8000: normal-consi
 m.pipeline.fused_post = os.environ.get("FIT_FUSED_POST", "1") == "1"
 batches = [synthetic_batch(m, [(2*i) % frames, (2*i+1) % frames], H, W, seed=i) for i in range(4)]
 for b in batches: b["Kinv"] = batches[0]["Kinv"]  # one intrinsics tensor for the run (--force_center_cam)
+if os.environ.get("FIT_PRINT_HINTS", "0") == "1":   # (the split decisions of the run, as taken)
+    from vidu4d_amd import _C as _Cm
+    _decisions = []
+    _orig_auto = _Cm.auto_split
+
+    def _spy_auto(depth, long_tiles, cus):
+        r = _orig_auto(depth, long_tiles, cus)
+        _decisions.append((depth, long_tiles, bool(r)))
+        return r
+    _Cm.auto_split = _spy_auto
 for i in range(6): tr.train_step(batches[i % 4])
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
@@ -56,7 +66,9 @@ if os.environ.get("FIT_TILE_STATS", "0") == "1":   # how far the forward's walk 
               f"alive pixels per such tile median {int(np.median(alive_at(k)[u])) if u.any() else 0}")
 if os.environ.get("FIT_PRINT_HINTS", "0") == "1":   # what the split decision sees
     from vidu4d_amd import _C
-    print("FIT_HINTS deepest blended list position", dict(_C._depth_hint), "longest list", dict(_C._len_hint))
+    print("FIT_DECISIONS first", _decisions[:8], "last", _decisions[-4:], "split in", sum(d[2] for d in _decisions), "of", len(_decisions))
+    print("FIT_HINTS deepest blended list position", list(_C._depth_hint.values()), "longest list", list(_C._len_hint.values()),
+          "tiles longer than 1024 entries", list(_C._long_tiles_hint.values()))
 if os.environ.get("FIT_WALK_STATS", "0") == "1":   # what the backward's walk of one step looks like (vidu4d_surfel_blend_stats)
     from vidu4d_amd import _C
     cnt = torch.zeros(16, dtype=torch.int64, device=dev)

@@ -5,7 +5,9 @@
 
 For each configuration it prints and stores (gpurun_out/ref_parity.json -> copied to profiles/):
   integers  radii / tiles_touched / point_list / sorted keys / ranges / n_contrib: number of differing entries
-  floats    per tensor: fraction of entries whose error exceeds 1e-4 of the tensor's scale, and the worst error
+  floats    per tensor: fraction of entries whose error exceeds 1e-4 of the tensor's scale, and the worst error;
+            round 5: the relative L2 error, and the element-wise relative error (median / p99 / max) over the entries whose
+            reference magnitude is above 1e-3 of the tensor's scale
 for the pairs  oracle vs strict reference, oracle vs default reference, product vs strict, product vs default.
 The budgets of tests/test_gpu_reference.py are set from these numbers (<= 2x measured).
 
@@ -25,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import surfel_oracle as so  # noqa: E402
 from oracle.ref_build import ref  # noqa: E402
-from tests.util import oracle_forward, to_np  # noqa: E402
+from tests.util import oracle_forward, relative_error_stats, to_np  # noqa: E402
 from vidu4d_amd.synthetic import make_scene, make_upstream_grads  # noqa: E402
 
 CONFIGS = {
@@ -47,8 +49,10 @@ def float_stats(got, want, rtol=1e-4):
     got, want = to_np(got).astype(np.float64), to_np(want).astype(np.float64)
     scale = np.abs(want).max() + 1e-30
     err = np.abs(got - want)
-    return {"outlier_frac": float((err > rtol * scale).mean()), "worst_rel": float(err.max() / scale),
-            "finite": bool(np.isfinite(got).all())}
+    out = {"outlier_frac": float((err > rtol * scale).mean()), "worst_rel": float(err.max() / scale),
+           "finite": bool(np.isfinite(got).all())}
+    out.update(relative_error_stats(got, want))   # (round 5: relative L2, element-wise relative p50 / p99 / max)
+    return out
 
 
 def int_diff(a, b):

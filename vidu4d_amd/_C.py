@@ -37,7 +37,7 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = int(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_LEN", "2048"))
 SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU", "2.5"))
-_long_tiles_hint: dict = {}  # tiles longer than the schedule's split threshold (Header word 4), latest frame of a shape
+_long_tiles_hint: dict = {}  # tiles longer than SPLIT_MIN entries (Header word 14), latest frame of a shape
 _cu_count: dict = {}
 _capacity_hint: dict = {}
 # Deferred capacity check (opt-in, for callers that can replay a step -- Stage3Trainer): the forward
@@ -170,6 +170,9 @@ class graph_capture_mode:
 
 
 HEADER_DEPTH_WORD = 12   # surfel_state.h Header::depth_used
+HEADER_LONG_TILES_WORD = 14   # Header::num_long_tiles: tiles longer than SPLIT_MIN (1024) entries -- the same count whether the
+#                               frame's forward walked whole tiles or split them (word 4, num_split_pos, follows the mode:
+#                               the split decision read it and was bistable -- ADVICE r4)
 
 
 def _depth_of(stat, slot) -> int:
@@ -179,7 +182,7 @@ def _depth_of(stat, slot) -> int:
 
 def _note_longest_list(slot, key):
     _len_hint[key] = max(int(slot[2]), int(0.9 * _len_hint.get(key, 0)))
-    _long_tiles_hint[key] = int(slot[4])
+    _long_tiles_hint[key] = int(slot[HEADER_LONG_TILES_WORD])
 
 
 def auto_split(depth: int, long_tiles: int, compute_units: int) -> bool:

@@ -131,6 +131,7 @@ struct TileOrderShared {
     uint32_t scan[16];
     uint32_t max;
     uint32_t any;
+    uint32_t n_long;
 };
 
 // by_class (recorded segments): a tile is split iff its length CLASS lies above the class of split_min -- the split tiles
@@ -147,13 +148,21 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
     if (threadIdx.x == 0) s_max = 0;
     s_bin[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mx = 0;
+    uint32_t mx = 0, n_long = 0;
     for (int t = threadIdx.x; t < num_tiles; t += 1024) {
-        mx = max(mx, img.ranges[2 * t + 1] - img.ranges[2 * t]);
+        const uint32_t len = img.ranges[2 * t + 1] - img.ranges[2 * t];
+        mx = max(mx, len);
+        n_long += len > (uint32_t)SPLIT_MIN;
         img.seg_first[t] = SEG_NONE;
     }
     for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     if (lane == 0) atomicMax(&s_max, mx);
+    // (Header::num_long_tiles: tiles longer than SPLIT_MIN, whatever table this call builds -- the caller's split decision
+    // reads THIS, not num_split_pos, whose meaning follows the mode of the call)
+    for (int off = 32; off; off >>= 1) n_long += (uint32_t)__shfl_xor((int)n_long, off);
+    if (threadIdx.x == 0) sh.n_long = 0;
+    __syncthreads();
+    if (lane == 0 && n_long) atomicAdd(&sh.n_long, n_long);
     __syncthreads();
     const uint32_t max_len = s_max;
     const uint64_t denom = (uint64_t)max_len + 1;
@@ -250,6 +259,7 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
         g.hdr->num_split_pos = split_pos;
         g.hdr->seg_len = (uint32_t)seg_len;
         g.hdr->split_min = (uint32_t)split_min;
+        g.hdr->num_long_tiles = sh.n_long;
         g.hdr->split_used = 0;
         g.hdr->truncated = 0;
     }

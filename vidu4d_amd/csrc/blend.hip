@@ -44,6 +44,16 @@ constexpr int FWD_BATCH = 256;  // list entries staged per round (one per thread
 #define SURFEL_BWD_BATCH 128
 #endif
 constexpr int BWD_BATCH = SURFEL_BWD_BATCH;
+// What the recorded segments (surfel_state.h) take for granted about these constants, all of which -D can override:
+//  * blend_fwd_kernel leaves a record only when a batch STARTS at a segment boundary (`base == rec_next`) and names the
+//    segment it is in base / rec_len: a segment is a whole number of forward batches -- and blend_bwd_kernel's "a walk that
+//    stopped in segment `stop` has no contributor beyond its end" rests on the same;
+//  * every tile the table lists has at least two segments (one prefix record and the final one in different slots);
+//  * bwd_prepare_kernel scans REC_MAX_TILES / 256 positions per thread.
+static_assert(REC_SEG_LEN % FWD_BATCH == 0, "a recorded segment must be a whole number of forward batches");
+static_assert(REC_MIN >= REC_SEG_LEN, "a tile with recorded segments must have at least two of them");
+static_assert(REC_MAX_TILES % 256 == 0, "bwd_prepare_kernel scans REC_MAX_TILES / 256 schedule positions per thread");
+static_assert(BWD_BATCH % 64 == 0 && FWD_BATCH % 64 == 0, "cull masks are 64-entry words");
 
 struct TileCoord {
     int tile, tx, ty;

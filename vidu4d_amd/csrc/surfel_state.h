@@ -121,8 +121,12 @@ struct Header {           // first 256 bytes of the geometry buffer
                             // tensor, its reset and its copy
     uint32_t num_live_full; // recorded segments: FULL segments the forward's walks reached (ImageState::live_prefix; written by
                             // the backward's preparation launch)
-    uint32_t pad[50];
+    uint32_t num_long_tiles; // word 14: tiles whose list is longer than SPLIT_MIN entries, whichever segment table the forward
+                             // built (num_split_pos counts positions of the table at hand: tiles above REC_MIN's length class
+                             // after a whole-tile forward, positions up to the last tile above SPLIT_MIN after a split one)
+    uint32_t pad[49];
 };
+static_assert(sizeof(Header) == 256, "the header is the first 256 bytes of the geometry buffer");
 
 struct GeomState {
     Header* hdr;
