@@ -120,7 +120,7 @@ def cpu_baseline(scene, n_images: int):
 
 
 def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: int = 0, seed: int = 0, barrier=None,
-                  densify: bool = False):
+                  densify: bool = False, optim_warp: bool = False, fused_warp_trainable: bool = True):
     """Second figure of SURVEY.md 8(d): images/s of the FULL Stage-3 fitting step (bob LBS warp with frozen,
     randomly initialised warp / camera networks -> rasterize 2 frames -> losses -> backward -> gradient clip ->
     densification statistics -> Adam) on an object-centric synthetic sequence of the same size.
@@ -130,19 +130,26 @@ def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: i
     densify: BASELINE.json configs[2] as written -- "densify+prune on": the schedule's densify_and_prune every 100 steps
     from step 500 on (lab4d/engine/trainer.py:549-572, gs/scene/gaussian_model.py:434-448) runs INSIDE the timed region
     (start_step 501 and >= 300 steps: three events), on the device (csrc/optim.hip); the surfel count before / after is
-    reported."""
+    reported.
+    optim_warp: the reference's DEFAULT flag value --gs_optim_warp=True (lab4d/config.py:157): the bone / articulation / camera /
+    skinning networks train too (AdamW, trainer.py:592-598; start_step >= optim_warp_neus_iters = 12 000 so that it steps).
+    Round 5: the fused warp then still applies -- the networks are evaluated for the step's frames with autograd, the delta-skin
+    MLP as library GEMMs, and the skinning kernel's backward reduces d/d (bone dual quaternions, cameras) over the surfels;
+    fused_warp_trainable=False times the ~40-kernel torch chain rounds 1-4 fell back to (same step, for the A/B)."""
     import numpy as np
     from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
     from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     frames = 120
-    m = DeformableSurfels(dict(fg_motion="gs-bob") | ({} if densify else dict(densify_until_iter=0)), num_frames=frames,
-                          device=dev)
+    m = DeformableSurfels(dict(fg_motion="gs-bob") | ({} if densify else dict(densify_until_iter=0)) |
+                          (dict(fused_warp_trainable=fused_warp_trainable) if optim_warp else {}), num_frames=frames, device=dev)
     d = rng.normal(size=(n_surfels, 3)).astype(np.float32)
     pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(n_surfels, 1)).astype(np.float32) ** (1 / 3)
     m.init_from_points(pts.astype(np.float32), rng.uniform(size=(n_surfels, 3)).astype(np.float32))
-    tr = Stage3Trainer(m)
+    tr = Stage3Trainer(m, (m.opts | dict(gs_optim_warp=True)) if optim_warp else None)
+    if optim_warp:
+        assert m.warp_networks_train() and m.fused_warp_ok() == bool(fused_warp_trainable)
     if start_step:
         m.active_sh_degree = m.max_sh_degree   # (reached at step 3000)
         tr.current_steps = start_step
@@ -175,7 +182,11 @@ def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: i
     out = {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps, "warmup_steps": warm,
            "seconds": dt * steps,
            "config": f"{n_surfels} surfels in a unit ball 3 units from the camera, {W}x{H}, 25 bones, 120 frames, "
-                     "warp / camera networks frozen (--gs_optim_warp=False), densify " + ("+ prune ON; " if densify else "off; ") + regime}
+                     + ("warp / camera / skinning networks TRAIN (--gs_optim_warp=True, the reference's default; AdamW steps on them), " +
+                        ("fused warp with parameter gradients from the skinning kernel" if fused_warp_trainable else
+                         "un-fused torch warp chain (rounds 1-4's fallback)") if optim_warp else
+                        "warp / camera networks frozen (--gs_optim_warp=False)") +
+                     ", densify " + ("+ prune ON; " if densify else "off; ") + regime}
     if densify:
         out["surfels_before"], out["surfels_after"] = n_before, int(m._xyz.shape[0])
         out["densification_events"] = [{"step": s, "surfels": [a, b]} for s, a, b in events]
@@ -804,6 +815,10 @@ def main():
             out["fit_step_geometry"] = fit_step_rate(dev, N, W, H, args.fit_steps, start_step=8001)
             if args.fit_densify_steps > 0:
                 out["fit_step_densify"] = fit_step_rate(dev, N, W, H, args.fit_densify_steps, start_step=501, densify=True)
+            # the reference's default flag value: the networks train too (step >= 12 000: their optimizer steps)
+            out["fit_step_optim_warp"] = fit_step_rate(dev, N, W, H, args.fit_steps, start_step=12001, optim_warp=True)
+            out["fit_step_optim_warp_unfused"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), start_step=12001,
+                                                               optim_warp=True, fused_warp_trainable=False)
         if world == 1:
             # MODELLED multi-GPU figures (no multi-GPU node is reachable from the build box; the driver
             # measures the real curve when it has one): measured 1-GPU step + the all-reduce cost model above

@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 17
+#define VIDU4D_SURFEL_ABI 18
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -325,16 +325,29 @@ int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const float* se3_q
  * writing g_xbT (which may be NULL): three quarters of the kernels' traffic.  Otherwise pass bone_A = bone_c = NULL.
  * frame_index (M device int64, or NULL; ABI 17): se3_qr / se3_qd / cam_q / cam_t are then TABLES over all frames of the
  * sequence ((frames,B,4), (frames,4), (frames,3): what frozen networks give once per run) and frame m of the call is their
- * row frame_index[m] -- the per-step row gathers happen inside the kernels. */
+ * row frame_index[m] -- the per-step row gathers happen inside the kernels.  table_rows (ABI 18): the number of rows of
+ * those tables; an index outside [0, table_rows) reads the first / last row (the torch indexing this replaces raised).
+ * g_params (backward, ABI 18; NULL = bones and cameras are constants, --gs_optim_warp=False): the gradients w.r.t. the
+ * frames' bone dual quaternions and cameras, for networks that train (the reference's default, lab4d/config.py:157;
+ * AdamW on them, lab4d/engine/trainer.py:592-598).  They are sums over all surfels; every workgroup of 256 surfels leaves
+ * ONE row of partial sums, g_params = float[vidu4d_lbs_skin_param_rows(N)][M][8 B + 8]:
+ *   [m][8 b .. 8 b + 3] d/d se3_qr[m][b]   [m][8 b + 4 .. 8 b + 7] d/d se3_qd[m][b]
+ *   [m][8 B .. 8 B + 3] d/d cam_q[m]       [m][8 B + 4 .. 8 B + 6] d/d cam_t[m]      ([m][8 B + 7]: 0)
+ * and the caller adds the rows up.  Needs the bone coordinates as an input (xbT != NULL, bone_A == NULL:
+ * VIDU4D_E_UNSUPPORTED otherwise) -- the gradient of the bone map then flows through whatever produced xbT -- and
+ * frame_index == NULL (per-frame rows).  The hemisphere signs and the anchor bone are piecewise constant, as in the
+ * reference's graph (lab4d/utils/geom_utils.py:66-74). */
 int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                             const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                             const float* cam_t, float* out_xyz, float* out_rot, int unit_rot, const float* bone_A,
-                            const float* bone_c, const int64_t* frame_index, void* stream);
+                            const float* bone_c, const int64_t* frame_index, int table_rows, void* stream);
 int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                              const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                              const float* cam_t, const float* g_out_xyz, const float* g_out_rot, float* g_xbT,
                              float* g_rawT, float* g_xyz, float* g_rot, int unit_rot, const float* bone_A,
-                             const float* bone_c, const int64_t* frame_index, void* stream);
+                             const float* bone_c, const int64_t* frame_index, int table_rows, float* g_params,
+                             void* stream);
+int vidu4d_lbs_skin_param_rows(int N);
 
 /* ---- the per-surfel part of the bob skinning field, once per optimizer step: Gaussian-bone coordinates of the rest
  *      pose and the delta-skin MLP on them (replaces gauss_mlp_skinning's bone transform and SkinningField.delta_field,

@@ -250,3 +250,118 @@ def test_lbs_skin_more_than_32_bones_against_torch(gpu_device, M, N, B):
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max())), (what, float((a - b).abs().max()))
     if B > 32:
         assert float(res[False][3][32:].abs().max()) > 0, "the bones beyond 32 must carry a gradient for this to test anything"
+
+
+@pytest.mark.parametrize("M,N,B,unit", [(2, 5000, 25, True), (1, 257, 25, False), (3, 1000, 7, True), (2, 700, 40, False)])
+def test_lbs_skin_gradients_of_bones_and_cameras(gpu_device, M, N, B, unit):
+    """Round 5: bones and cameras that TRAIN (--gs_optim_warp=True, the reference's default,
+    lab4d/config.py:157).  lbs_skin_apply's backward also returns d/d se3_qr, d/d se3_qd (M,B,4), d/d cam_q (M,4),
+    d/d cam_t (M,3) -- sums over all surfels, reduced in the kernel (csrc/lbs.hip, g_params) -- against autograd through the
+    torch statement of the same chain (the reference's graph: geom_utils.py:48-92, deformable_gaussian.py:1032-1046,
+    :1425-1430), next to the gradients the frozen path already had.  N = 257 / 700: a last workgroup that is mostly empty."""
+    from vidu4d_amd.lab4d.lbs_fused import lbs_skin_apply
+    dev = gpu_device
+    qr0, qd0, _, xyz, rot, cq0, ct0 = _inputs(dev, M, N, B, seed=91 + N)
+    g = torch.Generator().manual_seed(5)
+    xbT0 = (0.7 * torch.randn(3 * B, N, generator=g)).to(dev)
+    raw0 = (3.0 * torch.randn(B, N, generator=g)).to(dev)
+    gx, gr = torch.randn(M, N, 3, generator=g).to(dev), torch.randn(M, N, 4, generator=g).to(dev)
+    res = {}
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (xbT0, raw0, qr0, qd0, xyz, rot, cq0, ct0)]
+        xb, raw, qr, qd, x, r, cq, ct = leaves
+        if fused:
+            ox, orot = lbs_skin_apply(xb, raw, (qr, qd), x, r, cq, ct, unit_rot=unit)
+        else:
+            logits = -((xb.view(B, 3, N) ** 2).sum(1) + 0.1 * torch.relu(raw)).t()
+            ox, orot = _composite((qr, qd), logits, x, r, cq, ct)
+            if unit:
+                orot = torch.nn.functional.normalize(orot, dim=-1)
+        ((ox * gx).sum() + (orot * gr).sum()).backward()
+        res[fused] = [t.detach() for t in (ox, orot)] + [t.grad.detach() for t in leaves]
+    names = ("xyz_cam", "rot_cam", "g_xbT", "g_raw", "g_se3_qr", "g_se3_qd", "g_xyz", "g_rot", "g_cam_q", "g_cam_t")
+    for a, b, what in zip(res[True], res[False], names):
+        scale = float(b.abs().max())
+        assert scale > 0 or what == "g_raw", what
+        # (the sums run over up to 5000 surfels in another order than torch's: 1e-5 of the tensor's scale)
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-9, (what, float((a - b).abs().max()), scale)
+
+
+def test_fused_warp_with_networks_that_train_gives_every_parameter_its_gradient(gpu_device):
+    """The model's fused warp with bone / articulation / camera / skinning networks that require grad (fused_warp_ok no longer
+    asks for frozen networks).  (1) The warp itself -- canonical surfels -> camera-space centres and orientations of two
+    frames -- against the torch chain of rounds 1-4 (forward_warp; itself pinned against the imported reference,
+    tests/test_refpy_*): values, and the gradient of EVERY parameter that reaches it -- canonical centres and orientations, the
+    articulation MLP, the camera MLP, the skinning field incl. its delta MLP and Gaussian-bone scales -- to 1e-5 of each
+    tensor's scale.  (2) Through the rasterizer (render_frames): the same parameters receive gradients, equal to the torch
+    chain's to 1e-3 of scale (the two warps round differently in the last bits, which flips a few of the rasterizer's
+    per-pixel threshold decisions: test_render_frames_fused_equals_unfused holds the frozen path to the same bar)."""
+    from tests.test_gpu_stage3 import _model
+    from vidu4d_amd.lab4d.stage3 import make_intrinsics_inv
+    dev = gpu_device
+    H = W = 96
+
+    def make(fused):
+        m = _model(dev, seed=3, fused_warp=fused)
+        with torch.no_grad():   # (untrained delta / articulation output layers are ~0: give them weights that matter)
+            for mod in (m.warp, m.camera_mlp):
+                for p in mod.parameters():
+                    p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev))
+        assert m.warp_networks_train() and m.fused_warp_ok() == fused
+        return m
+
+    def grads(m):
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    def compare(got, want, tol, what):
+        assert set(got) == set(want), (what, set(got) ^ set(want))
+        bad = {}
+        for k, b in want.items():
+            scale = float(b.abs().max())
+            err = float((got[k] - b).abs().max())
+            if err > tol * scale + 1e-12:
+                bad[k] = (err, scale)
+        assert not bad, (what, bad)
+
+    fid = torch.tensor([1, 5], device=dev)
+    # ---- (1) the warp alone
+    res = {}
+    for fused in (True, False):
+        m = make(fused)
+        N = m._xyz.shape[0]
+        if fused:
+            x, r = m.forward_warp_fused(fid)
+            if m.__dict__.pop("_warp_rot_is_unit", False):
+                pass
+        else:
+            xyz = m._xyz[None, :, None].expand(2, -1, -1, -1)
+            rot = m._rotation[None].expand(2, -1, -1)
+            x, r, _ = m.forward_warp(xyz, rot, fid)
+            x = x[:, :, 0]
+            if m.opts.get("fused_rot_activation", True):   # (the fused kernel hands the orientations on normalised)
+                r = torch.nn.functional.normalize(r, dim=-1)
+        gen = torch.Generator().manual_seed(11)
+        gx, gr = torch.randn(2, N, 3, generator=gen).to(dev), torch.randn(2, N, 4, generator=gen).to(dev)
+        ((x * gx).sum() + (r * gr).sum()).backward()
+        res[fused] = (x.detach(), r.detach(), grads(m))
+    for a, b, what in zip(res[True][:2], res[False][:2], ("xyz_cam", "rot_cam")):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), what
+    net = [k for k in res[False][2] if k.startswith(("warp.", "camera_mlp."))]
+    assert len(net) >= 10, net
+    assert all(float(res[False][2][k].abs().max()) > 0 for k in net if "inst_embedding" not in k), "a network parameter without gradient"
+    compare(res[True][2], res[False][2], 1e-5, "warp")
+    # ---- (2) through the rasterizer
+    out = {}
+    for fused in (True, False):
+        m = make(fused)
+        r = m.render_frames(fid, make_intrinsics_inv(2, H, W, device=dev), [H, H], [W, W])
+        gen = torch.Generator().manual_seed(12)
+        wts = {k: torch.randn(r[k].shape, generator=gen).to(dev) for k in ("rendered", "mask", "rend_normal")}
+        sum((r[k] * wts[k]).sum() for k in wts).backward()
+        out[fused] = ({k: r[k].detach() for k in wts}, grads(m))
+    for k in out[False][0]:
+        assert float((out[True][0][k] - out[False][0][k]).abs().max()) <= 1e-3 * float(out[False][0][k].abs().max()), k
+    # (network parameters: sums over all surfels, 1e-3; a per-surfel tensor sees a flipped pixel in ONE of its rows: 1e-2)
+    compare({k: v for k, v in out[True][1].items() if k in net}, {k: v for k, v in out[False][1].items() if k in net}, 1e-3, "render, networks")
+    compare({k: v for k, v in out[True][1].items() if k not in net}, {k: v for k, v in out[False][1].items() if k not in net}, 1e-2,
+            "render, surfels")

@@ -100,14 +100,16 @@ def test_deferred_capacity_check_detects_overflow_and_replays(gpu_device):
         try:
             tr.train_step(batches[0])
             if mode == "deferred":  # pretend the previous frames were almost empty: the guess is far too small
-                for k in list(_C._capacity_hint):
-                    _C._capacity_hint[k] = 64
+                hints = m.raster_context.capacity_hint   # (the model's own rasterizer context holds its hints)
+                assert hints, "the first step left no capacity hint in the model's context"
+                for k in list(hints):
+                    hints[k] = 64
             tr.train_step(batches[1])
         finally:
             if mode == "exact":
                 _C._EXACT = old
         res[mode] = m._xyz.detach().clone(), m._features_dc.detach().clone()
-        assert not _C._pending
+        assert not m.raster_context.pending and not _C._pending
     for a, b in zip(res["deferred"], res["exact"]):
         # (Adam normalises the step: where a gradient is ~0 the order of the float atomics may flip its sign
         # in ANY two runs, so single entries may differ by a couple of learning rates; the bulk may not)

@@ -334,7 +334,8 @@ def test_long_list_sort_mode_follows_the_longest_list_of_earlier_frames():
 def test_auto_split_wants_deep_blending_and_too_few_long_tiles():
     """_C's host-side policy for Vidu4dSurfelForwardArgs::segment_split under VIDU4D_SURFEL_SPLIT=auto (no GPU involved): the
     forward is segment-parallel only when a pixel of the earlier frames blended deeper than SPLIT_AUTO_LEN AND those frames
-    had fewer long tiles (header word 4) than SPLIT_AUTO_TILES_PER_CU per compute unit -- a frame with enough long tiles
+    had fewer long tiles (header word 14: tiles longer than 1024 entries, the same count after a whole-tile and after a split
+    frame; word 4, which the rule read until round 4, follows the mode) than SPLIT_AUTO_TILES_PER_CU per compute unit -- a frame with enough long tiles
     fills the chip with whole-tile walks, which stop at saturation, and its backward is segment-parallel anyway."""
     import torch
     from vidu4d_amd import _C
@@ -347,10 +348,10 @@ def test_auto_split_wants_deep_blending_and_too_few_long_tiles():
     key = ("test-shape-split",)
     _C._long_tiles_hint.pop(key, None)
     slot = torch.zeros(16, dtype=torch.int32)
-    slot[0], slot[2], slot[4] = 1000, 5000, 720
+    slot[0], slot[2], slot[_C.HEADER_LONG_TILES_WORD], slot[4] = 1000, 5000, 720, 9999
     _C.check_slots([(slot, None, 2000, key)])
     assert _C._long_tiles_hint[key] == 720                          # the latest frame's count, no smoothing
-    slot[4] = 350
+    slot[_C.HEADER_LONG_TILES_WORD] = 350
     _C.check_slots([(slot, None, 2000, key)])
     assert _C._long_tiles_hint[key] == 350
     for d in (_C._long_tiles_hint, _C._len_hint, _C._unlimited, _C._capacity_hint):
@@ -463,3 +464,47 @@ def test_modelled_scaling_arithmetic():
     small = b.exchange_model_ms(200_000 * 13 * 4 + 12, 8)["ring_all_links"]
     rest = b.exchange_model_ms(200_000 * 45 * 4, 8)["ring_all_links"]
     assert abs(fit["serial_exchange_ms"]["ring_all_links"] - round(max(0.0, rest - b.WARP_BACKWARD_MS) + small, 3)) < 1e-9
+
+
+def test_raster_contexts_do_not_share_state():
+    """Round 5: the rasterizer's host-side state lives in RasterContext objects the caller owns; the
+    module-level API acts on the calling thread's current one.  No GPU involved."""
+    import threading
+    import torch
+    from vidu4d_amd import _C
+    assert _C.current() is _C._default and _C._capacity_hint is _C._default.capacity_hint and _C._pending is _C._default.pending
+    a, b = _C.RasterContext(), _C.RasterContext()
+    key = ("ctx-test",)
+    slot = torch.zeros(16, dtype=torch.int32)
+    slot[0], slot[2], slot[14] = 1000, 77, 5
+    with a:
+        assert _C.current() is a
+        assert _C.check_slots([(slot, None, 2000, key)]) is True          # -> a's hints
+        with b:                                                           # nests; b's deferred mode is b's alone
+            assert _C.current() is b
+            with _C.deferred_capacity_check():
+                assert b.deferred and not a.deferred and not _C._default.deferred
+            with _C.gradient_buffers(dL_dopacity=torch.zeros(4, 1)):
+                assert "dL_dopacity" in b.grad_out and not a.grad_out
+            assert not b.grad_out and not b.deferred
+            with _C.debug_flags(3):
+                assert b.flags() == 3 and a.flags() == int(_C.DEBUG_FLAGS)
+        assert _C.current() is a
+    assert _C.current() is _C._default
+    assert a.capacity_hint[key] >= 1000 and a.len_hint[key] == 77 and a.long_tiles_hint[key] == 5
+    assert key not in b.capacity_hint and key not in _C._capacity_hint and key not in _C._len_hint
+    assert _C.check_slots([(slot, None, 500, key)], context=b) is False and key in b.capacity_hint   # explicit context
+
+    # another thread's default context is its own (the main thread's is the module-level one)
+    seen = {}
+
+    def worker():
+        seen["ctx"] = _C.current()
+        with _C.deferred_capacity_check():
+            seen["deferred_here"], seen["deferred_main"] = _C.current().deferred, _C._default.deferred
+        with a:
+            seen["under_a"] = _C.current() is a
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen["ctx"] is not _C._default and seen["deferred_here"] and not seen["deferred_main"] and seen["under_a"]

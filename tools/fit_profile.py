@@ -67,8 +67,9 @@ if os.environ.get("FIT_TILE_STATS", "0") == "1":   # how far the forward's walk 
 if os.environ.get("FIT_PRINT_HINTS", "0") == "1":   # what the split decision sees
     from vidu4d_amd import _C
     print("FIT_DECISIONS first", _decisions[:8], "last", _decisions[-4:], "split in", sum(d[2] for d in _decisions), "of", len(_decisions))
-    print("FIT_HINTS deepest blended list position", list(_C._depth_hint.values()), "longest list", list(_C._len_hint.values()),
-          "tiles longer than 1024 entries", list(_C._long_tiles_hint.values()))
+    rc = m.raster_context
+    print("FIT_HINTS deepest blended list position", list(rc.depth_hint.values()), "longest list", list(rc.len_hint.values()),
+          "tiles longer than 1024 entries", list(rc.long_tiles_hint.values()))
 if os.environ.get("FIT_WALK_STATS", "0") == "1":   # what the backward's walk of one step looks like (vidu4d_surfel_blend_stats)
     from vidu4d_amd import _C
     cnt = torch.zeros(16, dtype=torch.int64, device=dev)

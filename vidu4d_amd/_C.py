@@ -18,6 +18,7 @@ import contextlib
 import ctypes as C
 import math
 import os
+import threading
 
 import torch
 
@@ -34,28 +35,15 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 # blends every segment up to the caller's limit, the whole-tile walk stops where the pixels saturate.  Stage-3 ball of
 # 200 k surfels at 512^2, two frames (tools/gpu_r4_z.sh): radius 1.0 = 720 long tiles, depth 4.5 k: 1.18 ms whole / 1.23
 # split (1.42 / 1.55 in the regularised regime); radius 0.7 = 350 tiles, 6.7 k: 1.30 / 1.19; 0.5: 1.59 / 1.21; 0.3: 2.78 / 2.00.
+# Round 5: "long" is now the same count in either mode -- tiles longer than SPLIT_MIN = 1024 entries, Header word 14; the
+# round-4 counts above were tiles above the recorded segments' 320-entry class after a whole-tile frame and positions up to
+# the last 1024-entry tile after a split one, so the rule could stay in whichever mode ran first.  Same scene, same threshold
+# (tools/gpu_r5_d.sh, profiles/r05_split_rule.txt): radius 1.0 = 604 tiles: 1.27 whole / 1.24 split; 0.85 = 440: 1.25 / 1.14;
+# 0.7 = 320: 1.25 / 1.05; 0.5 = 176: 1.52 / 1.02 -- the split is taken from radius 1.0 down, and is the faster or equal one.
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = int(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_LEN", "2048"))
 SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU", "2.5"))
-_long_tiles_hint: dict = {}  # tiles longer than SPLIT_MIN entries (Header word 14), latest frame of a shape
-_cu_count: dict = {}
-_capacity_hint: dict = {}
-# Deferred capacity check (opt-in, for callers that can replay a step -- Stage3Trainer): the forward
-# does not wait for the pair count at all; it leaves (event, pinned slot, capacity) in `_pending`, and
-# `check_deferred()` -- called once per step after everything is queued -- reports whether some frame
-# overflowed its binning buffer (it then rendered only the background) so that the caller can discard
-# the step and run it again.  The host can then run a whole step ahead of the GPU.
-_deferred = False
-_graph_mode = False   # deferred + nothing that cannot be captured into a hipGraph (no events)
-_pending: list = []
-_depth_stat: dict = {}   # key -> (device counter, pinned copy)
-_depth_hint: dict = {}
-_len_hint: dict = {}        # longest tile list of earlier frames of a shape (Header word 2; slowly decaying maximum)
 MSD_SORT_FROM = int(os.environ.get("VIDU4D_MSD_SORT_FROM", "10000"))  # longest list from which the long lists are MSD-split
-# Deferred calls also limit the split to the segments the previous frames needed (+25 %, +1): the
-# transmittance pass then skips the tail of long lists that saturate early.  A frame that needed more
-# sets Header::truncated, check_deferred() reports it like an overflow, and the next calls run unlimited.
-_unlimited: dict = {}
 # The segment-parallel alpha-only blend runs without its transmittance pre-pass (Vidu4dSurfelForwardArgs::
 # assume_unsaturated): segments are blended from T = 1 and scaled in the combine, which blends the one segment a pixel
 # saturates in again from the exact start (round 3; until then a saturating frame raised Header::truncated and was
@@ -66,47 +54,123 @@ _SPEC = os.environ.get("VIDU4D_SURFEL_SPEC", "1") == "1"
 # saturating segments costs more than the transmittance pre-pass it saves (blend_fwd + combine 250 + 311 us against
 # seg_T + blend_fwd + combine 148 + 255 + 50, profiles/r04_fit_step_geometry_kernel_stats*.csv).
 _SPEC_GEOM = os.environ.get("VIDU4D_SURFEL_SPEC_GEOM", "0") == "1"
-_pinned: dict = {}
 # Debugging switches (Vidu4dSurfel*Args::debug_flags).  VIDU4D_SURFEL_NO_CULL=1: the blend kernels' footprint culls are off
 # (every list entry is evaluated for every pixel of its tile, as the reference does); VIDU4D_SURFEL_WHOLE_TILE_BWD=1: the
-# backward of an unsplit forward walks every tile with one workgroup (no recorded segments).  Module attributes, so that a
-# test can A/B them inside one process.
+# backward of an unsplit forward walks every tile with one workgroup (no recorded segments).  The process-wide default; a
+# context (below) may override it for the calls made under it.
 DEBUG_FLAGS = ((_lib.DEBUG_NO_CULL if os.environ.get("VIDU4D_SURFEL_NO_CULL", "0") == "1" else 0) |
                (_lib.DEBUG_WHOLE_TILE_BACKWARD if os.environ.get("VIDU4D_SURFEL_WHOLE_TILE_BWD", "0") == "1" else 0))
-_walk_counters = None   # (device int64 tensor, one-shot): the next backward also counts its tile walk (vidu4d_surfel_diag.h)
+_cu_count: dict = {}
 
 
-_hint_scope = None
+class RasterContext:
+    """The host-side state of ONE caller's rasterizer calls (round 5: it used to be module globals).
+
+    The reference keeps every bit of state in the three buffers a forward returns and is re-entrant
+    (rasterize_points.cu:31-37, :92-103).  This build keeps a little more on the host, because it does not stall the GPU in
+    the middle of a forward: guesses from the caller's previous frames (pair count, deepest blended list position, longest
+    list, long tiles), the forwards whose pair count has not been checked yet (`pending`, deferred mode), one-shot gradient
+    output buffers and diagnostics.  Two models stepping alternately, or two threads rendering at once, must not share
+    that -- so it lives in a context object the CALLER owns:
+
+        ctx = _C.RasterContext()            # DeformableSurfels owns one (`model.raster_context`)
+        with ctx:                           # calls inside use it (a per-thread stack; nests)
+            color, radii, allmap = rasterizer(...)
+
+    The autograd functions remember the context of their forward and hand it to their backward (which the autograd engine
+    runs on a thread of its own).  The module-level API -- deferred_capacity_check(), check_deferred(), gradient_buffers(),
+    hint_scope(), debug_flags(), count_next_walk() -- acts on `current()`: the innermost `with ctx:` of the calling thread, or
+    that thread's own default context (the main thread's is the module-level `_capacity_hint`, `_pending`, ... of old)."""
+
+    def __init__(self, scope=None):
+        self.scope = scope            # part of the hint keys (kept from rounds 3-4: hint_scope())
+        self.deferred = False         # deferred capacity check: forwards do not wait for the pair count ...
+        self.graph_mode = False       # ... and record no events (hipGraph capture)
+        self.pending: list = []       # (event, pinned slot, depth stat, capacity, key, stream) of the unchecked forwards
+        self.grad_out: dict = {}      # one-shot caller-supplied gradient outputs (gradient_buffers)
+        self.grad_written = None
+        self.debug_flags = None       # None: the process-wide DEBUG_FLAGS
+        self.walk_counters = None     # (device int64 tensor, one-shot): the next backward counts its tile walk
+        self.capacity_hint: dict = {}
+        self.depth_hint: dict = {}
+        self.len_hint: dict = {}      # longest tile list of earlier frames of a shape (Header word 2; slowly decaying maximum)
+        self.long_tiles_hint: dict = {}   # tiles longer than SPLIT_MIN entries (Header word 14), latest frame of a shape
+        # Deferred calls also limit the split to the segments the previous frames needed (+25 %, +1): the transmittance
+        # pass then skips the tail of long lists that saturate early.  A frame that needed more sets Header::truncated,
+        # check_deferred() reports it like an overflow, and the next calls run unlimited.
+        self.unlimited: dict = {}
+        self.depth_stat: dict = {}    # key -> (device counter, pinned copy)
+        self.pinned: dict = {}
+
+    def __enter__(self):
+        _stack().append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _stack().pop()
+        return False
+
+    def flags(self) -> int:
+        return int(DEBUG_FLAGS if self.debug_flags is None else self.debug_flags)
+
+
+_tls = threading.local()
+_default = RasterContext()   # the main thread's default context
+
+
+def _stack() -> list:
+    st = getattr(_tls, "stack", None)
+    if st is None:
+        st = _tls.stack = []
+    return st
+
+
+def current() -> RasterContext:
+    """The context the calling thread's rasterizer calls use right now."""
+    st = _stack()
+    if st:
+        return st[-1]
+    if threading.current_thread() is threading.main_thread():
+        return _default
+    d = getattr(_tls, "default", None)
+    if d is None:
+        d = _tls.default = RasterContext()
+    return d
+
+
+# the main thread's default context under its old module-level names (tests and tools read / plant hints through them)
+_capacity_hint, _depth_hint, _len_hint = _default.capacity_hint, _default.depth_hint, _default.len_hint
+_long_tiles_hint, _unlimited, _pending = _default.long_tiles_hint, _default.unlimited, _default.pending
+_depth_stat, _pinned = _default.depth_stat, _default.pinned
 
 
 @contextlib.contextmanager
 def hint_scope(scope):
-    """The capacity / split-depth / longest-list hints of the rasterizer calls inside are kept per `scope` (any hashable:
-    DeformableSurfels passes id(self)) instead of per image shape alone."""
-    global _hint_scope
-    old, _hint_scope = _hint_scope, scope
+    """The capacity / split-depth / longest-list hints of the rasterizer calls inside are kept per `scope` (any hashable)
+    instead of per image shape alone.  (Rounds 3-4; a caller with a RasterContext of its own needs no scope.)"""
+    ctx = current()
+    old, ctx.scope = ctx.scope, scope
     try:
         yield
     finally:
-        _hint_scope = old
+        ctx.scope = old
 
 
 @contextlib.contextmanager
 def debug_flags(flags: int):
     """with debug_flags(_lib.DEBUG_NO_CULL): ... -- forward AND backward inside run with these switches."""
-    global DEBUG_FLAGS
-    old, DEBUG_FLAGS = DEBUG_FLAGS, int(flags)
+    ctx = current()
+    old, ctx.debug_flags = ctx.debug_flags, int(flags)
     try:
         yield
     finally:
-        DEBUG_FLAGS = old
+        ctx.debug_flags = old
 
 
 def count_next_walk(counters):
     """Diagnostic: the next rasterize_gaussians_backward call adds its tile-walk statistics to `counters`
     (int64, >= _lib.BLEND_STATS entries, on the device, zeroed by the caller)."""
-    global _walk_counters
-    _walk_counters = counters
+    current().walk_counters = counters
 
 
 def _ptr(t):
@@ -134,16 +198,19 @@ def _check_cuda(*ts):
 
 
 class deferred_capacity_check:
-    """Context manager: rasterize_gaussians calls inside do not block on the pair count."""
+    """Context manager: rasterize_gaussians calls inside (under the calling thread's current RasterContext) do not block on
+    the pair count.  Opt-in, for callers that can replay a step -- Stage3Trainer: the forward leaves (event, pinned slot,
+    capacity) in the context's `pending`, and `check_deferred()` -- called once per step after everything is queued --
+    reports whether some frame overflowed its binning buffer (it then rendered only the background) so that the caller can
+    discard the step and run it again.  The host can then run a whole step ahead of the GPU."""
 
     def __enter__(self):
-        global _deferred
-        self._old, _deferred = _deferred, True
+        self._ctx = current()
+        self._old, self._ctx.deferred = self._ctx.deferred, True
         return self
 
     def __exit__(self, *exc):
-        global _deferred
-        _deferred = self._old
+        self._ctx.deferred = self._old
         return False
 
 
@@ -154,18 +221,18 @@ class graph_capture_mode:
     replay and a stream synchronise pass them to `check_slots`."""
 
     def __enter__(self):
-        global _deferred, _graph_mode
-        self._old = (_deferred, _graph_mode)
-        _deferred = _graph_mode = True
-        self._n0 = len(_pending)
+        self._ctx = c = current()
+        self._old = (c.deferred, c.graph_mode)
+        c.deferred = c.graph_mode = True
+        self._n0 = len(c.pending)
         self.frames = []
         return self
 
     def __exit__(self, *exc):
-        global _deferred, _graph_mode
-        _deferred, _graph_mode = self._old
-        self.frames = [(p[1], p[2], p[3], p[4]) for p in _pending[self._n0:]]
-        del _pending[self._n0:]
+        c = self._ctx
+        c.deferred, c.graph_mode = self._old
+        self.frames = [(p[1], p[2], p[3], p[4]) for p in c.pending[self._n0:]]
+        del c.pending[self._n0:]
         return False
 
 
@@ -180,14 +247,14 @@ def _depth_of(stat, slot) -> int:
     return int(slot[HEADER_DEPTH_WORD]) if stat == "header" else int(stat[1][0])
 
 
-def _note_longest_list(slot, key):
-    _len_hint[key] = max(int(slot[2]), int(0.9 * _len_hint.get(key, 0)))
-    _long_tiles_hint[key] = int(slot[HEADER_LONG_TILES_WORD])
+def _note_longest_list(ctx, slot, key):
+    ctx.len_hint[key] = max(int(slot[2]), int(0.9 * ctx.len_hint.get(key, 0)))
+    ctx.long_tiles_hint[key] = int(slot[HEADER_LONG_TILES_WORD])
 
 
 def auto_split(depth: int, long_tiles: int, compute_units: int) -> bool:
     """VIDU4D_SURFEL_SPLIT=auto: blend this frame's long tiles segment-parallel?  depth: deepest list position a pixel of
-    the earlier frames blended; long_tiles: their tiles longer than the schedule's split threshold (0: not known yet)."""
+    the earlier frames blended; long_tiles: their tiles longer than SPLIT_MIN = 1024 entries (0: not known yet)."""
     return depth > SPLIT_AUTO_LEN and long_tiles < SPLIT_AUTO_TILES_PER_CU * compute_units
 
 
@@ -198,53 +265,55 @@ def _compute_units(dev) -> int:
     return n
 
 
-def check_slots(frames) -> bool:
+def check_slots(frames, context=None) -> bool:
+    ctx = context or current()
     ok = True
     for slot, stat, cap, key in frames:
         n = int(slot[0])
-        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 4096)
+        ctx.capacity_hint[key] = max(ctx.capacity_hint.get(key, 0), int(n * 1.25) + 4096)
         if stat is not None:
-            _depth_hint[key] = max(_depth_of(stat, slot), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
-        _note_longest_list(slot, key)
+            ctx.depth_hint[key] = max(_depth_of(stat, slot), int(0.9 * ctx.depth_hint.get(key, 0)))  # slowly decaying maximum
+        _note_longest_list(ctx, slot, key)
         if int(slot[6]):
-            _unlimited[key] = 4
+            ctx.unlimited[key] = 4
             ok = False
         ok = ok and n <= cap
     return ok
 
 
-def check_deferred() -> bool:
+def check_deferred(context=None) -> bool:
     """Waits for the pair counts of the deferred forwards queued since the last call (their events were
     recorded right after the tile scan, long passed by the time a step is fully queued), refreshes the
     capacity / split hints, and returns False if any of them overflowed its binning buffer."""
+    ctx = context or current()
     ok = True
-    for ev, slot, stat, cap, key, _sid in _pending:
+    for ev, slot, stat, cap, key, _sid in ctx.pending:
         if ev is not None:
             ev.synchronize()
         n = int(slot[0])
         # (a slowly decaying maximum: the buffers shrink again after a prune)
-        _capacity_hint[key] = max(int(n * 1.25) + 4096, int(0.98 * _capacity_hint.get(key, 0)))
+        ctx.capacity_hint[key] = max(int(n * 1.25) + 4096, int(0.98 * ctx.capacity_hint.get(key, 0)))
         if stat is not None:
-            _depth_hint[key] = max(_depth_of(stat, slot), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
-        _note_longest_list(slot, key)
+            ctx.depth_hint[key] = max(_depth_of(stat, slot), int(0.9 * ctx.depth_hint.get(key, 0)))  # slowly decaying maximum
+        _note_longest_list(ctx, slot, key)
         if int(slot[6]):  # the segment limit cut a tile short: this frame is incomplete,
-            _unlimited[key] = 4   # the next ones run unlimited
+            ctx.unlimited[key] = 4   # the next ones run unlimited
             ok = False
         ok = ok and n <= cap
-    _pending.clear()
+    ctx.pending.clear()
     return ok
 
 
-def _pinned_slot(device):
+def _pinned_slot(device, ctx):
     # one slot per (device, stream): frames rendered concurrently on different streams must not share it;
     # deferred forwards keep theirs until they have been checked, so the k-th pending forward of a stream
     # gets the k-th slot of that stream (the same ones every step)
     sid = torch.cuda.current_stream(device).cuda_stream
-    k = sum(1 for p in _pending if p[4][2] == str(device) and p[5] == sid) if _deferred else 0
+    k = sum(1 for p in ctx.pending if p[4][2] == str(device) and p[5] == sid) if ctx.deferred else 0
     key = (str(device), sid, k)
-    if key not in _pinned:
-        _pinned[key] = torch.zeros(16, dtype=torch.int32).pin_memory()  # Header words 0..15 (surfel_state.h)
-    return _pinned[key]
+    if key not in ctx.pinned:
+        ctx.pinned[key] = torch.zeros(16, dtype=torch.int32).pin_memory()  # Header words 0..15 (surfel_state.h)
+    return ctx.pinned[key]
 
 
 def _set_frame_cams(args, frame_cams, keep):
@@ -259,8 +328,10 @@ def _set_frame_cams(args, frame_cams, keep):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, frame_cams=None, sh_rest=None, raw_params=False, aux_planes=0):
+                        prefiltered, debug, frame_cams=None, sh_rest=None, raw_params=False, aux_planes=0, context=None):
     """-> (num_rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer)
+
+    context: the RasterContext whose hints / deferred mode / debug switches this call uses (default: current()).
 
     sh_rest / raw_params (extension: the canonical parameters as the optimizer holds them, no activation / concatenation
     launches in between): with sh_rest (P,15,3), `sh` is the (P,1,3) DC tensor; raw_params: `scales` are log-scales and
@@ -272,6 +343,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     share opacity / scales / sh are rasterized by one launch set: means3D (F,P,3), rotations (F,P,4) -> out_color
     (3,F,H,W), out_others (8,F,H,W), radii (F,P); viewmatrix / campos / tan_fov* arguments are ignored."""
     lib = _lib.load()
+    ctx = context or current()
+    _deferred, _graph_mode = ctx.deferred, ctx.graph_mode
     F = 1 if frame_cams is None else len(frame_cams)
     if frame_cams is not None:
         if not 1 <= F <= 8:
@@ -330,7 +403,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a.background, a.means3D, a.shs, a.colors_precomp = _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors)
     if sh_rest is not None:
         a.shs, a.sh_dc, a.sh_rest = None, _ptr(sh), _ptr(sh_rest)
-    a.raw_params, a.aux_planes, a.debug_flags = int(bool(raw_params)), int(aux_planes), int(DEBUG_FLAGS)
+    a.raw_params, a.aux_planes, a.debug_flags = int(bool(raw_params)), int(aux_planes), ctx.flags()
     a.opacities, a.scales, a.rotations = _ptr(opacity), _ptr(scales), _ptr(rotations)
     a.transMat_precomp = _ptr(transMat_precomp)
     a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
@@ -344,15 +417,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # (keying on P leaked one entry -- with a device tensor and a pinned buffer -- per surfel count).
     # ... and, where the caller names one, on its scope (hint_scope: a model instance) -- two models that render the same image
     # size no longer feed each other's guesses.  (key[2] stays the device: _pinned_slot reads it.)
-    key = (W, H, str(dev), F, _hint_scope)
+    key = (W, H, str(dev), F, ctx.scope)
     stat = None
-    hint = _capacity_hint.get(key)
+    hint = ctx.capacity_hint.get(key)
     if _SPLIT == "auto":
-        depth = _depth_hint.get(key, 0)
-        a.segment_split = int(auto_split(depth, _long_tiles_hint.get(key, 0), _compute_units(dev)))
+        depth = ctx.depth_hint.get(key, 0)
+        a.segment_split = int(auto_split(depth, ctx.long_tiles_hint.get(key, 0), _compute_units(dev)))
         if a.segment_split and _deferred and not debug:
-            if _unlimited.get(key, 0) > 0:
-                _unlimited[key] -= 1
+            if ctx.unlimited.get(key, 0) > 0:
+                ctx.unlimited[key] -= 1
             else:
                 a.segment_split = max(2, (int(depth * 1.25) + 511) // 512 + 1)
         if _deferred and not debug and hint is not None and not _EXACT:
@@ -361,17 +434,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             stat = "header"
             a.depth_used = geom.data_ptr() + 4 * HEADER_DEPTH_WORD
         else:
-            stat = _depth_stat.get((key, stream))
+            stat = ctx.depth_stat.get((key, stream))
             if stat is None:
-                stat = _depth_stat[(key, stream)] = (torch.zeros(1, dtype=torch.int32, device=dev),
+                stat = ctx.depth_stat[(key, stream)] = (torch.zeros(1, dtype=torch.int32, device=dev),
                                                      torch.zeros(1, dtype=torch.int32).pin_memory())
             a.depth_used = stat[0].data_ptr()
     else:
         a.segment_split = int(_SPLIT == "1")
     # long lists: the MSD split + bucket sorts from ~10 k entries per list on, one workgroup per list through global memory
     # below (dense Stage-3 ball, 5 k-entry lists: 81 us against 109; 3 %-coverage object, 25 k: 171 against 78)
-    a.long_list_sort = 0 if _len_hint.get(key, 1 << 30) >= MSD_SORT_FROM else 1
-    a.max_list_hint = int(_len_hint.get(key, 0))   # (0: unknown.  Short lists only: one sort launch instead of two)
+    a.long_list_sort = 0 if ctx.len_hint.get(key, 1 << 30) >= MSD_SORT_FROM else 1
+    a.max_list_hint = int(ctx.len_hint.get(key, 0))   # (0: unknown.  Short lists only: one sort launch instead of two)
     if a.segment_split and ((int(aux_planes) == _lib.AUX_ALPHA and _SPEC) or
                             (int(aux_planes) != _lib.AUX_ALPHA and int(aux_planes) and not (int(aux_planes) & ~_lib.AUX_GEOM)
                              and _SPEC_GEOM)):
@@ -395,7 +468,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     else:
         cap = hint
         binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
-        slot = _pinned_slot(dev)
+        slot = _pinned_slot(dev, ctx)
         if stat is not None and stat != "header":  # depth reached by the previous frame on this stream; then reset for this one
             stat[1].copy_(stat[0], non_blocking=True)
             stat[0].zero_()
@@ -409,7 +482,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             if not _graph_mode:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
-            _pending.append((ev, slot, stat, cap, key, stream))
+            ctx.pending.append((ev, slot, stat, cap, key, stream))
             binning._vidu4d_capacity = cap
             binning._vidu4d_split = int(a.segment_split)
             return cap, out_color, out_others, radii, geom, binning, img
@@ -421,13 +494,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         ev.synchronize()  # waits for preprocess + scan only; sort and blend keep running
         num_rendered = int(slot[0])
         if stat is not None:
-            _depth_hint[key] = max(int(stat[1][0]), int(0.9 * _depth_hint.get(key, 0)))  # slowly decaying maximum
+            ctx.depth_hint[key] = max(int(stat[1][0]), int(0.9 * ctx.depth_hint.get(key, 0)))  # slowly decaying maximum
         if num_rendered > cap:  # guess too small: queue the tail again with an exact buffer
             cap = num_rendered
             binning = torch.empty((lib.vidu4d_surfel_binning_bytes(cap),), dtype=torch.uint8, device=dev)
             _lib.check(lib.vidu4d_surfel_forward_run(C.byref(a), binning.data_ptr(), binning.numel(), cap, stream),
                        "surfel forward (re-run)")
-    _capacity_hint[key] = max(int(num_rendered * 1.25) + 4096, 4096)
+    ctx.capacity_hint[key] = max(int(num_rendered * 1.25) + 4096, 4096)
     # the capacity the buffers were carved with travels to backward inside the buffer tensor
     binning._vidu4d_capacity = cap
     binning._vidu4d_split = int(a.segment_split)
@@ -440,27 +513,24 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 # returned tensor as `.grad` (no accumulation pass over a pre-bound, zero-filled .grad: 2 x 46 MB per step at 200 k
 # surfels).  One-shot: the first backward call inside the context takes the buffers.  Process-wide state of a
 # single-threaded caller, like the capacity hints above.
-_grad_out: dict = {}
-_grad_written = None
-
-
 @contextlib.contextmanager
-def gradient_buffers(on_written=None, **buffers):
+def gradient_buffers(on_written=None, context=None, **buffers):
     """buffers: dL_dopacity (P,1), dL_dscales (P,2), dL_dsh (P,M,3) or dL_dsh_dc (P,1,3) / dL_dsh_rest (P,15,3): contiguous
     fp32 tensors on the device, 16-byte aligned.  on_written: called (once) right after the backward that took the buffers
     has been queued -- the place to record the event a collective over them waits for, while the rest of the step's
-    backward is still to come."""
-    global _grad_out, _grad_written
-    old, _grad_out = (_grad_out, _grad_written), {k: v for k, v in buffers.items() if v is not None}
-    _grad_written = on_written
+    backward is still to come.  State of `context` (default: the calling thread's current RasterContext): the backward of a
+    forward made under that context takes them."""
+    ctx = context or current()
+    old = (ctx.grad_out, ctx.grad_written)
+    ctx.grad_out, ctx.grad_written = {k: v for k, v in buffers.items() if v is not None}, on_written
     try:
         yield
     finally:
-        _grad_out, _grad_written = old
+        ctx.grad_out, ctx.grad_written = old
 
 
-def _grad_output(name, shape, opt):
-    t = _grad_out.pop(name, None)
+def _grad_output(ctx, name, shape, opt):
+    t = ctx.grad_out.pop(name, None)
     if (t is not None and t.numel() == math.prod(shape) and t.is_contiguous() and t.dtype == torch.float32
             and t.device == opt["device"] and t.data_ptr() % 16 == 0):
         return t.view(shape)   # (a fresh tensor object over the caller's memory: autograd may adopt it as .grad)
@@ -471,7 +541,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
                                  binning_capacity=None, segment_split=None, frame_cams=None, sh_rest=None,
-                                 raw_params=False, aux_planes=0):
+                                 raw_params=False, aux_planes=0, context=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations)
 
     sh_rest / raw_params as in rasterize_gaussians: dL_dsh is then the pair (dL_dsh_dc (P,1,3), dL_dsh_rest (P,15,3)),
@@ -481,6 +551,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dout_others (8,F,H,W)); per-frame gradients come back (F,P,.), those of opacity / scales / sh summed over the
     frames."""
     lib = _lib.load()
+    ctx = context or current()   # (the autograd functions pass their forward's: the engine's thread has no `with ctx:`)
     F = 1 if frame_cams is None else len(frame_cams)
     if frame_cams is not None:
         means3D, rotations = means3D.reshape(-1, 3), rotations.reshape(-1, 4)
@@ -500,15 +571,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dmeans3D = torch.empty(lead + (3,), **opt)
     dL_dmeans2D = torch.empty(lead + (3,), **opt)
     dL_dcolors = torch.empty(lead + (3,), **opt)
-    n_buffers = len(_grad_out)
-    dL_dopacity = _grad_output("dL_dopacity", (P, 1), opt)
+    n_buffers = len(ctx.grad_out)
+    dL_dopacity = _grad_output(ctx, "dL_dopacity", (P, 1), opt)
     dL_dtransMat = torch.empty(lead + (9,), **opt)
     if sh_rest is not None:
-        dL_dsh = (_grad_output("dL_dsh_dc", (P, 1, 3), opt), _grad_output("dL_dsh_rest", (P, 15, 3), opt))
+        dL_dsh = (_grad_output(ctx, "dL_dsh_dc", (P, 1, 3), opt), _grad_output(ctx, "dL_dsh_rest", (P, 15, 3), opt))
     else:
-        dL_dsh = _grad_output("dL_dsh", (P, M, 3), opt)
-    dL_dscales = _grad_output("dL_dscales", (P, 2), opt)
-    took_buffers = len(_grad_out) < n_buffers
+        dL_dsh = _grad_output(ctx, "dL_dsh", (P, M, 3), opt)
+    dL_dscales = _grad_output(ctx, "dL_dscales", (P, 2), opt)
+    took_buffers = len(ctx.grad_out) < n_buffers
     dL_drotations = torch.empty(lead + (4,), **opt)
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
@@ -558,15 +629,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         b.dL_dsh, b.dL_dsh_dc, b.dL_dsh_rest = None, dL_dsh[0].data_ptr(), dL_dsh[1].data_ptr()
     else:
         b.dL_dsh = _ptr(dL_dsh)
-    b.raw_params, b.aux_planes, b.debug_flags = int(bool(raw_params)), int(aux_planes), int(DEBUG_FLAGS)
-    global _walk_counters
-    if _walk_counters is not None:
-        b.diag_walk_counters, keep_counters, _walk_counters = _walk_counters.data_ptr(), _walk_counters, None  # noqa: F841
+    b.raw_params, b.aux_planes, b.debug_flags = int(bool(raw_params)), int(aux_planes), ctx.flags()
+    if ctx.walk_counters is not None:
+        b.diag_walk_counters, keep_counters, ctx.walk_counters = ctx.walk_counters.data_ptr(), ctx.walk_counters, None  # noqa: F841
     b.dL_dscales, b.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
     _lib.check(lib.vidu4d_surfel_backward(C.byref(b), _stream(dev)), "surfel backward")
-    global _grad_written
-    if _grad_written is not None and took_buffers:
-        cb, _grad_written = _grad_written, None
+    if ctx.grad_written is not None and took_buffers:
+        cb, ctx.grad_written = ctx.grad_written, None
         cb()
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 

@@ -195,6 +195,47 @@ __global__ __launch_bounds__(256) void lbs_kernel(int N, int B, const float* __r
 // the feature-major GEMMs of the delta MLP produce and consume (lab4d/lbs_fused.py).
 constexpr int MAX_FRAMES = 8;
 
+// ---- gradients w.r.t. the bone dual quaternions and the cameras (round 5: networks that train, --gs_optim_warp=True, the
+// reference's default, lab4d/config.py:157) are sums over ALL surfels of a frame: per frame B x 8 + 7 numbers.  Each wave
+// reduces eight of them at a time with a reduce-scatter in registers -- v_permlane32_swap folds the halves of the wave and
+// halves the values per lane, v_permlane16_swap the row pairs, one bank-masked DPP step the half rows, three DPP adds the
+// last eight lanes: 17 instructions for 8 sums over 64 lanes (a butterfly per value: 48) -- and the lane that ends up owning
+// a value adds it to the workgroup's row in LDS; the workgroup stores its row, and the host adds the rows up (one
+// torch.sum over ~800 rows of ~400 floats).  Value index owned by lane L: 4 (L >> 5) + 2 ((L >> 4) & 1) + ((L >> 3) & 1),
+// on the lanes with (L & 7) == 0.
+__device__ __forceinline__ void swap_add32(float& a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_add16(float& a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wave_reduce_scatter8(float (&v)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) swap_add32(v[k], v[k + 4]);
+    swap_add16(v[0], v[2]);
+    swap_add16(v[1], v[3]);
+    float t = v[0];
+    // lanes 0-7 of a row: v0 + its mirror lane's v0; lanes 8-15: v1 + the mirror lane's v1 (bank-masked DPP writes)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(t)
+        : "v"(v[1]));
+    return t;
+}
+
 // BCAP: compile-time bound of the bone loops (32 for the bob field's 25 bones: fully unrolled, the per-bone weights and
 // weight gradients stay in registers; the 64-bone instance indexes them dynamically, i.e. through scratch memory).
 // XB_FROM_XYZ: the Gaussian-bone coordinates are not read from xbT but evaluated here, x_bone = A xyz + c with the
@@ -220,7 +261,11 @@ constexpr int MAX_FRAMES = 8;
     do {                                                                                 \
         if (BX) asm volatile("" : "+v"(q_.w), "+v"(q_.x), "+v"(q_.y), "+v"(q_.z)); \
     } while (0)
-template <bool BACKWARD, int BCAP, bool XB_FROM_XYZ, int BX>
+// PG (backward, generic instance only): also produce the gradients w.r.t. the frames' bone dual quaternions and cameras --
+// per workgroup one row of `g_params`, (M, 8 B + 8) floats: bone b of frame m at [m][8 b .. 8 b + 7] = d/d qr (4), d/d qd (4);
+// the camera at [m][8 B .. 8 B + 6] = d/d cam_q (4), d/d cam_t (3).  The hemisphere signs and the anchor bone are piecewise
+// constant, as in the reference's torch graph (geom_utils.py:66-74: a comparison and a where).
+template <bool BACKWARD, int BCAP, bool XB_FROM_XYZ, int BX, bool PG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BX && BACKWARD) ? LBS_BX_WAVES_PER_EU : 1, 8)))
 void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
                                                        const float* __restrict__ rawT,
@@ -236,19 +281,36 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
                                                        float* __restrict__ g_xyz, float* __restrict__ g_rot,
                                                        int unit_rot, const float* __restrict__ bone_A,
                                                        const float* __restrict__ bone_c,
-                                                       const int64_t* __restrict__ frame_index)
+                                                       const int64_t* __restrict__ frame_index, int table_rows,
+                                                       float* __restrict__ g_params)
 {
+    static_assert(!PG || (BACKWARD && !BX), "parameter gradients: the generic backward instance");
     __shared__ float s_q[MAX_FRAMES][2 * MAX_BONES * 4];
     __shared__ unsigned long long s_sign[MAX_FRAMES][MAX_BONES];
     __shared__ float4 s_map[XB_FROM_XYZ ? 3 * BCAP : 1];  // row k of the bone map: (A[k][0..2], c[k])
+    __shared__ float s_pg[PG ? MAX_FRAMES * (8 * BCAP + 8) : 1];
+    const int pg_row = 8 * B + 8;
+    if (PG)
+        for (int i = threadIdx.x; i < M * pg_row; i += 256) s_pg[i] = 0.f;
+    // (a frame id outside the tables -- negative, or beyond the sequence -- reads their first / last row instead of whatever
+    // lies behind them: the caller's torch indexing used to raise for it)
+    auto table_row = [&](int m) {
+        if (!frame_index) return m;
+        const long long f = frame_index[m];
+        return (int)(f < 0 ? 0 : (f >= table_rows ? table_rows - 1 : f));
+    };
     if (XB_FROM_XYZ)
         for (int k = threadIdx.x; k < 3 * B; k += 256)
             s_map[k] = make_float4(bone_A[3 * k], bone_A[3 * k + 1], bone_A[3 * k + 2], bone_c[k]);
     // frame_index: se3_* / cam_* are TABLES over all frames of the sequence, frame m of this call is their row frame_index[m]
     // (the per-step row gathers of the frozen-network tables -- four launches -- happen here instead)
-    for (int m = 0; m < M; m++) stage_frame(se3_qr, se3_qd, frame_index ? (int)frame_index[m] : m, B, s_q[m], s_sign[m]);
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    for (int m = 0; m < M; m++) stage_frame(se3_qr, se3_qd, table_row(m), B, s_q[m], s_sign[m]);
+    int n = blockIdx.x * 256 + threadIdx.x;
+    // (PG: every thread stays for the workgroup's reductions; one beyond the last surfel works on the last one with weight 0)
+    const bool live_thread = n < N;
+    if (!PG && !live_thread) return;
+    if (PG && !live_thread) n = N - 1;
+    const float pg_live = live_thread ? 1.0f : 0.0f;
 
     const float cx_ = xyz[3 * n], cy_ = xyz[3 * n + 1], cz_ = xyz[3 * n + 2];
     int map_off = 0;  // (made opaque before the backward's last loop: rows re-read from LDS, not kept -- see sq_off below)
@@ -319,7 +381,7 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
         rotate(q, p, p1, px);
         const Q xt = qvec(px.x + tq.x, px.y + tq.y, px.z + tq.z);
         const Q rt = qmul(q, r);
-        const int mf = frame_index ? (int)frame_index[m] : m;
+        const int mf = table_row(m);
         const Q cq = ldq(cam_q + 4 * mf);
         const float* ct = cam_t + 3 * mf;
         Q c1, cx;
@@ -346,10 +408,20 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
             const Q u = qscale(rc, invn);
             g_rc = nrm > 1e-12f ? qscale(qadd(g_rc, qscale(u, -qdot(u, g_rc))), invn) : qscale(g_rc, invn);
         }
-        Q g_cq_unused, g_xt;
-        rotate_bwd(cq, xt, c1, g_xc, g_cq_unused, g_xt);
+        Q g_cq, g_xt;
+        rotate_bwd(cq, xt, c1, g_xc, g_cq, g_xt);
         g_xt.w = 0.f;
         const Q g_rt = qmul(qconj(cq), g_rc);
+        if (PG) {
+            // the camera of frame m: xc = cq xt cq* + ct, rc = cq rt  ->  d/d cq gets the rotation's adjoint plus
+            // g_rc conj(rt); d/d ct = g_xc.  Reduced over the wave, added to the workgroup's row.
+            g_cq = qadd(g_cq, qmul(g_rc, qconj(rt)));
+            float v[8] = {g_cq.w * pg_live, g_cq.x * pg_live, g_cq.y * pg_live, g_cq.z * pg_live,
+                          g_xc.x * pg_live, g_xc.y * pg_live, g_xc.z * pg_live, 0.f};
+            const float tot = wave_reduce_scatter8(v);
+            const int lane = threadIdx.x & 63;
+            if ((lane & 7) == 0) atomicAdd(&s_pg[m * pg_row + 8 * B + 4 * (lane >> 5) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)], tot);
+        }
         Q g_q, g_p;
         rotate_bwd(q, p, p1, g_xt, g_q, g_p);
         g_q = qadd(g_q, qmul(g_rt, qconj(r)));
@@ -372,7 +444,21 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
             const float sgn = ((hemi >> b) & 1ull) ? 1.0f : -1.0f;
             gw[b] += sgn * (qdot(g_Qr, ldq(sq2 + b * 4)) + qdot(g_Qd, ldq(sq2 + MAX_BONES * 4 + b * 4)));
             if (BX && BACKWARD) asm volatile("" : "+v"(gw[b]));
+            if (PG) {
+                // Qr = sum_b s_b w_b qr_b, Qd likewise: d/d qr_b = s_b w_b g_Qr, d/d qd_b = s_b w_b g_Qd, summed over the surfels
+                const float ws = sgn * w[b] * pg_live;
+                float v[8] = {ws * g_Qr.w, ws * g_Qr.x, ws * g_Qr.y, ws * g_Qr.z, ws * g_Qd.w, ws * g_Qd.x, ws * g_Qd.y, ws * g_Qd.z};
+                const float tot = wave_reduce_scatter8(v);
+                const int lane = threadIdx.x & 63;
+                if ((lane & 7) == 0) atomicAdd(&s_pg[m * pg_row + 8 * b + 4 * (lane >> 5) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)], tot);
+            }
         }
+    }
+    if (PG) {
+        __syncthreads();
+        float* row = g_params + (size_t)blockIdx.x * (size_t)(M * pg_row);
+        for (int i = threadIdx.x; i < M * pg_row; i += 256) row[i] = s_pg[i];
+        if (!live_thread) return;
     }
     if (!BACKWARD) return;
     // back through the softmax and the logits.  (Row offsets of the feature-major outputs from an N the compiler cannot
@@ -413,9 +499,16 @@ void lbs_skin_kernel(int M, int N, int B, const float* __restrict__ xbT,
 }
 
 template <bool BACKWARD, typename... Args>
-void launch_lbs_skin(int M, int N, int B, bool from_xyz, hipStream_t stream, Args... args)
+void launch_lbs_skin(int M, int N, int B, bool from_xyz, bool param_grads, hipStream_t stream, Args... args)
 {
     const dim3 grid((N + 255) / 256), block(256);
+    if constexpr (BACKWARD) {
+        if (param_grads) {   // (bone coordinates from memory: their map's gradient is torch's, through the GEMM that made them)
+            if (B <= 32) hipLaunchKernelGGL((lbs_skin_kernel<true, 32, false, 0, true>), grid, block, 0, stream, M, N, B, args...);
+            else hipLaunchKernelGGL((lbs_skin_kernel<true, MAX_BONES, false, 0, true>), grid, block, 0, stream, M, N, B, args...);
+            return;
+        }
+    }
 #ifndef LBS_BX_FORWARD
 #define LBS_BX_FORWARD 0
 #endif
@@ -475,16 +568,18 @@ extern "C" int vidu4d_lbs_backward(int M, int N, int B, const float* wT, const f
 extern "C" int vidu4d_lbs_skin_forward(int M, int N, int B, const float* xbT, const float* rawT, const float* se3_qr,
                                        const float* se3_qd, const float* xyz, const float* rot, const float* cam_q,
                                        const float* cam_t, float* out_xyz, float* out_rot, int unit_rot,
-                                       const float* bone_A, const float* bone_c, const int64_t* frame_index, void* stream)
+                                       const float* bone_A, const float* bone_c, const int64_t* frame_index, int table_rows,
+                                       void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
     if ((bone_A == nullptr) != (bone_c == nullptr) || (bone_A != nullptr) == (xbT != nullptr)) return VIDU4D_E_INVALID;
     if (!se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !out_xyz || !out_rot) return VIDU4D_E_INVALID;
+    if (frame_index && table_rows <= 0) return VIDU4D_E_INVALID;
     (void)hipGetLastError();
-    launch_lbs_skin<false>(M, N, B, bone_A != nullptr, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t,
+    launch_lbs_skin<false>(M, N, B, bone_A != nullptr, false, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t,
                            out_xyz, out_rot, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (float*)nullptr, (float*)nullptr, unit_rot, bone_A, bone_c, frame_index);
+                           (float*)nullptr, (float*)nullptr, unit_rot, bone_A, bone_c, frame_index, table_rows, (float*)nullptr);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 
@@ -493,7 +588,7 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
                                         const float* cam_t, const float* g_out_xyz, const float* g_out_rot,
                                         float* g_xbT /*(3B,N)*/, float* g_rawT /*(B,N) or NULL*/, float* g_xyz /*(N,3)*/,
                                         float* g_rot /*(N,4)*/, int unit_rot, const float* bone_A, const float* bone_c,
-                                        const int64_t* frame_index, void* stream)
+                                        const int64_t* frame_index, int table_rows, float* g_params, void* stream)
 {
     if (check(M, N, B) || M > MAX_FRAMES) return VIDU4D_E_INVALID;
     if (M == 0 || N == 0) return VIDU4D_OK;
@@ -501,9 +596,14 @@ extern "C" int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, c
     if (!se3_qr || !se3_qd || !xyz || !rot || !cam_q || !cam_t || !g_out_xyz || !g_out_rot || (xbT && !g_xbT) || !g_xyz ||
         !g_rot || (rawT && !g_rawT))
         return VIDU4D_E_INVALID;
+    if (frame_index && table_rows <= 0) return VIDU4D_E_INVALID;
+    // parameter gradients: with the bone coordinates as an input (their map's gradient then flows through whatever made them)
+    if (g_params && bone_A) return VIDU4D_E_UNSUPPORTED;
     (void)hipGetLastError();
-    launch_lbs_skin<true>(M, N, B, bone_A != nullptr, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot, cam_q, cam_t,
-                          (float*)nullptr, (float*)nullptr, g_out_xyz, g_out_rot, g_xbT, g_rawT, g_xyz, g_rot, unit_rot, bone_A,
-                          bone_c, frame_index);
+    launch_lbs_skin<true>(M, N, B, bone_A != nullptr, g_params != nullptr, (hipStream_t)stream, xbT, rawT, se3_qr, se3_qd, xyz, rot,
+                          cam_q, cam_t, (float*)nullptr, (float*)nullptr, g_out_xyz, g_out_rot, g_xbT, g_rawT, g_xyz, g_rot, unit_rot,
+                          bone_A, bone_c, frame_index, table_rows, g_params);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
+
+extern "C" int vidu4d_lbs_skin_param_rows(int N) { return (N + 255) / 256; }

@@ -54,16 +54,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
                        cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
                        rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        # the caller's host-side state (hints, deferred mode, gradient outputs): remembered for the backward, which the
+        # autograd engine runs on a thread of its own, outside any `with context:` of the caller
+        ctx.raster_context = rc = _C.current()
         if rs.debug:
             saved = _snapshot(native_args)
             try:
-                out = _C.rasterize_gaussians(*native_args)
+                out = _C.rasterize_gaussians(*native_args, context=rc)
             except Exception:
                 torch.save(saved, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            out = _C.rasterize_gaussians(*native_args)
+            out = _C.rasterize_gaussians(*native_args, context=rc)
         num_rendered, color, others, radii, geom_buf, binning_buf, img_buf = out
 
         ctx.raster_settings = rs
@@ -87,14 +90,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             saved = _snapshot(native_args)
             try:
                 grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity,
-                                                        segment_split=ctx.segment_split)
+                                                        segment_split=ctx.segment_split, context=ctx.raster_context)
             except Exception:
                 torch.save(saved, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         else:
             grads = _C.rasterize_gaussians_backward(*native_args, binning_capacity=ctx.binning_capacity,
-                                                        segment_split=ctx.segment_split)
+                                                    segment_split=ctx.segment_split, context=ctx.raster_context)
         (g_means2D, g_colors_precomp, g_opacities, g_means3D, g_cov3Ds_precomp, g_sh, g_scales,
          g_rotations) = grads
         return (g_means3D, g_means2D, g_sh, g_colors_precomp, g_opacities, g_scales, g_rotations, g_cov3Ds_precomp,
@@ -118,7 +121,9 @@ class _RasterizeFrames(torch.autograd.Function):
         out = _C.rasterize_gaussians(rs0.bg, means3D, empty, opacities, scales, rotations, rs0.scale_modifier, empty,
                                      rs0.viewmatrix, rs0.projmatrix, rs0.tanfovx, rs0.tanfovy, rs0.image_height,
                                      rs0.image_width, sh, rs0.sh_degree, rs0.campos, rs0.prefiltered, rs0.debug,
-                                     frame_cams=cams, sh_rest=sh_rest, raw_params=raw_params, aux_planes=aux_planes)
+                                     frame_cams=cams, sh_rest=sh_rest, raw_params=raw_params, aux_planes=aux_planes,
+                                     context=_C.current())
+        ctx.raster_context = _C.current()
         num_rendered, color, others, radii, geom_buf, binning_buf, img_buf = out
         ctx.settings, ctx.cams, ctx.num_rendered = rs0, cams, num_rendered
         ctx.binning_capacity = getattr(binning_buf, "_vidu4d_capacity", max(num_rendered, 1))
@@ -140,7 +145,7 @@ class _RasterizeFrames(torch.autograd.Function):
                                             rs.debug, binning_capacity=ctx.binning_capacity,
                                             segment_split=ctx.segment_split, frame_cams=ctx.cams,
                                             sh_rest=sh_rest if ctx.split_sh else None, raw_params=ctx.raw_params,
-                                            aux_planes=ctx.aux_planes)
+                                            aux_planes=ctx.aux_planes, context=ctx.raster_context)
         g_means2D, _g_colors, g_opacities, g_means3D, _g_T, g_sh, g_scales, g_rotations = g
         g_sh, g_sh_rest = g_sh if ctx.split_sh else (g_sh, None)
         return g_means3D, g_means2D, g_sh, g_opacities, g_scales, g_rotations, None, g_sh_rest, None, None

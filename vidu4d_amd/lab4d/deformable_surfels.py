@@ -77,6 +77,10 @@ class DeformableSurfels(GaussianModel):
                 self.camera_mlp.trans[2].bias.copy_(torch.tensor([0.0, 0.0, 3.0]))
         self.register_buffer("aabb", torch.zeros(2, 3))
         self.pipeline = PipelineParams()
+        # host-side state of this model's rasterizer calls (vidu4d_amd/_C.py RasterContext); a plain attribute, not a
+        # parameter / buffer: it is not part of the state dict
+        from .. import _C as _native
+        self.__dict__["raster_context"] = _native.RasterContext()
         self.pipeline.debug = opts.get("debug_cuda", False)
         self.background_feat = torch.zeros(3, device=self.device_)  # what render_view is handed upstream (:147, :1190)
         if opts.get("gs_learnable_bg", True):
@@ -199,12 +203,19 @@ class DeformableSurfels(GaussianModel):
         self._aux_dict = aux
         return xyz_cam, rot_cam, (q, t)
 
+    def warp_networks_train(self) -> bool:
+        return any(p.requires_grad for mod in (self.warp, self.camera_mlp) for p in mod.parameters())
+
     def fused_warp_ok(self, inst_id=None) -> bool:
-        """The fused HIP warp applies when bone and camera networks are frozen (--gs_optim_warp=False)
-        and all frames of the batch share one instance code."""
+        """The fused HIP warp applies when all frames of the batch share one instance code.  Frozen bone and camera
+        networks (--gs_optim_warp=False, the README's Stage-3 command) get the cached tables and the MFMA skinning field;
+        networks that TRAIN (--gs_optim_warp=True, the reference's default, lab4d/config.py:157: AdamW on them,
+        trainer.py:592-598) are evaluated with autograd for the step's frames and the skinning kernel's backward reduces
+        the gradients w.r.t. their bone dual quaternions and cameras (round 5; `fused_warp_trainable: False` restores the
+        torch chain of rounds 1-4 for an A/B)."""
         if not self._xyz.is_cuda or not self.opts.get("fused_warp", True):
             return False
-        if any(p.requires_grad for mod in (self.warp, self.camera_mlp) for p in mod.parameters()):
+        if self.warp_networks_train() and not self.opts.get("fused_warp_trainable", True):
             return False
         return inst_id is None or len(set(inst_id.tolist())) == 1
 
@@ -251,7 +262,12 @@ class DeformableSurfels(GaussianModel):
         w = self.warp
         table_rows = None   # (frame ids when se3 / cq / ct below are whole tables)
         self.__dict__["_warp_rot_is_unit"] = False
-        overrides = any(k in samples_dict for k in ("rest_articulation", "t_articulation", "field2cam"))
+        # networks that train are evaluated for the step's frames WITH autograd (no cached table): articulation, camera,
+        # the rest pose's bone map and the time-code bias are a handful of launches on (M, B, .) tensors; the delta-skin MLP
+        # runs as feature-major library GEMMs (its weight gradients are GEMMs over the surfels); the skinning kernel's
+        # backward hands back d/d se3 and d/d camera
+        trainable = self.warp_networks_train()
+        overrides = trainable or any(k in samples_dict for k in ("rest_articulation", "t_articulation", "field2cam"))
         if overrides:
             if "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
                 rest_art, t_art = samples_dict["rest_articulation"], samples_dict["t_articulation"]
@@ -420,15 +436,14 @@ class DeformableSurfels(GaussianModel):
         keeps the per-frame screen-space tensors the densification statistics need.
         aux_planes (stacked raw output only): bit mask of the allmap planes the caller reads, 0 = all
         (diff_surfel_rasterization.rasterize_frames)."""
-        if self._xyz.is_cuda and not self.__dict__.get("_in_hint_scope", False):
-            # the rasterizer's capacity / split hints are this model's own (two models of one image size do not share them)
+        if self._xyz.is_cuda:
+            # the rasterizer's host-side state -- capacity / split hints, unchecked deferred forwards, gradient outputs --
+            # is this model's own (`raster_context`): two models stepping alternately, or rendering on two threads, share none
             from .. import _C
-            self.__dict__["_in_hint_scope"] = True
-            try:
-                with _C.hint_scope(id(self)):
+            rc = self.raster_context
+            if _C.current() is not rc:
+                with rc:
                     return self.render_frames(frame_id, Kinv, H, W, inst_id, samples_dict, outputs, aux_planes)
-            finally:
-                self.__dict__["_in_hint_scope"] = False
         M = frame_id.shape[0]
         if self.fused_warp_ok(inst_id):
             xyz_cam, rot_cam = self.forward_warp_fused(frame_id, inst_id, samples_dict)  # (M,N,3), (M,N,4)

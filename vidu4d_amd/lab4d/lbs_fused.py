@@ -72,18 +72,22 @@ class _LbsSkinApply(Function):
                 frame_index=None):
         if not xyz.is_cuda:
             raise RuntimeError("lbs_skin_apply: HIP tensors required")
-        consts = [(se3_qr, "se3"), (se3_qd, "se3"), (cam_q, "field2cam"), (cam_t, "field2cam")]
-        if bone_A is not None:
-            consts += [(bone_A, "bone map"), (bone_c, "bone map")]
-        for t, name in consts:
-            if t.requires_grad:
-                raise RuntimeError(f"lbs_skin_apply: {name} requires grad; the fused path treats it as constant")
+        # bones and cameras that train (--gs_optim_warp=True, the reference's default): the backward reduces their gradients
+        # over the surfels (csrc/lbs.hip, g_params).  That instance takes the bone coordinates as an input -- the bone MAP's
+        # gradient flows through whatever made xbT -- and per-frame rows.
+        trainable = any(t.requires_grad for t in (se3_qr, se3_qd, cam_q, cam_t))
+        if bone_A is not None and (bone_A.requires_grad or bone_c.requires_grad):
+            raise RuntimeError("lbs_skin_apply: a bone map that requires grad must come in as xbT = A xyz + c (torch)")
+        if trainable and (bone_A is not None or frame_index is not None):
+            raise RuntimeError("lbs_skin_apply: bones / cameras that require grad need xbT (not the in-kernel bone map) and "
+                               "per-frame rows (no frame_index)")
         M, B = se3_qr.shape[:2]
         if frame_index is not None:   # se3 / cam are tables over all frames; this call's frames are their rows frame_index
             if frame_index.dtype != torch.int64 or not frame_index.is_cuda or frame_index.ndim != 1:
                 raise RuntimeError("lbs_skin_apply: frame_index must be a 1-d int64 tensor on the device")
             M = frame_index.shape[0]
             frame_index = frame_index.contiguous()
+        table_rows = int(se3_qr.shape[0])
         N = xyz.shape[0]
         if (xbT is None) == (bone_A is None):
             raise RuntimeError("lbs_skin_apply: pass the bone coordinates xbT OR the bone map (bone_A, bone_c)")
@@ -100,9 +104,9 @@ class _LbsSkinApply(Function):
         ptr = [None if a is None else a.data_ptr() for a in args]
         bptr = [None if a is None else a.data_ptr() for a in bmap]
         _lib.check(lib.vidu4d_lbs_skin_forward(M, N, B, *ptr, out_xyz.data_ptr(), out_rot.data_ptr(), int(unit_rot), *bptr,
-                                               None if frame_index is None else frame_index.data_ptr(),
+                                               None if frame_index is None else frame_index.data_ptr(), table_rows,
                                                torch.cuda.current_stream(xyz.device).cuda_stream), "lbs skin forward")
-        ctx.frame_index = frame_index
+        ctx.frame_index, ctx.table_rows, ctx.trainable = frame_index, table_rows, trainable
         ctx.present = [a is not None for a in args + bmap]
         ctx.unit_rot = bool(unit_rot)
         ctx.save_for_backward(*[a for a in args + bmap if a is not None])
@@ -126,14 +130,27 @@ class _LbsSkinApply(Function):
         lib = _lib.load()
         ptr = [None if a is None else a.data_ptr() for a in saved]
         bptr = [None if a is None else a.data_ptr() for a in bmap]
+        g_params = None
+        if ctx.trainable:   # one row of partial sums per workgroup of 256 surfels: (rows, M, 8 B + 8)
+            g_params = torch.empty(lib.vidu4d_lbs_skin_param_rows(N), M, 8 * B + 8, dtype=torch.float32, device=dev)
         _lib.check(lib.vidu4d_lbs_skin_backward(M, N, B, *ptr, g_xyz_out.data_ptr(), g_rot_out.data_ptr(),
                                                 None if g_xbT is None else g_xbT.data_ptr(),
                                                 None if g_rawT is None else g_rawT.data_ptr(), g_xyz.data_ptr(),
                                                 g_rot.data_ptr(), int(ctx.unit_rot), *bptr,
                                                 None if ctx.frame_index is None else ctx.frame_index.data_ptr(),
+                                                ctx.table_rows, None if g_params is None else g_params.data_ptr(),
                                                 torch.cuda.current_stream(dev).cuda_stream),
                    "lbs skin backward")
-        return g_xbT, g_rawT, None, None, g_xyz, g_rot, None, None, None, None, None, None
+        g_qr = g_qd = g_cq = g_ct = None
+        if g_params is not None:
+            tot = g_params.sum(0)                                   # (M, 8 B + 8)
+            bones = tot[:, :8 * B].view(M, B, 8)
+            need = ctx.needs_input_grad
+            g_qr = bones[..., :4].contiguous() if need[2] else None
+            g_qd = bones[..., 4:].contiguous() if need[3] else None
+            g_cq = tot[:, 8 * B:8 * B + 4].contiguous() if need[6] else None
+            g_ct = tot[:, 8 * B + 4:8 * B + 7].contiguous() if need[7] else None
+        return g_xbT, g_rawT, g_qr, g_qd, g_xyz, g_rot, g_cq, g_ct, None, None, None, None
 
 
 def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False, bone_map=None, frame_index=None):

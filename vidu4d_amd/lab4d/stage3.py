@@ -145,7 +145,13 @@ class Stage3Trainer:
                 groups.append({"params": [prm], "name": n})
                 lrs.append(c.learning_rate * (10.0 if any(n.endswith(e[1:]) or e in n for e in explicit) else 1.0))
             total = max(2, int(o.get("num_rounds", 1)) * int(o.get("iters_per_round", 200)))
-            self.optimizer = torch.optim.AdamW(groups, lr=c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4)
+            # (one group per tensor is the reference's layout, trainer.py:240-255; torch's default for-each implementation
+            # then issues six launches per GROUP -- ~600 per step for the bob networks, 3.9 ms of GPU time at 6.5 us each,
+            # 40 % of the whole step with training networks (tools/fit_optim_warp_profile.py).  `fused=True` is one
+            # multi-tensor launch per group and the same arithmetic.)
+            on_gpu = all(prm.is_cuda for _, prm in net_params)
+            self.optimizer = torch.optim.AdamW(groups, lr=c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
+                                               **({"fused": True} if on_gpu and o.get("fused_network_adamw", True) else {}))
             # trainer.py:268-275: a resumed run starts the networks at the full rate and decays to lr / 5; a fresh one
             # warms up from lr / 25 over two rounds
             if self.is_resumed:
@@ -284,7 +290,8 @@ class Stage3Trainer:
         # collective can start then instead of after the warp's backward (allreduce_gradients)
         early = self._note_rest_written if (self.world > 1 and "dL_dsh_rest" in direct and
                                             self.model.opts.get("early_exchange", True)) else None
-        return _C.gradient_buffers(on_written=early, **direct)
+        # (on the MODEL's rasterizer context: that is the one its forwards run under -- render_frames -- and their backward reads)
+        return _C.gradient_buffers(on_written=early, context=self.model.raster_context, **direct)
 
     def _note_rest_written(self):
         self._rest_ready = torch.cuda.Event()
@@ -521,12 +528,15 @@ class Stage3Trainer:
             # one check per step: if a frame outgrew its buffer -- it then rendered only the background --
             # the gradients of this step are dropped and the step is replayed with exact buffers.
             from .. import _C
-            self.begin_gradients()
-            with _C.deferred_capacity_check():
-                losses = self._forward_backward(batch, step)
-            if not _C.check_deferred():
+            # (everything below runs under the MODEL's rasterizer context: its hints, its unchecked forwards, the gradient
+            # outputs bound for its backward -- another model's step, or another thread's, has its own)
+            with m.raster_context:
                 self.begin_gradients()
-                losses = self._forward_backward(batch, step)
+                with _C.deferred_capacity_check():
+                    losses = self._forward_backward(batch, step)
+                if not _C.check_deferred():
+                    self.begin_gradients()
+                    losses = self._forward_backward(batch, step)
         else:
             self.begin_gradients()
             losses = self._forward_backward(batch, step)
