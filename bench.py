@@ -307,6 +307,31 @@ def torch_cpu_baseline_bounded(args, limit_s: float = 150.0):
                           f"{args.torch_cpu_images / limit_s:.4f} images/s)"}
 
 
+def host_cost_probe(limit_s: float = 120.0) -> dict:
+    """What the HOST needs per step, measured where it can be seen: the same bench loop on a scene whose kernels take next to
+    nothing (2 000 surfels, 64^2), so ms_per_step IS the Python + launch cost of a step -- through the stacked surface, the
+    reference's per-frame surface on two streams, and on one.  (`host_enqueue_ms_per_step` of the headline run equals its GPU
+    time whenever the GPU is the slower side: the host then waits in the launch queue.)"""
+    import subprocess
+    out = {}
+    cmd = [sys.executable, os.path.abspath(__file__), "--surfels", "2000", "--res", "64", "--steps", "300", "--warmup", "20",
+           "--cpu-images", "0", "--torch-cpu-images", "0", "--fit-steps", "0", "--repeats", "0", "--per-frame-surface", "1",
+           "--no-stage-timers", "--host-probe", "0"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if line:
+            d = json.loads(line[-1])
+            pf = d.get("value_per_frame_calls", {})
+            out = {"stacked_ms_per_step": round(d["ms_per_step"], 4),
+                   "per_frame_two_streams_ms_per_step": round(pf.get("ms_per_step", float("nan")), 4),
+                   "per_frame_one_stream_ms_per_step": round(pf.get("single_stream", {}).get("ms_per_step", float("nan")), 4)}
+    except subprocess.TimeoutExpired:
+        out = {"error": f"did not finish within {limit_s:.0f} s"}
+    out["what"] = "bench.py's own step loop at 2 000 surfels / 64^2 (kernels ~ nothing): Python + launch cost of a 2-frame step"
+    return out
+
+
 def replicas_main(args, world, rank, local_rank):
     """BASELINE.json configs[3]: `world` independent sequences, one process per GPU, nothing exchanged -- an RCCL
     barrier before the timed loop and one after it (the pattern of lab4d/utils/gpu_utils.py:6-128 /
@@ -370,6 +395,10 @@ def main():
                                                               "\"fit_step\" and \"fit_step_geometry\" (0 = skip)")
     ap.add_argument("--fit-densify-steps", type=int, default=320, help="steps of the fitting loop timed with densify + prune "
                     "ON from step 501 of the schedule (three densification events; BASELINE.json configs[2] verbatim; 0 = skip)")
+    ap.add_argument("--host-probe", type=int, default=1, help="also measure the host's own cost of a step (a child run on a "
+                    "scene whose kernels take next to nothing) -> \"host_cost\"")
+    ap.add_argument("--fit-optim-warp", type=int, default=1, help="also time the fitting step with TRAINING warp / camera networks "
+                    "(--gs_optim_warp=True, the reference's default) -> \"fit_step_optim_warp\" and its un-fused A/B")
     ap.add_argument("--exchange", choices=["overlapped", "serial"], default="overlapped",
                     help="N > 1: overlapped = the step's all-reduce runs beside the next step's kernels (two gradient "
                          "buffers, joined before its buffer is reused: the op-level loop has no optimizer between steps); "
@@ -681,15 +710,28 @@ def main():
                 step()
             sync()
             pf_rates.append(world * args.steps * FRAMES_PER_STEP / (time.perf_counter() - r0))
+        # ... and on ONE stream, frame after frame: what a caller that does not touch HIP streams gets -- the reference's
+        # own loop (deformable_gaussian.py:1175-1228) unmodified
+        mode["streams"] = False
+        for _ in range(min(args.warmup, 10)):
+            step()
+        sync()
+        p1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        pf1_elapsed = time.perf_counter() - p1
+        mode["streams"] = bool(args.frame_streams)
         mode["stacked"] = True
-        per_frame = (pf_elapsed, pf_rates)
+        per_frame = (pf_elapsed, pf_rates, pf1_elapsed)
     gc.enable()
     if use_dist:
-        tt = torch.tensor([elapsed, per_frame[0] if per_frame else 0.0], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, per_frame[0] if per_frame else 0.0, per_frame[2] if per_frame else 0.0], device=dev,
+                          dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0].item())
         if per_frame:
-            per_frame = (float(tt[1].item()), per_frame[1])
+            per_frame = (float(tt[1].item()), per_frame[1], float(tt[2].item()))
 
     # what the dominant kernel's tile walk looks like on this workload (a counting pass behind one extra step, outside
     # every timed region): lane utilisation = contributing (pixel, surfel) pairs / (64 lanes x pair evaluations)
@@ -755,6 +797,9 @@ def main():
                        "as `value`", "steps": args.steps}
         if per_frame[1]:
             out["value_per_frame_calls"]["repeats"] = summary(per_frame[1])
+        out["value_per_frame_calls"]["single_stream"] = {
+            "value": images / per_frame[2], "unit": "images/s", "ms_per_step": 1e3 * per_frame[2] / args.steps,
+            "surface": "the same calls on ONE HIP stream, frame after frame (an unmodified caller of the reference's loop)"}
     if rank == 0:
         # ---- roofline of the dominant kernel (live HIP-event stage timers, see above)
         from vidu4d_amd import _C
@@ -816,9 +861,10 @@ def main():
             if args.fit_densify_steps > 0:
                 out["fit_step_densify"] = fit_step_rate(dev, N, W, H, args.fit_densify_steps, start_step=501, densify=True)
             # the reference's default flag value: the networks train too (step >= 12 000: their optimizer steps)
-            out["fit_step_optim_warp"] = fit_step_rate(dev, N, W, H, args.fit_steps, start_step=12001, optim_warp=True)
-            out["fit_step_optim_warp_unfused"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), start_step=12001,
-                                                               optim_warp=True, fused_warp_trainable=False)
+            if args.fit_optim_warp:
+              out["fit_step_optim_warp"] = fit_step_rate(dev, N, W, H, args.fit_steps, start_step=12001, optim_warp=True)
+              out["fit_step_optim_warp_unfused"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), start_step=12001,
+                                                                 optim_warp=True, fused_warp_trainable=False)
         if world == 1:
             # MODELLED multi-GPU figures (no multi-GPU node is reachable from the build box; the driver
             # measures the real curve when it has one): measured 1-GPU step + the all-reduce cost model above
@@ -853,6 +899,8 @@ def main():
                                                                                                 cont["factor"]),
                                "warp_backward_ms_assumed": WARP_BACKWARD_MS}
             out["scaling_modelled"] = sm
+        if world == 1 and args.host_probe:
+            out["host_cost"] = host_cost_probe()
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_images)
         if world == 1 and args.torch_cpu_images > 0:

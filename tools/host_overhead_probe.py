@@ -35,7 +35,8 @@ def main():
     _lib._lib = Stub(real)
     _C._check_cuda = lambda *a: None
     _C._stream = lambda dev: 0
-    _C._pinned_slot = lambda dev: torch.zeros(16, dtype=torch.int32)
+    _slot = torch.zeros(16, dtype=torch.int32)
+    _C._pinned_slot = lambda dev, ctx: _slot
     _C._cu_count["cpu"] = 256
     torch.cuda.Event = FakeEvent
     torch.cuda.current_stream = lambda dev=None: type("S", (), {"cuda_stream": 0})()

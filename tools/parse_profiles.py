@@ -120,4 +120,41 @@ if sq:
                                          "counter_hbm_frac_of_8TBps": round(hbm, 4), "avg_duration_us": round(ns / 1e3, 1),
                                          "source": f"rocprofv3 --pmc SQ_ACTIVE_INST_VALU ... ({tag}_pmc_sq.csv)"}
     json.dump(traffic, open(os.path.join(summ, "pmc_traffic.json"), "w"), indent=1)
+
+# 4. L2 (TCC) counters: per-kernel mean per launch, hit rate (round 5: SURVEY.md 8d asks for an L2 / MALL-level figure)
+tcc = find("TCC", "*counter_collection.csv")
+if tcc:
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(tcc)):
+        name = r.get("Kernel_Name", "")
+        if "surfel::" not in name:
+            continue
+        key = next((v for k, v in SHORT.items() if k in name), None)
+        if key:
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {}
+    if stats:
+        for r in csv.DictReader(open(stats)):
+            key = next((v for k, v in SHORT.items() if k in r["Name"]), None)
+            if key and "surfel::" in r["Name"] and key != "tile_scan":
+                if key not in dur or int(r["Calls"]) > dur[key][1]:
+                    dur[key] = (float(r["AverageNs"]), int(r["Calls"]))
+    with open(os.path.join(summ, f"{tag}_pmc_tcc.csv"), "w") as f:
+        f.write("# per launch; L2 request = one 128-byte line (TCC_REQ_sum); TCC_EA0_RDREQ_sum: read requests that left the L2 towards "
+                "the fabric (Infinity Cache + HBM; FETCH_SIZE = this x 64 B)\n")
+        f.write("kernel,launches,TCC_HIT_sum,TCC_MISS_sum,TCC_REQ_sum,TCC_EA0_RDREQ_sum,l2_hit_rate,l2_request_GBps_at_128B\n")
+        for k, d in acc.items():
+            m = {c: (sum(v) / len(v)) for c, v in d.items() if v}
+            hit, miss, req = m.get("TCC_HIT_sum", float("nan")), m.get("TCC_MISS_sum", float("nan")), m.get("TCC_REQ_sum", float("nan"))
+            rate = hit / (hit + miss) if hit + miss > 0 else float("nan")
+            ns = dur.get(k, (float("nan"), 0))[0]
+            bw = req * 128.0 / ns if ns == ns else float("nan")   # bytes per ns = GB/s
+            n = len(next(iter(d.values())))
+            f.write(f"surfel::{k},{n},{hit:.4g},{miss:.4g},{req:.4g},{m.get('TCC_EA0_RDREQ_sum', float('nan')):.4g},{rate:.4f},{bw:.1f}\n")
+            if k in traffic:
+                traffic[k]["l2"] = {"hit_rate": round(rate, 4), "requests_per_launch": req, "l2_request_GBps_at_128B_per_request": round(bw, 1),
+                                    "fabric_read_requests_per_launch": m.get("TCC_EA0_RDREQ_sum"),
+                                    "note": "per-XCD L2 in front of the Infinity Cache; the counters cannot tell Infinity-Cache hits from HBM "
+                                            "reads (guide: FETCH_SIZE counts both) -- the step's working set (~100 MB) fits the 256 MiB cache"}
+    json.dump(traffic, open(os.path.join(summ, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in traffic.items()}))

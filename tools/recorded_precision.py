@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Recorded segments vs the whole-tile backward vs the CPU oracle: largest gradient difference over the tensor's scale
-(MEASUREMENT / test infrastructure; GPU box).  -> profiles/r04_recorded_precision.txt"""
+(MEASUREMENT / test infrastructure; GPU box).  -> profiles/r05_recorded_precision.txt"""
 import os
 import sys
 

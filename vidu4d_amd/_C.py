@@ -39,10 +39,12 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 # round-4 counts above were tiles above the recorded segments' 320-entry class after a whole-tile frame and positions up to
 # the last 1024-entry tile after a split one, so the rule could stay in whichever mode ran first.  Same scene, same threshold
 # (tools/gpu_r5_d.sh, profiles/r05_split_rule.txt): radius 1.0 = 604 tiles: 1.27 whole / 1.24 split; 0.85 = 440: 1.25 / 1.14;
-# 0.7 = 320: 1.25 / 1.05; 0.5 = 176: 1.52 / 1.02 -- the split is taken from radius 1.0 down, and is the faster or equal one.
+# 0.7 = 320: 1.25 / 1.05; 0.5 = 176: 1.52 / 1.02.  On the new count the threshold is 2.0 tiles per compute unit (512): radius
+# 0.85 and below split, radius 1.0 and bench.py's fitting scene (a filled unit ball: whole 0.98-1.01 ms / split 1.00-1.13,
+# three runs each, profiles/r05_split_rule.txt) walk whole tiles -- what round 4's rule did with its 2.5 on the other count.
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = int(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_LEN", "2048"))
-SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU", "2.5"))
+SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU", "2.0"))
 MSD_SORT_FROM = int(os.environ.get("VIDU4D_MSD_SORT_FROM", "10000"))  # longest list from which the long lists are MSD-split
 # The segment-parallel alpha-only blend runs without its transmittance pre-pass (Vidu4dSurfelForwardArgs::
 # assume_unsaturated): segments are blended from T = 1 and scaled in the combine, which blends the one segment a pixel

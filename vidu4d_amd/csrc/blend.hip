@@ -39,6 +39,13 @@
 
 namespace surfel {
 
+// SURFEL_WIDE_RECORD_READS=1 (experiment, round 5): the second half of a record (normal | rgb) read as two whole float4s
+// instead of the ds_read_b96 the compiler narrows them to (8 LDS cycles per wave instruction against 4, MI355X_MICROARCH.md):
+// measured SLOWER, blend_fwd 150 -> 154 us, blend_bwd 379 -> 384 us (profiles/r05_blend_micro_ab.txt) -- the LDS pipe is not
+// what bounds these loops, and the two extra live registers cost the backward six more spills.  Off.
+#ifndef SURFEL_WIDE_RECORD_READS
+#define SURFEL_WIDE_RECORD_READS 0
+#endif
 constexpr int FWD_BATCH = 256;  // list entries staged per round (one per thread)
 #ifndef SURFEL_BWD_BATCH
 #define SURFEL_BWD_BATCH 128
@@ -548,13 +555,19 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                 // v_cndmask 0 / 1 + v_cmp_ne, four VALU instructions of the expensive kind per trip for nothing)
                 okA = okA && !done;
                 if (okA) {
-                    const float4 q3 = ra[3], q4 = ra[4];
+                    float4 q3 = ra[3], q4 = ra[4];
+#if SURFEL_WIDE_RECORD_READS
+                    asm volatile("" : "+v"(q3.w), "+v"(q4.w));   // (ds_read_b128, 4 LDS cycles, instead of ds_read_b96, 8: see blend_bwd_kernel)
+#endif
                     const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
                     if (!fwd_accumulate<MODE>(s, ea, nrm, rgb, (uint32_t)(key_base + oa))) done = sat_local = true;
                 }
                 okB = okB && !done;
                 if (okB) {
-                    const float4 q3 = rb[3], q4 = rb[4];
+                    float4 q3 = rb[3], q4 = rb[4];
+#if SURFEL_WIDE_RECORD_READS
+                    asm volatile("" : "+v"(q3.w), "+v"(q4.w));
+#endif
                     const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
                     if (!fwd_accumulate<MODE>(s, eb, nrm, rgb, (uint32_t)(key_base + ob))) done = sat_local = true;
                 }
@@ -1261,7 +1274,12 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
                 PairGrad pg;
                 pg.w = pg.dL_dalpha = pg.dL_dz = 0.f;
                 if (ok) {
-                    const float4 q3 = r[3], q4 = r[4];
+                    float4 q3 = r[3], q4 = r[4];
+#if SURFEL_WIDE_RECORD_READS
+                    // (all four floats "used": a ds_read_b128 takes 4 LDS cycles per wave instruction, the ds_read_b96 the
+                    // compiler narrows these to -- only x, y, z are read -- takes 8: MI355X_MICROARCH.md, LDS table)
+                    asm volatile("" : "+v"(q3.w), "+v"(q4.w));
+#endif
                     const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
                     pg = bwd_pair_core<MODE>(s, e, nrm, rgb, off == off_median);
                 }
