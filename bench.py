@@ -314,7 +314,7 @@ def host_cost_probe(limit_s: float = 120.0) -> dict:
     time whenever the GPU is the slower side: the host then waits in the launch queue.)"""
     import subprocess
     out = {}
-    cmd = [sys.executable, os.path.abspath(__file__), "--surfels", "2000", "--res", "64", "--steps", "300", "--warmup", "20",
+    cmd = [sys.executable, os.path.abspath(__file__), "--surfels", "2000", "--res", "64", "--steps", "1000", "--warmup", "100",
            "--cpu-images", "0", "--torch-cpu-images", "0", "--fit-steps", "0", "--repeats", "0", "--per-frame-surface", "1",
            "--no-stage-timers", "--host-probe", "0"]
     try:
