@@ -184,6 +184,14 @@ typedef struct Vidu4dSurfelForwardArgs {
 #define VIDU4D_AUX_GEOM 0x1F   /* planes 0-4: depth, alpha, normal */
 #define VIDU4D_DEBUG_NO_CULL 1
 #define VIDU4D_DEBUG_WHOLE_TILE_BACKWARD 2
+#define VIDU4D_DEBUG_POSITION_ORDER 8  /* (ABI 18, read by the backward) after a segment-parallel forward the backward's workgroups
+                                        * take their units in schedule-position order (rounds 2-4) instead of full segments
+                                        * first, then the tails by descending size (round 5).  Same results up to the order of
+                                        * the float atomics. */
+#define VIDU4D_DEBUG_SERIAL_REPAIR 4   /* (ABI 18) the pre-pass-free segment-parallel forward (assume_unsaturated) adds its
+                                        * segments up in ONE launch that also blends the saturating segments of a tile again,
+                                        * one after the other (rounds 3-4); default since round 5: three launches -- scan,
+                                        * one workgroup per saturating (tile, segment), add up.  Same results. */
 #define VIDU4D_SURFEL_MAX_FRAMES 8
 size_t vidu4d_surfel_image_bytes_frames(int width, int height, int frames);
 

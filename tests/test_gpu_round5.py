@@ -127,3 +127,50 @@ def test_two_threads_rendering_concurrently(gpu_device):
             for x, y in zip(g, wg):
                 scale = float(y.abs().max()) + 1e-30
                 assert float((x - y).abs().max()) <= 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("aux", ["alpha", "geom"])
+@pytest.mark.parametrize("opacity", [0.6, 0.05, 0.004])
+def test_repairs_on_workgroups_of_their_own_equal_the_serial_combine(gpu_device, monkeypatch, opacity, aux):
+    """The pre-pass-free segment-parallel forward (assume_unsaturated) adds its segments up in three launches since round 5
+    -- scan, one workgroup per (tile, segment) some pixel saturates in, add up -- instead of one launch that walks a tile's
+    saturating segments one after the other (VIDU4D_DEBUG_SERIAL_REPAIR).  Same operations in the same order: images,
+    contributor counts, final transmittances and the per-segment state the backward starts from are BIT-identical; the
+    gradients differ by the order of the backward's float atomics only.  0.6: every covered pixel saturates, in the first
+    segments; 0.05: deep in the lists and not everywhere; 0.004: nothing saturates (no segment is flagged)."""
+    from tests.test_gpu_parity import _concentrated_scene
+    from vidu4d_amd import _C, _lib
+    dev = gpu_device
+    sc = _concentrated_scene(dev, opacity)
+    dc, do = (t.to(dev) for t in __import__("vidu4d_amd.synthetic", fromlist=["x"]).make_upstream_grads(sc.width, sc.height))
+    planes = _lib.AUX_ALPHA if aux == "alpha" else _lib.AUX_GEOM
+    keep = [1] if aux == "alpha" else [0, 1, 2, 3, 4]
+    do_live = torch.zeros_like(do)
+    do_live[keep] = do[keep]
+    monkeypatch.setattr(_C, "_SPLIT", "1")
+    monkeypatch.setattr(_C, "_SPEC", True)
+    monkeypatch.setattr(_C, "_SPEC_GEOM", True)
+    e = torch.empty(0, device=dev)
+
+    def run(flags):
+        with _C.debug_flags(flags):
+            out = _C.rasterize_gaussians(sc.bg, sc.means3D, e, sc.opacities, sc.scales, sc.rotations, 1.0, e, sc.viewmatrix,
+                                         sc.projmatrix, sc.tanfovx, sc.tanfovy, sc.height, sc.width, sc.shs, 3, sc.campos,
+                                         False, False, aux_planes=planes)
+            R, color, others, radii, geom, binning, img = out
+            g = _C.rasterize_gaussians_backward(sc.bg, sc.means3D, radii, e, sc.scales, sc.rotations, 1.0, e, sc.viewmatrix,
+                                                sc.projmatrix, sc.tanfovx, sc.tanfovy, dc, do_live, sc.shs, 3, sc.campos, geom,
+                                                R, binning, img, False, aux_planes=planes)
+        n = sc.width * sc.height
+        ncon = _C.read_state("n_contrib", None, geom, binning, img, sc.num_surfels, sc.width, sc.height, torch.int32, 2 * n)
+        fT = _C.read_state("final_T", None, geom, binning, img, sc.num_surfels, sc.width, sc.height, torch.float32, 3 * n)
+        return color, others, ncon, fT, [t for t in g if t.numel()], geom[:64].view(torch.int32).cpu()
+    serial = run(_lib.DEBUG_SERIAL_REPAIR)
+    three = run(0)
+    assert int(serial[5][3]) > 0 and int(serial[5][5]) == 1, "the scene must be blended segment-parallel"   # num_segments, split_used
+    assert int(three[5][6]) == 0 and int(serial[5][6]) == 0                                                   # truncated
+    assert torch.equal(three[5][8:9], serial[5][8:9])                                                          # min final T, bits
+    for a, b, what in zip(three[:4], serial[:4], ("colour", "planes", "contributors", "final T")):
+        assert torch.equal(a, b), what
+    for i, (a, b) in enumerate(zip(three[4], serial[4])):
+        assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max()) + 1e-12, i

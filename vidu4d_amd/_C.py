@@ -61,7 +61,9 @@ _SPEC_GEOM = os.environ.get("VIDU4D_SURFEL_SPEC_GEOM", "0") == "1"
 # backward of an unsplit forward walks every tile with one workgroup (no recorded segments).  The process-wide default; a
 # context (below) may override it for the calls made under it.
 DEBUG_FLAGS = ((_lib.DEBUG_NO_CULL if os.environ.get("VIDU4D_SURFEL_NO_CULL", "0") == "1" else 0) |
-               (_lib.DEBUG_WHOLE_TILE_BACKWARD if os.environ.get("VIDU4D_SURFEL_WHOLE_TILE_BWD", "0") == "1" else 0))
+               (_lib.DEBUG_WHOLE_TILE_BACKWARD if os.environ.get("VIDU4D_SURFEL_WHOLE_TILE_BWD", "0") == "1" else 0) |
+               (_lib.DEBUG_SERIAL_REPAIR if os.environ.get("VIDU4D_SURFEL_SERIAL_REPAIR", "0") == "1" else 0) |
+               (_lib.DEBUG_POSITION_ORDER if os.environ.get("VIDU4D_SURFEL_POSITION_ORDER", "0") == "1" else 0))
 _cu_count: dict = {}
 
 

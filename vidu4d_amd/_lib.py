@@ -78,7 +78,7 @@ class Stage3LossGrads(C.Structure):
 SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
 AUX_ALPHA = 0x02  # VIDU4D_AUX_ALPHA
 AUX_GEOM = 0x1F   # VIDU4D_AUX_GEOM: planes 0-4 (depth, alpha, normal)
-DEBUG_NO_CULL, DEBUG_WHOLE_TILE_BACKWARD = 1, 2   # VIDU4D_DEBUG_*
+DEBUG_NO_CULL, DEBUG_WHOLE_TILE_BACKWARD, DEBUG_SERIAL_REPAIR, DEBUG_POSITION_ORDER = 1, 2, 4, 8   # VIDU4D_DEBUG_*
 BLEND_STATS = 11  # VIDU4D_BLEND_STATS (vidu4d_surfel_diag.h)
 ADAM_MAX_TENSORS = 8
 CLIP_MAX_TENSORS = 16

@@ -166,6 +166,9 @@ struct WorkItem {
 // The largest schedule position p in [0, n) with prefix[p] <= idx (prefix non-decreasing, prefix[0] = 0): a search with 64
 // keys per step, one per lane -- one load round trip per step instead of one per bisection step (2 steps for 2048 positions
 // instead of 11; the bisection cost every workgroup of a segment-parallel launch 10-20 us before its first useful instruction).
+// MINUS_POS: the keys are prefix[p] - p (the FULL segments in front of position p when prefix counts all segments and
+// every position holds exactly one remainder: still non-decreasing).
+template <bool MINUS_POS = false>
 __device__ __forceinline__ uint32_t search_positions(const uint32_t* __restrict__ prefix, uint32_t n, uint32_t idx, int lane)
 {
     uint32_t lo = 0;  // the answer lies in [lo, lo + n)
@@ -173,7 +176,7 @@ __device__ __forceinline__ uint32_t search_positions(const uint32_t* __restrict_
         const uint32_t step = (n + 63u) / 64u;
         const uint32_t p = lo + (uint32_t)lane * step;
         const bool in = (uint32_t)lane * step < n;
-        const uint32_t key = in ? prefix[p] : 0xffffffffu;
+        const uint32_t key = in ? prefix[p] - (MINUS_POS ? p : 0u) : 0xffffffffu;
         const int cnt = __builtin_popcountll(__ballot(in && key <= idx));   // (keys ascend: a prefix of the lanes)
         const uint32_t first = (uint32_t)(cnt - 1) * step;
         lo += first;
@@ -263,6 +266,50 @@ __device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const 
             // (the segment the forward's walk stopped in, as its final record says: short of this one, nothing to do here)
             const uint32_t stop = __float_as_uint(seg_data[((size_t)w.slot * REC_REC_FLOATS + RS_STOP) * 256]);
             if (stop < (uint32_t)w.seg) w.valid = false;
+        }
+    }
+    w.tc.tile = tile;
+    w.tc.valid = true;
+    w.tc.tx = tile % grid_x;
+    w.tc.ty = tile / grid_x;
+    return w;
+}
+
+// The backward of a SEGMENT-PARALLEL forward (Header::split_used == 1), dispatched like the recorded one (round 5): the
+// split tiles are the schedule positions [0, S) (by length class), position p holds n_p = seg_prefix[p + 1] - seg_prefix[p]
+// segments of which n_p - 1 are FULL (SEG_LEN entries);
+//   [0, F)      F = num_segments - S: the full segments, position by position -- equal units, dispatched first;
+//   [F, F + T)  one tail per tile, largest first (ImageState::tail_order): the remainder segment of a split tile or a whole
+//               unsplit tile (up to SPLIT_MIN entries: twice a segment -- dispatched in position order behind ALL segments,
+//               as until round 5, the largest units of the launch started last: blend_bwd 427 us against 359 us for the
+//               recorded backward of the same frames, dense Stage-3 ball);
+//   beyond      nothing.
+__device__ __forceinline__ WorkItem find_work_split_ordered(const Header* hdr, const ImageState& img, int grid_x, int grid_y)
+{
+    WorkItem w;
+    w.seg = -1;
+    w.slot = 0;
+    w.valid = true;
+    const uint32_t S = hdr->num_split_pos, F = hdr->num_segments - S;
+    const uint32_t idx = blockIdx.x;
+    int tile;
+    if (idx < F) {
+        const uint32_t lo = search_positions<true>(img.seg_prefix, S, idx, threadIdx.x & 63);
+        tile = (int)img.tile_order[lo];
+        w.seg = (int)(idx - (img.seg_prefix[lo] - lo));
+        w.slot = img.seg_first[tile] + (uint32_t)w.seg;
+    } else {
+        const uint32_t j = idx - F;
+        if (j >= (uint32_t)(grid_x * grid_y)) {
+            w.valid = false;
+            return w;
+        }
+        tile = (int)img.tail_order[j];
+        const uint32_t first = img.seg_first[tile];
+        if (first != SEG_NONE) {   // the remainder of a split tile: its last segment
+            const uint32_t len = img.ranges[2 * tile + 1] - img.ranges[2 * tile];
+            w.seg = (int)((len + hdr->seg_len - 1u) / hdr->seg_len) - 1;
+            w.slot = first + (uint32_t)w.seg;
         }
     }
     w.tc.tile = tile;
@@ -453,7 +500,10 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
         hdr->split_used = !overflow && hdr->num_segments > 0;
     if (!SPLIT && rec_len && blockIdx.x == 0 && threadIdx.x == 0)
         hdr->split_used = (!overflow && hdr->num_segments > 0) ? 2u : 0u;
-    const WorkItem wk = find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
+    // (SPLIT: full segments first, then the remainders and the unsplit tiles by descending size -- find_work_split_ordered;
+    // until round 5 in schedule-position order, the unsplit tiles of up to SPLIT_MIN entries, twice a segment, last)
+    const WorkItem wk = (SPLIT && !overflow && !(flags & FLAG_POSITION_ORDER)) ? find_work_split_ordered(hdr, img, grid_x, grid_y)
+                                                                              : find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     TileCoord tc = wk.tc;
     size_t plane;
@@ -640,7 +690,17 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
 //   M2_p * (sum w_i) - 2 M1_p * (sum w_i m_i)      with sum w_i = T_start - T_end.
 // BLEND_LITE (colour + alpha plane only): the segments hold colour, end transmittance and last contributor, nothing else;
 // BLEND_GEOM: depth and normal sums as well.
-template <int MODE>
+// PHASE (round 5; spec only): the pass as THREE launches, so that the repair walks of a tile -- one per segment some pixel
+// of the tile saturates in -- run on workgroups of their own instead of one after the other inside the tile's workgroup
+// (on the dense Stage-3 ball every covered pixel saturates, in two to four different segments per tile: the serial repairs
+// were 150-310 us of a frame).  PHASE 1 ("scan") runs the first loop below, leaves what it found per
+// pixel -- the segment to repair, the exact transmittance in front of it, the sums so far -- in fields of the tile's first
+// three segment slots that the colour / planes-0-4 instances do not use (SG_M1 .. SG_MED_W: every split tile has at least
+// three segments), and flags the segments that need a walk (SG_MED_C of the slot's pixel 0); blend_repair_kernel takes one
+// flagged (tile, segment) per workgroup; PHASE 2 ("finalise") adds the repaired segment's sums and does everything behind
+// the repair.  Same operations on the same operands in the same order as PHASE 0, which remains what runs without `spec`
+// and under VIDU4D_DEBUG_SERIAL_REPAIR.
+template <int MODE, int PHASE = 0>
 __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                            ImageState img, const uint32_t* __restrict__ point_list,
                                                            const float* __restrict__ rec, int64_t capacity, int max_seg,
@@ -672,7 +732,11 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     // spec: the segment in which this pixel saturates (or comes within 0.1 % of it), and what the segments before it leave
     int repair_q = -1;
     float repair_T = 1.0f;
-    for (int q = 0; q < nseg; q++) {
+    static_assert(PHASE == 0 || MODE != BLEND_FULL, "the three-launch form is the speculated (colour / planes 0-4) instances'");
+    auto note = [&](int seg, int field) -> float& {   // per-pixel scratch of the three-launch form (see above)
+        return seg_data[((size_t)(first + (uint32_t)seg) * SEG_FLOATS + field) * 256 + threadIdx.x];
+    };
+    for (int q = 0; PHASE != 2 && q < nseg; q++) {
         float* d = seg_data + (size_t)(first + q) * SEG_FLOATS * 256 + threadIdx.x;
         const float T_start = T_raw;
         if (SPEC_OK && spec) {
@@ -723,7 +787,53 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
             s.median_weight = d[SG_MED_W * 256];
         }
     }
-    if constexpr (SPEC_OK) if (spec) {
+    if constexpr (PHASE == 1) {
+        note(0, SG_M1) = __int_as_float(repair_q);
+        note(0, SG_M2) = repair_T;
+        note(0, SG_DIST) = T_raw;
+        note(0, SG_MED_D) = s.T;
+        note(0, SG_MED_W) = __uint_as_float(s.last_contributor);
+        note(1, SG_M1) = s.C[0];
+        note(1, SG_M2) = s.C[1];
+        note(1, SG_DIST) = s.C[2];
+        note(1, SG_MED_D) = s.D;
+        note(1, SG_MED_W) = s.N[0];
+        note(2, SG_M1) = s.N[1];
+        note(2, SG_M2) = s.N[2];
+        // which segments of this tile some pixel must be blended again in
+        for (int q = threadIdx.x; q < nseg_all; q += 256)
+            seg_data[((size_t)(first + (uint32_t)q) * SEG_FLOATS + SG_MED_C) * 256] = __uint_as_float(0u);
+        __syncthreads();
+        if (px < W && py < H && repair_q >= 0)
+            seg_data[((size_t)(first + (uint32_t)repair_q) * SEG_FLOATS + SG_MED_C) * 256] = __uint_as_float(1u);
+        return;
+    }
+    if constexpr (PHASE == 2) {
+        repair_q = __float_as_int(note(0, SG_M1));
+        T_raw = note(0, SG_DIST);
+        s.T = note(0, SG_MED_D);
+        s.last_contributor = __float_as_uint(note(0, SG_MED_W));
+        s.C[0] = note(1, SG_M1);
+        s.C[1] = note(1, SG_M2);
+        s.C[2] = note(1, SG_DIST);
+        s.D = note(1, SG_MED_D);
+        s.N[0] = note(1, SG_MED_W);
+        s.N[1] = note(2, SG_M1);
+        s.N[2] = note(2, SG_M2);
+        if (px < W && py < H && repair_q >= 0 && repair_q < nseg) {   // what blend_repair_kernel left in the segment's slot
+            const float* d = seg_data + (size_t)(first + (uint32_t)repair_q) * SEG_FLOATS * 256 + threadIdx.x;
+            for (int ch = 0; ch < 3; ch++) s.C[ch] += d[(SG_C + ch) * 256];
+            if (GEOM) {
+                for (int ch = 0; ch < 3; ch++) s.N[ch] += d[(SG_N + ch) * 256];
+                s.D += d[SG_D * 256];
+            }
+            s.T = d[SG_TEND * 256];
+            const uint32_t last = __float_as_uint(d[SG_LAST * 256]);
+            if (last) s.last_contributor = last;
+            T_raw = 0.f;  // (saturated: not cut short by a segment limit)
+        }
+    }
+    if constexpr (SPEC_OK && PHASE == 0) if (spec) {
         // ---- the saturating segments, blended again for the pixels that saturate in them: the loop of blend_fwd_kernel,
         // restricted to the segment and to those pixels, from the exact transmittance (the product of the predecessors'
         // products in list order: what blend_seg_T_kernel + blend_fwd_kernel use for their start)
@@ -853,6 +963,84 @@ __global__ __launch_bounds__(256) void blend_combine_kernel(int W, int H, int gr
     }
 }
 
+// The repair walk of ONE (tile, segment) -- see blend_combine_kernel's PHASE note: workgroup b takes segment slot b (as
+// blend_fwd_kernel<true> numbers them), leaves at once unless PHASE 1 flagged the slot, and blends the segment again for
+// the pixels of the tile that saturate in it, from the exact transmittance PHASE 1 left per pixel; the sums go into the
+// segment's slot as absolute values (SG_TSEG = -2 says so), where PHASE 2 and the backward read them.
+template <int MODE>
+__global__ __launch_bounds__(256) void blend_repair_kernel(int W, int H, int grid_x, int grid_y, Header* hdr, ImageState img,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const float* __restrict__ rec, int64_t capacity, int max_seg,
+                                                          float* __restrict__ seg_data, int flags)
+{
+    static_assert(MODE != BLEND_FULL, "speculated instances only");
+    constexpr bool GEOM = MODE == BLEND_GEOM;
+    __shared__ float4 s_rec[FWD_BATCH * 5];
+    __shared__ unsigned long long s_mask[4][4];
+    if ((int64_t)hdr->num_rendered > capacity || blockIdx.x >= hdr->num_segments) return;
+    const WorkItem wk = find_work<true>(hdr, img, grid_x, grid_y, false);
+    if (wk.seg >= max_seg) return;
+    if (__float_as_uint(seg_data[((size_t)wk.slot * SEG_FLOATS + SG_MED_C) * 256]) == 0u) return;   // (wave-uniform)
+    TileCoord tc = wk.tc;
+    const int tile = tc.tile;
+    size_t plane_unused;
+    (void)frame_of_tile(tc, W, H, grid_y, plane_unused);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = tc.tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = tc.ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
+    const uint32_t first = wk.slot - (uint32_t)wk.seg;
+    const int q = wk.seg;
+    const int repair_q = __float_as_int(seg_data[((size_t)first * SEG_FLOATS + SG_M1) * 256 + threadIdx.x]);
+    const float repair_T = seg_data[((size_t)first * SEG_FLOATS + SG_M2) * 256 + threadIdx.x];
+    const bool mine = inside && repair_q == q;
+    const uint32_t r0 = img.ranges[2 * tile], r1 = img.ranges[2 * tile + 1];
+    FwdPixel t;  // the segment's partial sums, from the exact start
+    t.T = repair_T;
+    bool done = !mine;
+    const int begin = q * SEG_LEN;
+    int todo = min((int)(r1 - r0) - begin, SEG_LEN);
+    for (int base = begin; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
+        if (__syncthreads_count(done) == 256) break;
+        const bool have = (int)threadIdx.x < todo;
+        FootprintTest foot = no_footprint();
+        if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        publish_cull_masks(s_mask, have, foot, tc.tx * TILE, tc.ty * TILE, wave, lane, flags & FLAG_NO_CULL);
+        __syncthreads();
+        if (__all(done)) continue;
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            unsigned long long m = uniform_u64(s_mask[wave][k]);
+            while (m) {
+                const int j = k * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
+                const float Tu[3] = {a0.x, a0.y, a0.z}, Tv[3] = {a0.w, a1.x, a1.y}, Tw[3] = {a1.z, a1.w, a2.x};
+                PairEval e;
+                const bool ok = eval_pair_flat(Tu, Tv, Tw, a2.y, a2.z, a2.w, pixx, pixy, e) && !done;
+                if (!__any(ok)) continue;
+                if (ok) {
+                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                    const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+                    if (!fwd_accumulate<MODE>(t, e, nrm, rgb, (uint32_t)(base + j + 1))) done = true;
+                }
+            }
+        }
+    }
+    if (mine) {
+        float* d = seg_data + (size_t)wk.slot * SEG_FLOATS * 256 + threadIdx.x;
+        for (int ch = 0; ch < 3; ch++) d[(SG_C + ch) * 256] = t.C[ch];  // (absolute, unlike the speculated segments')
+        if (GEOM) {
+            for (int ch = 0; ch < 3; ch++) d[(SG_N + ch) * 256] = t.N[ch];
+            d[SG_D * 256] = t.D;
+        }
+        d[SG_TSEG * 256] = -2.0f;
+        d[SG_TEND * 256] = t.T;
+        d[SG_LAST * 256] = __uint_as_float(t.last_contributor);
+    }
+}
+
 template <bool SPLIT>
 static auto pick_fwd(int mode)
 {
@@ -899,6 +1087,20 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     hipLaunchKernelGGL(pick_fwd<true>(mode), dim3(segs + tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr,
                        img, point_list, capacity, max_seg, g.rec, background, b.seg_data, out_color, out_others, depth_used, spec,
                        flags, 0);
+    if (spec && !(flags & FLAG_SERIAL_REPAIR)) {
+        // the combine as three launches: scan the segments' records, blend the saturating (tile, segment) pairs again on
+        // workgroups of their own, add up (blend_combine_kernel's PHASE note)
+        auto scan = mode == BLEND_LITE ? &blend_combine_kernel<BLEND_LITE, 1> : &blend_combine_kernel<BLEND_GEOM, 1>;
+        auto repair = mode == BLEND_LITE ? &blend_repair_kernel<BLEND_LITE> : &blend_repair_kernel<BLEND_GEOM>;
+        auto fin = mode == BLEND_LITE ? &blend_combine_kernel<BLEND_LITE, 2> : &blend_combine_kernel<BLEND_GEOM, 2>;
+        hipLaunchKernelGGL(scan, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img, point_list,
+                           g.rec, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used, spec, flags);
+        hipLaunchKernelGGL(repair, dim3(segs), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img, point_list,
+                           g.rec, capacity, max_seg, b.seg_data, flags);
+        hipLaunchKernelGGL(fin, dim3(split_tiles), dim3(256), 0, stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img, point_list,
+                           g.rec, capacity, max_seg, background, b.seg_data, out_color, out_others, depth_used, spec, flags);
+        return;
+    }
     auto combine = mode == BLEND_LITE ? &blend_combine_kernel<BLEND_LITE>
                    : mode == BLEND_GEOM ? &blend_combine_kernel<BLEND_GEOM>
                                         : &blend_combine_kernel<BLEND_FULL>;
@@ -1057,6 +1259,7 @@ void blend_bwd_kernel(int W, int H, int grid_x, int grid_y, const Header* hdr,
     // (a forward that left no segment state: every tile is then walked whole)
     const uint32_t split_used = SPLIT ? hdr->split_used : 0u;
     const WorkItem wk = (SPLIT && split_used == 2u) ? find_work_recorded(hdr, img, grid_x, grid_y, seg_data)
+                        : (SPLIT && split_used == 1u && !(flags & FLAG_POSITION_ORDER)) ? find_work_split_ordered(hdr, img, grid_x, grid_y)
                                                     : find_work<SPLIT>(hdr, img, grid_x, grid_y, SPLIT && !split_used);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     TileCoord tc = wk.tc;

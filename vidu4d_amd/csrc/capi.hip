@@ -207,7 +207,11 @@ static int blend_mode(int aux_planes)
     if (aux_planes != 0 && (aux_planes & ~VIDU4D_AUX_GEOM) == 0) return BLEND_GEOM;  // some of the planes 0-4, nothing else
     return BLEND_FULL;
 }
-static int kernel_flags(int debug_flags) { return (debug_flags & VIDU4D_DEBUG_NO_CULL) ? FLAG_NO_CULL : 0; }
+static int kernel_flags(int debug_flags)
+{
+    return ((debug_flags & VIDU4D_DEBUG_NO_CULL) ? FLAG_NO_CULL : 0) | ((debug_flags & VIDU4D_DEBUG_SERIAL_REPAIR) ? FLAG_SERIAL_REPAIR : 0) |
+           ((debug_flags & VIDU4D_DEBUG_POSITION_ORDER) ? FLAG_POSITION_ORDER : 0);
+}
 // Does a whole-tile forward leave recorded segments for its backward (surfel_state.h)?  They pay by letting the dispatcher
 // balance the CUs when a launch has about as many tiles as the chip has workgroup slots (256 CUs x 6: the headline's 2048
 // tiles drain for a third of the launch); with several tiles per slot the whole-tile launch balances by itself and the
@@ -345,7 +349,9 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     const CameraParams cam = camera_of(a);
     // the segment table: for a segment-parallel forward, or (whole-tile forward) for the recorded segments of its backward
     const bool record = records_segments(a->segment_split, total_tiles(cam));
-    const ScheduleParams sp = {record ? REC_SEG_LEN : SEG_LEN, record ? REC_MIN : SPLIT_MIN, record ? 1 : 0};
+    // (by length CLASS in both cases since round 5: the split tiles are then exactly the schedule positions [0, S), and the
+    // schedule builder also orders the tails -- which the backward of a segment-parallel forward now dispatches by too)
+    const ScheduleParams sp = {record ? REC_SEG_LEN : SEG_LEN, record ? REC_MIN : SPLIT_MIN, 1};
     {
         StageTimer t(ST_EMIT, stream);
         launch_emit_keys(cam, P, a->radii, g, img, b, capacity, use_grouped_binning(total_tiles(cam)), sp, stream);

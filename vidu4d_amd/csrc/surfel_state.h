@@ -101,6 +101,8 @@ inline size_t seg_data_floats(int64_t capacity)
 }
 // debug_flags of the ABI as the kernels see them
 constexpr int FLAG_NO_CULL = 1;
+constexpr int FLAG_POSITION_ORDER = 8;  // VIDU4D_DEBUG_POSITION_ORDER: the split backward's workgroups in schedule-position order (rounds 2-4)
+constexpr int FLAG_SERIAL_REPAIR = 4;   // VIDU4D_DEBUG_SERIAL_REPAIR: the speculated combine as ONE launch (rounds 3-4)
 
 struct Header {           // first 256 bytes of the geometry buffer
     uint32_t num_rendered;  // R, written by the tile scan

@@ -203,8 +203,17 @@ class DeformableSurfels(GaussianModel):
         self._aux_dict = aux
         return xyz_cam, rot_cam, (q, t)
 
+    def _warp_param_list(self):
+        """The warp's and the camera's parameters as a plain list, collected once: `Module.parameters()` walks the module
+        tree (0.2 ms for the bob networks -- it was asked two or three times per step, a third of the step's host time,
+        tools/fit_host_probe.py)."""
+        lst = self.__dict__.get("_warp_params")
+        if lst is None:
+            lst = self.__dict__["_warp_params"] = [p for mod in (self.warp, self.camera_mlp) for p in mod.parameters()]
+        return lst
+
     def warp_networks_train(self) -> bool:
-        return any(p.requires_grad for mod in (self.warp, self.camera_mlp) for p in mod.parameters())
+        return any(p.requires_grad for p in self._warp_param_list())
 
     def fused_warp_ok(self, inst_id=None) -> bool:
         """The fused HIP warp applies when all frames of the batch share one instance code.  Frozen bone and camera
@@ -220,8 +229,7 @@ class DeformableSurfels(GaussianModel):
         return inst_id is None or len(set(inst_id.tolist())) == 1
 
     def _frozen_warp_table(self):
-        params = [p for mod in (self.warp, self.camera_mlp) for p in mod.parameters()]
-        version = sum(p._version for p in params)
+        version = sum(p._version for p in self._warp_param_list())
         tab = self.__dict__.get("_warp_table")
         if tab is None or tab["version"] != version:
             with torch.no_grad():

@@ -177,7 +177,10 @@ def skin_field_supported(sm) -> bool:
         return False
     if 3 * B > lim["in_max"] or B > lim["out_max"] or sm.xyz_channels != 3 * B:
         return False
-    return not any(p.requires_grad for p in sm.parameters())
+    plist = sm.__dict__.get("_param_list")   # (collected once: Module.parameters() walks the module tree, every step)
+    if plist is None:
+        plist = sm.__dict__["_param_list"] = list(sm.parameters())
+    return not any(p.requires_grad for p in plist)
 
 
 def prepare_skin_field(sm, A, c0) -> dict:
