@@ -331,8 +331,9 @@ def test_fused_warp_with_networks_that_train_gives_every_parameter_its_gradient(
         N = m._xyz.shape[0]
         if fused:
             x, r = m.forward_warp_fused(fid)
-            if m.__dict__.pop("_warp_rot_is_unit", False):
-                pass
+            m.__dict__.pop("_warp_rot_is_unit", None)
+            # (the networks' forward and backward ran as captured hipGraphs: DeformableSurfels._graphed_warp_networks)
+            assert m.__dict__["_net_graph"][1] is not None, "the networks were evaluated eagerly: graph capture failed"
         else:
             xyz = m._xyz[None, :, None].expand(2, -1, -1, -1)
             rot = m._rotation[None].expand(2, -1, -1)

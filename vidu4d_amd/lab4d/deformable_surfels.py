@@ -39,6 +39,28 @@ def Kmatinv(Kmat):
     return torch.inverse(Kmat)
 
 
+class _WarpNetEval(nn.Module):
+    """What the fused warp needs from the networks, as ONE callable of the step's frame ids (for graph capture,
+    DeformableSurfels._graphed_warp_networks): the bones' dual quaternions relative to the rest pose, the cameras, the rest
+    pose's bone map and the mean time code's first-layer bias -- the same calls forward_warp_fused makes eagerly."""
+
+    def __init__(self, warp, camera_mlp):
+        super().__init__()
+        self.warp, self.camera_mlp = warp, camera_mlp
+
+    def forward(self, frame_id):
+        w = self.warp
+        sm = w.skinning_model
+        t_art, rest_art = w.articulation.get_vals_and_mean(frame_id)
+        se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
+        cq, ct = self.camera_mlp.get_vals(frame_id)
+        A, c0 = sm.bone_affine((rest_art[0][:1], rest_art[1][:1]))
+        out = (se3[0].contiguous(), se3[1].contiguous(), cq.contiguous(), ct.contiguous(), A.contiguous(), c0.contiguous())
+        if sm.has_delta:
+            out = out + (sm.frame_bias(None, None, 1, frame_id.device).contiguous(),)
+        return out
+
+
 class DeformableSurfels(GaussianModel):
     """State-dict keys under `fields.field_params.fg.` as upstream: `_xyz`, `_features_dc`, `_features_rest`,
     `_scaling`, `_rotation`, `_opacity`, `_regist_feat`, `logsigma`, `logibeta`, `aabb`, `learnable_bkgd`,
@@ -212,6 +234,21 @@ class DeformableSurfels(GaussianModel):
             lst = self.__dict__["_warp_params"] = [p for mod in (self.warp, self.camera_mlp) for p in mod.parameters()]
         return lst
 
+    def _graphed_warp_networks(self, frame_id):
+        """frame ids (M,) -> (se3_qr, se3_qd, cam_q, cam_t, bone_A, bone_c[, frame_bias]) through hipGraphs of the networks'
+        forward and backward (captured on first use and whenever M or the set of trainable parameters changes)."""
+        key = (int(frame_id.shape[0]), tuple(p.requires_grad for p in self._warp_param_list()))
+        g = self.__dict__.get("_net_graph")
+        if g is None or g[0] != key:
+            mod = _WarpNetEval(self.warp, self.camera_mlp)
+            try:
+                fn = torch.cuda.make_graphed_callables(mod, (frame_id.clone(),), allow_unused_input=True)
+            except Exception as e:   # (capture is an optimisation: anything it cannot take runs eagerly, said once)
+                print(f"graphed_warp_networks: capture failed ({type(e).__name__}: {e}); evaluating the networks eagerly")
+                fn = None
+            g = self.__dict__["_net_graph"] = (key, fn)
+        return None if g[1] is None else g[1](frame_id)
+
     def warp_networks_train(self) -> bool:
         return any(p.requires_grad for p in self._warp_param_list())
 
@@ -277,13 +314,27 @@ class DeformableSurfels(GaussianModel):
         trainable = self.warp_networks_train()
         overrides = trainable or any(k in samples_dict for k in ("rest_articulation", "t_articulation", "field2cam"))
         if overrides:
-            if "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
+            graphed = None
+            if (trainable and not samples_dict and inst_id is None and frame_id.is_cuda and frame_id.dtype == torch.int64
+                    and torch.is_grad_enabled() and self.opts.get("graphed_warp_networks", True)
+                    and frame_id.shape[0] <= 8 and self.opts.get("fused_skin", True) and not self.opts.get("warp_aux", False)
+                    and (not w.skinning_model.has_delta or w.skinning_model.num_freq_xyz == 0)):
+                # networks that train: their forward for the step's frames (and, for the rest pose, for the mean over all
+                # frames) is ~450 small launches and their backward ~550 autograd nodes -- 9 of the step's 12 ms of HOST
+                # time (tools/fit_host_probe_optim_warp.py).  Shapes are static, so both directions are captured into
+                # hipGraphs once (torch.cuda.make_graphed_callables) and replayed: two graph launches per step.
+                graphed = self._graphed_warp_networks(frame_id)
+            if graphed is not None:
+                se3, cq, ct = (graphed[0], graphed[1]), graphed[2], graphed[3]
+                rest1 = None
+            elif "rest_articulation" in samples_dict and "t_articulation" in samples_dict:
                 rest_art, t_art = samples_dict["rest_articulation"], samples_dict["t_articulation"]
             else:
                 t_art, rest_art = w.articulation.get_vals_and_mean(frame_id)
-            se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
-            rest1 = (rest_art[0][:1], rest_art[1][:1])
-            cq, ct = samples_dict["field2cam"] if "field2cam" in samples_dict else self.camera_mlp.get_vals(frame_id)
+            if graphed is None:
+                se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
+                rest1 = (rest_art[0][:1], rest_art[1][:1])
+                cq, ct = samples_dict["field2cam"] if "field2cam" in samples_dict else self.camera_mlp.get_vals(frame_id)
         else:
             # frozen networks: bone transforms and cameras of ALL frames are constants of the run; they are
             # evaluated once (and again whenever a parameter is written) and indexed per step
@@ -300,7 +351,10 @@ class DeformableSurfels(GaussianModel):
         sm = w.skinning_model
         M = frame_id.shape[0]
         iid = None if inst_id is None else inst_id[:1]
-        if overrides:
+        if overrides and rest1 is None:   # (from the captured graphs)
+            A, c0 = graphed[4], graphed[5]
+            bias = graphed[6] if sm.has_delta else None
+        elif overrides:
             A, c0 = sm.bone_affine(rest1)
             bias = sm.frame_bias(None, iid, 1, self._xyz.device) if sm.has_delta else None
         else:
