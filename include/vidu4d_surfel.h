@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 18
+#define VIDU4D_SURFEL_ABI 19
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -356,6 +356,27 @@ int vidu4d_lbs_skin_backward(int M, int N, int B, const float* xbT, const float*
                              const float* bone_c, const int64_t* frame_index, int table_rows, float* g_params,
                              void* stream);
 int vidu4d_lbs_skin_param_rows(int N);
+
+/* ---- (ABI 19) from the articulation network's heads to the tables vidu4d_lbs_skin_* reads, for networks that train:
+ *      axis-angle and translation per bone -> unit dual quaternion (ArticulationFlatMLP.forward,
+ *      lab4d/nnutils/pose.py:300-323; quat_transform.py axis_angle_to_quaternion :136-160,
+ *      quaternion_translation_to_dual_quaternion :341-360), each frame's bones relative to the rest pose's
+ *      (dual_quaternion_mul(t, dual_quaternion_inverse(rest)), lab4d/nnutils/warping.py:415-425, quat_transform.py:420-469),
+ *      and the rest pose's object->bone rotation and translation with every row divided by the Gaussian bone's extent
+ *      (gauss_mlp_skinning's bone coordinates, lab4d/nnutils/skinning.py:117-141; quaternion_to_matrix,
+ *      quat_transform.py:221-255) -- ~75 elementwise launches forward and ~175 backward in the reference's graph, one here.
+ *      so3_t / trans_t (M, B, 3): the heads' outputs for the M frames; so3_rest / trans_rest (B, 3): for the mean time code;
+ *      inv_gauss (B, 3) = 1 / exp(log_gauss).  Outputs se3_qr / se3_qd (M, B, 4), bone_A (3B, 3) row 3 b + k =
+ *      R_b[k][:] * inv_gauss[b][k], bone_c (3B) = t_b[k] * inv_gauss[b][k]  (bone_A / bone_c may both be NULL: skipped).
+ *      The backward takes the gradients of the four outputs (any may be NULL = zero) and returns those of the five
+ *      inputs (g_inv_gauss may be NULL); it evaluates the forward's own code on dual numbers, one direction at a time. ---- */
+int vidu4d_bone_tables_forward(int M, int B, const float* so3_t, const float* trans_t, const float* so3_rest,
+                               const float* trans_rest, const float* inv_gauss, float* se3_qr, float* se3_qd,
+                               float* bone_A, float* bone_c, void* stream);
+int vidu4d_bone_tables_backward(int M, int B, const float* so3_t, const float* trans_t, const float* so3_rest,
+                                const float* trans_rest, const float* inv_gauss, const float* g_se3_qr,
+                                const float* g_se3_qd, const float* g_bone_A, const float* g_bone_c, float* g_so3_t,
+                                float* g_trans_t, float* g_so3_rest, float* g_trans_rest, float* g_inv_gauss, void* stream);
 
 /* ---- the per-surfel part of the bob skinning field, once per optimizer step: Gaussian-bone coordinates of the rest
  *      pose and the delta-skin MLP on them (replaces gauss_mlp_skinning's bone transform and SkinningField.delta_field,

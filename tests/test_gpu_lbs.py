@@ -366,3 +366,61 @@ def test_fused_warp_with_networks_that_train_gives_every_parameter_its_gradient(
     compare({k: v for k, v in out[True][1].items() if k in net}, {k: v for k, v in out[False][1].items() if k in net}, 1e-3, "render, networks")
     compare({k: v for k, v in out[True][1].items() if k not in net}, {k: v for k, v in out[False][1].items() if k not in net}, 1e-2,
             "render, surfels")
+
+
+@pytest.mark.parametrize("M,B,seed", [(2, 25, 0), (1, 7, 1), (8, 40, 2), (3, 130, 3)])
+def test_bone_table_kernels_match_the_torch_chain(gpu_device, M, B, seed):
+    """csrc/bone_tables.hip (heads -> relative bone transforms, rest pose's scaled bone map) against the torch statement
+    of the same chain with autograd: values to 2e-6, the five inputs' gradients to 1e-5 of scale (the arithmetic itself is
+    pinned on the host by tests/test_bone_tables_cpu.py; this is the launch: indexing, more than one workgroup, NULL parts)."""
+    from tests.test_bone_tables_cpu import _torch_chain
+    from vidu4d_amd.lab4d.bone_tables import bone_tables
+    dev = gpu_device
+    g = torch.Generator().manual_seed(seed)
+    ins = [0.5 * torch.randn(M, B, 3, generator=g), 0.1 * torch.randn(M, B, 3, generator=g), 0.5 * torch.randn(B, 3, generator=g),
+           0.1 * torch.randn(B, 3, generator=g), torch.exp(3.5 + 0.3 * torch.randn(B, 3, generator=g))]
+    gouts = [torch.randn(s, generator=g) for s in ((M, B, 4), (M, B, 4), (3 * B, 3), (3 * B,))]
+    a = [x.clone().requires_grad_() for x in ins]
+    want = _torch_chain(*a)
+    want_g = torch.autograd.grad(want, a, gouts)
+    b = [x.to(dev).requires_grad_() for x in ins]
+    got = bone_tables(*b)
+    for o, w in zip(got, want):
+        assert float((o.cpu() - w).abs().max()) <= 2e-6 * max(1.0, float(w.abs().max()))
+    got_g = torch.autograd.grad(got, b, [x.to(dev) for x in gouts])
+    for name, x, w in zip(("so3_t", "trans_t", "so3_rest", "trans_rest", "inv_gauss"), got_g, want_g):
+        assert float((x.cpu() - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max())), name
+    # only the bone transforms' gradients arrive (the tables unused): the rest pose still gets its share, the extents zero
+    got = bone_tables(*b)
+    part = torch.autograd.grad(got[:2], b, [x.to(dev) for x in gouts[:2]], allow_unused=True)
+    want_part = torch.autograd.grad(_torch_chain(*a)[:2], a, gouts[:2], allow_unused=True)
+    for x, w in zip(part[:4], want_part[:4]):
+        assert float((x.cpu() - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max()))
+    assert float(part[4].abs().max()) == 0.0
+
+
+def test_weight_gradient_contraction_over_the_surfels_in_chunks(gpu_device):
+    """bob_warp.contract_over_columns on the device at the bench's size: the batched GEMM over strided views of the
+    feature-major arrays (no copies) gives G @ X^T to float rounding; through feature_major_linear the three gradients
+    equal torch.addmm's."""
+    from vidu4d_amd.lab4d.bob_warp import SPLIT_K_CHUNK, contract_over_columns, feature_major_linear
+    dev = gpu_device
+    g = torch.Generator().manual_seed(5)
+    for O, I, N in ((64, 75, 200000), (25, 64, 200000), (64, 64, 8192 + 3), (75, 3, 50001)):
+        G, X = torch.randn(O, N, generator=g).to(dev), torch.randn(I, N, generator=g).to(dev)
+        want = G.double() @ X.double().t()
+        got = contract_over_columns(G, X)
+        assert float((got.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) + 1e-3 * N ** 0.5 * 1e-3
+    N = 5 * SPLIT_K_CHUNK + 9
+    X0 = torch.randn(75, N, generator=g).to(dev)
+    gy = torch.randn(64, N, generator=g).to(dev)
+    res = {}
+    for split in (True, False):
+        W = torch.randn(64, 75, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_()
+        b = torch.randn(64, generator=torch.Generator().manual_seed(2)).to(dev).requires_grad_()
+        X = X0.clone().requires_grad_()
+        Y = feature_major_linear(b, W, X, SPLIT_K_CHUNK) if split else torch.addmm(b[:, None], W, X)
+        Y.backward(gy)
+        res[split] = (Y.detach(), W.grad, b.grad, X.grad)
+    for a, c in zip(res[True], res[False]):
+        assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())

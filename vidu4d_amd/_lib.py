@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class ForwardArgs(C.Structure):
@@ -140,6 +140,8 @@ SYMBOLS = {
     "vidu4d_lbs_skin_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 10 + [C.c_int, _P, _P, _P, C.c_int, _P]),
     "vidu4d_lbs_skin_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_P] * 14 + [C.c_int, _P, _P, _P, C.c_int, _P, _P]),
     "vidu4d_lbs_skin_param_rows": (C.c_int, [C.c_int]),
+    "vidu4d_bone_tables_forward": (C.c_int, [C.c_int, C.c_int] + [_P] * 10),
+    "vidu4d_bone_tables_backward": (C.c_int, [C.c_int, C.c_int] + [_P] * 15),
     "vidu4d_knn_mean_dist2": (C.c_int, [C.c_int, _P, _P, _P]),
     "vidu4d_radius_count": (C.c_int, [C.c_int, _P, C.c_float, _P, _P]),
     "vidu4d_post_forward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),

@@ -32,6 +32,55 @@ from . import quat_transform as qt
 from .nets import ArticulationFlatMLP, CondDenseStack, TimeEmbedding, fourier_dim, fourier_features
 
 
+
+SPLIT_K_CHUNK = 2048
+
+
+class _FeatureMajorLinear(torch.autograd.Function):
+    """Y (O, N) = W (O, I) @ X (I, N) + b[:, None] over N surfels.  The forward and d/dX are ordinary library GEMMs; the
+    weight gradient G (O, N) @ X^T (N, I) contracts over the SURFELS, a shape (64 x 75 x 200 000) for which rocBLAS runs
+    16 x 256 tiles down the whole K in a handful of workgroups (722 us, rocprofv3, round 5).  It is evaluated as a batched
+    GEMM over K-chunks of `chunk` surfels -- strided views of the same arrays, no copy -- and a sum over the chunks: a few
+    hundred workgroups.  Same products, another summation order (float: ~1e-6 relative)."""
+
+    @staticmethod
+    def forward(ctx, b, W, X, chunk):
+        ctx.save_for_backward(W, X)
+        ctx.chunk = int(chunk)
+        return torch.addmm(b[:, None], W, X)
+
+    @staticmethod
+    def backward(ctx, G):
+        W, X = ctx.saved_tensors
+        G = G.contiguous()
+        gb = G.sum(1) if ctx.needs_input_grad[0] else None
+        gW = None
+        if ctx.needs_input_grad[1]:
+            gW = contract_over_columns(G, X, ctx.chunk)
+        gX = W.t().mm(G) if ctx.needs_input_grad[2] else None
+        return gb, gW, gX, None
+
+
+def contract_over_columns(G, X, chunk=SPLIT_K_CHUNK):
+    """G (O, N) @ X (I, N)^T -> (O, I), the long contraction cut into `chunk`-column pieces that run as one batched GEMM."""
+    O, N = G.shape
+    n_full = N // chunk if chunk > 0 else 0
+    if n_full < 4 or X.stride(1) != 1 or G.stride(1) != 1:
+        return G.mm(X.t())
+    body = n_full * chunk
+    Gc = G[:, :body].unflatten(1, (n_full, chunk)).permute(1, 0, 2)              # (n, O, chunk), row stride N
+    Xc = X[:, :body].unflatten(1, (n_full, chunk)).permute(1, 2, 0)              # (n, chunk, I), column stride N
+    out = torch.bmm(Gc, Xc).sum(0)
+    if body < N:
+        out = out + G[:, body:].mm(X[:, body:].t())
+    return out
+
+
+def feature_major_linear(b, W, X, chunk=SPLIT_K_CHUNK):
+    if chunk and (W.requires_grad or b.requires_grad) and torch.is_grad_enabled():
+        return _FeatureMajorLinear.apply(b, W, X, chunk)
+    return torch.addmm(b[:, None], W, X)
+
 class SkinningField(nn.Module):
     def __init__(self, num_coords, frame_info, num_inst, D=2, W=64, num_freq_xyz=0, num_freq_t=6, inst_channels=32,
                  skips=(4,), activation=None, init_scale=0.03, delta_skin=True, symm_idx=None):
@@ -78,18 +127,18 @@ class SkinningField(nn.Module):
         A = (R[0] * ig[:, :, None]).reshape(-1, 3)
         return A, (t[0] * ig).reshape(-1)
 
-    def delta_raw_T(self, xbT, frame_bias):
+    def delta_raw_T(self, xbT, frame_bias, split_k=SPLIT_K_CHUNK):
         """Raw delta-skin MLP output in feature-major layout: xbT (3B,N) -> (B,N).  Same weights and arithmetic as
         `forward` (first layer split into its coordinate columns and the per-frame bias), written as W @ X so that
         the (B,N) result is what csrc/lbs.hip reads with coalesced loads."""
         mlp = self.delta_field
         assert self.num_freq_xyz == 0 and not any(0 < s < mlp.D for s in mlp.skips)
         lin = mlp.linear_1[0]
-        h = F.relu(torch.addmm(frame_bias.reshape(-1, 1), lin.weight[:, :self.xyz_channels], xbT))
+        h = F.relu(feature_major_linear(frame_bias.reshape(-1), lin.weight[:, :self.xyz_channels], xbT, split_k))
         for i in range(1, mlp.D):
             li = getattr(mlp, f"linear_{i + 1}")[0]
-            h = F.relu(torch.addmm(li.bias[:, None], li.weight, h))
-        return torch.addmm(mlp.linear_final.bias[:, None], mlp.linear_final.weight, h)
+            h = F.relu(feature_major_linear(li.bias, li.weight, h, split_k))
+        return feature_major_linear(mlp.linear_final.bias, mlp.linear_final.weight, h, split_k)
 
     def frame_bias(self, frame_id, inst_id, M, device):
         """(M or 1, W): the first layer applied to the per-frame part of its input (time code | instance code)."""

@@ -17,6 +17,7 @@ from ..gs.gaussian_model import GaussianModel
 from ..gs.gaussian_renderer import GEOMETRY_KEYS, render
 from . import quat_transform as qt
 from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss
+from .bone_tables import bone_tables
 from .lbs_fused import lbs_apply, lbs_skin_apply, prepare_skin_field, skin_field, skin_field_supported
 from .nets import CameraMLP, make_frame_info
 
@@ -44,17 +45,27 @@ class _WarpNetEval(nn.Module):
     DeformableSurfels._graphed_warp_networks): the bones' dual quaternions relative to the rest pose, the cameras, the rest
     pose's bone map and the mean time code's first-layer bias -- the same calls forward_warp_fused makes eagerly."""
 
-    def __init__(self, warp, camera_mlp):
+    def __init__(self, warp, camera_mlp, fused_tables=True):
         super().__init__()
-        self.warp, self.camera_mlp = warp, camera_mlp
+        self.warp, self.camera_mlp, self.fused_tables = warp, camera_mlp, fused_tables
 
     def forward(self, frame_id):
         w = self.warp
         sm = w.skinning_model
-        t_art, rest_art = w.articulation.get_vals_and_mean(frame_id)
-        se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
+        art = w.articulation
+        if self.fused_tables and frame_id.is_cuda and hasattr(art, "head_outputs"):
+            # the heads' outputs for the frames and for the mean code in one pass, then ONE kernel per direction from there
+            # to the relative bone transforms and the rest pose's scaled bone map (csrc/bone_tables.hip) instead of the
+            # quaternion algebra as ~75 + ~175 elementwise launches
+            M = frame_id.shape[0]
+            so3, trans = art.head_outputs(torch.cat(art.time_embedding.forward_and_mean(frame_id)))
+            se3_qr, se3_qd, A, c0 = bone_tables(so3[:M], trans[:M], so3[M], trans[M], 1.0 / sm.get_gauss())
+            se3 = (se3_qr, se3_qd)
+        else:
+            t_art, rest_art = art.get_vals_and_mean(frame_id)
+            se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
+            A, c0 = sm.bone_affine((rest_art[0][:1], rest_art[1][:1]))
         cq, ct = self.camera_mlp.get_vals(frame_id)
-        A, c0 = sm.bone_affine((rest_art[0][:1], rest_art[1][:1]))
         out = (se3[0].contiguous(), se3[1].contiguous(), cq.contiguous(), ct.contiguous(), A.contiguous(), c0.contiguous())
         if sm.has_delta:
             out = out + (sm.frame_bias(None, None, 1, frame_id.device).contiguous(),)
@@ -240,7 +251,7 @@ class DeformableSurfels(GaussianModel):
         key = (int(frame_id.shape[0]), tuple(p.requires_grad for p in self._warp_param_list()))
         g = self.__dict__.get("_net_graph")
         if g is None or g[0] != key:
-            mod = _WarpNetEval(self.warp, self.camera_mlp)
+            mod = _WarpNetEval(self.warp, self.camera_mlp, bool(self.opts.get("fused_bone_tables", True)))
             try:
                 fn = torch.cuda.make_graphed_callables(mod, (frame_id.clone(),), allow_unused_input=True)
             except Exception as e:   # (capture is an optimisation: anything it cannot take runs eagerly, said once)

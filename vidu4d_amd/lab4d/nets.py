@@ -100,17 +100,36 @@ class TimeEmbedding(nn.Module):
         start, length = self.raw_fid_to_vstart[fid], self.raw_fid_to_vidlen[fid]
         return ((frame_id - start) - length / 2) / self.max_ts * 2 * self.time_scale
 
+    def time_features(self, frame_id: torch.Tensor) -> torch.Tensor:
+        """Fourier features of the frames' time coordinates: no parameter enters them, so integer ids look them up in a
+        table built once per device by the very operations below (bit-identical; ~15 launches less per call, which is
+        what a tiny-batch evaluation of the networks consists of)."""
+        if frame_id.dtype in (torch.int64, torch.int32) and frame_id.dim() == 1:
+            tab = self.__dict__.get("_time_feature_table")
+            if tab is None or tab.device != frame_id.device:
+                with torch.no_grad():
+                    ids = torch.arange(self.raw_fid_to_vid.shape[0], device=frame_id.device)
+                    tab = fourier_features(self.frame_to_tid(ids)[..., None], self.num_freq_t)
+                self.__dict__["_time_feature_table"] = tab
+            return tab[frame_id]
+        return fourier_features(self.frame_to_tid(frame_id)[..., None], self.num_freq_t)
+
     def forward(self, frame_id=None) -> torch.Tensor:
         if frame_id is None:
             vid, frame_id = self.frame_to_vid, self.frame_mapping
         else:
             vid = self.raw_fid_to_vid[frame_id]
-        t = self.frame_to_tid(frame_id)[..., None]
-        coeff = self.mapping1(fourier_features(t, self.num_freq_t))
+        coeff = self.mapping1(self.time_features(frame_id))
         return self.mapping2(torch.cat((coeff, self.inst_embedding(vid)), dim=-1))
 
     def get_mean_embedding(self, device=None) -> torch.Tensor:
         return self.forward(self.frame_mapping).mean(0, keepdim=True)
+
+    def forward_and_mean(self, frame_id: torch.Tensor):
+        """(codes of `frame_id` (M, C), mean code over all kept frames (1, C)) from ONE pass through the two layers."""
+        M = frame_id.shape[0]
+        both = self.forward(torch.cat((frame_id.long(), self.frame_mapping)))
+        return both[:M], both[M:].mean(0, keepdim=True)
 
 
 class ScaleLayer(nn.Module):
@@ -269,11 +288,14 @@ class ArticulationFlatMLP(TimeMLP):
         self.trans = _head(W, 3 * num_se3, act, scale=0.1)
         self.so3 = _head(W, 3 * num_se3, act)
 
-    def forward(self, t_embed, inst_id=None):
+    def head_outputs(self, t_embed):
+        """(axis-angle (..., B, 3), translation (..., B, 3)): what the two heads emit, before any quaternion algebra."""
         feat = self.features(t_embed)
         lead = t_embed.shape[:-1]
-        trans = self.trans(feat).reshape(*lead, self.num_se3, 3)
-        so3 = self.so3(feat).reshape(*lead, self.num_se3, 3)
+        return self.so3(feat).reshape(*lead, self.num_se3, 3), self.trans(feat).reshape(*lead, self.num_se3, 3)
+
+    def forward(self, t_embed, inst_id=None):
+        so3, trans = self.head_outputs(t_embed)
         return qt.quaternion_translation_to_dual_quaternion(qt.axis_angle_to_quaternion(so3), trans)
 
     def get_vals(self, frame_id=None):
@@ -283,6 +305,12 @@ class ArticulationFlatMLP(TimeMLP):
         return self.forward(self.time_embedding.get_mean_embedding())
 
     def get_vals_and_mean(self, frame_id=None):
+        if frame_id is not None and frame_id.dim() == 1 and not frame_id.is_floating_point():
+            # the frames' rows and the mean code's row through the stack and the heads TOGETHER: rows of a dense layer
+            # are independent, and a second pass of ~100 launches on one row is what it would cost
+            M = frame_id.shape[0]
+            qr, qd = self.forward(torch.cat(self.time_embedding.forward_and_mean(frame_id)))
+            return (qr[:M], qd[:M]), (qr[M:].expand(M, -1, -1).contiguous(), qd[M:].expand(M, -1, -1).contiguous())
         at_t = self.get_vals(frame_id)
         rest = self.get_mean_vals()
         return at_t, (rest[0].expand_as(at_t[0]).contiguous(), rest[1].expand_as(at_t[1]).contiguous())
