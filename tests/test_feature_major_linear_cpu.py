@@ -14,6 +14,8 @@ def test_split_contraction_equals_the_plain_one(O, I, N, chunk):
     want = (G.double() @ X.double().t())
     got = contract_over_columns(G, X, chunk)
     assert got.shape == (O, I)
+    Xt = X.t().contiguous().t()        # (I, N) as the transpose of row-major points: the bone map's input
+    assert torch.equal(contract_over_columns(G, Xt, chunk), got) or float((contract_over_columns(G, Xt, chunk) - got).abs().max()) <= 1e-4
     assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * 8
 
 

@@ -410,7 +410,8 @@ def test_weight_gradient_contraction_over_the_surfels_in_chunks(gpu_device):
         G, X = torch.randn(O, N, generator=g).to(dev), torch.randn(I, N, generator=g).to(dev)
         want = G.double() @ X.double().t()
         got = contract_over_columns(G, X)
-        assert float((got.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) + 1e-3 * N ** 0.5 * 1e-3
+        # (float32 sums of up to 200 000 products, in an order of the library's choosing)
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     N = 5 * SPLIT_K_CHUNK + 9
     X0 = torch.randn(75, N, generator=g).to(dev)
     gy = torch.randn(64, N, generator=g).to(dev)

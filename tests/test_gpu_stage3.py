@@ -179,3 +179,36 @@ def test_forward_only_render_entry_consumes_a_checkpoint(gpu_device, tmp_path):
         want = m.render_frames(fid, make_intrinsics_inv(6, 64, 64), [64] * 6, [64] * 6)["rendered"].clamp(0, 1)
     assert float(out["rgb"].astype(np.float32).max()) > 0.1
     assert np.abs(out["rgb"].astype(np.float32) - want.cpu().numpy()).max() <= 2e-3   # (float16 storage)
+
+
+def test_training_networks_through_captured_graphs_equals_eager(gpu_device):
+    """--gs_optim_warp=True through Stage3Trainer: the networks' forward / backward as captured hipGraphs whose gradients
+    land in .grad without a copy (lab4d/net_graphs.py), the round's accumulation adopting them (stage3._fold_net_gradients),
+    fused AdamW on per-rate groups -- against the same steps with the networks evaluated eagerly.  Six steps across the
+    step at which AdamW starts (two steps of accumulation before it, as upstream's never-zeroed .grad)."""
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+    dev = gpu_device
+    H = W = 96
+    res = {}
+    for graphs in (True, False):
+        m = _model(dev, n=4000, seed=7, densify_until_iter=0, graphed_warp_networks=graphs)
+        tr = Stage3Trainer(m, m.opts | dict(gs_optim_warp=True, optim_warp_neus_iters=2, num_rounds=2, iters_per_round=4))
+        before = {k: p.detach().clone() for k, p in m.named_parameters() if k.startswith(("warp.", "camera_mlp."))}
+        for step in range(6):
+            tr.train_step(synthetic_batch(m, [step % 8, (step + 3) % 8], H, W, seed=step))
+        if graphs:
+            g = m.__dict__.get("_net_graph")
+            assert g is not None and g[1] is not None, "the networks were not captured"
+        res[graphs] = {k: (p.detach() - before[k]) for k, p in m.named_parameters() if k in before}
+    moved = 0
+    for k, want in res[False].items():
+        got = res[True][k]
+        if float(want.abs().max()) == 0.0:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        moved += 1
+        # (AdamW's first steps are ~ lr * sign(g): entries whose gradient is ~0 may flip in any two runs -- the rasterizer's
+        # float atomics alone do that; the bulk of a tensor may not)
+        rel = float((got - want).norm() / want.norm())
+        assert rel <= 0.1, (k, rel)
+    assert moved >= 10

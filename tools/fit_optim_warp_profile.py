@@ -24,5 +24,5 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for i in range(3): tr.train_step(batches[i % 4])
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=70))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=90))
 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=20, max_name_column_width=70))

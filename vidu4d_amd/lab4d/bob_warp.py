@@ -65,11 +65,12 @@ def contract_over_columns(G, X, chunk=SPLIT_K_CHUNK):
     """G (O, N) @ X (I, N)^T -> (O, I), the long contraction cut into `chunk`-column pieces that run as one batched GEMM."""
     O, N = G.shape
     n_full = N // chunk if chunk > 0 else 0
-    if n_full < 4 or X.stride(1) != 1 or G.stride(1) != 1:
+    if n_full < 4:
         return G.mm(X.t())
     body = n_full * chunk
     Gc = G[:, :body].unflatten(1, (n_full, chunk)).permute(1, 0, 2)              # (n, O, chunk), row stride N
-    Xc = X[:, :body].unflatten(1, (n_full, chunk)).permute(1, 2, 0)              # (n, chunk, I), column stride N
+    Xc = X[:, :body].unflatten(1, (n_full, chunk)).permute(1, 2, 0)              # (n, chunk, I), column stride N (or, for
+    #                                                                              X = points^T, contiguous (chunk, 3) blocks)
     out = torch.bmm(Gc, Xc).sum(0)
     if body < N:
         out = out + G[:, body:].mm(X[:, body:].t())

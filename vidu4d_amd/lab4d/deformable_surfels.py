@@ -16,9 +16,10 @@ from ..gs.cameras import KCamera
 from ..gs.gaussian_model import GaussianModel
 from ..gs.gaussian_renderer import GEOMETRY_KEYS, render
 from . import quat_transform as qt
-from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss
+from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss, feature_major_linear
 from .bone_tables import bone_tables
 from .lbs_fused import lbs_apply, lbs_skin_apply, prepare_skin_field, skin_field, skin_field_supported
+from .net_graphs import GraphedNetworks
 from .nets import CameraMLP, make_frame_info
 
 
@@ -45,14 +46,38 @@ class _WarpNetEval(nn.Module):
     DeformableSurfels._graphed_warp_networks): the bones' dual quaternions relative to the rest pose, the cameras, the rest
     pose's bone map and the mean time code's first-layer bias -- the same calls forward_warp_fused makes eagerly."""
 
-    def __init__(self, warp, camera_mlp, fused_tables=True):
+    def __init__(self, warp, camera_mlp, fused_tables=True, branches=True):
         super().__init__()
-        self.warp, self.camera_mlp, self.fused_tables = warp, camera_mlp, fused_tables
+        self.warp, self.camera_mlp, self.fused_tables, self.branches = warp, camera_mlp, fused_tables, branches
+
+    def _side_streams(self, device):
+        st = self.__dict__.get("_streams")
+        if st is None or st[0].device != device:
+            st = self.__dict__["_streams"] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        return st
 
     def forward(self, frame_id):
         w = self.warp
         sm = w.skinning_model
         art = w.articulation
+        if self.branches and frame_id.is_cuda:
+            # The camera network, the skinning field's mean time code and the articulation network are three independent
+            # chains of ~6 us launches that occupy a compute unit each: they run on three HIP streams (forked from and
+            # joined to the calling one), so a captured graph has three branches and its critical path is the longest of
+            # them instead of their sum -- forward AND backward: autograd runs a node on its forward's stream.
+            main = torch.cuda.current_stream(frame_id.device)
+            s_cam, s_bias = self._side_streams(frame_id.device)
+            s_cam.wait_stream(main)
+            with torch.cuda.stream(s_cam):
+                cq, ct = self.camera_mlp.get_vals(frame_id)
+                cq, ct = cq.contiguous(), ct.contiguous()
+            bias = None
+            if sm.has_delta:
+                s_bias.wait_stream(main)
+                with torch.cuda.stream(s_bias):
+                    bias = sm.frame_bias(None, None, 1, frame_id.device).contiguous()
+        else:
+            main = cq = bias = None
         if self.fused_tables and frame_id.is_cuda and hasattr(art, "head_outputs"):
             # the heads' outputs for the frames and for the mean code in one pass, then ONE kernel per direction from there
             # to the relative bone transforms and the rest pose's scaled bone map (csrc/bone_tables.hip) instead of the
@@ -65,10 +90,18 @@ class _WarpNetEval(nn.Module):
             t_art, rest_art = art.get_vals_and_mean(frame_id)
             se3 = qt.dual_quaternion_mul(t_art, qt.dual_quaternion_inverse(rest_art))
             A, c0 = sm.bone_affine((rest_art[0][:1], rest_art[1][:1]))
-        cq, ct = self.camera_mlp.get_vals(frame_id)
+        if cq is None:
+            cq, ct = self.camera_mlp.get_vals(frame_id)
+            bias = sm.frame_bias(None, None, 1, frame_id.device) if sm.has_delta else None
+        else:
+            main.wait_stream(s_cam)
+            cq.record_stream(main), ct.record_stream(main)
+            if bias is not None:
+                main.wait_stream(s_bias)
+                bias.record_stream(main)
         out = (se3[0].contiguous(), se3[1].contiguous(), cq.contiguous(), ct.contiguous(), A.contiguous(), c0.contiguous())
         if sm.has_delta:
-            out = out + (sm.frame_bias(None, None, 1, frame_id.device).contiguous(),)
+            out = out + (bias.contiguous(),)
         return out
 
 
@@ -251,9 +284,13 @@ class DeformableSurfels(GaussianModel):
         key = (int(frame_id.shape[0]), tuple(p.requires_grad for p in self._warp_param_list()))
         g = self.__dict__.get("_net_graph")
         if g is None or g[0] != key:
-            mod = _WarpNetEval(self.warp, self.camera_mlp, bool(self.opts.get("fused_bone_tables", True)))
+            mod = _WarpNetEval(self.warp, self.camera_mlp, bool(self.opts.get("fused_bone_tables", True)),
+                               bool(self.opts.get("parallel_network_branches", True)))
             try:
-                fn = torch.cuda.make_graphed_callables(mod, (frame_id.clone(),), allow_unused_input=True)
+                if self.opts.get("graphed_warp_networks", True) == "torch":   # (A/B: gradients through AccumulateGrad copies)
+                    fn = torch.cuda.make_graphed_callables(mod, (frame_id.clone(),), allow_unused_input=True)
+                else:
+                    fn = GraphedNetworks(mod, frame_id, self._warp_param_list())
             except Exception as e:   # (capture is an optimisation: anything it cannot take runs eagerly, said once)
                 print(f"graphed_warp_networks: capture failed ({type(e).__name__}: {e}); evaluating the networks eagerly")
                 fn = None
@@ -394,7 +431,8 @@ class DeformableSurfels(GaussianModel):
                 xbT, rawT = skin_field(self._xyz, bias[0].detach(), sf_tab, want_xb=bone_map is None)
             else:
                 bone_map = None
-                xbT = torch.addmm(c0[:, None], A, self._xyz.t())
+                # (d/dA contracts over the surfels like the MLP's weight gradients: bob_warp.feature_major_linear)
+                xbT = feature_major_linear(c0, A, self._xyz.t())
                 rawT = sm.delta_raw_T(xbT, bias[0]) if sm.has_delta else None
             # (the renderer's rotation activation -- F.normalize per frame, 6 launches forward and backward -- is
             # applied inside the kernel: render_frames hands these orientations on as already activated)

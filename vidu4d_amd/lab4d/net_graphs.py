@@ -1,0 +1,76 @@
+"""The networks' forward and backward for a step's frames as two captured hipGraphs whose parameter gradients LAND IN
+`.grad` WITHOUT A COPY.
+
+`torch.cuda.make_graphed_callables` (round 5's first form) returns the captured backward's gradients to autograd, whose
+AccumulateGrad nodes cannot adopt a graph's static buffers and clone them: one 4.5 us device copy and one engine node per
+parameter tensor and step (66 tensors: 0.3 ms of a 4.4 ms step, `profiles/r05_fit_optim_warp_profile.txt`).  Here the
+backward replays the graph and hands every parameter its static gradient buffer directly -- `p.grad = buffer` when the
+parameter has none (the usual case: `zero_grad(set_to_none=True)`), `p.grad += buffer` otherwise; a `.grad` that still IS
+the buffer from an earlier backward (gradient accumulation over several backward calls) is detached from it first.
+Consequences, stated: gradients of these parameters arrive through `.backward()` only (`torch.autograd.grad` w.r.t. them
+returns None), tensor hooks on them do not fire, and a gradient stays valid until the next backward through the same graphs.
+The module is called with integer frame ids only; its outputs are float tensors of fixed shapes."""
+from __future__ import annotations
+
+import torch
+
+
+class GraphedNetworks:
+    def __init__(self, module: torch.nn.Module, frame_id: torch.Tensor, params, warmup: int = 3):
+        self.params = [p for p in params if p.requires_grad]
+        dev = frame_id.device
+        self.static_in = frame_id.clone()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # lazily built tables, library handles and workspaces: before any capture
+            for _ in range(warmup):
+                outs = module(self.static_in)
+                torch.autograd.grad(outs, self.params, [torch.ones_like(o) for o in outs], allow_unused=True)
+            del outs
+        torch.cuda.current_stream(dev).wait_stream(side)
+        pool = torch.cuda.graph_pool_handle()
+        self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph, pool=pool):
+            self.static_outs = tuple(module(self.static_in))
+        self.static_gouts = tuple(torch.zeros_like(o) for o in self.static_outs)
+        with torch.cuda.graph(self.bwd_graph, pool=pool):
+            self.static_grads = torch.autograd.grad(self.static_outs, self.params, self.static_gouts, allow_unused=True)
+        self.live = [(p, g) for p, g in zip(self.params, self.static_grads) if g is not None]
+        owner = self
+
+        class _Replay(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, frame_id, anchor):
+                owner.static_in.copy_(frame_id)
+                owner.fwd_graph.replay()
+                return tuple(o.detach() for o in owner.static_outs)
+
+            @staticmethod
+            @torch.autograd.function.once_differentiable
+            def backward(ctx, *gouts):
+                for s, g in zip(owner.static_gouts, gouts):
+                    if g is None:
+                        s.zero_()
+                    else:
+                        s.copy_(g)
+                for p, g in owner.live:   # (an accumulated gradient that aliases the buffer the replay overwrites)
+                    if p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                        p.grad = p.grad.clone()
+                owner.bwd_graph.replay()
+                for p, g in owner.live:
+                    if p.grad is None:
+                        p.grad = g
+                    else:
+                        p.grad.add_(g)
+                return None, None
+
+        self._fn = _Replay
+        # (autograd only runs a Function's backward if an input requires grad: a scalar that does, and gets None back)
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+
+    def __call__(self, frame_id: torch.Tensor):
+        if torch.is_grad_enabled() and self.live:
+            return self._fn.apply(frame_id, self._anchor)
+        self.static_in.copy_(frame_id)
+        self.fwd_graph.replay()
+        return tuple(o.detach() for o in self.static_outs)

@@ -412,10 +412,22 @@ class Stage3Trainer:
             self.model._features_rest.grad[:, :self._rest_slot.shape[1]].copy_(self._rest_slot)
         self._fold_net_gradients(from_slots=True)
 
-    def _fold_net_gradients(self, from_slots: bool):
+    def _fold_net_gradients(self, from_slots: bool, adopt: bool = False):
         """Adds this step's (exchanged) network gradients to the round's accumulated ones and makes those the
-        parameters' .grad -- what upstream's never-zeroed .grad holds when check_grad and, later, AdamW read it."""
+        parameters' .grad -- what upstream's never-zeroed .grad holds when check_grad and, later, AdamW read it.
+        adopt: the networks' optimizer steps at the end of THIS step and empties the accumulation (_optimizer_step), so a
+        first contribution is taken as it is instead of copied (66 tensors: 66 device copies per step; the tensor may be a
+        captured graph's static buffer, lab4d/net_graphs.py, which the next step's backward overwrites -- by then unused)."""
         if not self.optim_warp:
+            return
+        if adopt and not from_slots:
+            for i, p in enumerate(self._net_params):
+                g = p.grad
+                if g is not None and self._net_accum[i] is not None:
+                    g = self._net_accum[i].add_(g)
+                if g is not None:
+                    self._net_accum[i] = g
+                p.grad = self._net_accum[i]
             return
         for i, p in enumerate(self._net_params):
             if p.grad is None:
@@ -554,7 +566,7 @@ class Stage3Trainer:
             self.begin_gradients()
             losses = self._forward_backward(batch, step)
         if self.world == 1:
-            self._fold_net_gradients(from_slots=False)
+            self._fold_net_gradients(from_slots=False, adopt=self.optimizer is not None and step >= self.optim_warp_from)
         self.allreduce_gradients(async_op=True)   # in flight while the statistics below are gathered
         self.gather_densification_stats(step)
         self.finish_step(step)
