@@ -13,7 +13,7 @@ extern "C" void bt_backward(int M, int B, const float* so3_t, const float* trans
                             const float* inv_gauss, const float* g_qr, const float* g_qd, const float* g_A, const float* g_c,
                             float* g_so3_t, float* g_trans_t, float* g_so3_r, float* g_trans_r, float* g_inv_gauss)
 {
-    for (int b = 0; b < B; ++b)
-        bone_tables::bone_tables_bwd_body(b, M, B, so3_t, trans_t, so3_r, trans_r, inv_gauss, g_qr, g_qd, g_A, g_c, g_so3_t,
+    for (int i = 0; i < B * bone_tables::bone_tables_bwd_dirs(M); ++i)
+        bone_tables::bone_tables_bwd_body(i, M, B, so3_t, trans_t, so3_r, trans_r, inv_gauss, g_qr, g_qd, g_A, g_c, g_so3_t,
                                           g_trans_t, g_so3_r, g_trans_r, g_inv_gauss);
 }

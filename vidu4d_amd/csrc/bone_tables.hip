@@ -10,8 +10,8 @@
 // as ~75 elementwise torch launches forward and ~175 backward on (M, B, 4) tensors: latency, not work.
 // Here one thread carries one (frame, bone) through the chain.  The backward does not restate the chain's adjoint by
 // hand: the same templated function is evaluated on first-order dual numbers, one input direction at a time
-// (15 directions of ~150 flops for 25 bones), and the gradient is the contraction of those tangents with the incoming
-// gradients -- one source of truth for values and derivatives.
+// (6 M + 9 directions of ~150 flops per bone, one thread each), and the gradient is the contraction of those tangents
+// with the incoming gradients -- one source of truth for values and derivatives.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -72,7 +72,8 @@ extern "C" int vidu4d_bone_tables_backward(int M, int B, const float* so3_t, con
     if (M > 0 && (!so3_t || !trans_t || !g_so3_t || !g_trans_t)) return VIDU4D_E_INVALID;
     if (g_bone_A && !inv_gauss) return VIDU4D_E_INVALID;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(bone_tables_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, M, B, so3_t, trans_t,
+    const int n = B * bone_tables::bone_tables_bwd_dirs(M);
+    hipLaunchKernelGGL(bone_tables_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, M, B, so3_t, trans_t,
                        so3_rest, trans_rest, inv_gauss, g_se3_qr, g_se3_qd, g_bone_A, g_bone_c, g_so3_t, g_trans_t,
                        g_so3_rest, g_trans_rest, g_inv_gauss);
     return done();
