@@ -446,6 +446,16 @@ typedef struct Vidu4dSkinFieldArgs {
      * above, which costs every launch ~20 us; b_in is still read from b_in.  NULL: gather. */
     const float* packed_fwd;
     const float* packed_bwd;
+    /* optional (extension, ABI 19): networks that TRAIN (--gs_optim_warp=True, lab4d/config.py:157).  Feature-major arrays
+     * from which the caller takes the weight gradients as contractions over the surfels:
+     *   h_store  (forward output)  float[D][W][N]   hidden layer l's activations (after the ReLU)
+     *   g_store  (backward output) float[D][W][N]   the gradient w.r.t. hidden layer l's PRE-activation (needs relu_masks)
+     *   gx_store (backward output) float[3B][N]     the whole gradient w.r.t. the bone coordinates (g_xbT + the MLP's)
+     * d w_out = g_rawT h_store[D-1]^T, d w_hid[l-1] = g_store[l] h_store[l-1]^T, d w_in = g_store[0] xbT^T,
+     * d bone_A = gx_store xyz, the biases the row sums.  g_store and gx_store come together; all NULL: frozen networks. */
+    float* h_store;
+    float* g_store;
+    float* gx_store;
 } Vidu4dSkinFieldArgs;
 int vidu4d_skin_field_forward(const Vidu4dSkinFieldArgs* args, void* stream);
 int vidu4d_skin_field_backward(const Vidu4dSkinFieldArgs* args, void* stream);

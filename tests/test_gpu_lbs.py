@@ -428,3 +428,65 @@ def test_weight_gradient_contraction_over_the_surfels_in_chunks(gpu_device):
         res[split] = (Y.detach(), W.grad, b.grad, X.grad)
     for a, c in zip(res[True], res[False]):
         assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
+
+
+@pytest.mark.parametrize("N", [5000, 70001])
+def test_skin_field_with_weights_that_train(gpu_device, N):
+    """csrc/skin_field.hip's TRAIN instances (lbs_fused.skin_field_train): bone coordinates and delta-skin MLP on the matrix
+    cores with EVERY input differentiable -- canonical centres, the step's first-layer bias, the bone map (A, c) and all
+    weights and biases of the MLP -- against the feature-major library GEMMs with autograd."""
+    from tests.test_gpu_stage3 import _model
+    from vidu4d_amd.lab4d.lbs_fused import skin_field_shape_supported, skin_field_train
+    dev = gpu_device
+    m = _model(dev, n=N, seed=4)
+    sm = m.warp.skinning_model
+    assert skin_field_shape_supported(sm)
+    with torch.no_grad():
+        for p in sm.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev))
+    B = sm.log_gauss.shape[0]
+    g = torch.Generator().manual_seed(N)
+    A0, c0_0 = (3.0 * torch.randn(3 * B, 3, generator=g)).to(dev), torch.randn(3 * B, generator=g).to(dev)
+    bias0 = torch.randn(sm.delta_field.W, generator=g).to(dev)
+    xyz0 = m._xyz.detach().clone()
+    g_xb, g_raw = torch.randn(3 * B, N, generator=g).to(dev), torch.randn(B, N, generator=g).to(dev)
+    def both(g_xb, g_raw):
+        res = {}
+        for fused in (True, False):
+            sm.zero_grad(set_to_none=True)
+            xyz, A, c0, bias = (t.clone().requires_grad_() for t in (xyz0, A0, c0_0, bias0))
+            if fused:
+                xbT, rawT = skin_field_train(xyz, bias, A, c0, sm)
+            else:
+                xbT = torch.addmm(c0[:, None], A, xyz.t())
+                rawT = sm.delta_raw_T(xbT, bias, split_k=0)
+            torch.autograd.backward([xbT, rawT], [g_xb, g_raw])
+            grads = {"xyz": xyz.grad, "A": A.grad, "c": c0.grad, "bias": bias.grad}
+            grads.update({k: p.grad for k, p in sm.delta_field.named_parameters() if p.grad is not None})
+            res[fused] = (xbT.detach(), rawT.detach(), {k: v.clone() for k, v in grads.items()})
+        return res
+
+    res = both(g_xb, g_raw)
+    for a, b in zip(res[True][:2], res[False][:2]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    # A hidden unit whose pre-activation is within rounding of zero is "on" in one evaluation and "off" in the other (two
+    # summation orders; 128 units x N surfels: seen once in 70 001) -- a kink of the function, not an error of either.  Such
+    # surfels show in d/d xyz, a per-surfel quantity; they are few, and with THEIR upstream gradients zeroed (a surfel's
+    # share of every weight gradient is linear in them) everything must agree.
+    d = (res[True][2]["xyz"] - res[False][2]["xyz"]).abs().max(1).values
+    flipped = torch.nonzero(d > 2e-5 * float(res[False][2]["xyz"].abs().max())).flatten()
+    assert flipped.numel() <= max(1, N // 20000), flipped.numel()
+    if flipped.numel():
+        g_xb, g_raw = g_xb.clone(), g_raw.clone()
+        g_xb[:, flipped] = 0
+        g_raw[:, flipped] = 0
+        res = both(g_xb, g_raw)
+    assert set(res[True][2]) == set(res[False][2]) and len(res[False][2]) >= 9, set(res[True][2]) ^ set(res[False][2])
+    for k, b in res[False][2].items():
+        a = res[True][2][k]
+        assert float(b.abs().max()) > 0, k
+        # (sums over up to 70 001 surfels in another order; 2e-5 of the tensor's scale)
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
+    # the first layer's weight: only its coordinate columns enter here
+    w1g = res[True][2]["linear_1.0.weight"]
+    assert float(w1g[:, 3 * B:].abs().max()) == 0.0

@@ -12,6 +12,7 @@ dev = torch.device("cuda:0")
 N, H, W, frames = 200000, 512, 512, 120
 VARIANTS = [
     ("all on", {}),
+    ("delta MLP as library GEMMs", dict(fused_skin_field_trainable=False)),
     ("dense stacks as library calls", dict(fused_dense_stacks=False)),
     ("one branch instead of three", dict(parallel_network_branches=False)),
     ("quaternion algebra as torch ops", dict(fused_bone_tables=False)),

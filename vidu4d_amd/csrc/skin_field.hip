@@ -28,7 +28,9 @@
 //
 // The backward recomputes the forward (cheaper than storing it), keeps the ReLU masks as bits and returns the gradient
 // with respect to the canonical centres only: bones and network weights are constants of Stage-3 (--gs_optim_warp=False);
-// a caller that trains them uses the torch path.
+// (round 5) a caller that trains them gets TRAIN instances, which additionally leave every hidden layer's activations (forward:
+// h_store) and masked pre-activation gradients (backward: g_store) and the whole gradient w.r.t. the bone coordinates
+// (gx_store) in feature-major arrays, from which the weight gradients are contractions over the surfels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -184,11 +186,24 @@ __device__ __forceinline__ uint32_t relu_tiles(f32x16 (&h)[2])
     return mask;
 }
 
+// Networks that train (TRAIN instances): a layer's 64 rows of this tile to a feature-major (layers, 64, N) array -- the
+// activations from the forward, the pre-activation gradients from the backward -- from which the weight gradients are taken
+// as contractions over the surfels (lab4d/lbs_fused.py).  Lanes 0-31 write 128 contiguous bytes of a row, lanes 32-63 of
+// the row four further down.
+__device__ __forceinline__ void store_rows(float* dst, int layer, const f32x16 (&t)[2], int half, uint32_t Ns, int n)
+{
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            dst[(uint32_t)(layer * W + 32 * ob + rowv(v, half)) * (size_t)Ns + (uint32_t)n] = t[ob][v];
+}
+
 // Hidden layers of the forward for one tile; h = last hidden activations (D layout), masks[l] = active units of layer l.
 __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, const Plan& p, const float* lds, int lane,
                                                int n, uint32_t Ns, bool valid, float x, float y, float z, float* xbT_out,
                                                f32x16 (&h)[2], uint32_t (&masks)[MAX_HIDDEN], uint32_t* mask_out,
-                                               size_t mask_stride)
+                                               size_t mask_stride, float* h_store = nullptr)
 {
     const int half = lane >> 5;
     load_bias(h, lds, p, 0, half);
@@ -218,6 +233,7 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
     }
     masks[0] = relu_tiles(h);
     if (mask_out) mask_out[0] = masks[0];
+    if (h_store && valid) store_rows(h_store, 0, h, half, Ns, n);
 #pragma unroll 1
     for (int layer = 1; layer < a.D; layer++) {
         f32x16 acc[2];
@@ -236,6 +252,7 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
         if (mask_out) mask_out[layer * mask_stride] = masks[layer];
         h[0] = acc[0];
         h[1] = acc[1];
+        if (h_store && valid) store_rows(h_store, layer, h, half, Ns, n);
     }
 }
 
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_pack_kernel
     stage<BACKWARD>(a, p, out);
 }
 
-template <bool BACKWARD>
+template <bool BACKWARD, bool TRAIN>
 __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu4dSkinFieldArgs a)
 {
     constexpr int THREADS = threads_of<BACKWARD>();
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
             for (int l = 0; l < a.D; l++) masks[l] = mask_slot[l * mask_layer_stride];
         } else {
             hidden_forward(a, p, lds, lane, n, Ns, valid, x, y, z, BACKWARD ? nullptr : a.xbT, h, masks,
-                           BACKWARD ? nullptr : mask_slot, mask_layer_stride);
+                           BACKWARD ? nullptr : mask_slot, mask_layer_stride, (TRAIN && !BACKWARD) ? a.h_store : nullptr);
         }
         if (!BACKWARD) {
             f32x16 out;
@@ -343,6 +360,13 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
 #pragma unroll
                 for (int v = 0; v < 16; v++) acc[ob][v] = 0.f;
             const float* s = lds + p.t_hid + (layer - 1) * 64 * 64 + lane;
+            if (TRAIN) {   // (the masked gradient once, in place: what the MFMAs below contract is what is stored)
+#pragma unroll
+                for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                    for (int v = 0; v < 16; v++) g[sb][v] = ((m >> (16 * sb + v)) & 1u) ? g[sb][v] : 0.f;
+                if (valid) store_rows(a.g_store, layer, g, half, Ns, n);
+            }
 #pragma unroll
             for (int sb = 0; sb < 2; sb++)
 #pragma unroll
@@ -367,6 +391,13 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
         {
             const uint32_t m = masks[0];
             const float* s = lds + p.t_in + lane;
+            if (TRAIN) {
+#pragma unroll
+                for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                    for (int v = 0; v < 16; v++) g[sb][v] = ((m >> (16 * sb + v)) & 1u) ? g[sb][v] : 0.f;
+                if (valid) store_rows(a.g_store, 0, g, half, Ns, n);
+            }
 #pragma unroll
             for (int sb = 0; sb < 2; sb++)
 #pragma unroll
@@ -375,6 +406,15 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
 #pragma unroll
                     for (int ob = 0; ob < 3; ob++) gx[ob] = mfma(s[((sb * 16 + v) * 3 + ob) * 64], b, gx[ob]);
                     interleave_reads_and_mfmas<3>();
+                }
+        }
+        if (TRAIN && valid) {   // the whole gradient w.r.t. the bone coordinates: d/dA = gx xyz^T, d/dc = sum gx
+#pragma unroll
+            for (int ob = 0; ob < 3; ob++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    const int k = 32 * ob + rowv(v, half);
+                    if (k < 3 * a.B) a.gx_store[(uint32_t)k * (size_t)Ns + (uint32_t)n] = gx[ob][v];
                 }
         }
         // ---- x_bone = A xyz + c: d xyz = A^T d x_bone; this lane holds 48 of the surfel's rows, its partner the others
@@ -408,19 +448,31 @@ int check_args(const Vidu4dSkinFieldArgs* a, bool backward)
     if (!a->xyz || !a->bone_A || !a->bone_c || !a->w_in || !a->b_in || !a->w_out || !a->b_out) return VIDU4D_E_INVALID;
     if (a->D > 1 && (!a->w_hid || !a->b_hid)) return VIDU4D_E_INVALID;
     if (!backward) return a->rawT ? VIDU4D_OK : VIDU4D_E_INVALID;  // (xbT may be NULL: a caller that evaluates the bone map itself)
+    if ((a->g_store != nullptr) != (a->gx_store != nullptr)) return VIDU4D_E_INVALID;
+    if (a->g_store && !a->relu_masks) return VIDU4D_E_INVALID;   // (the stored gradients are the masked ones)
     return (a->g_rawT && a->g_xyz) ? VIDU4D_OK : VIDU4D_E_INVALID;
 }
+
+template <bool BACKWARD, bool TRAIN>
+int launch_instance(const Vidu4dSkinFieldArgs* a, void* stream);
 
 template <bool BACKWARD>
 int launch(const Vidu4dSkinFieldArgs* a, void* stream)
 {
     const int rc = check_args(a, BACKWARD);
     if (rc != VIDU4D_OK || a->N == 0) return rc;
+    const bool train = BACKWARD ? a->g_store != nullptr : a->h_store != nullptr;
+    return train ? launch_instance<BACKWARD, true>(a, stream) : launch_instance<BACKWARD, false>(a, stream);
+}
+
+template <bool BACKWARD, bool TRAIN>
+int launch_instance(const Vidu4dSkinFieldArgs* a, void* stream)
+{
     const Plan p = make_plan(a->B, a->D, BACKWARD);
     const size_t bytes = (size_t)p.total * sizeof(float);
     static bool attr_set = false;  // (one attribute call per template instance; idempotent, benign if raced)
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skin_field_kernel<BACKWARD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skin_field_kernel<BACKWARD, TRAIN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return VIDU4D_E_HIP;
         attr_set = true;
@@ -433,7 +485,7 @@ int launch(const Vidu4dSkinFieldArgs* a, void* stream)
     int grid = (tiles + per_wg - 1) / per_wg;
     if (grid > cus) grid = cus;  // one resident workgroup per CU, waves loop over tiles
     (void)hipGetLastError();
-    hipLaunchKernelGGL(skin_field_kernel<BACKWARD>, dim3(grid), dim3(THREADS), bytes, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((skin_field_kernel<BACKWARD, TRAIN>), dim3(grid), dim3(THREADS), bytes, (hipStream_t)stream, *a);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
 

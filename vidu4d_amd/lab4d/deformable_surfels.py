@@ -18,7 +18,8 @@ from ..gs.gaussian_renderer import GEOMETRY_KEYS, render
 from . import quat_transform as qt
 from .bob_warp import apply_qt_to_gaussian, create_warp, cross_entropy_skin_loss, feature_major_linear
 from .bone_tables import bone_tables
-from .lbs_fused import lbs_apply, lbs_skin_apply, prepare_skin_field, skin_field, skin_field_supported
+from .lbs_fused import (lbs_apply, lbs_skin_apply, prepare_skin_field, skin_field, skin_field_shape_supported,
+                        skin_field_supported, skin_field_train)
 from .net_graphs import GraphedNetworks
 from .nets import CameraMLP, make_frame_info
 
@@ -431,6 +432,13 @@ class DeformableSurfels(GaussianModel):
                 # (3B, N) array and its gradient never cross HBM)
                 bone_map = (sf_tab["bone_A"], sf_tab["bone_c"]) if self.opts.get("fused_bone_map", True) else None
                 xbT, rawT = skin_field(self._xyz, bias[0].detach(), sf_tab, want_xb=bone_map is None)
+            elif (overrides and sm.has_delta and self.opts.get("fused_skin_field_trainable", True)
+                  and skin_field_shape_supported(sm)):
+                # weights that TRAIN: the same MFMA kernels in their TRAIN instances (hidden activations and masked
+                # pre-activation gradients left in feature-major arrays), the weight gradients as contractions over the
+                # surfels -- instead of four library GEMMs forward and eight backward whose activations cross HBM
+                bone_map = None
+                xbT, rawT = skin_field_train(self._xyz, bias[0], A, c0, sm)
             else:
                 bone_map = None
                 # (d/dA contracts over the surfels like the MLP's weight gradients: bob_warp.feature_major_linear)

@@ -168,6 +168,11 @@ def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False, bone_
 def skin_field_supported(sm) -> bool:
     """True when SkinningField `sm` has the shape csrc/skin_field.hip is written for (the bob field: width 64,
     no positional encoding of the bone coordinates, no skip connection inside the stack) and frozen weights."""
+    return _skin_field_frozen(sm)
+
+
+def skin_field_shape_supported(sm) -> bool:
+    """The shape condition alone (skin_field_train serves weights that require grad)."""
     lim = _lib.SKIN_FIELD
     if not sm.has_delta or sm.num_freq_xyz != 0:
         return False
@@ -176,6 +181,12 @@ def skin_field_supported(sm) -> bool:
     if mlp.W != lim["width"] or not (1 <= mlp.D <= lim["max_hidden"]) or any(0 < s_ < mlp.D for s_ in mlp.skips):
         return False
     if 3 * B > lim["in_max"] or B > lim["out_max"] or sm.xyz_channels != 3 * B:
+        return False
+    return True
+
+
+def _skin_field_frozen(sm) -> bool:
+    if not skin_field_shape_supported(sm):
         return False
     plist = sm.__dict__.get("_param_list")   # (collected once: Module.parameters() walks the module tree, every step)
     if plist is None:
@@ -281,3 +292,89 @@ def skin_field(xyz, b_in, tab, want_xb=True):
     prepare_skin_field.  -> xbT (3B,N) Gaussian-bone coordinates (None when want_xb is False: lbs_skin_apply with
     bone_map evaluates them itself), rawT (B,N) raw delta-skin output."""
     return _SkinField.apply(xyz, b_in, tab, want_xb)
+
+
+# ---- the same kernels for networks that TRAIN (--gs_optim_warp=True): TRAIN instances leave the hidden activations and the
+# masked pre-activation gradients in feature-major arrays; the weight gradients are contractions over the surfels
+# (bob_warp.contract_over_columns: batched GEMMs over K-chunks), the bias gradients row sums.
+def _train_buffers(sm, dev):
+    """Persistent padded weight arrays in the kernels' layout (the padding stays zero; refreshed by one copy each per step)."""
+    lim = _lib.SKIN_FIELD
+    W, IN, OUT = lim["width"], lim["in_max"], lim["out_max"]
+    bufs = sm.__dict__.get("_skin_field_train_bufs")
+    D = sm.delta_field.D
+    if bufs is None or bufs["w_in"].device != dev:
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        bufs = sm.__dict__["_skin_field_train_bufs"] = {"w_in": z(W, IN), "w_out": z(OUT, W), "b_out": z(OUT),
+                                                        "w_hid": z(max(D - 1, 1), W, W), "b_hid": z(max(D - 1, 1), W)}
+    return bufs
+
+
+class _SkinFieldTrain(Function):
+    @staticmethod
+    def forward(ctx, xyz, b_in, A, c0, w1, w_out, b_out, sm_bufs, *hidden):
+        """hidden = (w_2, b_2, ..., w_D, b_D); w1 (W, 3B) the first layer's coordinate columns; sm_bufs: _train_buffers."""
+        if not xyz.is_cuda:
+            raise RuntimeError("skin_field: HIP tensors required")
+        N, B, D = xyz.shape[0], w_out.shape[0], 1 + len(hidden) // 2
+        W = _lib.SKIN_FIELD["width"]
+        x, b = _c(xyz), _c(b_in).reshape(-1)
+        with torch.no_grad():
+            sm_bufs["w_in"][:, :3 * B].copy_(w1)
+            sm_bufs["w_out"][:B].copy_(w_out)
+            sm_bufs["b_out"][:B].copy_(b_out)
+            for i in range(D - 1):
+                sm_bufs["w_hid"][i].copy_(hidden[2 * i])
+                sm_bufs["b_hid"][i].copy_(hidden[2 * i + 1])
+        tab = dict(sm_bufs, B=B, D=D, bone_A=_c(A), bone_c=_c(c0))
+        dev = xyz.device
+        xbT = torch.empty(3 * B, N, dtype=torch.float32, device=dev)
+        rawT = torch.empty(B, N, dtype=torch.float32, device=dev)
+        masks = torch.empty(D * 64 * ((N + 31) // 32), dtype=torch.int32, device=dev)
+        h = torch.empty(D, W, N, dtype=torch.float32, device=dev)
+        a = _skin_field_args(tab, N, x, b, xbT=xbT, rawT=rawT, relu_masks=masks, h_store=h)
+        _lib.check(_lib.load().vidu4d_skin_field_forward(a, torch.cuda.current_stream(dev).cuda_stream), "skin field forward")
+        ctx.save_for_backward(x, b, masks, h, xbT, tab["bone_A"], tab["bone_c"])
+        ctx.tab = tab     # (the padded weights: unchanged until the next forward of this model)
+        ctx.dims = (N, B, D, W)
+        return xbT, rawT
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_xbT, g_rawT):
+        from .bob_warp import contract_over_columns
+        x, b, masks, h, xbT, A, c0 = ctx.saved_tensors
+        N, B, D, W = ctx.dims
+        dev = x.device
+        g_xbT = None if g_xbT is None else _c(g_xbT)
+        g_rawT = torch.zeros(B, N, device=dev) if g_rawT is None else _c(g_rawT)
+        g_xyz = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        g = torch.empty(D, W, N, dtype=torch.float32, device=dev)
+        gx = torch.empty(3 * B, N, dtype=torch.float32, device=dev)
+        a = _skin_field_args(ctx.tab, N, x, b, g_xbT=g_xbT, g_rawT=g_rawT, g_xyz=g_xyz, relu_masks=masks, g_store=g, gx_store=gx)
+        _lib.check(_lib.load().vidu4d_skin_field_backward(a, torch.cuda.current_stream(dev).cuda_stream), "skin field backward")
+        need = ctx.needs_input_grad
+        g_A = contract_over_columns(gx, x.t()) if need[2] else None
+        g_c = gx.sum(1) if need[3] else None
+        g_w1 = contract_over_columns(g[0], xbT) if need[4] else None
+        g_b_in = g[0].sum(1) if need[1] else None
+        g_wo = contract_over_columns(g_rawT, h[D - 1]) if need[5] else None
+        g_bo = g_rawT.sum(1) if need[6] else None
+        hidden = []
+        for i in range(1, D):
+            hidden.append(contract_over_columns(g[i], h[i - 1]) if need[8 + 2 * (i - 1)] else None)
+            hidden.append(g[i].sum(1) if need[9 + 2 * (i - 1)] else None)
+        return (g_xyz if need[0] else None, g_b_in, g_A, g_c, g_w1, g_wo, g_bo, None, *hidden)
+
+
+def skin_field_train(xyz, b_in, A, c0, sm):
+    """skin_field for a SkinningField whose weights (and bone map, and time-code bias) require grad: xbT (3B,N), rawT (B,N)
+    with gradients w.r.t. xyz, b_in, A, c0 and every weight and bias of the delta MLP."""
+    mlp = sm.delta_field
+    B3 = A.shape[0]
+    hidden = []
+    for i in range(1, mlp.D):
+        lin = getattr(mlp, f"linear_{i + 1}")[0]
+        hidden += [lin.weight, lin.bias]
+    return _SkinFieldTrain.apply(xyz, b_in, A, c0, mlp.linear_1[0].weight[:, :B3], mlp.linear_final.weight,
+                                 mlp.linear_final.bias, _train_buffers(sm, xyz.device), *hidden)
