@@ -429,7 +429,8 @@ class Stage3Trainer:
                     self._net_accum[i] = g
                 p.grad = self._net_accum[i]
             return
-        for i, p in enumerate(self._net_params):
+        acc, new = [], []   # (the in-place additions of all tensors as ONE for-each call: 66 launches -> a few, every step of
+        for i, p in enumerate(self._net_params):   # the 12 000 before AdamW starts)
             if p.grad is None:
                 g = None
             elif from_slots:
@@ -437,8 +438,14 @@ class Stage3Trainer:
             else:
                 g = p.grad
             if g is not None:
-                self._net_accum[i] = g.detach().clone() if self._net_accum[i] is None else self._net_accum[i].add_(g)
+                if self._net_accum[i] is None:
+                    self._net_accum[i] = g.detach().clone()
+                else:
+                    acc.append(self._net_accum[i])
+                    new.append(g.detach())
             p.grad = self._net_accum[i]
+        if acc:
+            torch._foreach_add_(acc, new)
 
     def clip_gradients(self, max_norm: float = 5.0):
         """clip_grad_norm_ over the parameters that have a gradient (trainer.py:861-869)."""
