@@ -36,6 +36,9 @@ class GraphedNetworks:
         with torch.cuda.graph(self.bwd_graph, pool=pool):
             self.static_grads = torch.autograd.grad(self.static_outs, self.params, self.static_gouts, allow_unused=True)
         self.live = [(p, g) for p, g in zip(self.params, self.static_grads) if g is not None]
+        # (the autograd graph of the captured forward is not needed again: keeping it would keep the parameters' AccumulateGrad
+        # nodes of the CAPTURE stream alive, which later backwards through the same parameters outside the graphs would find)
+        self.static_outs = tuple(o.detach() for o in self.static_outs)
         owner = self
 
         class _Replay(torch.autograd.Function):
