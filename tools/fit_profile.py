@@ -13,7 +13,10 @@ m = DeformableSurfels(opts, num_frames=frames, device=dev)
 pts = rng.normal(size=(N, 3)).astype(np.float32); pts = RADIUS * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32), )
 with torch.no_grad(): m._scaling.add_(0.0)
-tr = Stage3Trainer(m)
+if os.environ.get("FIT_OPTIM_WARP", "0") == "1":   # networks that train (--gs_optim_warp=True); FIT_STEP0=12001: AdamW stepping
+    tr = Stage3Trainer(m, m.opts | dict(gs_optim_warp=True, num_rounds=120, iters_per_round=200))
+else:
+    tr = Stage3Trainer(m)
 tr.current_steps = int(os.environ.get("FIT_STEP0", "0"))  # > 8000: normal-consistency regulariser on
 m.pipeline.fused_post = os.environ.get("FIT_FUSED_POST", "1") == "1"
 batches = [synthetic_batch(m, [(2*i) % frames, (2*i+1) % frames], H, W, seed=i) for i in range(4)]
