@@ -11,9 +11,6 @@
 // fixed operation order, so they agree bit-for-bit with oracle/surfel_oracle.c.  Everything else
 // may be FMA-contracted; it is compared with a tolerance.
 #pragma once
-#ifndef SURFEL_BRANCHFREE_GEOM
-#define SURFEL_BRANCHFREE_GEOM 0   // (bwd_pair_geometry without its if / else: measured)
-#endif
 
 #include <stdint.h>
 #include <math.h>
@@ -882,32 +879,6 @@ SURFEL_HD void bwd_pair_geometry(const BwdPixel& s, const PairEval& e, const Pai
         }
         return;
     }
-#if SURFEL_BRANCHFREE_GEOM
-    {
-        // The two cases as one straight line: the homography branch's factors are zero where the low-pass disc won (then
-        // every dk / dl below is an exact zero), the disc's factor is zero where it lost -- two selects and a subtraction
-        // instead of a divergent if / else whose other side writes eight zeros.  Same operands, same operations: same bits.
-        const bool hom = e.rho3d <= e.rho2d;
-        const float dL_dG_h = hom ? dL_dG : 0.f, dL_dz_h = hom ? dL_dz : 0.f, dL_dG_2 = dL_dG - dL_dG_h;
-        const float dL_dsx = dL_dG_h * -G * e.sx + dL_dz_h * Tw[0];
-        const float dL_dsy = dL_dG_h * -G * e.sy + dL_dz_h * Tw[1];
-        const float dpx = dL_dsx * e.ipz, dpy = dL_dsy * e.ipz, dpz = -(dpx * e.sx + dpy * e.sy);
-        const float dkx = e.ly * dpz - e.lz * dpy, dky = e.lz * dpx - e.lx * dpz, dkz = e.lx * dpy - e.ly * dpx;
-        const float dlx = dpy * e.kz - dpz * e.ky, dly = dpz * e.kx - dpx * e.kz, dlz = dpx * e.ky - dpy * e.kx;
-        g[A_T + 0] = dkx;
-        g[A_T + 1] = dky;
-        g[A_T + 2] = dkz;
-        g[A_T + 3] = dlx;
-        g[A_T + 4] = dly;
-        g[A_T + 5] = dlz;
-        g[A_T + 6] = pixx * dkx + pixy * dlx + dL_dz_h * e.sx;
-        g[A_T + 7] = pixx * dky + pixy * dly + dL_dz_h * e.sy;
-        g[A_T + 8] = pixx * dkz + pixy * dlz + dL_dz;
-        g[A_M2D + 0] = dL_dG_2 * (-G * 2.0f * e.dx);
-        g[A_M2D + 1] = dL_dG_2 * (-G * 2.0f * e.dy);
-        return;
-    }
-#endif
     if (e.rho3d <= e.rho2d) {
         const float dL_dsx = dL_dG * -G * e.sx + dL_dz * Tw[0];
         const float dL_dsy = dL_dG * -G * e.sy + dL_dz * Tw[1];
