@@ -1,0 +1,34 @@
+"""Host logic around csrc/dense_stack.hip: how a network's modules are read into the kernel's layer list (no GPU)."""
+import torch
+import torch.nn as nn
+
+from vidu4d_amd.lab4d import dense_stack as ds
+from vidu4d_amd.lab4d.nets import ArticulationFlatMLP, CameraMLP, ScaleLayer, make_frame_info
+
+
+def test_layer_lists_of_the_two_time_networks():
+    info = make_frame_info([0, 9])
+    art = ArticulationFlatMLP(info, num_se3=25)
+    cam = CameraMLP(torch.eye(4).repeat(9, 1, 1), frame_info=info)
+    for net, heads, outs, scales in ((art, (art.so3, art.trans), (75, 75), (1.0, 0.1)), (cam, (cam.quat, cam.trans), (4, 3), (1.0, 1.0))):
+        trunk = [ds.sequential_layers(getattr(net, f"linear_{i + 1}")) for i in range(net.D)] + [ds.sequential_layers(net.linear_final)]
+        assert all(len(l) == 1 and l[0][1] and l[0][2] == 1.0 for l in trunk)      # Linear + ReLU each, the final one too
+        assert all(l[0][0].weight.shape == (256, 256) for l in trunk)
+        for head, out, scale in zip(heads, outs, scales):
+            lay = ds.sequential_layers(head)
+            assert [(l[0].weight.shape[0], l[1]) for l in lay] == [(128, True), (out, False)]
+            assert abs(lay[1][2] - scale) < 1e-7 and lay[0][2] == 1.0
+        # on the CPU the stack is not taken: the library layers are the statement of the same arithmetic there
+        assert net.fused_heads(torch.zeros(2, 256), *heads) is None
+
+
+def test_unsupported_sequences_are_refused():
+    assert ds.sequential_layers(nn.Sequential(nn.Linear(4, 4), nn.Tanh())) is None
+    assert ds.sequential_layers(nn.Sequential(nn.ReLU())) is None
+    lay = ds.sequential_layers(nn.Sequential(nn.Linear(4, 4), ScaleLayer(0.5), ScaleLayer(0.5)))
+    assert len(lay) == 1 and not lay[0][1] and abs(lay[0][2] - 0.25) < 1e-7
+    # a ReLU after a scaled layer is not "scale * relu(Wx + b)": refused
+    assert ds.sequential_layers(nn.Sequential(nn.Linear(4, 4), ScaleLayer(0.5), nn.ReLU())) is None
+    s = ScaleLayer(0.1)
+    s.load_state_dict({"scale": torch.tensor([0.3])})
+    assert abs(s.scale_value - 0.3) < 1e-7
