@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libvidu4d_surfel.so")
 SOURCES = ["preprocess.hip", "binning.hip", "blend.hip", "quaternion.hip", "lbs.hip", "bone_tables.hip", "dense_stack.hip", "knn.hip", "post.hip", "optim.hip", "skin_field.hip", "loss.hip", "capi.hip"]
-HEADERS = ["surfel_math.h", "surfel_state.h", "post_math.h", "wave_utils.h", os.path.join(INCLUDE, "vidu4d_surfel.h"),
+HEADERS = ["surfel_math.h", "surfel_state.h", "post_math.h", "wave_utils.h", "wave_reduce.h", "bone_tables_math.h",
+           os.path.join(INCLUDE, "vidu4d_surfel.h"),
            os.path.join(INCLUDE, "vidu4d_surfel_diag.h")]
 ARCH = "gfx950"
 # -munsafe-fp-atomics: hardware global_atomic_add_f32 / ds_add_f32 instead of CAS loops.
