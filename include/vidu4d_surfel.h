@@ -378,6 +378,13 @@ int vidu4d_bone_tables_backward(int M, int B, const float* so3_t, const float* t
                                 const float* g_se3_qd, const float* g_bone_A, const float* g_bone_c, float* g_so3_t,
                                 float* g_trans_t, float* g_so3_rest, float* g_trans_rest, float* g_inv_gauss, void* stream);
 
+/* ---- (ABI 19) the camera network's tail (CameraMLP.get_vals, lab4d/nnutils/pose.py:120-150): cam_q[m] =
+ *      normalize(raw_quat[m]) * normalize(base_quat[m]) (F.normalize: v / max(|v|, 1e-12); Hamilton product, w first), M rows
+ *      of 4, one launch per direction instead of ~10 + ~30 elementwise ones; the backward on dual numbers like bone_tables. ---- */
+int vidu4d_camera_tail_forward(int M, const float* raw_quat, const float* base_quat, float* cam_q, void* stream);
+int vidu4d_camera_tail_backward(int M, const float* raw_quat, const float* base_quat, const float* g_cam_q,
+                                float* g_raw_quat, float* g_base_quat, void* stream);
+
 /* ---- (ABI 19) a stack of dense layers on a handful of rows, one launch per direction: the time-conditioned networks of
  *      the bob warp evaluated for the frames of a step (TimeMLP and its heads: lab4d/nnutils/time.py:11-133,
  *      pose.py:29-150 CameraMLP, :153-323 ArticulationFlatMLP; BaseMLP layers base.py:8-157).  A trunk of n_trunk layers

@@ -17,3 +17,13 @@ extern "C" void bt_backward(int M, int B, const float* so3_t, const float* trans
         bone_tables::bone_tables_bwd_body(i, M, B, so3_t, trans_t, so3_r, trans_r, inv_gauss, g_qr, g_qd, g_A, g_c, g_so3_t,
                                           g_trans_t, g_so3_r, g_trans_r, g_inv_gauss);
 }
+
+extern "C" void ct_forward(int M, const float* raw, const float* base, float* out)
+{
+    for (int m = 0; m < M; ++m) bone_tables::camera_tail_fwd_body(m, M, raw, base, out);
+}
+
+extern "C" void ct_backward(int M, const float* raw, const float* base, const float* g_out, float* g_raw, float* g_base)
+{
+    for (int i = 0; i < 8 * M; ++i) bone_tables::camera_tail_bwd_body(i, M, raw, base, g_out, g_raw, g_base);
+}

@@ -80,3 +80,27 @@ def test_zero_rotation_takes_the_series_branch(host_lib):
     host_lib.bt_backward(M, B, *[_ptr(x) for x in (so3_t, trans_t, so3_r, trans_r, ig)], *[_ptr(x) for x in go],
                          *[_ptr(x) for x in gi])
     assert all(np.isfinite(x).all() for x in gi)
+
+
+def test_camera_tail_matches_autograd(host_lib):
+    """normalize(raw) * normalize(base) (CameraMLP.get_vals' tail): values and both gradients, incl. a row whose raw
+    quaternion is exactly zero (F.normalize's clamp: output 0, gradient through the clamp's constant branch)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    M = 9
+    raw, base = torch.randn(M, 4, generator=g) * 3, torch.randn(M, 4, generator=g)
+    raw[4] = 0
+    a, b = raw.clone().requires_grad_(), base.clone().requires_grad_()
+    want = qt.quaternion_mul(F.normalize(a, dim=-1), F.normalize(b, dim=-1))
+    go = torch.randn(M, 4, generator=g)
+    wa, wb = torch.autograd.grad(want, (a, b), go)
+    r, s_, o = raw.numpy().copy(), base.numpy().copy(), np.zeros((M, 4), np.float32)
+    host_lib.ct_forward(M, _ptr(r), _ptr(s_), _ptr(o))
+    assert np.abs(o - want.detach().numpy()).max() <= 1e-6
+    gr, gb = np.full((M, 4), np.nan, np.float32), np.full((M, 4), np.nan, np.float32)
+    gon = go.numpy().copy()
+    host_lib.ct_backward(M, _ptr(r), _ptr(s_), _ptr(gon), _ptr(gr), _ptr(gb))
+    keep = [i for i in range(M) if i != 4]   # (at the zero row torch's gradient is g / eps-scaled: both are "whatever the clamp gives")
+    assert np.abs(gr[keep] - wa.numpy()[keep]).max() <= 1e-5 * max(1.0, float(wa[keep].abs().max()))
+    assert np.abs(gb - wb.numpy()).max() <= 1e-5 * max(1.0, float(wb.abs().max()))
+    assert np.isfinite(gr).all() and np.isfinite(gb).all()

@@ -490,3 +490,23 @@ def test_skin_field_with_weights_that_train(gpu_device, N):
     # the first layer's weight: only its coordinate columns enter here
     w1g = res[True][2]["linear_1.0.weight"]
     assert float(w1g[:, 3 * B:].abs().max()) == 0.0
+
+
+def test_camera_tail_kernel_matches_the_torch_ops(gpu_device):
+    """csrc/bone_tables.hip camera_tail: normalize(raw) * normalize(base) and both gradients on the device (the arithmetic
+    is pinned on the host by tests/test_bone_tables_cpu.py)."""
+    import torch.nn.functional as F
+    from vidu4d_amd.lab4d import quat_transform as qt
+    from vidu4d_amd.lab4d.bone_tables import camera_tail
+    dev = gpu_device
+    g = torch.Generator().manual_seed(1)
+    for M in (1, 2, 8, 100):
+        raw, base, go = (torch.randn(M, 4, generator=g).to(dev) for _ in range(3))
+        res = {}
+        for fused in (True, False):
+            a, b = raw.clone().requires_grad_(), base.clone().requires_grad_()
+            out = camera_tail(a, b) if fused else qt.quaternion_mul(F.normalize(a, dim=-1), F.normalize(b, dim=-1))
+            out.backward(go)
+            res[fused] = (out.detach(), a.grad, b.grad)
+        for x, y in zip(res[True], res[False]):
+            assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))

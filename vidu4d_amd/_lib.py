@@ -151,6 +151,8 @@ SYMBOLS = {
     "vidu4d_lbs_skin_param_rows": (C.c_int, [C.c_int]),
     "vidu4d_bone_tables_forward": (C.c_int, [C.c_int, C.c_int] + [_P] * 10),
     "vidu4d_bone_tables_backward": (C.c_int, [C.c_int, C.c_int] + [_P] * 15),
+    "vidu4d_camera_tail_forward": (C.c_int, [C.c_int, _P, _P, _P, _P]),
+    "vidu4d_camera_tail_backward": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P]),
     "vidu4d_dense_stack_acts_floats": (C.c_int, [C.POINTER(DenseStack)]),
     "vidu4d_dense_stack_forward": (C.c_int, [C.POINTER(DenseStack), _P, _P, _P]),
     "vidu4d_dense_stack_backward": (C.c_int, [C.POINTER(DenseStack), _P, _P, _P, _P, _P, _P, _P]),

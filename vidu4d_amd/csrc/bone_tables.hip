@@ -37,6 +37,17 @@ __global__ void bone_tables_bwd_kernel(int M, int B, const float* so3_t, const f
                                       g_qr, g_qd, g_A, g_c, g_so3_t, g_trans_t, g_so3_r, g_trans_r, g_inv_gauss);
 }
 
+__global__ void camera_tail_fwd_kernel(int M, const float* raw, const float* base, float* out)
+{
+    bone_tables::camera_tail_fwd_body(blockIdx.x * blockDim.x + threadIdx.x, M, raw, base, out);
+}
+
+__global__ void camera_tail_bwd_kernel(int M, const float* raw, const float* base, const float* g_out, float* g_raw,
+                                       float* g_base)
+{
+    bone_tables::camera_tail_bwd_body(blockIdx.x * blockDim.x + threadIdx.x, M, raw, base, g_out, g_raw, g_base);
+}
+
 int done()
 {
     const hipError_t e = hipGetLastError();
@@ -76,5 +87,28 @@ extern "C" int vidu4d_bone_tables_backward(int M, int B, const float* so3_t, con
     hipLaunchKernelGGL(bone_tables_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, M, B, so3_t, trans_t,
                        so3_rest, trans_rest, inv_gauss, g_se3_qr, g_se3_qd, g_bone_A, g_bone_c, g_so3_t, g_trans_t,
                        g_so3_rest, g_trans_rest, g_inv_gauss);
+    return done();
+}
+
+extern "C" int vidu4d_camera_tail_forward(int M, const float* raw_quat, const float* base_quat, float* cam_q, void* stream)
+{
+    if (M < 0) return VIDU4D_E_INVALID;
+    if (M == 0) return VIDU4D_OK;
+    if (!raw_quat || !base_quat || !cam_q) return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(camera_tail_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, (hipStream_t)stream, M, raw_quat, base_quat,
+                       cam_q);
+    return done();
+}
+
+extern "C" int vidu4d_camera_tail_backward(int M, const float* raw_quat, const float* base_quat, const float* g_cam_q,
+                                           float* g_raw_quat, float* g_base_quat, void* stream)
+{
+    if (M < 0) return VIDU4D_E_INVALID;
+    if (M == 0) return VIDU4D_OK;
+    if (!raw_quat || !base_quat || !g_cam_q || !g_raw_quat || !g_base_quat) return VIDU4D_E_INVALID;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(camera_tail_bwd_kernel, dim3((8 * M + 63) / 64), dim3(64), 0, (hipStream_t)stream, M, raw_quat,
+                       base_quat, g_cam_q, g_raw_quat, g_base_quat);
     return done();
 }

@@ -229,4 +229,46 @@ VIDU4D_HD void bone_tables_bwd_body(int idx, int M, int B, const float* so3_t, c
         g_inv_gauss[b * 3 + k - 6] = acc;
 }
 
+// ---- the camera network's tail (CameraMLP.get_vals, reference lab4d/nnutils/pose.py:120-150): the rotation head's raw
+// quaternion and the video's learnable base quaternion, both normalised (F.normalize: v / max(|v|, 1e-12)), composed.
+template <class T>
+VIDU4D_HD Quat<T> normalised(const T* v)
+{
+    const T n = m_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    const bool tiny = !(value(n) > 1e-12f);
+    const T inv = 1.f / m_select(tiny, lift(1e-12f, n), n);
+    return {v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+}
+template <class T>
+VIDU4D_HD void camera_rotation(const T* raw4, const T* base4, T* out4)
+{
+    const Quat<T> q = qmul(normalised(raw4), normalised(base4));
+    out4[0] = q.w, out4[1] = q.x, out4[2] = q.y, out4[3] = q.z;
+}
+
+VIDU4D_HD void camera_tail_fwd_body(int m, int M, const float* raw, const float* base, float* out)
+{
+    if (m >= M) return;
+    float o[4];
+    camera_rotation(raw + 4 * m, base + 4 * m, o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[4 * m + k] = o[k];
+}
+
+// one thread per (row, input direction): 0-3 the raw quaternion's components, 4-7 the base quaternion's
+VIDU4D_HD void camera_tail_bwd_body(int idx, int M, const float* raw, const float* base, const float* g_out, float* g_raw,
+                                    float* g_base)
+{
+    if (idx >= 8 * M) return;
+    const int m = idx >> 3, dir = idx & 7;
+    Dual r[4], b[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = {raw[4 * m + k], k == dir ? 1.f : 0.f}, b[k] = {base[4 * m + k], k + 4 == dir ? 1.f : 0.f};
+    camera_rotation(r, b, o);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += g_out[4 * m + k] * o[k].d;
+    (dir < 4 ? g_raw : g_base)[4 * m + (dir & 3)] = acc;
+}
+
 }  // namespace bone_tables

@@ -59,3 +59,31 @@ class _BoneTables(torch.autograd.Function):
 
 
 bone_tables = _BoneTables.apply
+
+
+class _CameraTail(torch.autograd.Function):
+    """cam_q = normalize(raw) * normalize(base): CameraMLP.get_vals' tail in one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, raw, base):
+        if not raw.is_cuda or raw.shape != base.shape or raw.shape[-1] != 4 or raw.dim() != 2:
+            raise RuntimeError("camera_tail: two (M, 4) HIP tensors expected")
+        r, b = _f32(raw), _f32(base)
+        out = torch.empty_like(r)
+        _lib.check(_lib.load().vidu4d_camera_tail_forward(r.shape[0], r.data_ptr(), b.data_ptr(), out.data_ptr(), _stream(raw)),
+                   "camera_tail forward")
+        ctx.save_for_backward(r, b)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        r, b = ctx.saved_tensors
+        g = _f32(g)
+        gr, gb = torch.empty_like(r), torch.empty_like(b)
+        _lib.check(_lib.load().vidu4d_camera_tail_backward(r.shape[0], r.data_ptr(), b.data_ptr(), g.data_ptr(), gr.data_ptr(),
+                                                           gb.data_ptr(), _stream(r)), "camera_tail backward")
+        return gr, gb
+
+
+camera_tail = _CameraTail.apply

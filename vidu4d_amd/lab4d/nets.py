@@ -275,17 +275,27 @@ class CameraMLP(TimeMLP):
         self.base_quat = nn.Parameter(torch.zeros(self.time_embedding.num_vids, 4))
         self.register_buffer("init_vals", rtmat, persistent=False)
 
-    def forward(self, t_embed, fused=False):
+    def head_outputs(self, t_embed, fused=False):
+        """(raw rotation quaternion (R, 4), translation (R, 3)): the two heads' outputs."""
         both = self.fused_heads(t_embed, self.quat, self.trans) if fused else None
         if both is None:
             feat = self.features(t_embed)
             both = self.quat(feat), self.trans(feat)
-        return F.normalize(both[0], dim=-1), both[1]
+        return both
+
+    def forward(self, t_embed, fused=False):
+        quat, trans = self.head_outputs(t_embed, fused)
+        return F.normalize(quat, dim=-1), trans
 
     def get_vals(self, frame_id=None, fused=False):
         te = self.time_embedding
-        quat, trans = self.forward(te(frame_id), fused=fused)
         vid = te.frame_to_vid if frame_id is None else te.raw_fid_to_vid[frame_id]
+        if fused and frame_id is not None and frame_id.is_cuda and frame_id.dim() == 1:
+            # both normalisations and the product in one launch per direction (csrc/bone_tables.hip: ~10 + ~30 otherwise)
+            from .bone_tables import camera_tail
+            quat, trans = self.head_outputs(te(frame_id), fused=True)
+            return camera_tail(quat, self.base_quat[vid]), trans
+        quat, trans = self.forward(te(frame_id), fused=fused)
         return qt.quaternion_mul(quat, F.normalize(self.base_quat[vid], dim=-1)), trans
 
     def base_init(self):
