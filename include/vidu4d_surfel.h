@@ -455,7 +455,7 @@ typedef struct Vidu4dSkinFieldArgs {
     const float* packed_bwd;
     /* optional (extension, ABI 19): networks that TRAIN (--gs_optim_warp=True, lab4d/config.py:157).  Feature-major arrays
      * from which the caller takes the weight gradients as contractions over the surfels:
-     *   h_store  (forward output)  float[D][W][N]   hidden layer l's activations (after the ReLU)
+     *   h_store  (forward output)  float[D][h_store_rows or W][N]   hidden layer l's activations (after the ReLU), rows 0..W-1
      *   g_store  (backward output) float[D][W][N]   the gradient w.r.t. hidden layer l's PRE-activation (needs relu_masks)
      *   gx_store (backward output) float[3B][N]     the whole gradient w.r.t. the bone coordinates (g_xbT + the MLP's)
      * d w_out = g_rawT h_store[D-1]^T, d w_hid[l-1] = g_store[l] h_store[l-1]^T, d w_in = g_store[0] xbT^T,
@@ -463,6 +463,8 @@ typedef struct Vidu4dSkinFieldArgs {
     float* h_store;
     float* g_store;
     float* gx_store;
+    int h_store_rows;   /* rows per layer of h_store: 0 = W; W + 1 leaves room for a row of ones behind each layer, which folds
+                           the bias gradient into the weight gradient's contraction (d [w | b] = g [h; 1]^T) */
 } Vidu4dSkinFieldArgs;
 int vidu4d_skin_field_forward(const Vidu4dSkinFieldArgs* args, void* stream);
 int vidu4d_skin_field_backward(const Vidu4dSkinFieldArgs* args, void* stream);

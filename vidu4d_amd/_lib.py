@@ -52,7 +52,7 @@ class SkinFieldArgs(C.Structure):
     _fields_ = [("N", C.c_int), ("B", C.c_int), ("W", C.c_int), ("D", C.c_int)] + [
         (n, C.c_void_p) for n in ("xyz", "bone_A", "bone_c", "w_in", "b_in", "w_hid", "b_hid", "w_out", "b_out", "xbT",
                                   "rawT", "g_xbT", "g_rawT", "g_xyz", "relu_masks", "packed_fwd", "packed_bwd", "h_store",
-                                  "g_store", "gx_store")]
+                                  "g_store", "gx_store")] + [("h_store_rows", C.c_int)]
 
 
 LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 8, 1024, 32

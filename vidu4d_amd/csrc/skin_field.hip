@@ -190,13 +190,13 @@ __device__ __forceinline__ uint32_t relu_tiles(f32x16 (&h)[2])
 // activations from the forward, the pre-activation gradients from the backward -- from which the weight gradients are taken
 // as contractions over the surfels (lab4d/lbs_fused.py).  Lanes 0-31 write 128 contiguous bytes of a row, lanes 32-63 of
 // the row four further down.
-__device__ __forceinline__ void store_rows(float* dst, int layer, const f32x16 (&t)[2], int half, uint32_t Ns, int n)
+__device__ __forceinline__ void store_rows(float* dst, int first_row, const f32x16 (&t)[2], int half, uint32_t Ns, int n)
 {
 #pragma unroll
     for (int ob = 0; ob < 2; ob++)
 #pragma unroll
         for (int v = 0; v < 16; v++)
-            dst[(uint32_t)(layer * W + 32 * ob + rowv(v, half)) * (size_t)Ns + (uint32_t)n] = t[ob][v];
+            dst[(uint32_t)(first_row + 32 * ob + rowv(v, half)) * (size_t)Ns + (uint32_t)n] = t[ob][v];
 }
 
 // Hidden layers of the forward for one tile; h = last hidden activations (D layout), masks[l] = active units of layer l.
@@ -233,6 +233,8 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
     }
     masks[0] = relu_tiles(h);
     if (mask_out) mask_out[0] = masks[0];
+    // (h_store_rows: rows per layer of the caller's array, W or more -- e.g. W + 1 with a row of ones behind each layer)
+    const int h_rows = a.h_store_rows > 0 ? a.h_store_rows : W;
     if (h_store && valid) store_rows(h_store, 0, h, half, Ns, n);
 #pragma unroll 1
     for (int layer = 1; layer < a.D; layer++) {
@@ -252,7 +254,7 @@ __device__ __forceinline__ void hidden_forward(const Vidu4dSkinFieldArgs& a, con
         if (mask_out) mask_out[layer * mask_stride] = masks[layer];
         h[0] = acc[0];
         h[1] = acc[1];
-        if (h_store && valid) store_rows(h_store, layer, h, half, Ns, n);
+        if (h_store && valid) store_rows(h_store, layer * h_rows, h, half, Ns, n);
     }
 }
 
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(threads_of<BACKWARD>()) void skin_field_kernel(Vidu
                 for (int sb = 0; sb < 2; sb++)
 #pragma unroll
                     for (int v = 0; v < 16; v++) g[sb][v] = ((m >> (16 * sb + v)) & 1u) ? g[sb][v] : 0.f;
-                if (valid) store_rows(a.g_store, layer, g, half, Ns, n);
+                if (valid) store_rows(a.g_store, layer * W, g, half, Ns, n);
             }
 #pragma unroll
             for (int sb = 0; sb < 2; sb++)
@@ -447,6 +449,7 @@ int check_args(const Vidu4dSkinFieldArgs* a, bool backward)
     if (a->N == 0) return VIDU4D_OK;
     if (!a->xyz || !a->bone_A || !a->bone_c || !a->w_in || !a->b_in || !a->w_out || !a->b_out) return VIDU4D_E_INVALID;
     if (a->D > 1 && (!a->w_hid || !a->b_hid)) return VIDU4D_E_INVALID;
+    if (a->h_store_rows != 0 && a->h_store_rows < W) return VIDU4D_E_INVALID;
     if (!backward) return a->rawT ? VIDU4D_OK : VIDU4D_E_INVALID;  // (xbT may be NULL: a caller that evaluates the bone map itself)
     if ((a->g_store != nullptr) != (a->gx_store != nullptr)) return VIDU4D_E_INVALID;
     if (a->g_store && !a->relu_masks) return VIDU4D_E_INVALID;   // (the stored gradients are the masked ones)

@@ -297,8 +297,11 @@ def skin_field(xyz, b_in, tab, want_xb=True):
 # ---- the same kernels for networks that TRAIN (--gs_optim_warp=True): TRAIN instances leave the hidden activations and the
 # masked pre-activation gradients in feature-major arrays; the weight gradients are contractions over the surfels
 # (bob_warp.contract_over_columns: batched GEMMs over K-chunks), the bias gradients row sums.
-def _train_buffers(sm, dev):
-    """Persistent padded weight arrays in the kernels' layout (the padding stays zero; refreshed by one copy each per step)."""
+def _train_buffers(sm, dev, N, B):
+    """Persistent arrays of the TRAIN path: the padded weights in the kernels' layout (padding stays zero; one copy each per
+    step) and, per surfel count, what the contractions over the surfels read -- the bone coordinates, every hidden layer's
+    activations and the homogeneous centres, each block FOLLOWED BY A ROW OF ONES (written once): g [x; 1]^T gives the weight
+    gradient and the bias gradient in one batched GEMM instead of a GEMM and a 50 MB row sum."""
     lim = _lib.SKIN_FIELD
     W, IN, OUT = lim["width"], lim["in_max"], lim["out_max"]
     bufs = sm.__dict__.get("_skin_field_train_bufs")
@@ -307,6 +310,14 @@ def _train_buffers(sm, dev):
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
         bufs = sm.__dict__["_skin_field_train_bufs"] = {"w_in": z(W, IN), "w_out": z(OUT, W), "b_out": z(OUT),
                                                         "w_hid": z(max(D - 1, 1), W, W), "b_hid": z(max(D - 1, 1), W)}
+    if bufs.get("N") != N:
+        bufs["N"] = N
+        xb1 = torch.empty(3 * B + 1, N, dtype=torch.float32, device=dev)
+        xb1[3 * B] = 1.0
+        h1 = torch.empty(D, W + 1, N, dtype=torch.float32, device=dev)
+        h1[:, W] = 1.0
+        xyz1 = torch.ones(N, 4, dtype=torch.float32, device=dev)
+        bufs.update(xb1=xb1, h1=h1, xyz1=xyz1)
     return bufs
 
 
@@ -326,16 +337,18 @@ class _SkinFieldTrain(Function):
             for i in range(D - 1):
                 sm_bufs["w_hid"][i].copy_(hidden[2 * i])
                 sm_bufs["b_hid"][i].copy_(hidden[2 * i + 1])
-        tab = dict(sm_bufs, B=B, D=D, bone_A=_c(A), bone_c=_c(c0))
+            sm_bufs["xyz1"][:, :3].copy_(x)
+        tab = dict(B=B, D=D, bone_A=_c(A), bone_c=_c(c0), **{k: sm_bufs[k] for k in ("w_in", "w_out", "b_out", "w_hid", "b_hid")})
         dev = xyz.device
-        xbT = torch.empty(3 * B, N, dtype=torch.float32, device=dev)
+        xb1, h1 = sm_bufs["xb1"], sm_bufs["h1"]
+        xbT = xb1[:3 * B]
         rawT = torch.empty(B, N, dtype=torch.float32, device=dev)
         masks = torch.empty(D * 64 * ((N + 31) // 32), dtype=torch.int32, device=dev)
-        h = torch.empty(D, W, N, dtype=torch.float32, device=dev)
-        a = _skin_field_args(tab, N, x, b, xbT=xbT, rawT=rawT, relu_masks=masks, h_store=h)
+        a = _skin_field_args(tab, N, x, b, xbT=xbT, rawT=rawT, relu_masks=masks, h_store=h1)
+        a.h_store_rows = W + 1
         _lib.check(_lib.load().vidu4d_skin_field_forward(a, torch.cuda.current_stream(dev).cuda_stream), "skin field forward")
-        ctx.save_for_backward(x, b, masks, h, xbT, tab["bone_A"], tab["bone_c"])
-        ctx.tab = tab     # (the padded weights: unchanged until the next forward of this model)
+        ctx.save_for_backward(x, b, masks)
+        ctx.tab, ctx.bufs = tab, sm_bufs   # (persistent arrays: unchanged until the next forward of this model)
         ctx.dims = (N, B, D, W)
         return xbT, rawT
 
@@ -343,9 +356,10 @@ class _SkinFieldTrain(Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_xbT, g_rawT):
         from .bob_warp import contract_over_columns
-        x, b, masks, h, xbT, A, c0 = ctx.saved_tensors
+        x, b, masks = ctx.saved_tensors
         N, B, D, W = ctx.dims
         dev = x.device
+        xb1, h1, xyz1 = ctx.bufs["xb1"], ctx.bufs["h1"], ctx.bufs["xyz1"]
         g_xbT = None if g_xbT is None else _c(g_xbT)
         g_rawT = torch.zeros(B, N, device=dev) if g_rawT is None else _c(g_rawT)
         g_xyz = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -354,16 +368,21 @@ class _SkinFieldTrain(Function):
         a = _skin_field_args(ctx.tab, N, x, b, g_xbT=g_xbT, g_rawT=g_rawT, g_xyz=g_xyz, relu_masks=masks, g_store=g, gx_store=gx)
         _lib.check(_lib.load().vidu4d_skin_field_backward(a, torch.cuda.current_stream(dev).cuda_stream), "skin field backward")
         need = ctx.needs_input_grad
-        g_A = contract_over_columns(gx, x.t()) if need[2] else None
-        g_c = gx.sum(1) if need[3] else None
-        g_w1 = contract_over_columns(g[0], xbT) if need[4] else None
-        g_b_in = g[0].sum(1) if need[1] else None
-        g_wo = contract_over_columns(g_rawT, h[D - 1]) if need[5] else None
-        g_bo = g_rawT.sum(1) if need[6] else None
+        # every contraction against [x; 1]: the last column is the bias gradient (the row sum of its left operand)
+        g_A = g_c = g_w1 = g_b_in = g_wo = g_bo = None
+        if need[2] or need[3]:
+            t = contract_over_columns(gx, xyz1.t())            # (3B, 4)
+            g_A, g_c = t[:, :3], t[:, 3]
+        if need[4] or need[1]:
+            t = contract_over_columns(g[0], xb1)                # (W, 3B + 1)
+            g_w1, g_b_in = t[:, :3 * B], t[:, 3 * B]
+        if need[5] or need[6]:
+            t = contract_over_columns(g_rawT, h1[D - 1])        # (B, W + 1)
+            g_wo, g_bo = t[:, :W], t[:, W]
         hidden = []
         for i in range(1, D):
-            hidden.append(contract_over_columns(g[i], h[i - 1]) if need[8 + 2 * (i - 1)] else None)
-            hidden.append(g[i].sum(1) if need[9 + 2 * (i - 1)] else None)
+            t = contract_over_columns(g[i], h1[i - 1])          # (W, W + 1)
+            hidden += [t[:, :W], t[:, W]]
         return (g_xyz if need[0] else None, g_b_in, g_A, g_c, g_w1, g_wo, g_bo, None, *hidden)
 
 
@@ -377,4 +396,5 @@ def skin_field_train(xyz, b_in, A, c0, sm):
         lin = getattr(mlp, f"linear_{i + 1}")[0]
         hidden += [lin.weight, lin.bias]
     return _SkinFieldTrain.apply(xyz, b_in, A, c0, mlp.linear_1[0].weight[:, :B3], mlp.linear_final.weight,
-                                 mlp.linear_final.bias, _train_buffers(sm, xyz.device), *hidden)
+                                 mlp.linear_final.bias, _train_buffers(sm, xyz.device, xyz.shape[0], mlp.linear_final.weight.shape[0]),
+                                 *hidden)
