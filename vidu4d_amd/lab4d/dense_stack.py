@@ -1,8 +1,8 @@
 """A time-conditioned network's dense layers on a handful of rows as ONE launch per direction (csrc/dense_stack.hip).
 
-    time_mlp_heads(x (R, 256), trunk, head_a, head_b) -> (out_a (R, Oa), out_b (R, Ob))
+    dense_stack(x (R, 256), trunk, head_a, head_b) -> (out_a (R, Oa), out_b (R, Ob))
 
-`trunk`, `head_a`, `head_b` are lists of (weight, bias, relu, scale) -- the layers of a nets.TimeMLP (reference
+`trunk`, `head_a`, `head_b` are lists of (nn.Linear, relu: bool, scale: float) -- the layers of a nets.TimeMLP (reference
 lab4d/nnutils/time.py:11-133: linear_1..linear_D + linear_final, each followed by its ReLU) and of the two heads on its
 features (pose.py:29-150 CameraMLP.trans / .quat, :153-323 ArticulationFlatMLP.trans (ScaleLayer 0.1) / .so3).  Values as
 F.linear / F.relu to float rounding; differentiable once w.r.t. x and every weight and bias."""
