@@ -1,9 +1,10 @@
 """The networks' forward and backward for a step's frames as two captured hipGraphs whose parameter gradients LAND IN
 `.grad` WITHOUT A COPY.
 
-`torch.cuda.make_graphed_callables` (round 5's first form) returns the captured backward's gradients to autograd, whose
-AccumulateGrad nodes cannot adopt a graph's static buffers and clone them: one 4.5 us device copy and one engine node per
-parameter tensor and step (66 tensors: 0.3 ms of a 4.4 ms step, `profiles/r05_fit_optim_warp_profile.txt`).  Here the
+`torch.cuda.make_graphed_callables` (round 5's first form) returns the captured backward's gradients to autograd: one
+AccumulateGrad engine node per parameter tensor and step (66 tensors), a copy wherever a static buffer cannot be adopted,
+and the trainer's round accumulation copied each again -- together + 20 % of the step in the same-process A/B
+(`graphed_warp_networks: "torch"`, `profiles/r05_fit_optim_warp_ab.txt`).  Here the
 backward replays the graph and hands every parameter its static gradient buffer directly -- `p.grad = buffer` when the
 parameter has none (the usual case: `zero_grad(set_to_none=True)`), `p.grad += buffer` otherwise; a `.grad` that still IS
 the buffer from an earlier backward (gradient accumulation over several backward calls) is detached from it first.
