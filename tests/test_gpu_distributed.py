@@ -126,3 +126,54 @@ def test_bench_two_ranks_on_one_gpu(gpu_device):
     assert c["world"] == 2 and c["ranks_seen"] == 2 and c["rank_sum_ok"] and c["backend"] == "gloo"
     assert c["frames_of_each_rank_head"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
     assert c["payload_bytes"] == 20000 * 58 * 4 and c["allreduce_ms_p50"] > 0
+
+
+def _worker_networks(rank, world, port, out):
+    """Two ranks, networks that TRAIN (--gs_optim_warp=True, AdamW from step 1): the networks' gradients come out of the
+    captured graphs' static buffers, are packed into the flat exchange buffer behind the surfels', summed, folded into the
+    round's accumulation and stepped -- the replicas' networks must stay identical."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+        from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(0)
+        torch.manual_seed(0)
+        opts = dict(fg_motion="gs-bob", densify_until_iter=0, gs_optim_warp=True, optim_warp_neus_iters=1, num_rounds=2,
+                    iters_per_round=4)
+        m = DeformableSurfels(opts, num_frames=8, device=dev)
+        n = 3000
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        m.init_from_points(0.25 * d / np.linalg.norm(d, axis=1, keepdims=True), rng.uniform(size=(n, 3)).astype(np.float32))
+        with torch.no_grad():
+            m._opacity.fill_(1.0)
+        before = torch.cat([p.detach().reshape(-1) for p in list(m.warp.parameters()) + list(m.camera_mlp.parameters())]).cpu()
+        tr = Stage3Trainer(m, opts)
+        assert tr.world == world and tr.optim_warp and tr._flat_needed()
+        for step in range(4):                      # step 0 accumulates, AdamW steps from step 1
+            ids = [(2 * (step * world + rank)) % 8, (2 * (step * world + rank) + 1) % 8]
+            tr.train_step(synthetic_batch(m, ids, 64, 64, seed=step))
+        torch.cuda.synchronize()
+        graphs = m.__dict__.get("_net_graph")
+        sig = torch.cat([p.detach().reshape(-1) for p in list(m.warp.parameters()) + list(m.camera_mlp.parameters())]).cpu()
+        gathered = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(gathered, sig)
+        out[rank] = (all(torch.equal(gathered[0], t) for t in gathered), bool(torch.isfinite(sig).all()),
+                     float((sig - before).abs().max()), graphs is not None and graphs[1] is not None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_networks_that_train_keep_identical_networks(gpu_device):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_networks, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        identical, finite, moved, graphed = out[r]
+        assert finite and identical, "the replicas' networks diverged"
+        assert moved > 0, "AdamW never moved the networks"
+        assert graphed, "the networks were not evaluated through captured graphs"
