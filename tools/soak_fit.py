@@ -15,6 +15,7 @@ from vidu4d_amd.lab4d.stage3 import Stage3Trainer, make_intrinsics_inv
 
 dev = torch.device("cuda:0")
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1300
+TRAIN_NETS = os.environ.get("SOAK_TRAIN_NETS", "0") == "1"   # the warp / camera / skinning networks train (round 5)
 H = W = 192
 FRAMES = 16
 
@@ -51,10 +52,15 @@ def run(tag, **opts):
               # trainer.py:573-588, a fixed radius -- which on this sparse toy cloud is nobody: switched off here)
               outlier_filtering_interval=10 ** 9, **opts)
     s.load_state_dict(nets, strict=False)
-    for mod in (s.warp, s.camera_mlp):
-        for p in mod.parameters():
-            p.requires_grad_(False)
-    tr = Stage3Trainer(s)
+    if TRAIN_NETS:   # --gs_optim_warp=True, the reference's default: gradients accumulate from step 0, AdamW from step 300
+        tr = Stage3Trainer(s, s.opts | dict(gs_optim_warp=True, optim_warp_neus_iters=300, num_rounds=STEPS // 200 + 2,
+                                            iters_per_round=200))
+        assert tr.optim_warp and s.warp_networks_train()
+    else:
+        for mod in (s.warp, s.camera_mlp):
+            for p in mod.parameters():
+                p.requires_grad_(False)
+        tr = Stage3Trainer(s)
     tr.current_steps = int(os.environ.get("SOAK_STEP0", "0"))  # > 8000: the normal-consistency regulariser is on
     hist, counts = [], []
     t0 = time.perf_counter()
@@ -84,8 +90,12 @@ def run(tag, **opts):
     return hist, err
 
 
-h1, e1 = run("default path")
-h2, e2 = run("extensions off", canonical_params=False, alpha_only_blend=False, stacked_frames=False, fused_loss=False)
+if TRAIN_NETS:
+    h1, e1 = run("networks train, default path (captured graphs, fused kernels)")
+    h2, e2 = run("networks train, un-fused torch warp (rounds 1-4)", fused_warp_trainable=False)
+else:
+    h1, e1 = run("default path")
+    h2, e2 = run("extensions off", canonical_params=False, alpha_only_blend=False, stacked_frames=False, fused_loss=False)
 # (once the normal-consistency term is on, the loss carries its constant lambda * (1 - ...) ~ 0.049 on a mostly empty image:
 # convergence is judged on the image error then)
 if int(os.environ.get("SOAK_STEP0", "0")) + STEPS <= 8000:
