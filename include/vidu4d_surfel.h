@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 19
+#define VIDU4D_SURFEL_ABI 20
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -192,6 +192,12 @@ typedef struct Vidu4dSurfelForwardArgs {
                                         * segments up in ONE launch that also blends the saturating segments of a tile again,
                                         * one after the other (rounds 3-4); default since round 5: three launches -- scan,
                                         * one workgroup per saturating (tile, segment), add up.  Same results. */
+#define VIDU4D_SCHED_XCD_BLOCK(B) (((B) & 15) << 8)   /* (ABI 20, read by the forward; not a debugging switch but carried in
+                                        * debug_flags) the blend and sort launches' schedule as EIGHT longest-first queues,
+                                        * one per XCD: the tiles of a BxB-tile block of a frame go to one XCD (workgroup b runs
+                                        * on XCD b mod 8), so that a surfel's record is gathered through one L2 instead of ~3.
+                                        * 0: one longest-first queue over all tiles (rounds 1-5).  Same results up to the order
+                                        * of the backward's float atomics. */
 #define VIDU4D_SURFEL_MAX_FRAMES 8
 size_t vidu4d_surfel_image_bytes_frames(int width, int height, int frames);
 
@@ -286,7 +292,10 @@ enum Vidu4dSurfelStateArray {
     VIDU4D_STATE_SORTED_KEYS = 4,   /* uint64[num_rendered] (tile << 32 | depth bits); dst must be HOST memory */
     VIDU4D_STATE_RANGES = 5,        /* uint32[tiles][2] */
     VIDU4D_STATE_FINAL_T = 6,       /* float[3][H*W]: T, dist1, dist2 (the distortion moments about a per-tile reference depth) */
-    VIDU4D_STATE_N_CONTRIB = 7      /* uint32[2][H*W]: last, median */
+    VIDU4D_STATE_N_CONTRIB = 7,     /* uint32[2][H*W]: last, median */
+    VIDU4D_STATE_TILE_ORDER = 8,    /* uint32[tiles] (ABI 20): the blend / sort launches' schedule -- workgroup b takes tile [b] */
+    VIDU4D_STATE_TAIL_ORDER = 9,    /* uint32[tiles] (ABI 20): the recorded backward's tail units, by schedule position */
+    VIDU4D_STATE_HEADER = 10        /* uint32[64] (ABI 20): the geometry buffer's header words (vidu4d_amd/csrc/surfel_state.h) */
 };
 int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* args, const void* binning_buffer, int64_t capacity,
                              int what, void* dst, size_t dst_bytes, int64_t* count, void* stream);

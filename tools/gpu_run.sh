@@ -1,0 +1,89 @@
+#!/bin/bash
+# ONE parametrised runner for everything that is measured on the MI355X box through gpurun (it replaces the 63 one-off
+# tools/gpu_r4_*.sh / gpu_r5_*.sh scripts of rounds 4-5).  Usage, from the repository root:
+#     gpurun --timeout 1500 -- 'bash tools/gpu_run.sh <task> [args...] ; bash tools/gpu_run.sh <task> ...'
+# Every task writes under gpurun_out/<tag>/ (merged back into the build container); the summaries that are to be judged are
+# copied into profiles/ by hand afterwards.  TAG=<name> in the environment changes the output directory (default r06).
+#
+#   tests [pytest args]      the GPU suite (default: tests -m gpu -q)
+#   bench <name> [args]      one bench.py line -> <name>.json  (the default command when no args are given)
+#   opbench <name> [args]    bench.py's op-level figure only (no fit steps / CPU legs / per-frame surface): quick A/B lines
+#   xcd_ab                   item 1(i): the XCD-local schedule, block sizes 0 1 2 4 8, op-level + the TCC (L2) counters
+#   profile <tag> [args]     tools/profile_round.sh (kernel stats + FETCH / WRITE / SQ / TCC passes)
+#   fit_ab                   the fitting step's regimes (tools/fit_profile.py) with the schedule / graph switches
+#   matrix                   the final-tree measurement matrix: cfgA / cfgB (headline, default + driver form) / cfgE lines
+#   py <script> [args]       any tools/*.py under a timeout, output kept
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+TAG=${TAG:-r06}
+O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
+TASK=${1:-tests}; shift || true
+QUICK="--cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --fit-densify-steps 0 --per-frame-surface 0 --host-probe 0 --fit-optim-warp 0"
+
+line() {  # prints the fields of a bench line that the A/B tables quote
+python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+except Exception as e:
+    print(sys.argv[1], "no JSON line:", e); sys.exit(0)
+st = d.get("stage_ms_avg", {})
+print(sys.argv[1].split("/")[-1], "value", round(d["value"], 1), "median", d.get("repeats", {}).get("median"),
+      "blend_fwd", st.get("blend_fwd"), "blend_bwd", st.get("blend_bwd"), "roofline", round(d["roofline"]["frac"], 4))
+for k in ("fit_step", "fit_step_geometry", "fit_step_densify", "fit_step_optim_warp", "fit_step_optim_warp_unfused",
+          "fit_step_graph", "fit_step_optim_warp_graph"):
+    v = d.get(k)
+    if v: print("   ", k, v.get("images_per_s"), v.get("ms_per_step"))
+pf = d.get("value_per_frame_calls")
+if pf: print("    per_frame", pf.get("value"), pf.get("single_stream", {}).get("value"), "host", d.get("host_cost"))
+PY
+}
+
+case "$TASK" in
+tests)
+    ARGS=${*:-tests -m gpu -q}
+    timeout 2400 python -m pytest $ARGS --timeout=900 > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+    grep -E "^(FAILED|ERROR)|passed|failed|rc " $O/pytest.log | tail -15
+    ;;
+bench)
+    NAME=$1; shift
+    timeout 1500 python bench.py "$@" > $O/$NAME.log 2>&1; grep "^{" $O/$NAME.log | tail -1 > $O/$NAME.json; line $O/$NAME.json
+    ;;
+opbench)
+    NAME=$1; shift
+    timeout 600 python bench.py $QUICK --repeats 3 "$@" > $O/$NAME.log 2>&1; grep "^{" $O/$NAME.log | tail -1 > $O/$NAME.json; line $O/$NAME.json
+    ;;
+xcd_ab)
+    for B in 0 1 2 4 8 0; do
+        VIDU4D_SURFEL_XCD_BLOCK=$B timeout 600 python bench.py $QUICK --repeats 3 "$@" > $O/xcd_$B.log 2>&1
+        grep "^{" $O/xcd_$B.log | tail -1 > $O/xcd_$B.json; echo -n "B=$B "; line $O/xcd_$B.json
+    done | tee $O/r06_xcd_schedule_ab.txt
+    R=$(pwd); cd /tmp
+    for B in 0 2 4 8; do
+        VIDU4D_SURFEL_XCD_BLOCK=$B rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace -d $R/$O/tcc_$B -o pmc \
+            --output-format csv -- python $R/bench.py --steps 4 --warmup 2 $QUICK --repeats 0 --no-stage-timers "$@" > $R/$O/tcc_$B.log 2>&1
+        python $R/tools/gpu_run_counters.py $R/$O/tcc_$B blend_bwd blend_fwd | sed "s/^/B=$B /"
+    done | tee -a $R/$O/r06_xcd_schedule_ab.txt
+    cd $R
+    ;;
+profile)
+    T=${1:-r06}; shift || true
+    bash tools/profile_round.sh $T "$@" > $O/profile_round_$T.log 2>&1; tail -3 $O/profile_round_$T.log
+    mkdir -p $O/summary_$T; cp gpurun_out/prof_$T/summary/* $O/summary_$T/ 2>/dev/null
+    ;;
+fit_ab)
+    timeout 1200 python tools/fit_profile.py "$@" 2>&1 | grep -v "amdgpu.ids\|Warn\|warn" | tee $O/fit_ab.txt | tail -30
+    ;;
+matrix)
+    timeout 1500 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log | tail -1 > $O/r06_bench_line_cfgB.json; line $O/r06_bench_line_cfgB.json
+    timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver.log 2>&1; grep "^{" $O/bench_driver.log | tail -1 > $O/r06_bench_line_cfgB_driver_form.json; line $O/r06_bench_line_cfgB_driver_form.json
+    timeout 900 python bench.py --surfels 50000 --res 256 --frames 32 --cpu-images 0 --torch-cpu-images 0 > $O/bench_cfgA.log 2>&1; grep "^{" $O/bench_cfgA.log | tail -1 > $O/r06_bench_line_cfgA.json; line $O/r06_bench_line_cfgA.json
+    timeout 1500 python bench.py --surfels 1000000 --res 1920 --height 1080 --frames 240 --cpu-images 0 --torch-cpu-images 0 --fit-densify-steps 0 --host-probe 0 > $O/bench_cfgE.log 2>&1; grep "^{" $O/bench_cfgE.log | tail -1 > $O/r06_bench_line_cfgE.json; line $O/r06_bench_line_cfgE.json
+    ;;
+py)
+    S=$1; shift
+    timeout 1500 python $S "$@" 2>&1 | grep -v "amdgpu.ids" | tee $O/$(basename $S .py).txt | tail -40
+    ;;
+*)
+    echo "unknown task $TASK"; exit 2
+    ;;
+esac

@@ -33,12 +33,12 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 # whole-tile forward runs segment-parallel anyway (recorded segments), the only thing the split still buys is parallelism
 # for the FORWARD, and a frame with enough long tiles to fill the chip has it already -- while the segment-parallel forward
 # blends every segment up to the caller's limit, the whole-tile walk stops where the pixels saturate.  Stage-3 ball of
-# 200 k surfels at 512^2, two frames (tools/gpu_r4_z.sh): radius 1.0 = 720 long tiles, depth 4.5 k: 1.18 ms whole / 1.23
+# 200 k surfels at 512^2, two frames (round 4): radius 1.0 = 720 long tiles, depth 4.5 k: 1.18 ms whole / 1.23
 # split (1.42 / 1.55 in the regularised regime); radius 0.7 = 350 tiles, 6.7 k: 1.30 / 1.19; 0.5: 1.59 / 1.21; 0.3: 2.78 / 2.00.
 # Round 5: "long" is now the same count in either mode -- tiles longer than SPLIT_MIN = 1024 entries, Header word 14; the
 # round-4 counts above were tiles above the recorded segments' 320-entry class after a whole-tile frame and positions up to
 # the last 1024-entry tile after a split one, so the rule could stay in whichever mode ran first.  Same scene, same threshold
-# (tools/gpu_r5_d.sh, profiles/r05_split_rule.txt): radius 1.0 = 604 tiles: 1.27 whole / 1.24 split; 0.85 = 440: 1.25 / 1.14;
+# (profiles/r05_split_rule.txt): radius 1.0 = 604 tiles: 1.27 whole / 1.24 split; 0.85 = 440: 1.25 / 1.14;
 # 0.7 = 320: 1.25 / 1.05; 0.5 = 176: 1.52 / 1.02.  On the new count the threshold is 2.0 tiles per compute unit (512): radius
 # 0.85 and below split, radius 1.0 and bench.py's fitting scene (a filled unit ball: whole 0.98-1.01 ms / split 1.00-1.13,
 # three runs each, profiles/r05_split_rule.txt) walk whole tiles -- what round 4's rule did with its 2.5 on the other count.
@@ -64,6 +64,10 @@ DEBUG_FLAGS = ((_lib.DEBUG_NO_CULL if os.environ.get("VIDU4D_SURFEL_NO_CULL", "0
                (_lib.DEBUG_WHOLE_TILE_BACKWARD if os.environ.get("VIDU4D_SURFEL_WHOLE_TILE_BWD", "0") == "1" else 0) |
                (_lib.DEBUG_SERIAL_REPAIR if os.environ.get("VIDU4D_SURFEL_SERIAL_REPAIR", "0") == "1" else 0) |
                (_lib.DEBUG_POSITION_ORDER if os.environ.get("VIDU4D_SURFEL_POSITION_ORDER", "0") == "1" else 0))
+# The blend / sort launches' schedule (round 6): B > 0 = eight longest-first queues, one per XCD, the tiles of a BxB-tile block
+# of a frame on one XCD (VIDU4D_SCHED_XCD_BLOCK, csrc/binning.hip grouped_order); 0 = one queue over all tiles (rounds 1-5).
+# The process-wide default; RasterContext.xcd_block overrides it for the calls made under a context.
+XCD_BLOCK = int(os.environ.get("VIDU4D_SURFEL_XCD_BLOCK", "0"))
 _cu_count: dict = {}
 
 
@@ -94,6 +98,7 @@ class RasterContext:
         self.grad_out: dict = {}      # one-shot caller-supplied gradient outputs (gradient_buffers)
         self.grad_written = None
         self.debug_flags = None       # None: the process-wide DEBUG_FLAGS
+        self.xcd_block = None         # None: the process-wide XCD_BLOCK
         self.walk_counters = None     # (device int64 tensor, one-shot): the next backward counts its tile walk
         self.capacity_hint: dict = {}
         self.depth_hint: dict = {}
@@ -115,7 +120,8 @@ class RasterContext:
         return False
 
     def flags(self) -> int:
-        return int(DEBUG_FLAGS if self.debug_flags is None else self.debug_flags)
+        block = XCD_BLOCK if self.xcd_block is None else self.xcd_block
+        return int(DEBUG_FLAGS if self.debug_flags is None else self.debug_flags) | _lib.sched_xcd_block(block)
 
 
 _tls = threading.local()

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class ForwardArgs(C.Structure):
@@ -80,6 +80,13 @@ SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
 AUX_ALPHA = 0x02  # VIDU4D_AUX_ALPHA
 AUX_GEOM = 0x1F   # VIDU4D_AUX_GEOM: planes 0-4 (depth, alpha, normal)
 DEBUG_NO_CULL, DEBUG_WHOLE_TILE_BACKWARD, DEBUG_SERIAL_REPAIR, DEBUG_POSITION_ORDER = 1, 2, 4, 8   # VIDU4D_DEBUG_*
+
+
+def sched_xcd_block(block: int) -> int:
+    """VIDU4D_SCHED_XCD_BLOCK(B): the schedule bits of Vidu4dSurfelForwardArgs::debug_flags"""
+    return (int(block) & 15) << 8
+
+
 BLEND_STATS = 11  # VIDU4D_BLEND_STATS (vidu4d_surfel_diag.h)
 ADAM_MAX_TENSORS = 8
 CLIP_MAX_TENSORS = 16
@@ -174,7 +181,7 @@ SYMBOLS = {
 }
 
 STATE = dict(num_rendered=0, records=1, tiles_touched=2, point_list=3, sorted_keys=4, ranges=5, final_T=6,
-             n_contrib=7)
+             n_contrib=7, tile_order=8, tail_order=9, header=10)
 
 _lib = None
 

@@ -132,14 +132,100 @@ struct TileOrderShared {
     uint32_t max;
     uint32_t any;
     uint32_t n_long;
+    // XCD-local schedule (grouped_order): one histogram / queue per XCD group
+    uint32_t bin8[8][1024];
+    uint32_t scan8[8][16];
+    uint32_t n8[8], na[8], nb[8];
 };
+
+// XCD group of a tile: the BxB-tile block of its frame it lies in, blocks dealt to the eight XCDs so that every block row
+// and every block column of a frame holds all of them (3 is odd: bx + 3 by runs through all residues along either axis),
+// i.e. every group gets its share of border tiles (short lists) and interior tiles (long ones).
+__device__ __forceinline__ uint32_t xcd_group(int t, const ScheduleParams& sp)
+{
+    const int frame = t / sp.frame_tiles, r = t - frame * sp.frame_tiles;
+    const int bx = (r % sp.grid_x) / sp.xcd_block, by = (r / sp.grid_x) / sp.xcd_block;
+    return (uint32_t)(bx + 3 * by + 5 * frame) & 7u;
+}
+
+// XCD-local longest-first order (round 6).  Workgroup b of a launch runs on XCD b mod 8 (observed,
+// MI355X_MICROARCH.md "Workgroup dispatch"), and each XCD has its own L2: with ONE longest-first queue neighbouring tiles
+// land on different XCDs and a surfel's record -- gathered by every tile whose list holds it, ~3 of them -- is fetched by
+// ~3 L2s (blend_bwd: L2 hit rate 21 %, 2.9 x its algorithmic bytes behind the L2, profiles/r05_pmc_tcc.csv).  Here every
+// tile has a group g (xcd_group: its block's XCD) and the tiles of a group form their own longest-first queue (a bucket
+// sort on `cls_of`, 1024 classes, as before); out[] interleaves the eight queues: while all of them hold a tile of rank r,
+// position 8 r + g takes the rank-r tile of group g, so position mod 8 = group = XCD; shorter queues drop out of the rotation.
+// Two regions: the tiles whose class lies below cls_min (the split tiles: they must be exactly the first positions,
+// blend.hip find_work_recorded / find_work_split_ordered) are interleaved first, the others behind them with the rotation
+// continued (so that position mod 8 = group holds there as well).  cls_min = 1024: one region.
+template <class ClassFn>
+__device__ __forceinline__ void grouped_order(uint32_t* __restrict__ out, int num_tiles, TileOrderShared& sh,
+                                              const ScheduleParams& sp, ClassFn cls_of, uint32_t cls_min)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < 8; g++) sh.bin8[g][threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&sh.bin8[xcd_group(t, sp)][cls_of(t)], 1u);
+    __syncthreads();
+    uint32_t c[8], inc[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        c[g] = sh.bin8[g][threadIdx.x];
+        inc[g] = wave_inclusive_scan(c[g], lane);
+        if (lane == 63) sh.scan8[g][wave] = inc[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            if (w < wave) wbase += sh.scan8[g][w];
+        sh.bin8[g][threadIdx.x] = wbase + inc[g] - c[g];  // rank of the class's first tile in its group's queue
+        if (threadIdx.x == 1023) sh.n8[g] = wbase + inc[g];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const uint32_t n = sh.n8[threadIdx.x], a = cls_min < 1024u ? sh.bin8[threadIdx.x][cls_min] : n;
+        sh.na[threadIdx.x] = a;
+        sh.nb[threadIdx.x] = n - a;
+    }
+    __syncthreads();
+    uint32_t na[8], nb[8], S = 0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        na[g] = sh.na[g];
+        nb[g] = sh.nb[g];
+        S += na[g];
+    }
+    __syncthreads();  // (the region counts are read: the cursors below overwrite bin8[.][cls_min])
+    for (int t = threadIdx.x; t < num_tiles; t += 1024) {
+        const uint32_t g = xcd_group(t, sp), cls = cls_of(t);
+        uint32_t r = atomicAdd(&sh.bin8[g][cls], 1u), pos;
+        if (cls < cls_min) {
+            pos = 0;
+#pragma unroll
+            for (uint32_t h = 0; h < 8; h++) pos += min(na[h], r) + ((h < g && na[h] > r) ? 1u : 0u);
+        } else {
+            r -= na[g];
+            const uint32_t ig = (g - S) & 7u;   // (the rotation continues behind the first region: position mod 8 = group)
+            pos = S;
+#pragma unroll
+            for (uint32_t h = 0; h < 8; h++) pos += min(nb[h], r) + ((((h - S) & 7u) < ig && nb[h] > r) ? 1u : 0u);
+        }
+        out[pos] = (uint32_t)t;
+    }
+}
 
 // by_class (recorded segments): a tile is split iff its length CLASS lies above the class of split_min -- the split tiles
 // are then exactly the schedule positions [0, num_split_pos), which is what lets blend_bwd number the full segments and the
 // remainders separately (blend.hip find_work_recorded); every split tile is longer than split_min.
-__device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_tiles, TileOrderShared& sh, int seg_len,
-                                           int split_min, int by_class)
+__device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_tiles, TileOrderShared& sh, const ScheduleParams sp)
 {
+    const int seg_len = sp.seg_len, split_min = sp.split_min, by_class = sp.by_class;
+    // (the XCD-local order keeps the split tiles in front only when they are split by length class)
+    const bool xcd = sp.xcd_block > 0 && by_class && sp.grid_x > 0 && sp.frame_tiles > 0;
     uint32_t* s_bin = sh.bin;
     uint32_t* s_scan = sh.scan;
     uint32_t& s_max = sh.max;
@@ -170,19 +256,24 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
         const uint32_t len = img.ranges[2 * t + 1] - img.ranges[2 * t];
         return 1023u - (uint32_t)(((uint64_t)len << 10) / denom);
     };
-    for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&s_bin[bucket(t)], 1u);
-    __syncthreads();
-    const uint32_t c = s_bin[threadIdx.x];
-    const uint32_t inc = wave_inclusive_scan(c, lane);
-    if (lane == 63) s_scan[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
+    const uint32_t cls_min = 1023u - (uint32_t)(((uint64_t)min((uint32_t)split_min, max_len) << 10) / denom);
+    if (xcd) {
+        grouped_order(img.tile_order, num_tiles, sh, sp, bucket, cls_min);
+    } else {
+        for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&s_bin[bucket(t)], 1u);
+        __syncthreads();
+        const uint32_t c = s_bin[threadIdx.x];
+        const uint32_t inc = wave_inclusive_scan(c, lane);
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++)
-        if (w < wave) wbase += s_scan[w];
-    s_bin[threadIdx.x] = wbase + inc - c;  // exclusive start of this length class
-    __syncthreads();
-    for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tile_order[atomicAdd(&s_bin[bucket(t)], 1u)] = (uint32_t)t;
+        for (int w = 0; w < 16; w++)
+            if (w < wave) wbase += s_scan[w];
+        s_bin[threadIdx.x] = wbase + inc - c;  // exclusive start of this length class
+        __syncthreads();
+        for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tile_order[atomicAdd(&s_bin[bucket(t)], 1u)] = (uint32_t)t;
+    }
     __syncthreads();  // tile_order is read back below (same workgroup: the barrier orders the global accesses)
 
     // Segment table for the tiles longer than split_min (blend.hip; SPLIT_MIN for a segment-parallel forward, REC_MIN for
@@ -191,7 +282,6 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
     // at the first chunk of 1024 positions that holds none (a length class may straddle SPLIT_MIN,
     // hence "none in a whole chunk" and not "the first short tile").
     uint32_t carry = 0, split_pos = 0;
-    const uint32_t cls_min = 1023u - (uint32_t)(((uint64_t)min((uint32_t)split_min, max_len) << 10) / denom);
     for (int base = 0; base < num_tiles; base += 1024) {
         const int pos = base + threadIdx.x;
         uint32_t nseg = 0, tile = 0;
@@ -238,19 +328,25 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
             const uint32_t tail = img.seg_first[t] == SEG_NONE ? len : len - ((len - 1u) / (uint32_t)seg_len) * (uint32_t)seg_len;
             return 1023u - (uint32_t)(((uint64_t)tail << 10) / denom2);
         };
-        for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&s_bin[tail_bucket(t)], 1u);
-        __syncthreads();
-        const uint32_t c2 = s_bin[threadIdx.x];
-        const uint32_t inc2 = wave_inclusive_scan(c2, lane);
-        if (lane == 63) s_scan[wave] = inc2;
-        __syncthreads();
-        uint32_t wbase2 = 0;
+        if (xcd) {
+            // (the tails follow the full segments, whose count the recorded backward pads to a multiple of 8 -- bwd_prepare_kernel --
+            // so tail j runs on XCD j mod 8: the same eight queues, on the tail's size)
+            grouped_order(img.tail_order, num_tiles, sh, sp, tail_bucket, 1024u);
+        } else {
+            for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&s_bin[tail_bucket(t)], 1u);
+            __syncthreads();
+            const uint32_t c2 = s_bin[threadIdx.x];
+            const uint32_t inc2 = wave_inclusive_scan(c2, lane);
+            if (lane == 63) s_scan[wave] = inc2;
+            __syncthreads();
+            uint32_t wbase2 = 0;
 #pragma unroll
-        for (int w = 0; w < 16; w++)
-            if (w < wave) wbase2 += s_scan[w];
-        s_bin[threadIdx.x] = wbase2 + inc2 - c2;
-        __syncthreads();
-        for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tail_order[atomicAdd(&s_bin[tail_bucket(t)], 1u)] = (uint32_t)t;
+            for (int w = 0; w < 16; w++)
+                if (w < wave) wbase2 += s_scan[w];
+            s_bin[threadIdx.x] = wbase2 + inc2 - c2;
+            __syncthreads();
+            for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tail_order[atomicAdd(&s_bin[tail_bucket(t)], 1u)] = (uint32_t)t;
+        }
     }
     if (threadIdx.x == 0) {
         img.seg_prefix[split_pos] = carry;  // closes the last split tile's interval
@@ -262,14 +358,15 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
         g.hdr->num_long_tiles = sh.n_long;
         g.hdr->split_used = 0;
         g.hdr->truncated = 0;
+        g.hdr->xcd_block = xcd ? (uint32_t)sp.xcd_block : 0u;
+        g.hdr->live_xcd = 0;
     }
 }
 
-__global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageState img, int num_tiles, int seg_len, int split_min,
-                                                          int by_class)
+__global__ __launch_bounds__(1024) void tile_order_kernel(GeomState g, ImageState img, int num_tiles, ScheduleParams sp)
 {
     __shared__ TileOrderShared sh;
-    tile_order(g, img, num_tiles, sh, seg_len, split_min, by_class);
+    tile_order(g, img, num_tiles, sh, sp);
 }
 
 // Grouped path, ONE launch (round 1 used three dependent ones, 22 us of mostly launch latency for ~1 MB):
@@ -345,7 +442,7 @@ void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, 
 
 void launch_tile_order(const GeomState& g, const ImageState& img, int num_tiles, const ScheduleParams& sp, hipStream_t stream)
 {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles, sp.seg_len, sp.split_min, sp.by_class);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, g, img, num_tiles, sp);
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void emit_keys_kernel(CameraParams cam, int P, const int32_t* radii,
@@ -389,8 +486,7 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_keys_grouped_kernel(CameraPa
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cur[];
     if (blockIdx.x == gridDim.x - 1) {
-        tile_order(g, img, cam.grid_x * cam.grid_y * cam.frames, *reinterpret_cast<TileOrderShared*>(s_cur), sp.seg_len,
-                   sp.split_min, sp.by_class);
+        tile_order(g, img, cam.grid_x * cam.grid_y * cam.frames, *reinterpret_cast<TileOrderShared*>(s_cur), sp);
         return;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) g.hdr->num_buckets = 0;  // (work list of the long-list sort that follows)

@@ -185,6 +185,24 @@ __device__ __forceinline__ uint32_t search_positions(const uint32_t* __restrict_
     return __builtin_amdgcn_readfirstlane(lo);
 }
 
+// The same over the positions g, g + 8, g + 16, ... (n of them): the largest k in [0, n) with prefix[g + 8 k] <= idx.
+__device__ __forceinline__ uint32_t search_positions_mod8(const uint32_t* __restrict__ prefix, uint32_t g, uint32_t n, uint32_t idx,
+                                                          int lane)
+{
+    uint32_t lo = 0;
+    while (n > 1) {
+        const uint32_t step = (n + 63u) / 64u;
+        const uint32_t k = lo + (uint32_t)lane * step;
+        const bool in = (uint32_t)lane * step < n;
+        const uint32_t key = in ? prefix[g + 8u * k] : 0xffffffffu;
+        const int cnt = __builtin_popcountll(__ballot(in && key <= idx));
+        const uint32_t first = (uint32_t)(cnt - 1) * step;
+        lo += first;
+        n = min(step, n - first);
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
 template <bool SPLIT>
 __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageState& img, int grid_x, int grid_y,
                                               bool overflow)
@@ -245,7 +263,27 @@ __device__ __forceinline__ WorkItem find_work_recorded(const Header* hdr, const 
     const uint32_t idx = blockIdx.x;
     const int lane = threadIdx.x & 63;
     int tile;
-    if (idx < F) {
+    if (idx < F && hdr->live_xcd) {
+        // XCD-local schedule (round 6): workgroup 8 i + g runs on XCD g and takes the i-th live full segment of the schedule
+        // positions = g mod 8 -- whose tiles are the ones dealt to XCD g (binning.hip grouped_order) -- so the segments of a
+        // tile gather their records through the L2 its neighbours' segments use.  live_prefix holds the prefix per residue
+        // class, F is 8 x the largest class total (bwd_prepare_kernel): a class with fewer segments leaves its last few
+        // workgroups without work.
+        const uint32_t g = idx & 7u, i = idx >> 3;
+        if (S <= g) {
+            w.valid = false;
+            return w;
+        }
+        const uint32_t pos = g + 8u * search_positions_mod8(img.live_prefix, g, (S - g + 7u) / 8u, i, lane);
+        const uint32_t seg = i - img.live_prefix[pos];
+        if (seg >= img.live_count[pos]) {
+            w.valid = false;
+            return w;
+        }
+        tile = (int)img.tile_order[pos];
+        w.seg = (int)seg;
+        w.slot = img.seg_first[tile] + seg;
+    } else if (idx < F) {
         // (positions without a live full segment repeat their neighbour's key: the search takes the last of equal keys)
         const uint32_t lo = search_positions(img.live_prefix, S, idx, lane);
         tile = (int)img.tile_order[lo];
@@ -1675,7 +1713,38 @@ __global__ __launch_bounds__(256) void bwd_prepare_kernel(uint4* __restrict__ ac
     }
     uint32_t total;
     uint32_t run = block_exclusive_scan(sum, s_wave, total);
-    if (threadIdx.x == 0) hdr->num_live_full = total;
+    if (hdr->xcd_block) {
+        // XCD-local schedule: the prefix per residue class of the position (find_work_recorded), F = 8 x the largest class
+        // total -- unless the classes are so uneven that the padding would outgrow the launch (the host's grid allows a
+        // quarter more than the segments there can be, launch_blend_bwd): then the plain numbering below.
+        static_assert(PER % 8 == 0, "a thread's positions start at residue 0");
+        uint32_t sum8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, run8[8], most = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) sum8[i & 7] += v[i];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            uint32_t tot;
+            __syncthreads();
+            run8[g] = block_exclusive_scan(sum8[g], s_wave, tot);
+            most = max(most, tot);
+        }
+        if (8u * most <= total + total / 4u + 64u) {
+            if (threadIdx.x == 0) {
+                hdr->num_live_full = 8u * most;
+                hdr->live_xcd = 1u;
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                if (lo + i < S) img.live_prefix[lo + i] = run8[i & 7];
+                run8[i & 7] += v[i];
+            }
+            return;
+        }
+    }
+    if (threadIdx.x == 0) {
+        hdr->num_live_full = total;
+        hdr->live_xcd = 0u;
+    }
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         if (lo + i < S) img.live_prefix[lo + i] = run;
@@ -1697,7 +1766,9 @@ void launch_blend_bwd(const BackwardArgs& a, hipStream_t stream)
     if (a.split && a.seg_data) {
         // upper bound of the segment count (the device knows the exact one; the workgroups beyond it leave at once).
         // Recorded segments (find_work_recorded): the FULL segments, at most capacity / REC_SEG_LEN, then one tail per tile.
-        const int64_t segs = a.recorded ? a.capacity / REC_SEG_LEN + 1 : seg_capacity(a.capacity);
+        // (+ a quarter and 64: the XCD-local numbering pads the full segments to 8 x the largest residue class, bwd_prepare_kernel)
+        const int64_t rec_segs = a.capacity / REC_SEG_LEN + 1;
+        const int64_t segs = a.recorded ? rec_segs + rec_segs / 4 + 64 : seg_capacity(a.capacity);
         hipLaunchKernelGGL(pick_bwd<true>(a.mode), dim3((int)segs + tiles), dim3(256), pad, stream, a.cam.W, a.cam.H,
                            a.cam.grid_x, grid_y, a.geom.hdr, a.img, a.point_list, a.geom.rec, a.background, a.seg_data,
                            a.max_seg, a.dL_dcolor, a.dL_dothers, a.acc, a.flags

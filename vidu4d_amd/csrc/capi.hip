@@ -351,7 +351,9 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     const bool record = records_segments(a->segment_split, total_tiles(cam));
     // (by length CLASS in both cases since round 5: the split tiles are then exactly the schedule positions [0, S), and the
     // schedule builder also orders the tails -- which the backward of a segment-parallel forward now dispatches by too)
-    const ScheduleParams sp = {record ? REC_SEG_LEN : SEG_LEN, record ? REC_MIN : SPLIT_MIN, 1};
+    // (VIDU4D_SCHED_XCD_BLOCK(B) in debug_flags: the XCD-local longest-first schedule over BxB-tile blocks, binning.hip)
+    const ScheduleParams sp = {record ? REC_SEG_LEN : SEG_LEN, record ? REC_MIN : SPLIT_MIN, 1,
+                               (a->debug_flags >> FLAG_XCD_SHIFT) & 15, cam.grid_x, cam.grid_x * cam.grid_y};
     {
         StageTimer t(ST_EMIT, stream);
         launch_emit_keys(cam, P, a->radii, g, img, b, capacity, use_grouped_binning(total_tiles(cam)), sp, stream);
@@ -518,6 +520,9 @@ extern "C" int vidu4d_surfel_state_read(const Vidu4dSurfelForwardArgs* a, const 
         case VIDU4D_STATE_RANGES: src = img.ranges; n = (size_t)gx * gy * 2; break;
         case VIDU4D_STATE_FINAL_T: src = img.final_T; n = 3 * hw; break;
         case VIDU4D_STATE_N_CONTRIB: src = img.n_contrib; n = 2 * hw; break;
+        case VIDU4D_STATE_TILE_ORDER: src = img.tile_order; n = (size_t)gx * gy; break;
+        case VIDU4D_STATE_TAIL_ORDER: src = img.tail_order; n = (size_t)gx * gy; break;
+        case VIDU4D_STATE_HEADER: src = g.hdr; n = sizeof(Header) / 4; break;
         default: return fail(VIDU4D_E_INVALID, "unknown state array %d", what);
     }
     if ((what == VIDU4D_STATE_POINT_LIST || what == VIDU4D_STATE_SORTED_KEYS) && (int64_t)R > capacity)

@@ -101,6 +101,7 @@ inline size_t seg_data_floats(int64_t capacity)
 }
 // debug_flags of the ABI as the kernels see them
 constexpr int FLAG_NO_CULL = 1;
+constexpr int FLAG_XCD_SHIFT = 8;      // bits 8-11: VIDU4D_SCHED_XCD_BLOCK(B) (read by the forward's schedule builder)
 constexpr int FLAG_POSITION_ORDER = 8;  // VIDU4D_DEBUG_POSITION_ORDER: the split backward's workgroups in schedule-position order (rounds 2-4)
 constexpr int FLAG_SERIAL_REPAIR = 4;   // VIDU4D_DEBUG_SERIAL_REPAIR: the speculated combine as ONE launch (rounds 3-4)
 
@@ -126,7 +127,13 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t num_long_tiles; // word 14: tiles whose list is longer than SPLIT_MIN entries, whichever segment table the forward
                              // built (num_split_pos counts positions of the table at hand: tiles above REC_MIN's length class
                              // after a whole-tile forward, positions up to the last tile above SPLIT_MIN after a split one)
-    uint32_t pad[49];
+    uint32_t xcd_block;      // word 15 (round 6): 0, or the block size B (tiles) of the XCD-local schedule -- tile_order / tail_order hold
+                             // eight longest-first queues interleaved, position p taking from the queue of the tiles whose BxB-tile
+                             // block maps to XCD p mod 8 (binning.hip tile_order; ScheduleParams::xcd_block)
+    uint32_t live_xcd;       // word 16: 1 when the recorded backward numbers its live full segments per residue class of the
+                             // schedule position (workgroup 8 i + g takes the i-th live segment of the positions = g mod 8, so a
+                             // tile's segments stay on its XCD); written by the backward's preparation launch
+    uint32_t pad[47];
 };
 static_assert(sizeof(Header) == 256, "the header is the first 256 bytes of the geometry buffer");
 
@@ -336,6 +343,10 @@ void launch_tile_scan(const GeomState& g, const ImageState& img, int num_tiles, 
 // the schedule without exception).  Built by launch_emit_keys -- by an extra workgroup of the emit launch where it can.
 struct ScheduleParams {
     int seg_len, split_min, by_class;
+    // XCD-local longest-first schedule (round 6): 0 = one longest-first queue over all tiles (rounds 1-5); B > 0 = the tiles
+    // of a BxB-tile block of a frame share an XCD (workgroup b runs on XCD b mod 8: MI355X_MICROARCH.md, observed), i.e.
+    // eight length-sorted queues interleaved over the schedule positions.  grid_x / frame_tiles: the tile grid of ONE frame.
+    int xcd_block, grid_x, frame_tiles;
 };
 void launch_tile_order(const GeomState& g, const ImageState& img, int num_tiles, const ScheduleParams& sp, hipStream_t stream);
 void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
