@@ -588,7 +588,7 @@ int vidu4d_densify_apply(int N, const int32_t* inclusive_counts, int n_orig, int
  *      pipe.depth_ratio) -- evaluated inside the kernels from rays_d[m] (H*W,3) / rays_o[m] (3) with surf_depth
  *      (M*H*W floats) as the workspace between forward and backward, or, when surf_normal[m] (3,H,W) is given, read
  *      from there (its gradient then goes to g_surf_normal[m], if not NULL, instead of the depth planes). ---- */
-#define VIDU4D_LOSS_MAX_FRAMES 8
+#define VIDU4D_LOSS_MAX_FRAMES 32   /* (ABI 20; 8 before: a step of imgs_per_gpu > 4 -- two frames per image pair -- fell to the torch losses) */
 #define VIDU4D_LOSS_BLOCKS 1024
 #define VIDU4D_LOSS_SUMS_FLOATS 32
 typedef struct Vidu4dStage3LossArgs {

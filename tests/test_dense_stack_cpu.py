@@ -32,3 +32,17 @@ def test_unsupported_sequences_are_refused():
     s = ScaleLayer(0.1)
     s.load_state_dict({"scale": torch.tensor([0.3])})
     assert abs(s.scale_value - 0.3) < 1e-7
+
+
+def test_negative_scale_behind_a_relu_is_left_to_the_library_layers():
+    """The dense-stack kernels recover a ReLU's mask from the stored, scaled activation (h_out > 0): right for a positive
+    ScaleLayer behind a ReLU only -- sequential_layers refuses anything else, and the module then runs its torch
+    layers."""
+    import torch.nn as nn
+    from vidu4d_amd.lab4d.dense_stack import sequential_layers
+    from vidu4d_amd.lab4d.nets import ScaleLayer
+    lin = nn.Linear(4, 4)
+    assert sequential_layers(nn.Sequential(lin, nn.ReLU(), ScaleLayer(0.5))) == [(lin, True, 0.5)]
+    assert sequential_layers(nn.Sequential(lin, ScaleLayer(-2.0))) == [(lin, False, -2.0)]   # (no ReLU: any scale)
+    assert sequential_layers(nn.Sequential(lin, nn.ReLU(), ScaleLayer(-0.5))) is None
+    assert sequential_layers(nn.Sequential(lin, nn.ReLU(), ScaleLayer(0.0))) is None

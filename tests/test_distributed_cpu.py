@@ -362,3 +362,17 @@ def test_collective_self_check_two_ranks_gloo():
         assert c["frames_of_each_rank_head"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
         assert c["payload_bytes"] == 4000 and c["allreduce_ms_p50"] > 0 and c["allreduce_reps"] == 3
         assert c["payload_zeroed"] and c["device_of_each_rank"] == [-1, -1]
+
+
+def test_physical_device_identity_across_nodes_and_isolation():
+    """the self-check's "ranks share a device" test compared LOCAL device indices -- a 2-node x 8-GPU launch
+    repeats every index, and per-process HIP_VISIBLE_DEVICES isolation makes every rank device 0.  The identity is
+    (host, PCI domain / bus / device) now (/root/reference/lab4d/train.py:28-36 trusts its launcher instead)."""
+    from vidu4d_amd.lab4d.dist_check import physical_device_id, shared_physical_devices
+    two_nodes = [(h, 0, 0x10 + g, 0, g) for h in (111, 222) for g in range(8)]         # indices 0..7 twice
+    isolated = [(111, 0, 0x10 + g, 0, 0) for g in range(8)]                             # every rank sees "device 0"
+    assert shared_physical_devices(two_nodes) == [] and shared_physical_devices(isolated) == []
+    clash = isolated[:3] + [(111, 0, 0x11, 0, 5)]                                       # same bus as rank 1, another index
+    assert shared_physical_devices(clash) == [(111, 0, 0x11, 0)]
+    me = physical_device_id(torch.device("cpu"))
+    assert len(me) == 5 and me[1:] == [-1, -1, -1, -1]

@@ -136,3 +136,158 @@ def test_xcd_local_schedule_stacked_and_modes(gpu_device):
             assert float((ga - gb).abs().max()) <= 2e-5 * (float(ga.abs().max()) + 1e-30)
     finally:
         _C._SPLIT = old
+
+
+# ---- ADVICE r5 ---------------------------------------------------------------------------------------------------------------
+def _net_model(dev, seed=3, freeze_skin=False, **opts):
+    from tests.test_gpu_stage3 import _model
+    m = _model(dev, seed=seed, **opts)
+    with torch.no_grad():
+        for mod in (m.warp, m.camera_mlp):
+            for p in mod.parameters():
+                p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev))
+    if freeze_skin:
+        for p in m.warp.skinning_model.parameters():
+            p.requires_grad_(False)
+        m.__dict__.pop("_warp_params", None)
+    return m
+
+
+def test_second_forward_before_the_backward_is_refused_not_wrong(gpu_device):
+    """With networks that train the fused warp's activations live in per-model persistent arrays and its networks' outputs
+    are captured graphs' static buffers: a second grad-enabled forward of the same model before the first one's backward
+    overwrote what that backward reads -- silently wrong gradients.  Now the stale backward raises; a render under
+    torch.no_grad() in between is fine for the skinning field (temporaries) and refused by the graphed networks."""
+    dev = gpu_device
+    fid = torch.tensor([1, 5], device=dev)
+
+    def loss(m, ids):
+        x, r = m.forward_warp_fused(ids)
+        m.__dict__.pop("_warp_rot_is_unit", None)
+        return x.sum() + r.sum()
+
+    m = _net_model(dev)
+    l1 = loss(m, fid)
+    l2 = loss(m, torch.tensor([2, 6], device=dev))
+    with pytest.raises(RuntimeError, match="evaluated again"):
+        l1.backward()
+    for p in m.parameters():
+        p.grad = None
+    l2.backward()   # (the latest forward is intact)
+    want = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    # ... and with the networks evaluated eagerly (no static buffers), a no_grad render in between leaves the pending
+    # backward's activations alone
+    m2 = _net_model(dev, graphed_warp_networks=False)
+    l = loss(m2, torch.tensor([2, 6], device=dev))
+    with torch.no_grad():
+        loss(m2, fid)
+    l.backward()
+    got = {k: p.grad for k, p in m2.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    for k in want:
+        assert float((got[k] - want[k]).abs().max()) <= 2e-5 * float(want[k].abs().max()) + 1e-12, k
+
+
+def test_partial_freeze_frozen_skinning_field_under_training_bones(gpu_device):
+    """A frozen skinning field under an articulation / camera that trains: the fused warp used to hand the frozen
+    MFMA instances a bone map that requires grad and raise; it runs the TRAIN instances now and agrees with the torch chain."""
+    dev = gpu_device
+    fid = torch.tensor([1, 5], device=dev)
+    res = {}
+    for fused in (True, False):
+        m = _net_model(dev, freeze_skin=True, fused_warp=fused)
+        N = m._xyz.shape[0]
+        if fused:
+            x, r = m.forward_warp_fused(fid)
+            m.__dict__.pop("_warp_rot_is_unit", None)
+        else:
+            x, r, _ = m.forward_warp(m._xyz[None, :, None].expand(2, -1, -1, -1), m._rotation[None].expand(2, -1, -1), fid)
+            x, r = x[:, :, 0], torch.nn.functional.normalize(r, dim=-1)
+        gen = torch.Generator().manual_seed(11)
+        gx, gr = torch.randn(2, N, 3, generator=gen).to(dev), torch.randn(2, N, 4, generator=gen).to(dev)
+        ((x * gx).sum() + (r * gr).sum()).backward()
+        res[fused] = (x.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * float(res[False][0].abs().max())
+    assert set(res[True][1]) == set(res[False][1]) and not any("skinning_model" in k for k in res[True][1])
+    for k, b in res[False][1].items():
+        assert float((res[True][1][k] - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
+
+
+def test_frame_id_outside_the_sequence_raises(gpu_device):
+    """The kernels index the frozen networks' tables with the frame ids and clamp (csrc/lbs.hip table_row); the torch indexing
+    they replace -- and the reference, lab4d/nnutils/embedding.py -- raise on an id outside the sequence."""
+    from tests.test_gpu_stage3 import _model
+    from vidu4d_amd.lab4d.stage3 import synthetic_batch
+    dev = gpu_device
+    m = _model(dev, frames=8)
+    for p in list(m.warp.parameters()) + list(m.camera_mlp.parameters()):
+        p.requires_grad_(False)
+    m.__dict__.pop("_warp_params", None)
+    ok = m.forward_warp_fused(torch.tensor([0, 7], device=dev))
+    assert torch.isfinite(ok[0]).all()
+    for bad in ([0, 8], [-1, 3]):
+        with pytest.raises(IndexError, match="frame id out of range"):
+            m.forward_warp_fused(torch.tensor(bad, device=dev))
+    b = synthetic_batch(m, [3, 9], 32, 32)   # (a producer's host-side range note: no device read needed)
+    assert b["frameid"]._vidu4d_host_range == (3, 9)
+    with pytest.raises(IndexError):
+        m.forward_warp_fused(b["frameid"])
+
+
+# ---- more than 8 frames per step (VERDICT r5 missing 3) ------------------------------------------------------------------------
+@pytest.mark.parametrize("train_nets", [False, True])
+def test_ten_frames_per_step_run_in_groups_of_eight(gpu_device, train_nets):
+    """The reference's loop takes any imgs_per_gpu (lab4d/nnutils/deformable_gaussian.py:1175-1228); the stacked rasterizer,
+    the fused warp and the loss kernels took at most 8 frames and a step of 10 fell back to the per-frame chain (or failed in
+    the loss).  M = 10 now runs as a group of 8 and a group of 2: planes bit-identical to the per-frame calls, gradients to the
+    order of the float atomics; the trainer's step on the fused path equals the un-fused one."""
+    from tests.test_gpu_stage3 import _model
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer, make_intrinsics_inv, synthetic_batch
+    dev, H, W, M = gpu_device, 64, 64, 10
+    ids = torch.arange(M, device=dev)
+
+    def make(**opts):
+        m = _model(dev, n=3000, frames=12, seed=5, **opts)
+        for p in list(m.warp.parameters()) + list(m.camera_mlp.parameters()):
+            p.requires_grad_(train_nets)
+        m.__dict__.pop("_warp_params", None)
+        return m
+
+    res = {}
+    for stacked in (True, False):
+        m = make(stacked_frames=stacked)
+        r = m.render_frames(ids, make_intrinsics_inv(M, H, W, device="cpu"), [H] * M, [W] * M, outputs=("raw",))
+        if "raw_stacked" in r:
+            color, allmap = r["raw_stacked"]
+            assert color.shape == (3, M, H, W) and allmap.shape == (8, M, H, W)
+            frames = [(color[:, i], allmap[:, i]) for i in range(M)]
+        else:
+            assert not stacked
+            frames = r["raw"]
+        gen = torch.Generator().manual_seed(2)
+        wc, wa = torch.randn(M, 3, H, W, generator=gen).to(dev), torch.randn(M, 8, H, W, generator=gen).to(dev)
+        sum((c * wc[i]).sum() + (a * wa[i]).sum() for i, (c, a) in enumerate(frames)).backward()
+        assert len(m._radii_batch) == M and len(m._viewspace_points_batch) == M
+        res[stacked] = ([(c.detach(), a.detach()) for c, a in frames], [r_.clone() for r_ in m._radii_batch],
+                        {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                        [v.grad.clone() for v in m._viewspace_points_batch])
+    for (c1, a1), (c2, a2) in zip(res[True][0], res[False][0]):
+        assert torch.equal(c1, c2) and torch.equal(a1, a2)
+    assert all(torch.equal(a, b) for a, b in zip(res[True][1], res[False][1]))
+    assert set(res[True][2]) == set(res[False][2])
+    for k, b in res[False][2].items():
+        assert float((res[True][2][k] - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-12, k
+    for a, b in zip(res[True][3], res[False][3]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-12
+    # ---- the trainer's step: fused loss kernels over 10 frames against the torch statement of the losses
+    out = {}
+    for fused in (True, False):
+        m = make(fused_loss=fused, stacked_frames=fused)
+        tr = Stage3Trainer(m, dict(m.opts, gs_optim_warp=train_nets))
+        losses = tr.train_step(synthetic_batch(m, list(range(M)), H, W, seed=1))
+        out[fused] = ({k: float(v) for k, v in losses.items()}, m._xyz.detach().clone(), m._features_dc.detach().clone())
+    for k in ("rgb", "mask"):
+        assert abs(out[True][0][k] - out[False][0][k]) <= 1e-5 * abs(out[False][0][k]) + 1e-9, (k, out[True][0], out[False][0])
+    for a, b in zip(out[True][1:], out[False][1:]):   # (one Adam step: an entry whose tiny gradient changes sign moves by 2 lr)
+        d = (a - b).abs()
+        assert float(d.median()) <= 1e-6 and float(d.max()) <= 4 * 2.5e-3, (float(d.median()), float(d.max()))

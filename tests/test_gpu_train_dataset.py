@@ -21,7 +21,7 @@ def test_train_main_reads_the_reference_layout(tmp_path, gpu_device, capsys):
     train.main(["--seqname", fx.SEQ, "--logname", "t", "--logroot", logroot, "--fg_motion", "gs-bob",
                 "--data_root", str(tmp_path / "database"), "--data_prefix", "crop", "--train_res", "16",
                 "--feature_type", fx.FEATURE_TYPE, "--delta_list", "2,4", "--num_rounds", "1", "--iters_per_round", "3",
-                "--num_surfels", "2000", "--gs_optim_warp=False", "--allow_random_warp", "--save_freq", "1"])
+                "--num_surfels", "2000", "--gs_optim_warp=False", "--allow_random_warp", "--save_freq", "1", "--rgb_loss_only"])
     out = capsys.readouterr().out
     assert "2 video(s), 12 frames (crop-16)" in out and "round 0: 3 steps" in out
     run = os.path.join(logroot, f"{fx.SEQ}-t")
@@ -45,7 +45,7 @@ def test_train_main_with_the_reference_default_of_networks_that_train(tmp_path, 
     logroot = str(tmp_path / "logdir")
     common = ["--seqname", fx.SEQ, "--logroot", logroot, "--fg_motion", "gs-bob", "--data_root", str(tmp_path / "database"),
               "--data_prefix", "crop", "--train_res", "16", "--feature_type", fx.FEATURE_TYPE, "--delta_list", "2,4",
-              "--num_surfels", "2000", "--allow_random_warp", "--save_freq", "1"]
+              "--num_surfels", "2000", "--allow_random_warp", "--save_freq", "1", "--rgb_loss_only"]
     train.main(common + ["--logname", "frozen", "--num_rounds", "1", "--iters_per_round", "1", "--gs_optim_warp=False"])
     train.main(common + ["--logname", "train", "--num_rounds", "2", "--iters_per_round", "4", "--optim_warp_neus_iters", "3"])
     out = capsys.readouterr().out

@@ -508,3 +508,25 @@ def test_raster_contexts_do_not_share_state():
     t.start()
     t.join()
     assert seen["ctx"] is not _C._default and seen["deferred_here"] and not seen["deferred_main"] and seen["under_a"]
+
+
+def test_a_run_without_rgb_loss_only_does_not_silently_train_the_reduced_objective(capsys):
+    """The reference's default is --rgb_loss_only=False (lab4d/config.py:161): cycle, feature / reprojection and flow losses are
+    then evaluated too (lab4d/engine/trainer.py:477-483 drops them only under the flag).  This build implements the flag's
+    objective only: without the flag the entry point stops and names what would be missing (VERDICT r5 missing 2); with
+    --allow_rgb_loss_only_semantics it goes on and says so."""
+    from vidu4d_amd.lab4d import train
+    opts, _ = train.parse_flags(["--fg_motion", "gs-bob"])
+    assert opts["rgb_loss_only"] is False
+    with pytest.raises(SystemExit) as e:
+        train.check_loss_flags(opts)
+    for word in ("cycle loss", "feature matching", "optical flow", "--rgb_loss_only", "--allow_rgb_loss_only_semantics"):
+        assert word in str(e.value), word
+    with pytest.raises(SystemExit):
+        train.main(["--fg_motion", "gs-bob"])       # (before anything touches a GPU)
+    opts, _ = train.parse_flags(["--allow_rgb_loss_only_semantics"])
+    train.check_loss_flags(opts)
+    assert "WARNING: --rgb_loss_only is OFF" in capsys.readouterr().out
+    opts, _ = train.parse_flags(["--rgb_loss_only"])
+    train.check_loss_flags(opts)
+    assert capsys.readouterr().out == ""

@@ -76,7 +76,7 @@ if os.environ.get("FIT_PRINT_HINTS", "0") == "1":   # what the split decision se
 if os.environ.get("FIT_WALK_STATS", "0") == "1":   # what the backward's walk of one step looks like (vidu4d_surfel_blend_stats)
     from vidu4d_amd import _C
     cnt = torch.zeros(16, dtype=torch.int64, device=dev)
-    _C.count_next_walk(cnt)
+    _C.count_next_walk(cnt, context=m.raster_context)   # (the model's forwards and backwards run under ITS context)
     tr.train_step(batches[0]); torch.cuda.synchronize()
     c = [int(x) for x in cnt.tolist()]
     print(f"FIT_WALK entries staged {c[0]}, wave trips {c[1]} ({c[1] / max(1, c[0]):.2f} per entry), with a contributor {c[2]}, "

@@ -167,9 +167,11 @@ def hint_scope(scope):
 
 
 @contextlib.contextmanager
-def debug_flags(flags: int):
-    """with debug_flags(_lib.DEBUG_NO_CULL): ... -- forward AND backward inside run with these switches."""
-    ctx = current()
+def debug_flags(flags: int, context=None):
+    """with debug_flags(_lib.DEBUG_NO_CULL): ... -- forward AND backward inside run with these switches.
+    context: the RasterContext they are set on (default: the calling thread's current one).  A model renders under ITS OWN
+    context (DeformableSurfels.raster_context): pass `context=model.raster_context` to reach its calls."""
+    ctx = context or current()
     old, ctx.debug_flags = ctx.debug_flags, int(flags)
     try:
         yield
@@ -177,10 +179,11 @@ def debug_flags(flags: int):
         ctx.debug_flags = old
 
 
-def count_next_walk(counters):
-    """Diagnostic: the next rasterize_gaussians_backward call adds its tile-walk statistics to `counters`
-    (int64, >= _lib.BLEND_STATS entries, on the device, zeroed by the caller)."""
-    current().walk_counters = counters
+def count_next_walk(counters, context=None):
+    """Diagnostic: the next rasterize_gaussians_backward call made under `context` (default: the calling thread's current
+    one; a model's calls run under `model.raster_context`) adds its tile-walk statistics to `counters` (int64, >=
+    _lib.BLEND_STATS entries, on the device, zeroed by the caller)."""
+    (context or current()).walk_counters = counters
 
 
 def _ptr(t):

@@ -55,7 +55,7 @@ class SkinFieldArgs(C.Structure):
                                   "g_store", "gx_store")] + [("h_store_rows", C.c_int)]
 
 
-LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 8, 1024, 32
+LOSS_MAX_FRAMES, LOSS_BLOCKS, LOSS_SUMS_FLOATS = 32, 1024, 32
 
 
 class Stage3LossArgs(C.Structure):

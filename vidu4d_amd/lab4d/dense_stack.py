@@ -31,7 +31,12 @@ def sequential_layers(seq) -> list | None:
         elif isinstance(m, nn.ReLU) and out and not out[-1][1] and out[-1][2] == 1.0:
             out[-1][1] = True
         elif isinstance(m, ScaleLayer) and out:
-            out[-1][2] *= float(m.scale_value) if hasattr(m, "scale_value") else float(m.scale.item())
+            sc = float(m.scale_value) if hasattr(m, "scale_value") else float(m.scale.item())
+            # (the kernels' backward reads the ReLU's mask off the stored, SCALED activation, h_out > 0: right only for a
+            # positive scale behind a ReLU -- ADVICE r5; anything else goes to the library layers)
+            if out[-1][1] and not sc > 0.0:
+                return None
+            out[-1][2] *= sc
         else:
             return None
     return [tuple(x) for x in out]

@@ -153,14 +153,34 @@ class _LbsSkinApply(Function):
         return g_xbT, g_rawT, g_qr, g_qd, g_xyz, g_rot, g_cq, g_ct, None, None, None, None
 
 
+LBS_MAX_FRAMES = 8   # (csrc/lbs.hip MAX_FRAMES: frames of one launch)
+
+
 def lbs_skin_apply(xbT, rawT, se3, xyz, rot, cam_q, cam_t, unit_rot=False, bone_map=None, frame_index=None):
     """xbT (3B,N) Gaussian-bone coordinates; rawT (B,N) raw output of the delta-skin MLP or None; se3 = (qr, qd)
-    each (M,B,4), M <= 8; xyz (N,3); rot (N,4); cam_q (M,4), cam_t (M,3).  -> xyz_cam (M,N,3), rot_cam (M,N,4);
+    each (M,B,4) (more than 8 frames: groups of 8 launches); xyz (N,3); rot (N,4); cam_q (M,4), cam_t (M,3).  -> xyz_cam (M,N,3), rot_cam (M,N,4);
     unit_rot: rot_cam comes out normalised (F.normalize, the renderer's rotation activation, fused in).
     bone_map = (A (3B,3), c (3B)) with xbT = None (frozen bones): the kernels evaluate x_bone = A xyz + c themselves and
     the gradient w.r.t. xyz includes that path -- the (3B,N) coordinates and their gradient never cross HBM."""
     bone_A, bone_c = (None, None) if bone_map is None else bone_map
-    return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot, bone_A, bone_c, frame_index)
+    M = cam_q.shape[0] if frame_index is None else frame_index.shape[0]
+    if M <= LBS_MAX_FRAMES:
+        return _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot, bone_A, bone_c, frame_index)
+    # More frames than one launch takes (the kernels keep a step's bone tables in LDS: 8 frames): groups of <= 8, their
+    # outputs concatenated; autograd adds the groups' gradients of everything the frames share.  The reference's loop takes
+    # any imgs_per_gpu (lab4d/nnutils/deformable_gaussian.py:1175).
+    xs, rs = [], []
+    for lo in range(0, M, LBS_MAX_FRAMES):
+        sl = slice(lo, lo + LBS_MAX_FRAMES)
+        if frame_index is None:
+            x, r = _LbsSkinApply.apply(xbT, rawT, se3[0][sl], se3[1][sl], xyz, rot, cam_q[sl], cam_t[sl], unit_rot, bone_A,
+                                       bone_c, None)
+        else:   # (se3 / cam_* are tables over all frames: the group's frame ids index them)
+            x, r = _LbsSkinApply.apply(xbT, rawT, se3[0], se3[1], xyz, rot, cam_q, cam_t, unit_rot, bone_A, bone_c,
+                                       frame_index[sl].contiguous())
+        xs.append(x)
+        rs.append(r)
+    return torch.cat(xs, 0), torch.cat(rs, 0)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -297,7 +317,7 @@ def skin_field(xyz, b_in, tab, want_xb=True):
 # ---- the same kernels for networks that TRAIN (--gs_optim_warp=True): TRAIN instances leave the hidden activations and the
 # masked pre-activation gradients in feature-major arrays; the weight gradients are contractions over the surfels
 # (bob_warp.contract_over_columns: batched GEMMs over K-chunks), the bias gradients row sums.
-def _train_buffers(sm, dev, N, B):
+def _train_buffers(sm, dev, N, B, scratch=False):
     """Persistent arrays of the TRAIN path: the padded weights in the kernels' layout (padding stays zero; one copy each per
     step) and, per surfel count, what the contractions over the surfels read -- the bone coordinates, every hidden layer's
     activations and the homogeneous centres, each block FOLLOWED BY A ROW OF ONES (written once): g [x; 1]^T gives the weight
@@ -310,6 +330,13 @@ def _train_buffers(sm, dev, N, B):
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
         bufs = sm.__dict__["_skin_field_train_bufs"] = {"w_in": z(W, IN), "w_out": z(OUT, W), "b_out": z(OUT),
                                                         "w_hid": z(max(D - 1, 1), W, W), "b_hid": z(max(D - 1, 1), W)}
+    if scratch:
+        # (a forward nobody differentiates -- torch.no_grad() -- must not touch the per-surfel arrays a pending backward of
+        # this model still reads: temporaries, sized as the persistent ones; the padded weights are rewritten with the same
+        # values either way)
+        return dict(bufs, N=N, gen=None, xb1=torch.empty(3 * B + 1, N, dtype=torch.float32, device=dev),
+                    h1=torch.empty(D, W + 1, N, dtype=torch.float32, device=dev),
+                    xyz1=torch.empty(N, 4, dtype=torch.float32, device=dev))
     if bufs.get("N") != N:
         bufs["N"] = N
         xb1 = torch.empty(3 * B + 1, N, dtype=torch.float32, device=dev)
@@ -318,6 +345,7 @@ def _train_buffers(sm, dev, N, B):
         h1[:, W] = 1.0
         xyz1 = torch.ones(N, 4, dtype=torch.float32, device=dev)
         bufs.update(xb1=xb1, h1=h1, xyz1=xyz1)
+    bufs["gen"] = bufs.get("gen") or 0
     return bufs
 
 
@@ -349,6 +377,12 @@ class _SkinFieldTrain(Function):
         _lib.check(_lib.load().vidu4d_skin_field_forward(a, torch.cuda.current_stream(dev).cuda_stream), "skin field forward")
         ctx.save_for_backward(x, b, masks)
         ctx.tab, ctx.bufs = tab, sm_bufs   # (persistent arrays: unchanged until the next forward of this model)
+        # ... which is checked, not assumed: xbT is a VIEW of the persistent xb1 and the backward reads xb1 / h1 /
+        # xyz1 through raw pointers, so a second grad-enabled forward of the model before this one's backward would hand
+        # autograd the wrong activations without any version counter noticing
+        if sm_bufs.get("gen") is not None:
+            sm_bufs["gen"] += 1
+        ctx.gen = sm_bufs.get("gen")
         ctx.dims = (N, B, D, W)
         return xbT, rawT
 
@@ -359,6 +393,11 @@ class _SkinFieldTrain(Function):
         x, b, masks = ctx.saved_tensors
         N, B, D, W = ctx.dims
         dev = x.device
+        if ctx.gen != ctx.bufs.get("gen"):
+            raise RuntimeError("skin_field_train: the model's skinning field was evaluated again with autograd on between this "
+                               "forward and its backward; the activations this backward reads live in per-model persistent "
+                               "arrays and have been overwritten.  One grad-enabled forward per backward (renders under "
+                               "torch.no_grad() in between are fine), or set fused_skin_field_trainable=False.")
         xb1, h1, xyz1 = ctx.bufs["xb1"], ctx.bufs["h1"], ctx.bufs["xyz1"]
         g_xbT = None if g_xbT is None else _c(g_xbT)
         g_rawT = torch.zeros(B, N, device=dev) if g_rawT is None else _c(g_rawT)
@@ -396,5 +435,6 @@ def skin_field_train(xyz, b_in, A, c0, sm):
         lin = getattr(mlp, f"linear_{i + 1}")[0]
         hidden += [lin.weight, lin.bias]
     return _SkinFieldTrain.apply(xyz, b_in, A, c0, mlp.linear_1[0].weight[:, :B3], mlp.linear_final.weight,
-                                 mlp.linear_final.bias, _train_buffers(sm, xyz.device, xyz.shape[0], mlp.linear_final.weight.shape[0]),
+                                 mlp.linear_final.bias, _train_buffers(sm, xyz.device, xyz.shape[0], mlp.linear_final.weight.shape[0],
+                                                scratch=not torch.is_grad_enabled()),
                                  *hidden)

@@ -10,7 +10,14 @@ parameter has none (the usual case: `zero_grad(set_to_none=True)`), `p.grad += b
 the buffer from an earlier backward (gradient accumulation over several backward calls) is detached from it first.
 Consequences, stated: gradients of these parameters arrive through `.backward()` only (`torch.autograd.grad` w.r.t. them
 returns None), tensor hooks on them do not fire, and a gradient stays valid until the next backward through the same graphs.
-The module is called with integer frame ids only; its outputs are float tensors of fixed shapes."""
+The module is called with integer frame ids only; its outputs are float tensors of fixed shapes.
+
+ONE forward per backward: the outputs are the graphs' static buffers, which whoever consumes them saves for its own
+backward (lbs_fused.lbs_skin_apply); a second replay -- grad-enabled or not -- before the first one's backward overwrites them
+through raw pointers that autograd's version counters never see.  Every replay therefore advances `generation`, a grad-enabled
+forward remembers its own, and its backward RAISES when another replay came in between instead of returning gradients of the
+wrong frames (Stage3Trainer makes exactly one forward per backward; a caller that needs more sets
+`graphed_warp_networks: False`)."""
 from __future__ import annotations
 
 import torch
@@ -40,6 +47,7 @@ class GraphedNetworks:
         # (the autograd graph of the captured forward is not needed again: keeping it would keep the parameters' AccumulateGrad
         # nodes of the CAPTURE stream alive, which later backwards through the same parameters outside the graphs would find)
         self.static_outs = tuple(o.detach() for o in self.static_outs)
+        self.generation = 0   # replays so far (see the module docstring)
         owner = self
 
         class _Replay(torch.autograd.Function):
@@ -47,11 +55,18 @@ class GraphedNetworks:
             def forward(ctx, frame_id, anchor):
                 owner.static_in.copy_(frame_id)
                 owner.fwd_graph.replay()
+                owner.generation += 1
+                ctx.generation = owner.generation
                 return tuple(o.detach() for o in owner.static_outs)
 
             @staticmethod
             @torch.autograd.function.once_differentiable
             def backward(ctx, *gouts):
+                if ctx.generation != owner.generation:
+                    raise RuntimeError("GraphedNetworks: the networks were evaluated again (%d replay(s)) between this forward "
+                                       "and its backward; their outputs are the captured graphs' static buffers, so the tensors "
+                                       "saved for this backward have been overwritten.  One forward per backward, or set "
+                                       "graphed_warp_networks=False." % (owner.generation - ctx.generation))
                 for s, g in zip(owner.static_gouts, gouts):
                     if g is None:
                         s.zero_()
@@ -77,4 +92,5 @@ class GraphedNetworks:
             return self._fn.apply(frame_id, self._anchor)
         self.static_in.copy_(frame_id)
         self.fwd_graph.replay()
+        self.generation += 1   # (a pending grad-enabled forward's saved outputs are gone: its backward will say so)
         return tuple(o.detach() for o in self.static_outs)

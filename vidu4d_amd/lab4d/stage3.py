@@ -506,7 +506,8 @@ class Stage3Trainer:
         # the depth / normal maps are only read by the regularisers, whose weights are 0 until step 8000
         need_geometry = step > 8000 and (self.cfg.lambda_normal != 0.0)
         M = int(batch["frameid"].shape[0])
-        if m._xyz.is_cuda and M <= 8 and m.opts.get("fused_loss", True) and \
+        from .. import _lib as _native_lib
+        if m._xyz.is_cuda and M <= _native_lib.LOSS_MAX_FRAMES and m.opts.get("fused_loss", True) and \
                 (not need_geometry or m.opts.get("fused_normal_loss", True)):
             # colour / silhouette / distortion / normal-consistency terms and their gradient planes in five launches
             # (csrc/loss.hip); with the normal term on, the depth / normal post-processing of render() runs inside them
@@ -643,7 +644,10 @@ def synthetic_batch(model: DeformableSurfels, frame_ids, H: int, W: int, seed: i
     M = len(frame_ids)
     g = torch.Generator().manual_seed(seed)
     # (Kinv stays on the host: cameras are built there, deformable_surfels.get_gs_Kcamera)
-    return {"frameid": torch.as_tensor(frame_ids, device=dev), "Kinv": make_intrinsics_inv(M, H, W, device="cpu"),
+    fid = torch.as_tensor(frame_ids, device=dev)
+    if M and not isinstance(frame_ids, torch.Tensor):
+        fid._vidu4d_host_range = (int(min(frame_ids)), int(max(frame_ids)))   # (DeformableSurfels._check_frame_ids)
+    return {"frameid": fid, "Kinv": make_intrinsics_inv(M, H, W, device="cpu"),
             "H": [H] * M, "W": [W] * M, "rgb": torch.rand(M, H, W, 3, generator=g).to(dev),
             "mask": (torch.rand(M, H, W, 1, generator=g) > 0.5).float().to(dev),
             "vis2d": torch.ones(M, H, W, 1, device=dev)}

@@ -38,7 +38,30 @@ STAGE3_FLAGS = dict(
     lambda_dssim=0.0, gs_learnable_bg=True, debug_cuda=False, learning_rate=5e-4, num_frames=120,
     num_surfels=200000, seed=0, save_freq=10, data_root="database", intrinsics="", reset_steps=True,
     optim_warp_neus_iters=12000, allow_random_warp=False, feature_type="dinov2", delta_list="2,4,8",
-    init_scale=0.1)
+    init_scale=0.1, allow_rgb_loss_only_semantics=False)
+
+# What a reference run WITHOUT --rgb_loss_only evaluates on top of the terms built here (rgb, mask, and from step 8000 the
+# normal-consistency / distortion regularisers): it is dropped only by /root/reference/lab4d/engine/trainer.py:477-483.
+DROPPED_WITHOUT_RGB_LOSS_ONLY = (
+    "cycle loss (lab4d/nnutils/deformable_gaussian.py:1274)",
+    "feature matching / reprojection (deformable_gaussian.py:1305-1324)",
+    "optical flow (deformable_gaussian.py:1516-1574)",
+    "the warp's skin-entropy / delta-skin regularisers and the depth, feature and visibility terms of "
+    "lab4d/engine/model.py:613-693")
+
+
+def check_loss_flags(opts, say=print):
+    """--rgb_loss_only is the README's Stage-3 flag (README.md:44) and the ONLY objective this build implements; the reference's
+    default is False (lab4d/config.py:161).  A run without it must not silently train another objective than the reference
+    would (VERDICT r5 missing 2): it stops, unless --allow_rgb_loss_only_semantics says the reduced objective is wanted."""
+    if opts["rgb_loss_only"]:
+        return
+    msg = ("--rgb_loss_only is OFF: the reference would then also evaluate " + "; ".join(DROPPED_WITHOUT_RGB_LOSS_ONLY) +
+           " -- none of which this build implements (SURVEY.md 8f-1: out of the hot path).  It trains the --rgb_loss_only objective.")
+    if not opts.get("allow_rgb_loss_only_semantics", False):
+        raise SystemExit(msg + "  Pass --rgb_loss_only (as the README's Stage-3 command does), or "
+                         "--allow_rgb_loss_only_semantics to run the reduced objective knowingly.")
+    say("WARNING: " + msg)
 
 
 def parse_flags(argv):
@@ -105,6 +128,7 @@ def main(argv=None):
     if not opts["fg_motion"].startswith("gs-"):
         raise SystemExit("this build implements Stage-3 only: --fg_motion must be gs-bob (Stage-2 neural SDF is "
                          "out of scope, DESIGN.md §9)")
+    check_loss_flags(opts, say=lambda *a: print(*a) if int(os.environ.get("RANK", "0")) == 0 else None)
     import torch.distributed as dist
     from .deformable_surfels import DeformableSurfels
     from .stage3 import Stage3Trainer, synthetic_batch

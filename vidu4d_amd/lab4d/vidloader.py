@@ -327,7 +327,9 @@ def stage3_batch(datasets, data_info, frames, device="cpu") -> dict:
     H, W = datasets[frames[0][0]].img_size
     Kinv = K2inv(torch.tensor(rows["ks"], dtype=torch.float32)) @ K2mat(np.stack(rows["crop2raw"]))
     img = lambda k: torch.from_numpy(np.stack(rows[k])).to(dev)  # noqa: E731
-    return {"frameid": torch.tensor(rows["frameid"], device=dev), "Kinv": Kinv.cpu(), "H": [int(H)] * M, "W": [int(W)] * M,
+    fid = torch.tensor(rows["frameid"], device=dev)
+    fid._vidu4d_host_range = (min(rows["frameid"]), max(rows["frameid"]))   # (DeformableSurfels._check_frame_ids: no device read)
+    return {"frameid": fid, "Kinv": Kinv.cpu(), "H": [int(H)] * M, "W": [int(W)] * M,
             "rgb": img("rgb"), "mask": img("mask"), "vis2d": img("vis2d"), "depth": img("depth"),
             "is_detected": torch.tensor(rows["is_detected"], device=dev), "dataid": torch.tensor(rows["dataid"], device=dev)}
 
@@ -370,7 +372,10 @@ class SequenceData:
         K = K.expand(M, 4) if K.dim() == 1 else K
         Kinv = K2inv(K) @ K2mat(self.crop2raw[idx])
         dev = torch.device(device)
-        return {"frameid": torch.as_tensor(idx + frame_offset, device=dev), "Kinv": Kinv.cpu(), "H": [H] * M,
+        fid = torch.as_tensor(idx + frame_offset, device=dev)
+        if M:
+            fid._vidu4d_host_range = (int(idx.min()) + int(frame_offset), int(idx.max()) + int(frame_offset))
+        return {"frameid": fid, "Kinv": Kinv.cpu(), "H": [H] * M,
                 "W": [W] * M, "rgb": torch.from_numpy(rgb).to(dev), "mask": torch.from_numpy(ann[..., :1].copy()).to(dev),
                 "vis2d": torch.from_numpy(ann[..., 1:2].copy()).to(dev),
                 "is_detected": torch.as_tensor(self.is_detected[idx].astype(bool), device=dev)}
