@@ -376,3 +376,112 @@ def test_physical_device_identity_across_nodes_and_isolation():
     assert shared_physical_devices(clash) == [(111, 0, 0x11, 0)]
     me = physical_device_id(torch.device("cpu"))
     assert len(me) == 5 and me[1:] == [-1, -1, -1, -1]
+
+
+# ---- the 8-rank launch that cannot be measured here, rehearsed ---------------------------------------------
+_OPTS8 = dict(fg_motion="gs-bob", densify_from_iter=0, densification_interval=2, densify_grad_threshold=1e-9,
+              opacity_reset_interval=1000, frame_streams=False, outlier_filtering_interval=2, outlier_radius=0.05,
+              outlier_nb_points=3)
+
+
+def _kdtree_count(points, radius):
+    """scipy's cKDTree behind simple_knn.radius_neighbor_count's contract (points strictly within `radius`, the query
+    included): the stand-in for csrc/knn.hip in THIS TEST (tests/test_gpu_knn.py holds the kernel to the same tree)."""
+    from scipy.spatial import cKDTree
+    p = points.detach().double().numpy()
+    tree = cKDTree(p)
+    return torch.tensor([len(tree.query_ball_point(x, radius * (1 - 1e-12))) for x in p], dtype=torch.int32)
+
+
+def _model8():
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)                       # identical networks and surfels on every rank
+    m = DeformableSurfels(dict(_OPTS8), num_frames=16, device="cpu")
+    n = 120
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    m.init_from_points(0.25 * d / np.linalg.norm(d, axis=1, keepdims=True), rng.uniform(size=(n, 3)).astype(np.float32))
+    with torch.no_grad():
+        m._opacity.fill_(1.0)
+        m._opacity[:15] = -10.0                # transparent: pruned by the densify step (opacity < 0.005)
+        m._xyz[15:19] += 5.0                   # far from everything: the outlier pass's victims
+    tr = Stage3Trainer(m, dict(_OPTS8))
+    tr.outlier_neighbor_count = _kdtree_count
+    return m, tr
+
+
+def _frames8(step, rank, world):
+    """rank r renders frames r and r + world of the step's 2 * world frames (rank r takes frames r, r + 8, ...)"""
+    return [(step + rank) % 16, (step + rank + world) % 16]
+
+
+def _train_worker8(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vidu4d_amd.gs import gaussian_renderer as gr
+        from vidu4d_amd.lab4d.stage3 import synthetic_batch
+        gr.GaussianRasterizer = _TorchRasterizer
+        torch.set_num_threads(1)
+        m, tr = _model8()
+        assert tr.world == world and tr.rank == rank
+        counts = []
+        for step in range(4):                  # steps 2 (densify / prune) and -- with the outlier pass's interval 2 -- 2 again
+            tr.train_step(synthetic_batch(m, _frames8(step, rank, world), 24, 24, seed=step))
+            counts.append(int(m._xyz.shape[0]))
+        sig = torch.cat([p.detach().reshape(-1) for p in tr.surfel_params()])
+        sizes = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([sig.numel()]))
+        same = all(int(x) == sig.numel() for x in sizes)
+        identical = False
+        if same:
+            gathered = [torch.zeros_like(sig) for _ in range(world)]
+            dist.all_gather(gathered, sig)
+            identical = all(torch.equal(gathered[0], t) for t in gathered)
+        out[rank] = (same, identical, counts, [p.detach().clone() for p in tr.surfel_params()] if rank == 0 else None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_gloo_ranks_equal_one_rank_over_the_same_sixteen_frames(monkeypatch):
+    """EIGHT ranks (the node north_star names; SCALE_rNN.json has been "skipped" for six rounds) over gloo on the CPU: rank r
+    renders frames r and r + 8 of every step's 16, one exchange per step, then clip, densify / prune, the outlier pass
+    (trainer.py:573-588) and Adam on every rank.  (1) The eight replicas hold bit-identical surfels after four steps incl. a
+    densify / prune and an outlier prune; (2) they end where ONE process ends that back-propagates the same 16 frames into
+    one gradient buffer and divides by 8 -- /root/reference/lab4d/train.py:28-36 + DDP's mean, trainer.py:126-131."""
+    world = 8
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker8, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        same, identical, counts, _ = out[r]
+        assert same and identical, f"rank {r}: replicas diverged"
+        assert counts == out[0][2]
+    counts, got = out[0][2], out[0][3]
+    assert counts[-1] != 120 and len(set(counts)) > 1, counts   # (densify / prune / outlier pass changed the surfel count)
+
+    from vidu4d_amd.gs import gaussian_renderer as gr
+    from vidu4d_amd.lab4d.stage3 import synthetic_batch
+    monkeypatch.setattr(gr, "GaussianRasterizer", _TorchRasterizer)
+    m, tr = _model8()
+    assert tr.world == 1
+    one = []
+    for step in range(4):
+        if step % 1000 == 0:
+            m.oneupSHdegree()
+        tr.begin_gradients()
+        for rank in range(world):
+            tr._forward_backward(synthetic_batch(m, _frames8(step, rank, world), 24, 24, seed=step), step)   # gradients accumulate
+            tr.gather_densification_stats(step)
+        for p in tr.exchanged_params():
+            p.grad.div_(world)
+        tr.finish_step(step)
+        one.append(int(m._xyz.shape[0]))
+    assert one == counts, (one, counts)
+    want = [p.detach() for p in tr.surfel_params()]
+    assert [tuple(a.shape) for a in got] == [tuple(b.shape) for b in want]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=0, atol=4e-6 * float(b.abs().max()) + 1e-9), float((a - b).abs().max())

@@ -183,6 +183,9 @@ class Stage3Trainer:
         # gradients (after the exchange) are added to these buffers; a parameter autograd never touched keeps
         # grad = None (AdamW then skips it, weight decay included).
         self._net_accum = [None] * len(self._net_params)
+        # the outlier pass of trainer.py:573-588 (open3d remove_radius_outlier(nb_points=20, radius=0.004))
+        self.outlier_radius, self.outlier_nb_points = float(o.get("outlier_radius", 0.004)), int(o.get("outlier_nb_points", 20))
+        self.outlier_neighbor_count = None   # (None: csrc/knn.hip on the GPU, no pass for surfels on the CPU)
 
     # ---- the path's only exchange
     def surfel_params(self):
@@ -616,13 +619,16 @@ class Stage3Trainer:
                                 generator=gen)
                 if step % c.opacity_reset_interval == 0:  # (step 0 included, as upstream: trainer.py:570)
                     m.reset_opacity()
-                if (m._xyz.is_cuda and c.densify_from_iter < step < c.outlier_stop_iter
-                        and step % c.outlier_filtering_interval == 0):
+                if (c.densify_from_iter < step < c.outlier_stop_iter and step % c.outlier_filtering_interval == 0
+                        and (m._xyz.is_cuda or self.outlier_neighbor_count is not None)):
                     # trainer.py:573-588: open3d remove_radius_outlier(nb_points=20, radius=0.004) on the CPU
                     # upstream; here the neighbour count is a HIP kernel and nothing leaves the GPU.  Every rank
-                    # holds the same surfels, so every rank prunes the same ones.
-                    from ..simple_knn import radius_neighbor_count
-                    m.prune_points(radius_neighbor_count(m.get_xyz, 0.004) <= 20)
+                    # holds the same surfels, so every rank prunes the same ones.  (`outlier_neighbor_count`: a stand-in
+                    # for surfels that live on the CPU -- the gloo tests plant scipy's cKDTree; the product has none.)
+                    count = self.outlier_neighbor_count
+                    if count is None:
+                        from ..simple_knn import radius_neighbor_count as count
+                    m.prune_points(count(m.get_xyz, self.outlier_radius) <= self.outlier_nb_points)
         # (parameters re-created by densify / prune / reset_opacity have no gradient and are skipped, as upstream)
         self._optimizer_step(step)
         for p in self.surfel_params():
