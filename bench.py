@@ -120,7 +120,7 @@ def cpu_baseline(scene, n_images: int):
 
 
 def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: int = 0, seed: int = 0, barrier=None,
-                  densify: bool = False, optim_warp: bool = False, fused_warp_trainable: bool = True):
+                  densify: bool = False, optim_warp: bool = False, fused_warp_trainable: bool = True, captured: bool = True):
     """Second figure of SURVEY.md 8(d): images/s of the FULL Stage-3 fitting step (bob LBS warp with frozen,
     randomly initialised warp / camera networks -> rasterize 2 frames -> losses -> backward -> gradient clip ->
     densification statistics -> Adam) on an object-centric synthetic sequence of the same size.
@@ -135,14 +135,16 @@ def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: i
     skinning networks train too (AdamW, trainer.py:592-598; start_step >= optim_warp_neus_iters = 12 000 so that it steps).
     Round 5: the fused warp then still applies -- the networks are evaluated for the step's frames with autograd, the delta-skin
     MLP as library GEMMs, and the skinning kernel's backward reduces d/d (bone dual quaternions, cameras) over the surfels;
-    fused_warp_trainable=False times the ~40-kernel torch chain rounds 1-4 fell back to (same step, for the A/B)."""
+    fused_warp_trainable=False times the ~40-kernel torch chain rounds 1-4 fell back to (same step, for the A/B).
+    captured (round 6): the trainer's default -- plain steps replayed from ONE captured hipGraph (lab4d/captured_step.py);
+    False: the eager loop of rounds 1-5, for the A/B."""
     import numpy as np
     from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
     from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     frames = 120
-    m = DeformableSurfels(dict(fg_motion="gs-bob") | ({} if densify else dict(densify_until_iter=0)) |
+    m = DeformableSurfels(dict(fg_motion="gs-bob", captured_step=bool(captured)) | ({} if densify else dict(densify_until_iter=0)) |
                           (dict(fused_warp_trainable=fused_warp_trainable) if optim_warp else {}), num_frames=frames, device=dev)
     d = rng.normal(size=(n_surfels, 3)).astype(np.float32)
     pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(n_surfels, 1)).astype(np.float32) ** (1 / 3)
@@ -180,7 +182,7 @@ def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: i
               "the blend kernels run their colour + planes-0-4 instances (aux_planes = AUX_GEOM; no median sample, no distortion "
               "moments, no transmittance pre-pass), depth / normal post-processing inside the loss kernels")
     out = {"images_per_s": 2.0 / dt, "ms_per_step": 1e3 * dt, "frames_per_step": 2, "steps": steps, "warmup_steps": warm,
-           "seconds": dt * steps,
+           "seconds": dt * steps, "captured_step": dict(tr.captured_stats, enabled=bool(tr.captured_step)),
            "config": f"{n_surfels} surfels in a unit ball 3 units from the camera, {W}x{H}, 25 bones, 120 frames, "
                      + ("warp / camera / skinning networks TRAIN (--gs_optim_warp=True, the reference's default; AdamW steps on them), " +
                         ("fused warp with parameter gradients from the skinning kernel" if fused_warp_trainable else
@@ -732,6 +734,13 @@ def main():
         elapsed = float(tt[0].item())
         if per_frame:
             per_frame = (float(tt[1].item()), per_frame[1], float(tt[2].item()))
+        # every rank's own host time of the timed region (N Python processes share the node's cores: the host side is
+        # what a frame-parallel launch multiplies, and what no single-GPU run can show)
+        hh = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(hh, torch.tensor([1e3 * enqueued / args.steps], dtype=torch.float64, device=dev))
+        host_ms_of_each_rank = [round(float(h.item()), 4) for h in hh]
+    else:
+        host_ms_of_each_rank = None
 
     # what the dominant kernel's tile walk looks like on this workload (a counting pass behind one extra step, outside
     # every timed region): lane utilisation = contributing (pixel, surfel) pairs / (64 lanes x pair evaluations)
@@ -760,7 +769,7 @@ def main():
                    else f"train images/sec (fwd+bwd raster) @{N} surfels, {W}x{H}") +
                   (f" [object-centric scene, radius {args.object_radius}]" if args.scene == "object" else ""),
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "host_enqueue_ms_per_step": 1e3 * enqueued / args.steps, "settle_steps_before_warmup": settle, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "host_enqueue_ms_per_step": 1e3 * enqueued / args.steps, "host_enqueue_ms_per_step_of_each_rank": host_ms_of_each_rank, "settle_steps_before_warmup": settle, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{baseline_config_label(N, W, H)} op-level: Stage-3 gs-bob rasterizer fwd+bwd, {N} surfels, "
                                f"{W}x{H}, SH degree 3, {args.frames} frames sharded one-frame-per-GPU, "
@@ -864,7 +873,11 @@ def main():
             if args.fit_optim_warp:
               out["fit_step_optim_warp"] = fit_step_rate(dev, N, W, H, args.fit_steps, start_step=12001, optim_warp=True)
               out["fit_step_optim_warp_unfused"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), start_step=12001,
-                                                                 optim_warp=True, fused_warp_trainable=False)
+                                                                 optim_warp=True, fused_warp_trainable=False, captured=False)
+              # (the same steps driven by the eager Python loop of rounds 1-5: what the captured graph replaces)
+              out["fit_step_optim_warp_eager"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), start_step=12001,
+                                                               optim_warp=True, captured=False)
+              out["fit_step_eager"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), captured=False)
         if world == 1:
             # MODELLED multi-GPU figures (no multi-GPU node is reachable from the build box; the driver
             # measures the real curve when it has one): measured 1-GPU step + the all-reduce cost model above

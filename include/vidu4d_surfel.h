@@ -526,9 +526,19 @@ typedef struct Vidu4dAdamTensor {
     float lr;
     float bias_correction1;      /* 1 - beta1^step */
     float bias_correction2_sqrt; /* sqrt(1 - beta2^step) */
+    /* optional (ABI 20): {lr, bias_correction1, bias_correction2_sqrt} read from DEVICE memory when the kernel runs, instead
+     * of the three values above -- a launch captured into a hipGraph bakes its by-value arguments, these change every step
+     * (the host writes them with one small async copy in front of the replay; lab4d/captured_step.py) */
+    const float* device_scalars;
 } Vidu4dAdamTensor;
 int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
                      const float* grad_scale, int zero_grads, void* stream);
+/* (ABI 20) the same with a device-side guard: when *skip != 0 at run time the launch changes nothing (no update, no zero fill).
+ * A fitting step replayed from a captured hipGraph cannot ask the host whether its forward outgrew the binning buffer (it then
+ * rendered the background only): the step's verdict is a device word, and the update that would apply garbage gradients reads
+ * it.  skip == NULL: vidu4d_adam_step. */
+int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
+                             const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream);
 
 /* ---- the gradient clip's norm and coefficient: torch.nn.utils.clip_grad_norm_(params, max_norm) as Trainer.check_grad
  *      calls it (lab4d/engine/trainer.py:861-869) is a norm per tensor, a stack, a norm, an add, a division, a clamp and

@@ -1,0 +1,129 @@
+"""The plain Stage-3 fitting step as one captured hipGraph (vidu4d_amd/lab4d/captured_step.py) against the
+eager loop it replaces (Stage3Trainer._train_step_eager = /root/reference/lab4d/engine/trainer.py:439-602 per iteration):
+same trajectory with frozen networks and with networks that train, through densify / prune steps (which stay eager and
+re-key the graph), and through a step whose forward outgrows the captured binning buffer (skipped on the device, taken back
+and run eagerly one step later)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(dev, captured, n=6000, seed=0, frames=16, **opts):
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    o = dict(fg_motion="gs-bob", sh_degree=3, densify_until_iter=0, captured_step=captured)
+    o.update(opts)
+    m = DeformableSurfels(o, num_frames=frames, device=dev)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    pts = 0.3 * d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 1.0, size=(n, 1)).astype(np.float32)
+    m.init_from_points(pts, rng.uniform(size=(n, 3)).astype(np.float32))
+    with torch.no_grad():
+        for mod in (m.warp, m.camera_mlp):   # (untrained output layers are ~0: weights that matter)
+            for p in mod.parameters():
+                p.add_(0.03 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev))
+    tr = Stage3Trainer(m, o)
+    return m, tr
+
+
+def _close(a, b, lr, what):
+    """two runs of the same steps: equal up to the order of the backward's float atomics -- after Adam's normalisation an
+    entry whose tiny gradient changes sign moves by 2 lr per step, everything else agrees to rounding"""
+    d = (a - b).abs()
+    assert float(d.median()) <= 1e-6 + 1e-5 * float(b.abs().median()), (what, float(d.median()))
+    assert float(d.max()) <= 8 * lr + 1e-4 * float(b.abs().max()), (what, float(d.max()))
+
+
+@pytest.mark.parametrize("regime", ["frozen", "frozen_geometry", "networks_train"])
+def test_captured_steps_follow_the_eager_trajectory(gpu_device, regime):
+    from vidu4d_amd.lab4d.stage3 import synthetic_batch
+    dev, H, W, steps = gpu_device, 96, 96, 14
+    opts = {}
+    if regime == "networks_train":
+        opts = dict(gs_optim_warp=True, optim_warp_neus_iters=2, iters_per_round=100, num_rounds=1)
+    out = {}
+    for captured in (True, False):
+        m, tr = _trainer(dev, captured, **opts)
+        if regime == "frozen_geometry":
+            tr.current_steps = 8001
+            m.active_sh_degree = m.max_sh_degree
+        losses = []
+        for i in range(steps):
+            l = tr.train_step(synthetic_batch(m, [(2 * i) % 16, (2 * i + 1) % 16], H, W, seed=i))
+            losses.append({k: float(v) for k, v in l.items()})
+        torch.cuda.synchronize(dev)
+        nets = torch.cat([p.detach().reshape(-1) for p in list(m.warp.parameters()) + list(m.camera_mlp.parameters())])
+        out[captured] = (losses, [p.detach().clone() for p in tr.surfel_params()], nets.clone(), dict(tr.captured_stats),
+                         tr.current_steps)
+        if captured:
+            assert tr.captured_stats["captures"] == 1 and tr.captured_stats["replays"] >= steps - 6, tr.captured_stats
+            assert tr.captured_stats["taken_back"] == 0
+        else:
+            assert tr.captured_stats["replays"] == 0
+    assert out[True][4] == out[False][4] == steps + (8001 if regime == "frozen_geometry" else 0)
+    for la, lb in zip(out[True][0], out[False][0]):
+        for k in lb:
+            assert abs(la[k] - lb[k]) <= 2e-4 * abs(lb[k]) + 1e-7, (k, la, lb)
+    lrs = (5e-5, 2.5e-3, 2.5e-3 / 20, 0.05, 5e-3, 1e-3, 2.5e-3, 2.5e-3)
+    for a, b, lr in zip(out[True][1], out[False][1], lrs):
+        _close(a, b, lr, "surfels")
+    if regime == "networks_train":
+        assert float((out[True][2] - out[False][2]).abs().max()) <= 8 * 5e-3 + 1e-6   # (10 x the base rate for the explicit ones)
+        d = (out[True][2] - out[False][2]).abs()
+        assert float(d.median()) <= 1e-6
+    else:
+        assert torch.equal(out[True][2], out[False][2])
+
+
+def test_a_step_that_outgrows_the_captured_buffers_is_skipped_taken_back_and_rerun(gpu_device):
+    """After the graph has been captured the surfels are blown up in place (same tensors: same key): the forward's pair count
+    exceeds the captured binning capacity, it renders the background only.  The graph's skip word keeps Adam and the
+    statistics from touching anything, the host finds the verdict one step later in the pinned header copy, takes the step's
+    bookkeeping back and runs it eagerly -- the run ends where the eager run ends that saw the same change at the same step."""
+    from vidu4d_amd.lab4d.stage3 import synthetic_batch
+    dev, H, W, steps, blow_at = gpu_device, 96, 96, 14, 8
+    out = {}
+    for captured in (True, False):
+        m, tr = _trainer(dev, captured, densify_until_iter=10000, densify_from_iter=5000)   # (the statistics are gathered)
+        for i in range(steps):
+            if i == blow_at:
+                with torch.no_grad():
+                    m._scaling.add_(1.2)     # (log-scales: 3.3 x the extent, ~10 x the pairs)
+            tr.train_step(synthetic_batch(m, [(2 * i) % 16, (2 * i + 1) % 16], H, W, seed=i))
+        tr._settle_captured() if captured else None
+        torch.cuda.synchronize(dev)
+        out[captured] = ([p.detach().clone() for p in tr.surfel_params()], dict(tr.captured_stats), tr.current_steps,
+                         m.denom.clone(), {id(p): float(tr.gs_optimizer.state[p]["step"]) for p in tr.surfel_params()
+                                           if p in tr.gs_optimizer.state})
+    assert out[True][1]["taken_back"] >= 1 and out[True][1]["captures"] >= 2, out[True][1]
+    assert out[True][2] == out[False][2] == steps
+    assert sorted(out[True][4].values()) == sorted(out[False][4].values())      # every Adam step counted once
+    assert torch.equal(out[True][3], out[False][3])                             # ... and every step's statistics once
+    lrs = (5e-5, 2.5e-3, 2.5e-3 / 20, 0.05, 5e-3, 1e-3, 2.5e-3, 2.5e-3)
+    for a, b, lr in zip(out[True][0], out[False][0], lrs):
+        _close(a, b, lr, "surfels")
+
+
+def test_captured_steps_around_densify_and_prune(gpu_device):
+    """Densify / prune / opacity-reset steps stay eager and re-create the surfel tensors: the graph is re-captured for the new
+    set; surfel counts and parameters follow the eager loop."""
+    from vidu4d_amd.lab4d.stage3 import synthetic_batch
+    dev, H, W, steps = gpu_device, 96, 96, 40
+    out = {}
+    for captured in (True, False):
+        m, tr = _trainer(dev, captured, n=4000, densify_until_iter=1000, densify_from_iter=4, densification_interval=12,
+                         densify_grad_threshold=1e-12, opacity_reset_interval=10000, outlier_filtering_interval=10000)
+        counts = []
+        for i in range(steps):
+            tr.train_step(synthetic_batch(m, [(2 * i) % 16, (2 * i + 1) % 16], H, W, seed=i))
+            counts.append(int(m._xyz.shape[0]))
+        torch.cuda.synchronize(dev)
+        out[captured] = (counts, [p.detach().clone() for p in tr.surfel_params()], dict(tr.captured_stats))
+    assert out[True][0] == out[False][0] and len(set(out[True][0])) >= 3, out[True][0]
+    assert out[True][2]["captures"] >= 2 and out[True][2]["replays"] >= 15, out[True][2]
+    for a, b in zip(out[True][1], out[False][1]):
+        d = (a - b).abs()
+        assert float(d.median()) <= 1e-6 + 1e-5 * float(b.abs().median())

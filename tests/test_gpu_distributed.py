@@ -128,6 +128,37 @@ def test_bench_two_ranks_on_one_gpu(gpu_device):
     assert c["payload_bytes"] == 20000 * 58 * 4 and c["allreduce_ms_p50"] > 0
 
 
+def test_bench_eight_ranks_on_one_gpu(gpu_device):
+    """The launch that cannot be measured from the build container, rehearsed: `bench.py --gpus 8` end to
+    end -- eight Python ranks, rank-strided frames r, r + 8, ..., the exchange in the step, the self-check block -- with all
+    eight sharing this GPU over gloo.  Asserts the code path (the JSON line, all eight ranks seen, every rank's frames) and
+    reports every rank's host time per step: eight interpreters on shared cores is the regime SCALE_rNN.json would run in.
+    Reference launch: /root/reference/lab4d/train.py:28-36, lab4d/dataloader/data_utils.py:56-61."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIDU4D_BENCH_BACKEND="gloo", MASTER_PORT=str(_free_port()))
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--surfels", "20000",
+           "--res", "128", "--frames", "32", "--cpu-images", "0", "--torch-cpu-images", "0", "--fit-steps", "0", "--repeats", "0",
+           "--per-frame-surface", "0", "--host-probe", "0", "--fit-optim-warp", "0", "--no-stage-timers"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["parallelism"].startswith("frame-parallel x8")
+    assert d["config"]["frames_of_rank0"][:3] == [0, 8, 16]
+    assert d["value"] > 0 and abs(d["value"] - 8 * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]   # all ranks' images
+    c = d["rccl"]
+    assert c["world"] == 8 and c["ranks_seen"] == 8 and c["rank_sum_ok"] and c["backend"] == "gloo"
+    assert c["frames_of_each_rank_head"] == [[r_ + 8 * k for k in range(4)] for r_ in range(8)]
+    host = d["host_enqueue_ms_per_step_of_each_rank"]
+    assert len(host) == 8 and all(h > 0 for h in host)
+    print("bench --gpus 8 over gloo on one GPU: images/s", round(d["value"], 1), "host ms per step of each rank", host)
+
+
 def _worker_networks(rank, world, port, out):
     """Two ranks, networks that TRAIN (--gs_optim_warp=True, AdamW from step 1): the networks' gradients come out of the
     captured graphs' static buffers, are packed into the flat exchange buffer behind the surfels', summed, folded into the

@@ -94,6 +94,7 @@ class RasterContext:
         self.scope = scope            # part of the hint keys (kept from rounds 3-4: hint_scope())
         self.deferred = False         # deferred capacity check: forwards do not wait for the pair count ...
         self.graph_mode = False       # ... and record no events (hipGraph capture)
+        self.graph_headers = None     # graph_capture_mode: the captured forwards' (device header view, capacity)
         self.pending: list = []       # (event, pinned slot, depth stat, capacity, key, stream) of the unchecked forwards
         self.grad_out: dict = {}      # one-shot caller-supplied gradient outputs (gradient_buffers)
         self.grad_written = None
@@ -239,6 +240,7 @@ class graph_capture_mode:
         c.deferred = c.graph_mode = True
         self._n0 = len(c.pending)
         self.frames = []
+        self.headers = c.graph_headers = []   # (header words as a device int32 view, capacity) of the captured forwards
         return self
 
     def __exit__(self, *exc):
@@ -246,6 +248,7 @@ class graph_capture_mode:
         c.deferred, c.graph_mode = self._old
         self.frames = [(p[1], p[2], p[3], p[4]) for p in c.pending[self._n0:]]
         del c.pending[self._n0:]
+        c.graph_headers = None
         return False
 
 
@@ -495,6 +498,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             if not _graph_mode:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
+            elif ctx.graph_headers is not None:
+                # (a captured step cannot ask the host for its verdict: lab4d/captured_step.py derives a device word from
+                # the header -- pair count against this capacity, the truncated flag -- that the step's updates read)
+                ctx.graph_headers.append((geom[:64].view(torch.int32), cap))
             ctx.pending.append((ev, slot, stat, cap, key, stream))
             binning._vidu4d_capacity = cap
             binning._vidu4d_split = int(a.segment_split)

@@ -38,7 +38,7 @@ class AdamTensor(C.Structure):
     """struct Vidu4dAdamTensor"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("numel", C.c_int64), ("lr", C.c_float), ("bias_correction1", C.c_float),
-                ("bias_correction2_sqrt", C.c_float)]
+                ("bias_correction2_sqrt", C.c_float), ("device_scalars", C.c_void_p)]
 
 
 class DensifyAttr(C.Structure):
@@ -174,6 +174,7 @@ SYMBOLS = {
     "vidu4d_stage3_loss_forward": (C.c_int, [C.POINTER(Stage3LossArgs), _P]),
     "vidu4d_stage3_loss_backward": (C.c_int, [C.POINTER(Stage3LossArgs), _P, C.POINTER(Stage3LossGrads), _P]),
     "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P]),
+    "vidu4d_adam_step_guarded": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P, _P]),
     "vidu4d_grad_clip_coef": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, _P, _P, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,

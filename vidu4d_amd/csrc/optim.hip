@@ -30,6 +30,7 @@ struct AdamLaunch {
     float beta2, one_minus_beta1, one_minus_beta2, eps;
     const float* grad_scale;
     int zero_grads;
+    const uint32_t* skip;   // device word: non-zero = this launch changes nothing (vidu4d_adam_step_guarded)
 };
 
 constexpr int ADAM_PER_THREAD = 4;
@@ -43,8 +44,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
 #pragma unroll
     for (int i = 1; i < VIDU4D_ADAM_MAX_TENSORS; i++)
         if (i < a.n && blockIdx.x >= a.first_block[i]) k = i;
+    if (a.skip && *a.skip) return;   // (wave-uniform: the step's forward did not fit its buffers, its gradients are garbage)
     const Vidu4dAdamTensor t = a.t[k];
-    const float step_size = t.lr / t.bias_correction1;
+    // (captured launches read the step's scalars from device memory: same float values the host would have passed by value)
+    const float lr = t.device_scalars ? t.device_scalars[0] : t.lr;
+    const float bc1 = t.device_scalars ? t.device_scalars[1] : t.bias_correction1;
+    const float bc2_sqrt = t.device_scalars ? t.device_scalars[2] : t.bias_correction2_sqrt;
+    const float step_size = lr / bc1;
     const float w = a.one_minus_beta1, w2 = a.one_minus_beta2;
     const float gs = a.grad_scale ? *a.grad_scale : 1.0f;
     const int64_t base = (int64_t)(blockIdx.x - a.first_block[k]) * ADAM_PER_BLOCK + threadIdx.x;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
         if (e < t.numel) {
             const float mn = fmaf(w, g[j] - m[j], m[j]);  // lerp with weight < 0.5 (ATen/native/Lerp.h)
             const float vn = fmaf(w2 * g[j], g[j], a.beta2 * v[j]);
-            const float denom = sqrtf(vn) / t.bias_correction2_sqrt + a.eps;
+            const float denom = sqrtf(vn) / bc2_sqrt + a.eps;
             if (a.zero_grads) t.grad[e] = 0.f;
             t.exp_avg[e] = mn;
             t.exp_avg_sq[e] = vn;
@@ -314,6 +320,12 @@ __global__ __launch_bounds__(256) void densify_gather_kernel(DensifyLaunch L)
 extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
                                 const float* grad_scale, int zero_grads, void* stream)
 {
+    return vidu4d_adam_step_guarded(n, tensors, beta1, beta2, eps, grad_scale, zero_grads, nullptr, stream);
+}
+
+extern "C" int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
+                                        const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream)
+{
     if (n < 0 || n > VIDU4D_ADAM_MAX_TENSORS || (n && !tensors)) return VIDU4D_E_INVALID;
     AdamLaunch a;
     a.n = 0;
@@ -323,11 +335,12 @@ extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double b
     a.eps = (float)eps;
     a.grad_scale = grad_scale;
     a.zero_grads = zero_grads;
+    a.skip = skip;
     unsigned blocks = 0;
     for (int i = 0; i < n; i++) {
         const Vidu4dAdamTensor& t = tensors[i];
         if (t.numel < 0 || (t.numel && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq))) return VIDU4D_E_INVALID;
-        if (!(t.bias_correction1 > 0.f) || !(t.bias_correction2_sqrt > 0.f)) return VIDU4D_E_INVALID;
+        if (!t.device_scalars && (!(t.bias_correction1 > 0.f) || !(t.bias_correction2_sqrt > 0.f))) return VIDU4D_E_INVALID;
         if (t.numel == 0) continue;
         a.t[a.n] = t;
         a.first_block[a.n] = blocks;

@@ -24,9 +24,12 @@ class SurfelAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, foreach=False, fused=False)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=None, zero_grads=False):
+    def step(self, closure=None, grad_scale=None, zero_grads=False, captured=None):
         """grad_scale: device scalar the gradients are multiplied by on the way in (the clip coefficient, instead of a
-        pass of its own over the gradients); zero_grads: leave the gradient arrays zero-filled."""
+        pass of its own over the gradients); zero_grads: leave the gradient arrays zero-filled.
+        captured (lab4d/captured_step.py): a `CapturedScalars` -- the launch is being captured into a hipGraph: the per-step
+        scalars (learning rate, bias corrections) are read from its device rows instead of being passed by value, the launch
+        carries its skip word, and the step counts are NOT advanced here (`captured.advance()` does that before every replay)."""
         if closure is not None:
             raise RuntimeError("SurfelAdam: closures are not supported")
         batches = {}
@@ -42,26 +45,79 @@ class SurfelAdam(torch.optim.Adam):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                t = float(st["step"])
                 if zero_grads and not p.grad.is_contiguous():
                     raise RuntimeError("SurfelAdam: zero_grads needs contiguous gradients")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                rec = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                      p.numel(), float(group["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t))
+                if captured is not None:
+                    rec = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                          p.numel(), 0.0, 0.0, 0.0, captured.row(group, p, st))
+                else:
+                    st["step"] += 1
+                    t = float(st["step"])
+                    rec = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                          p.numel(), float(group["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), None)
                 batches.setdefault((p.device, b1, b2, group["eps"]), []).append((rec, g))
         lib = _lib.load()
+        skip = None if captured is None or captured.skip is None else captured.skip.data_ptr()
         for (dev, b1, b2, eps), items in batches.items():
             stream = torch.cuda.current_stream(dev).cuda_stream
             for i in range(0, len(items), _lib.ADAM_MAX_TENSORS):
                 chunk = items[i:i + _lib.ADAM_MAX_TENSORS]
                 arr = (_lib.AdamTensor * len(chunk))(*[c[0] for c in chunk])
-                _lib.check(lib.vidu4d_adam_step(len(chunk), arr, b1, b2, eps, None if grad_scale is None else grad_scale.data_ptr(),
-                                                int(bool(zero_grads)), stream), "adam step")
+                _lib.check(lib.vidu4d_adam_step_guarded(len(chunk), arr, b1, b2, eps,
+                                                        None if grad_scale is None else grad_scale.data_ptr(),
+                                                        int(bool(zero_grads)), skip, stream), "adam step")
         return None
 
 
+class CapturedScalars:
+    """The per-step scalars of a SurfelAdam launch that lives in a captured hipGraph: one device row {lr, 1 - beta1^t,
+    sqrt(1 - beta2^t)} per parameter tensor, refreshed from the host's step counts by ONE small async copy in front of every
+    replay -- the same float values `step()` passes by value when it runs eagerly, so a captured step updates bit for bit
+    what the eager step updates.  `skip`: the device word the launch reads (non-zero: change nothing)."""
+    MAX_ROWS = 16
+
+    def __init__(self, device, skip=None):
+        self.dev = torch.zeros(self.MAX_ROWS, 4, dtype=torch.float32, device=device)
+        self.host = torch.zeros(2, self.MAX_ROWS, 4, dtype=torch.float32).pin_memory()   # (two: the copy queued for the last
+        self._flip = 0                                                                   # replay may not have run yet)
+        self.rows: list = []   # (group, state dict) per row, in the order the capture met them
+        self.skip = skip
+
+    def row(self, group, p, st) -> int:
+        if len(self.rows) >= self.MAX_ROWS:
+            raise RuntimeError("CapturedScalars: more parameter tensors than rows")
+        self.rows.append((group, st))
+        return self.dev[len(self.rows) - 1].data_ptr()
+
+    def advance(self):
+        """One optimizer step on the host's side of the books: every row's step count + 1, its scalars to the device (queued
+        on the current stream, in front of the replay that reads them)."""
+        self._flip ^= 1
+        h = self.host[self._flip]
+        for i, (group, st) in enumerate(self.rows):
+            st["step"] += 1
+            t = float(st["step"])
+            b1, b2 = group["betas"]
+            h[i, 0], h[i, 1], h[i, 2] = float(group["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
+        self.dev.copy_(h, non_blocking=True)
+
+    def rewind(self, steps: int = 1):
+        """The last `steps` replays changed nothing (their skip word was set): take their step counts back."""
+        for _, st in self.rows:
+            st["step"] -= steps
+
+
 _clip_ws: dict = {}
+
+
+def ensure_clip_workspace(dev, stream_id):
+    """The clip kernel's arrival counters for (device, stream), zero-filled ONCE -- a capture on that stream must find them
+    (a workspace first made inside a capture would live in the graph's private pool and die with it)."""
+    key = (dev, stream_id)
+    if key not in _clip_ws:
+        _clip_ws[key] = torch.zeros(_lib.CLIP_WORKSPACE_FLOATS, dtype=torch.float32, device=dev)
+    return _clip_ws[key]
 
 
 def clip_coef(grads, max_norm: float):

@@ -286,6 +286,15 @@ class DeformableSurfels(GaussianModel):
     def _graphed_warp_networks(self, frame_id):
         """frame ids (M,) -> (se3_qr, se3_qd, cam_q, cam_t, bone_A, bone_c[, frame_bias]) through hipGraphs of the networks'
         forward and backward (captured on first use and whenever M or the set of trainable parameters changes)."""
+        if self.opts.get("graphed_warp_networks", True) == "inline":
+            # (a caller that captures the WHOLE step -- lab4d/captured_step.py -- wants the same launches, three branches and
+            # fused stacks, as nodes of ITS graph: the module itself, under autograd)
+            mod = self.__dict__.get("_net_eval_inline")
+            if mod is None:
+                mod = self.__dict__["_net_eval_inline"] = _WarpNetEval(
+                    self.warp, self.camera_mlp, bool(self.opts.get("fused_bone_tables", True)),
+                    bool(self.opts.get("parallel_network_branches", True)), bool(self.opts.get("fused_dense_stacks", True)))
+            return mod(frame_id)
         key = (int(frame_id.shape[0]), tuple(p.requires_grad for p in self._warp_param_list()))
         g = self.__dict__.get("_net_graph")
         if g is None or g[0] != key:

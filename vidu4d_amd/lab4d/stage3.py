@@ -163,8 +163,13 @@ class Stage3Trainer:
             # 40 % of the whole step with training networks (tools/fit_optim_warp_profile.py).  `fused=True` is one
             # multi-tensor launch per group and the same arithmetic.)
             on_gpu = all(prm.is_cuda for _, prm in net_params)
-            self.optimizer = torch.optim.AdamW(groups, lr=c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
-                                               **({"fused": True} if on_gpu and o.get("fused_network_adamw", True) else {}))
+            fused = on_gpu and o.get("fused_network_adamw", True)
+            # (captured steps, lab4d/captured_step.py: the step counters and the learning rates live on the device -- torch's
+            # capturable form of the same update; the scheduler below fills the rate tensors)
+            capt = fused and self.world == 1 and bool(o.get("captured_step", True))
+            self.optimizer = torch.optim.AdamW(groups, lr=torch.tensor(float(c.learning_rate), device=m._xyz.device) if capt
+                                               else c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
+                                               **({"fused": True} if fused else {}), **({"capturable": True} if capt else {}))
             # trainer.py:268-275: a resumed run starts the networks at the full rate and decays to lr / 5; a fresh one
             # warms up from lr / 25 over two rounds
             if self.is_resumed:
@@ -183,6 +188,11 @@ class Stage3Trainer:
         # gradients (after the exchange) are added to these buffers; a parameter autograd never touched keeps
         # grad = None (AdamW then skips it, weight decay included).
         self._net_accum = [None] * len(self._net_params)
+        # plain steps as one captured hipGraph (lab4d/captured_step.py; `captured_step: False` restores the eager loop)
+        self.captured_step = bool(o.get("captured_step", True)) and m._xyz.is_cuda and self.world == 1
+        self._captured, self._cap_stream, self._inflight, self._streak = {}, None, None, (None, 0)
+        self.capture_after = int(o.get("capture_after", 3))   # eager steps of a shape before it is captured (hints settle)
+        self.captured_stats = {"captures": 0, "replays": 0, "taken_back": 0}
         # the outlier pass of trainer.py:573-588 (open3d remove_radius_outlier(nb_points=20, radius=0.004))
         self.outlier_radius, self.outlier_nb_points = float(o.get("outlier_radius", 0.004)), int(o.get("outlier_nb_points", 20))
         self.outlier_neighbor_count = None   # (None: csrc/knn.hip on the GPU, no pass for surfels on the CPU)
@@ -553,7 +563,81 @@ class Stage3Trainer:
         total.backward()
         return losses
 
+    # ---- plain steps as one captured hipGraph (lab4d/captured_step.py)
+    def _plain_step(self, step: int) -> bool:
+        """No host decision inside the step: no SH-degree raise, no densify / prune / opacity reset / outlier pass, and -- with
+        networks that train -- AdamW stepping (from optim_warp_neus_iters on) and no start of a round."""
+        c, m = self.cfg, self.model
+        if step % 1000 == 0 and m.active_sh_degree < m.max_sh_degree:
+            return False
+        if step < c.densify_until_iter:
+            if step > c.densify_from_iter and step % c.densification_interval == 0:
+                return False
+            if step % c.opacity_reset_interval == 0:
+                return False
+            if c.densify_from_iter < step < c.outlier_stop_iter and step % c.outlier_filtering_interval == 0:
+                return False
+        if self.optimizer is not None and (step < self.optim_warp_from or step % self.iters_per_round == 0):
+            return False
+        return True
+
+    def _capture_key(self, batch: dict, step: int):
+        m = self.model
+        K = batch["Kinv"]
+        cams = (tuple(float(x) for x in K.reshape(-1).tolist()) if not K.is_cuda else (K.data_ptr(), K._version),
+                tuple(int(h) for h in batch["H"]), tuple(int(w) for w in batch["W"]))
+        shapes = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor) and v.is_cuda)
+        nets = tuple(p._version for p in m._warp_param_list()) if self.optimizer is None else ()
+        # (every surfel tensor: densify / prune re-create all of them, reset_opacity the opacity alone)
+        return (tuple(p.data_ptr() for p in self.surfel_params()), int(m._xyz.shape[0]), int(m.active_sh_degree), step > 8000,
+                step < self.cfg.densify_until_iter, cams, shapes, nets)
+
+    def _settle_captured(self):
+        """The verdict of the captured step in flight (its forward finished long ago: the header copy sits in pinned memory):
+        a step that did not fit its buffers changed nothing on the device -- take the host's books of it back and run it
+        eagerly, as the eager loop's replay would have, before anything else happens."""
+        fl, self._inflight = self._inflight, None
+        if fl is None:
+            return
+        cs, batch = fl
+        if cs.verdict():
+            return
+        self.captured_stats["taken_back"] += 1
+        torch.cuda.current_stream(self.model._xyz.device).synchronize()
+        cs.take_back()
+        self.current_steps -= 1
+        self._captured.clear()          # (the hints have moved: what was captured with the old ones goes)
+        self._streak = (None, 0)
+        self._train_step_eager(batch)
+
     def train_step(self, batch: dict) -> dict:
+        if not self.captured_step:
+            return self._train_step_eager(batch)
+        self._settle_captured()
+        step = self.current_steps
+        if not self._plain_step(step):
+            self._streak = (None, 0)
+            return self._train_step_eager(batch)
+        key = self._capture_key(batch, step)
+        cs = self._captured.get(key)
+        if cs is None:
+            last, n = self._streak
+            n = n + 1 if last == key else 1
+            self._streak = (key, n)
+            if n <= self.capture_after:
+                return self._train_step_eager(batch)
+            from .captured_step import CapturedStep
+            if len(self._captured) >= 4:
+                self._captured.clear()
+            cs = self._captured[key] = CapturedStep(self, batch, step)
+            self.captured_stats["captures"] += 1
+        losses = cs.replay(batch)
+        self.captured_stats["replays"] += 1
+        self._inflight = (cs, batch)
+        self.current_steps += 1
+        return losses
+
+    def _train_step_eager(self, batch: dict) -> dict:
         m, c = self.model, self.cfg
         step = self.current_steps
         if step % 1000 == 0:
@@ -583,15 +667,18 @@ class Stage3Trainer:
         self.finish_step(step)
         return {k: v.detach() for k, v in losses.items()}
 
-    def gather_densification_stats(self, step: int):
+    def gather_densification_stats(self, step: int, keep=None):
         """max_radii2D / xyz_gradient_accum / denom from the frames rendered last (trainer.py:549-556); does not read the
-        parameter gradients, so it runs while the exchange is in flight."""
+        parameter gradients, so it runs while the exchange is in flight.  keep (captured steps): a device bool -- False when the
+        step's forward did not fit its buffers, the statistics of such a step are not taken (the eager loop replays it first)."""
         m = self.model
         if step >= self.cfg.densify_until_iter:
             return
         with torch.no_grad():
             for i in range(len(m._radii_batch)):
                 vis, radii = m._visibility_filter_batch[i], m._radii_batch[i]
+                if keep is not None:
+                    vis = vis & keep
                 m.max_radii2D.copy_(torch.where(vis, torch.maximum(m.max_radii2D, radii.float()), m.max_radii2D))
                 m.add_densification_stats(m._viewspace_points_batch[i], vis)
 
