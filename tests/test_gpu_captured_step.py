@@ -93,7 +93,7 @@ def test_a_step_that_outgrows_the_captured_buffers_is_skipped_taken_back_and_rer
                 with torch.no_grad():
                     m._scaling.add_(1.2)     # (log-scales: 3.3 x the extent, ~10 x the pairs)
             tr.train_step(synthetic_batch(m, [(2 * i) % 16, (2 * i + 1) % 16], H, W, seed=i))
-        tr._settle_captured() if captured else None
+        tr.settle()
         torch.cuda.synchronize(dev)
         out[captured] = ([p.detach().clone() for p in tr.surfel_params()], dict(tr.captured_stats), tr.current_steps,
                          m.denom.clone(), {id(p): float(tr.gs_optimizer.state[p]["step"]) for p in tr.surfel_params()

@@ -43,13 +43,11 @@ class CapturedStep:
         self.static = {k: torch.empty_like(v) for k, v in batch.items() if isinstance(v, torch.Tensor) and v.is_cuda}
         self.host_items = {k: v for k, v in batch.items() if k not in self.static}   # (Kinv, H, W: part of the key)
         self.skip = torch.zeros(1, dtype=torch.int32, device=dev)         # non-zero: this replay changes nothing
-        self.skip_f = torch.zeros(1, dtype=torch.float32, device=dev)     # ... as the fused AdamW's `found_inf`
+        self.skip_f = torch.zeros((), dtype=torch.float32, device=dev)    # ... as the fused AdamW's `found_inf` (0-dim, as its step counters)
         self.scalars = CapturedScalars(dev, skip=self.skip)
         self.adamw = tr.optimizer is not None and step >= tr.optim_warp_from
         self.replays = 0
-        if tr._cap_stream is None or tr._cap_stream.device != dev:
-            tr._cap_stream = torch.cuda.Stream(dev)
-        s = tr._cap_stream
+        s = tr._step_stream()
         # what the step's launches create lazily PER STREAM must exist before the capture (made inside it, it would live in
         # the graph's private pool -- or be a host allocation in the middle of a capture): the clip kernel's counters, the
         # pinned slots the forwards' headers are copied to
@@ -100,7 +98,7 @@ class CapturedStep:
             b = (hdr[0] > int(capacity)) | (hdr[6] != 0)
             bad = b if bad is None else (bad | b)
         self.skip.copy_(bad.to(torch.int32).reshape(1))
-        self.skip_f.copy_(bad.to(torch.float32).reshape(1))
+        self.skip_f.copy_(bad.to(torch.float32).reshape(()))
         tr._fold_net_gradients(from_slots=False, adopt=self.adamw)
         tr.gather_densification_stats(step, keep=~bad)
         with torch.no_grad():

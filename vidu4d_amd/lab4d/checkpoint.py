@@ -39,6 +39,8 @@ def model_state(model) -> dict:
 
 def save_checkpoint(trainer, save_dir: str, round_count: int, save_freq: int = 1, rank: int = 0):
     """-> path written, or None when this rank / round does not save."""
+    if hasattr(trainer, "settle"):
+        trainer.settle()   # (a captured step still in flight: its verdict first, lab4d/captured_step.py)
     if rank != 0 or round_count % max(1, save_freq) != 0:
         return None
     os.makedirs(save_dir, exist_ok=True)

@@ -610,9 +610,39 @@ class Stage3Trainer:
         self._streak = (None, 0)
         self._train_step_eager(batch)
 
+    def _step_stream(self):
+        dev = self.model._xyz.device
+        if self._cap_stream is None or self._cap_stream.device != dev:
+            self._cap_stream = torch.cuda.Stream(dev)
+        return self._cap_stream
+
     def train_step(self, batch: dict) -> dict:
         if not self.captured_step:
             return self._train_step_eager(batch)
+        # Every step of a trainer whose plain steps are captured -- eager ones included -- runs on ONE side stream: a graph
+        # is captured on a non-default stream, and autograd keeps a parameter's gradient-accumulation node on the stream it
+        # was first used on; eager steps on the default stream would leave nodes there that a later capture trips over.
+        s, cur = self._step_stream(), torch.cuda.current_stream(self.model._xyz.device)
+        if cur == s:
+            return self._train_step_on_stream(batch)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            out = self._train_step_on_stream(batch)
+        cur.wait_stream(s)
+        return out
+
+    def settle(self):
+        """The verdict of a captured step still in flight (train_step asks for it at the start of the NEXT step): call before
+        reading the model after the last step of a run (checkpoints, evaluation)."""
+        if not self.captured_step or self._inflight is None:
+            return
+        s, cur = self._step_stream(), torch.cuda.current_stream(self.model._xyz.device)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            self._settle_captured()
+        cur.wait_stream(s)
+
+    def _train_step_on_stream(self, batch: dict) -> dict:
         self._settle_captured()
         step = self.current_steps
         if not self._plain_step(step):

@@ -228,6 +228,7 @@ def main(argv=None):
                 batch = synthetic_batch(model, ids, res, res, seed=step)
             losses = trainer.train_step(batch)
             step += 1
+        trainer.settle()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         say(f"round {rnd}: {opts['iters_per_round']} steps, {opts['iters_per_round'] * per_step * world / dt:.1f} "
