@@ -45,7 +45,10 @@ def test_captured_steps_follow_the_eager_trajectory(gpu_device, regime):
     if regime == "networks_train":
         opts = dict(gs_optim_warp=True, optim_warp_neus_iters=2, iters_per_round=100, num_rounds=1)
     out = {}
-    for captured in (True, False):
+    # (the eager loop TWICE: the backward's float atomics make two runs of the same steps differ, and with networks that
+    # train AdamW's normalised updates amplify that over the steps -- the captured run is held to the eager run within a few
+    # times what two eager runs differ by)
+    for name, captured in (("captured", True), ("eager", False), ("eager2", False)):
         m, tr = _trainer(dev, captured, **opts)
         if regime == "frozen_geometry":
             tr.current_steps = 8001
@@ -54,28 +57,35 @@ def test_captured_steps_follow_the_eager_trajectory(gpu_device, regime):
         for i in range(steps):
             l = tr.train_step(synthetic_batch(m, [(2 * i) % 16, (2 * i + 1) % 16], H, W, seed=i))
             losses.append({k: float(v) for k, v in l.items()})
+        tr.settle()
         torch.cuda.synchronize(dev)
         nets = torch.cat([p.detach().reshape(-1) for p in list(m.warp.parameters()) + list(m.camera_mlp.parameters())])
-        out[captured] = (losses, [p.detach().clone() for p in tr.surfel_params()], nets.clone(), dict(tr.captured_stats),
-                         tr.current_steps)
+        out[name] = (losses, [p.detach().clone() for p in tr.surfel_params()], nets.clone(), dict(tr.captured_stats),
+                     tr.current_steps)
         if captured:
             assert tr.captured_stats["captures"] == 1 and tr.captured_stats["replays"] >= steps - 6, tr.captured_stats
             assert tr.captured_stats["taken_back"] == 0
         else:
             assert tr.captured_stats["replays"] == 0
-    assert out[True][4] == out[False][4] == steps + (8001 if regime == "frozen_geometry" else 0)
-    for la, lb in zip(out[True][0], out[False][0]):
+    assert out["captured"][4] == out["eager"][4] == steps + (8001 if regime == "frozen_geometry" else 0)
+    for la, lb, lc in zip(out["captured"][0], out["eager"][0], out["eager2"][0]):
         for k in lb:
-            assert abs(la[k] - lb[k]) <= 2e-4 * abs(lb[k]) + 1e-7, (k, la, lb)
+            noise = abs(lb[k] - lc[k])
+            assert abs(la[k] - lb[k]) <= max(2e-4 * abs(lb[k]), 4 * noise) + 1e-7, (k, la, lb, lc)
     lrs = (5e-5, 2.5e-3, 2.5e-3 / 20, 0.05, 5e-3, 1e-3, 2.5e-3, 2.5e-3)
-    for a, b, lr in zip(out[True][1], out[False][1], lrs):
-        _close(a, b, lr, "surfels")
+    for a, b, c, lr in zip(out["captured"][1], out["eager"][1], out["eager2"][1], lrs):
+        d, noise = (a - b).abs(), (b - c).abs()
+        assert float(d.median()) <= 4 * float(noise.median()) + 1e-6 + 1e-5 * float(b.abs().median()), (lr, float(d.median()))
+        assert float(d.max()) <= 8 * lr + 4 * float(noise.max()) + 1e-4 * float(b.abs().max()), (lr, float(d.max()))
+    d, noise = (out["captured"][2] - out["eager"][2]).abs(), (out["eager"][2] - out["eager2"][2]).abs()
     if regime == "networks_train":
-        assert float((out[True][2] - out[False][2]).abs().max()) <= 8 * 5e-3 + 1e-6   # (10 x the base rate for the explicit ones)
-        d = (out[True][2] - out[False][2]).abs()
-        assert float(d.median()) <= 1e-6
+        assert float(noise.max()) > 0 or float(d.max()) == 0
+        assert float(d.median()) <= 4 * float(noise.median()) + 1e-6 and float(d.max()) <= 4 * float(noise.max()) + 8 * 5e-3
+        # ... and the networks did train, under AdamW's schedule, in both
+        start = torch.cat([p.detach().reshape(-1) for p in list(_trainer(dev, False, **opts)[0].warp.parameters())])
+        assert float((out["captured"][2][:start.numel()] - start).abs().max()) > 1e-4
     else:
-        assert torch.equal(out[True][2], out[False][2])
+        assert float(d.max()) == 0.0
 
 
 def test_a_step_that_outgrows_the_captured_buffers_is_skipped_taken_back_and_rerun(gpu_device):

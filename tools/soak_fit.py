@@ -75,8 +75,10 @@ def run(tag, **opts):
             assert np.isfinite(v), (tag, step, losses)
             hist.append(round(v, 5))
             counts.append(int(s._xyz.shape[0]))
+    tr.settle()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    print(f"[{tag}] captured-step statistics: {tr.captured_stats}")
     for n, p in s.named_parameters():
         assert torch.isfinite(p).all(), (tag, n)
     with torch.no_grad():
@@ -90,7 +92,13 @@ def run(tag, **opts):
     return hist, err
 
 
-if TRAIN_NETS:
+if os.environ.get("SOAK_CAPTURED_AB", "0") == "1":
+    # round 6: the plain steps replayed from ONE captured hipGraph (the trainer's default) against the eager loop of rounds 1-5
+    h1, e1 = run("captured steps (default)" + (", networks train" if TRAIN_NETS else ""))
+    h2, e2 = run("eager loop (captured_step=False)" + (", networks train" if TRAIN_NETS else ""), captured_step=False)
+    worst = max(abs(a - b) / max(abs(b), 1e-9) for a, b in zip(h1, h2))
+    print(f"captured vs eager: largest relative difference of the loss samples {worst:.2e}")
+elif TRAIN_NETS:
     h1, e1 = run("networks train, default path (captured graphs, fused kernels)")
     h2, e2 = run("networks train, un-fused torch warp (rounds 1-4)", fused_warp_trainable=False)
 else:
