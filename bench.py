@@ -120,7 +120,7 @@ def cpu_baseline(scene, n_images: int):
 
 
 def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: int = 0, seed: int = 0, barrier=None,
-                  densify: bool = False, optim_warp: bool = False, fused_warp_trainable: bool = True, captured: bool = True):
+                  densify: bool = False, optim_warp: bool = False, fused_warp_trainable: bool = True, captured="auto"):
     """Second figure of SURVEY.md 8(d): images/s of the FULL Stage-3 fitting step (bob LBS warp with frozen,
     randomly initialised warp / camera networks -> rasterize 2 frames -> losses -> backward -> gradient clip ->
     densification statistics -> Adam) on an object-centric synthetic sequence of the same size.
@@ -136,15 +136,16 @@ def fit_step_rate(dev, n_surfels: int, W: int, H: int, steps: int, start_step: i
     Round 5: the fused warp then still applies -- the networks are evaluated for the step's frames with autograd, the delta-skin
     MLP as library GEMMs, and the skinning kernel's backward reduces d/d (bone dual quaternions, cameras) over the surfels;
     fused_warp_trainable=False times the ~40-kernel torch chain rounds 1-4 fell back to (same step, for the A/B).
-    captured (round 6): the trainer's default -- plain steps replayed from ONE captured hipGraph (lab4d/captured_step.py);
-    False: the eager loop of rounds 1-5, for the A/B."""
+    captured (round 6): "auto" = the trainer's default -- plain steps replayed from ONE captured hipGraph
+    (lab4d/captured_step.py) when the networks train, the eager loop when they are frozen (GPU-bound there: the graph's
+    per-node cost makes it slower); True / False force it on / off for the A/B lines."""
     import numpy as np
     from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
     from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     frames = 120
-    m = DeformableSurfels(dict(fg_motion="gs-bob", captured_step=bool(captured)) | ({} if densify else dict(densify_until_iter=0)) |
+    m = DeformableSurfels(dict(fg_motion="gs-bob", captured_step=captured) | ({} if densify else dict(densify_until_iter=0)) |
                           (dict(fused_warp_trainable=fused_warp_trainable) if optim_warp else {}), num_frames=frames, device=dev)
     d = rng.normal(size=(n_surfels, 3)).astype(np.float32)
     pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(n_surfels, 1)).astype(np.float32) ** (1 / 3)
@@ -877,7 +878,8 @@ def main():
               # (the same steps driven by the eager Python loop of rounds 1-5: what the captured graph replaces)
               out["fit_step_optim_warp_eager"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), start_step=12001,
                                                                optim_warp=True, captured=False)
-              out["fit_step_eager"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), captured=False)
+              # (... and the frozen step forced through the captured graph: slower than its eager loop, which is GPU-bound)
+              out["fit_step_captured"] = fit_step_rate(dev, N, W, H, max(10, args.fit_steps // 2), captured=True)
         if world == 1:
             # MODELLED multi-GPU figures (no multi-GPU node is reachable from the build box; the driver
             # measures the real curve when it has one): measured 1-GPU step + the all-reduce cost model above

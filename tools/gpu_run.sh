@@ -30,7 +30,7 @@ st = d.get("stage_ms_avg", {})
 print(sys.argv[1].split("/")[-1], "value", round(d["value"], 1), "median", d.get("repeats", {}).get("median"),
       "blend_fwd", st.get("blend_fwd"), "blend_bwd", st.get("blend_bwd"), "roofline", round(d["roofline"]["frac"], 4))
 for k in ("fit_step", "fit_step_geometry", "fit_step_densify", "fit_step_optim_warp", "fit_step_optim_warp_unfused",
-          "fit_step_graph", "fit_step_optim_warp_graph"):
+          "fit_step_optim_warp_eager", "fit_step_captured"):
     v = d.get(k)
     if v: print("   ", k, v.get("images_per_s"), v.get("ms_per_step"))
 pf = d.get("value_per_frame_calls")
@@ -72,6 +72,37 @@ profile)
     ;;
 fit_ab)
     timeout 1200 python tools/fit_profile.py "$@" 2>&1 | grep -v "amdgpu.ids\|Warn\|warn" | tee $O/fit_ab.txt | tail -30
+    ;;
+graph_env_ab)
+    # the captured fitting step against the eager loop, and what the HIP runtime's graph switches do to it
+    {
+    for W_ in 0 1; do
+      for E in "FIT_OPTS={\"captured_step\":false}" "X=1" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=1" "DEBUG_HIP_FORCE_GRAPH_QUEUES=1" "DEBUG_HIP_FORCE_GRAPH_QUEUES=8" "DEBUG_HIP_GRAPH_BATCH_SIZE=512"; do
+        echo -n "optim_warp=$W_ $E : "
+        if [ $W_ = 1 ]; then X1="FIT_OPTIM_WARP=1 FIT_STEP0=12001"; else X1="FIT_STEP0=0"; fi
+        env $X1 "$E" FIT_K=80 FIT_NO_TORCH_PROF=1 timeout 300 python tools/fit_profile.py 2>&1 | grep FIT_STEP
+      done
+    done
+    } | tee $O/r06_graph_env_ab.txt
+    R=$(pwd); cd /tmp
+    for C in true false; do
+      FIT_OPTS="{\"captured_step\":$C}" FIT_K=30 FIT_NO_TORCH_PROF=1 rocprofv3 --kernel-trace --stats -d $R/$O/fittrace_$C -o trace --output-format csv -- python $R/tools/fit_profile.py > $R/$O/fittrace_$C.log 2>&1
+      f=$(find $R/$O/fittrace_$C -name '*kernel_stats.csv' | head -1)
+      python $R/tools/fit_kernel_stats.py $f 36 > $R/$O/r06_fit_step_kernel_stats_captured_$C.csv; head -3 $R/$O/r06_fit_step_kernel_stats_captured_$C.csv; grep FIT_STEP $R/$O/fittrace_$C.log
+      rm -rf $R/$O/fittrace_$C
+    done
+    cd $R
+    ;;
+trace_gaps)
+    # GPU-side anatomy of the fitting step with training networks: captured graph against the eager loop
+    R=$(pwd); cd /tmp
+    for C in true false; do
+      FIT_OPTIM_WARP=1 FIT_STEP0=12001 FIT_OPTS="{\"captured_step\":$C}" FIT_K=40 FIT_NO_TORCH_PROF=1 rocprofv3 --kernel-trace -d $R/$O/gaps_$C -o trace --output-format csv -- python $R/tools/fit_profile.py > $R/$O/gaps_$C.log 2>&1
+      f=$(find $R/$O/gaps_$C -name '*kernel_trace.csv' | head -1)
+      echo "captured_step=$C $(grep FIT_STEP $R/$O/gaps_$C.log)"; python $R/tools/trace_gaps.py $f blend_bwd_kernel 20
+      rm -rf $R/$O/gaps_$C
+    done | tee $R/$O/r06_fit_optim_warp_gaps.txt
+    cd $R
     ;;
 matrix)
     timeout 1500 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log | tail -1 > $O/r06_bench_line_cfgB.json; line $O/r06_bench_line_cfgB.json

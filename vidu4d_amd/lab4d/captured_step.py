@@ -88,7 +88,8 @@ class CapturedStep:
         tr = self.tr
         m = tr.model
         with m.raster_context:
-            tr.__dict__.pop("_flat_is_zero", None)   # (the flat gradient buffer, where there is one, is zeroed IN the graph)
+            # (the flat gradient buffer, where there is one: left zero-filled by the Adam launch of the step before -- eager or
+            # replayed -- as in the eager loop; a skipped replay leaves garbage there and `take_back` says so)
             tr.begin_gradients()
             with _C.graph_capture_mode() as cap:
                 losses = tr._forward_backward(self._batch(), step)
@@ -104,7 +105,9 @@ class CapturedStep:
         with torch.no_grad():
             tr.clip_gradients(5.0)
             coef = tr.__dict__.pop("_clip_coef", None)
-            tr.gs_optimizer.step(grad_scale=coef, zero_grads=False, captured=self.scalars)
+            whole = tr._flat is not None and all(p.grad is not None for p in tr.exchanged_params())
+            tr.gs_optimizer.step(grad_scale=coef, zero_grads=whole, captured=self.scalars)
+            self.leaves_flat_zero = whole
             if self.adamw:
                 tr.optimizer.found_inf = self.skip_f    # (read by the fused step: nothing is updated, its step counter taken back)
                 try:
@@ -125,6 +128,8 @@ class CapturedStep:
         if self.adamw:
             tr.scheduler.step()
             tr._net_accum = [None] * len(tr._net_params)
+        if self.leaves_flat_zero:
+            tr._flat_is_zero = True
         self.replays += 1
         return self.losses
 
@@ -143,6 +148,7 @@ class CapturedStep:
     def take_back(self):
         """The last replay was skipped on the device: the host's books of it."""
         tr = self.tr
+        tr.__dict__.pop("_flat_is_zero", None)   # (the skipped Adam did not zero the flat gradient buffer)
         self.scalars.rewind(1)
         if self.adamw:
             tr.scheduler.last_epoch -= 2

@@ -166,7 +166,7 @@ class Stage3Trainer:
             fused = on_gpu and o.get("fused_network_adamw", True)
             # (captured steps, lab4d/captured_step.py: the step counters and the learning rates live on the device -- torch's
             # capturable form of the same update; the scheduler below fills the rate tensors)
-            capt = fused and self.world == 1 and bool(o.get("captured_step", True))
+            capt = fused and self.world == 1 and bool(o.get("captured_step", "auto"))
             self.optimizer = torch.optim.AdamW(groups, lr=torch.tensor(float(c.learning_rate), device=m._xyz.device) if capt
                                                else c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
                                                **({"fused": True} if fused else {}), **({"capturable": True} if capt else {}))
@@ -189,7 +189,12 @@ class Stage3Trainer:
         # grad = None (AdamW then skips it, weight decay included).
         self._net_accum = [None] * len(self._net_params)
         # plain steps as one captured hipGraph (lab4d/captured_step.py; `captured_step: False` restores the eager loop)
-        self.captured_step = bool(o.get("captured_step", True)) and m._xyz.is_cuda and self.world == 1
+        # "auto" (default): where it pays -- networks that TRAIN, whose eager step is bound by ~2.3 ms of Python (measured, same
+        # box, 200 k surfels / 512^2: 3.01 -> 2.65 ms per step); with frozen networks the eager step is GPU-bound already and
+        # a replayed graph costs ~1.5 us more per node on this runtime (1.10 -> 1.19 ms): eager stays (profiles/r06_graph_env_ab.txt)
+        want = o.get("captured_step", "auto")
+        want = self.optimizer is not None if want == "auto" else bool(want)
+        self.captured_step = want and m._xyz.is_cuda and self.world == 1
         self._captured, self._cap_stream, self._inflight, self._streak = {}, None, None, (None, 0)
         self.capture_after = int(o.get("capture_after", 3))   # eager steps of a shape before it is captured (hints settle)
         self.captured_stats = {"captures": 0, "replays": 0, "taken_back": 0}
