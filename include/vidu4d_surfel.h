@@ -543,10 +543,12 @@ int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta
 /* ---- the gradient clip's norm and coefficient: torch.nn.utils.clip_grad_norm_(params, max_norm) as Trainer.check_grad
  *      calls it (lab4d/engine/trainer.py:861-869) is a norm per tensor, a stack, a norm, an add, a division, a clamp and
  *      a multiply per tensor; here ONE launch reads the n gradient arrays (grads[i], numel[i]; HOST arrays, n <=
- *      VIDU4D_CLIP_MAX_TENSORS) and writes out[0] = the 2-norm over all of them, out[1] = min(1, max_norm / (norm + 1e-6))
- *      -- the factor vidu4d_adam_step takes as grad_scale.  workspace: VIDU4D_CLIP_WORKSPACE_FLOATS device floats whose
+ *      VIDU4D_CLIP_MAX_TENSORS; 96 since ABI 20: the surfels' flat buffer and the bob networks' 66 tensors in one launch)
+ *      and writes THREE floats: out[0] = the 2-norm over all of them, out[1] = min(1, max_norm / (norm + 1e-6)) -- the
+ *      factor vidu4d_adam_step takes as grad_scale -- and (ABI 20) out[2] = 1 / out[1], the grad_scale of an optimizer
+ *      that divides by it (torch's fused AdamW).  workspace: VIDU4D_CLIP_WORKSPACE_FLOATS device floats whose
  *      FIRST word is zero at entry (the kernel leaves it zero again); partial sums are added in a fixed order. ---- */
-#define VIDU4D_CLIP_MAX_TENSORS 16
+#define VIDU4D_CLIP_MAX_TENSORS 96
 #define VIDU4D_CLIP_WORKSPACE_FLOATS 1056
 int vidu4d_grad_clip_coef(int n, const float* const* grads, const int64_t* numel, float max_norm, float* workspace,
                           float* out, void* stream);

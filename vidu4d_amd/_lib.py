@@ -89,7 +89,7 @@ def sched_xcd_block(block: int) -> int:
 
 BLEND_STATS = 11  # VIDU4D_BLEND_STATS (vidu4d_surfel_diag.h)
 ADAM_MAX_TENSORS = 8
-CLIP_MAX_TENSORS = 16
+CLIP_MAX_TENSORS = 96
 CLIP_WORKSPACE_FLOATS = 1056
 DENSIFY_MAX_ATTRS = 8
 

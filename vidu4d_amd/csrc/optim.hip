@@ -190,7 +190,9 @@ __global__ __launch_bounds__(CLIP_THREADS) void clip_kernel(ClipLaunch a)
         for (int i = 0; i < CLIP_THREADS / 64; i++) tot += s_t[i];
         const float norm = (float)sqrt(tot);
         a.out[0] = norm;
-        a.out[1] = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
+        const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
+        a.out[1] = coef;
+        a.out[2] = 1.0f / coef;   // (ABI 20: what a fused AdamW that DIVIDES by its grad_scale takes, torch/optim/adamw.py)
     }
 }
 

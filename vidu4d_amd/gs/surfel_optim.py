@@ -120,10 +120,11 @@ def ensure_clip_workspace(dev, stream_id):
     return _clip_ws[key]
 
 
-def clip_coef(grads, max_norm: float):
+def clip_coef(grads, max_norm: float, with_inverse: bool = False):
     """(norm, coef) device scalars of torch.nn.utils.clip_grad_norm_ over `grads` (contiguous fp32 HIP tensors) from ONE
     launch (csrc/optim.hip::clip_kernel): norm = the 2-norm over all of them, coef = min(1, max_norm / (norm + 1e-6)) --
-    what SurfelAdam.step takes as grad_scale.  (lab4d/engine/trainer.py:861-869.)"""
+    what SurfelAdam.step takes as grad_scale.  (lab4d/engine/trainer.py:861-869.)
+    with_inverse: (norm, coef, 1 / coef) -- 1 / coef is the `grad_scale` of torch's fused AdamW, which divides by it."""
     grads = [g for g in grads if g is not None and g.numel()]
     if not grads:
         raise RuntimeError("clip_coef: no gradients")
@@ -132,25 +133,25 @@ def clip_coef(grads, max_norm: float):
         raise RuntimeError("clip_coef: fp32 HIP tensors on one device required")
     grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    if key not in _clip_ws:  # (zero-filled once; the kernel leaves the arrival counter zero)
-        _clip_ws[key] = torch.zeros(_lib.CLIP_WORKSPACE_FLOATS, dtype=torch.float32, device=dev)
-    out = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = ensure_clip_workspace(*key)   # (zero-filled once; the kernel leaves the arrival counter zero)
+    out = torch.empty(3, dtype=torch.float32, device=dev)
     lib = _lib.load()
     sq = None
     for i in range(0, len(grads), _lib.CLIP_MAX_TENSORS):
         chunk = grads[i:i + _lib.CLIP_MAX_TENSORS]
         if len(grads) > _lib.CLIP_MAX_TENSORS:  # (more tensors than one launch takes: combine the chunk norms)
-            out = torch.empty(2, dtype=torch.float32, device=dev)
+            out = torch.empty(3, dtype=torch.float32, device=dev)
         ptrs = (C.c_void_p * len(chunk))(*[g.data_ptr() for g in chunk])
         nums = (C.c_int64 * len(chunk))(*[g.numel() for g in chunk])
-        _lib.check(lib.vidu4d_grad_clip_coef(len(chunk), ptrs, nums, float(max_norm), _clip_ws[key].data_ptr(),
+        _lib.check(lib.vidu4d_grad_clip_coef(len(chunk), ptrs, nums, float(max_norm), ws.data_ptr(),
                                              out.data_ptr(), key[1]), "grad clip")
         if len(grads) > _lib.CLIP_MAX_TENSORS:
             sq = out[0] * out[0] if sq is None else sq + out[0] * out[0]
     if sq is not None:
         norm = sq.sqrt()
-        return norm, torch.clamp(max_norm / (norm + 1e-6), max=1.0)
-    return out[0], out[1]
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        return (norm, coef, 1.0 / coef) if with_inverse else (norm, coef)
+    return (out[0], out[1], out[2]) if with_inverse else (out[0], out[1])
 
 
 _ATTRS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "regist_feat")

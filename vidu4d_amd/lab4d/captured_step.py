@@ -103,17 +103,22 @@ class CapturedStep:
         tr._fold_net_gradients(from_slots=False, adopt=self.adamw)
         tr.gather_densification_stats(step, keep=~bad)
         with torch.no_grad():
-            tr.clip_gradients(5.0)
+            tr.clip_gradients(5.0, step)
             coef = tr.__dict__.pop("_clip_coef", None)
+            inv = tr.__dict__.pop("_clip_inv", None)
             whole = tr._flat is not None and all(p.grad is not None for p in tr.exchanged_params())
             tr.gs_optimizer.step(grad_scale=coef, zero_grads=whole, captured=self.scalars)
             self.leaves_flat_zero = whole
             if self.adamw:
                 tr.optimizer.found_inf = self.skip_f    # (read by the fused step: nothing is updated, its step counter taken back)
+                if inv is not None:
+                    tr.optimizer.grad_scale = inv       # (the clip, folded in: Stage3Trainer._fold_clip_into_both)
                 try:
                     tr.optimizer.step()
                 finally:
                     del tr.optimizer.found_inf
+                    if inv is not None:
+                        del tr.optimizer.grad_scale
         return {k: v.detach() for k, v in losses.items()}
 
     def replay(self, batch):

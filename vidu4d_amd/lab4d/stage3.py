@@ -465,8 +465,35 @@ class Stage3Trainer:
         if acc:
             torch._foreach_add_(acc, new)
 
-    def clip_gradients(self, max_norm: float = 5.0):
+    def _adamw_steps(self, step: int) -> bool:
+        return self.optimizer is not None and step >= self.optim_warp_from
+
+    def _fold_clip_into_both(self, step: int) -> bool:
+        """Networks that train, AdamW stepping THIS step (round 6): the gradients are consumed by the two optimizers right
+        behind the clip and discarded (trainer.py:592-598), so the clip's scaling rides along in both -- the one-launch surfel
+        Adam multiplies by the coefficient on the way in, torch's fused AdamW divides by its `grad_scale` = 1 / coefficient --
+        and norm + coefficient + its inverse come from ONE launch over the flat surfel buffer and the networks' tensors,
+        instead of clip_grad_norm_'s per-tensor norms, stack, norm, clamp and a multiply pass over 47 MB.  While the networks'
+        gradients still ACCUMULATE over a round (before optim_warp_neus_iters) upstream's in-place clip scales what has
+        accumulated, every step: that stays torch's clip_grad_norm_."""
+        from ..gs.surfel_optim import SurfelAdam
+        return (self._adamw_steps(step) and isinstance(self.gs_optimizer, SurfelAdam) and self.world == 1
+                and bool(self.opts.get("fold_clip_into_optimizers", True))
+                and any(g.get("fused") for g in self.optimizer.param_groups))
+
+    def clip_gradients(self, max_norm: float = 5.0, step: int | None = None):
         """clip_grad_norm_ over the parameters that have a gradient (trainer.py:861-869)."""
+        if step is not None and self._fold_clip_into_both(step):
+            from ..gs.surfel_optim import clip_coef
+            if self._flat is not None and all(self._bound(p) for p in self.exchanged_params() if p.grad is not None):
+                grads = [self._flat]        # (every surfel gradient is a view of it; the networks' places in it stay zero)
+            else:
+                grads = [p.grad for p in self.exchanged_params() if not any(p is q for q in self._net_params)]
+            grads = grads + [p.grad for p in self._net_params]
+            if not any(g is not None for g in grads):
+                return None
+            norm, self._clip_coef, self._clip_inv = clip_coef(grads, max_norm, with_inverse=True)
+            return norm
         if self._fold_clip_into_adam():
             # norm and coefficient from one launch; the surfel Adam multiplies the gradients by the coefficient on the
             # way in (csrc/optim.hip)
@@ -506,7 +533,14 @@ class Stage3Trainer:
         else:
             self.gs_optimizer.step()
         if self.optimizer is not None and step >= self.optim_warp_from:
-            self.optimizer.step()
+            inv = self.__dict__.pop("_clip_inv", None)
+            if inv is not None:
+                self.optimizer.grad_scale = inv     # (the fused step divides the gradients by it: the clip, folded in)
+            try:
+                self.optimizer.step()
+            finally:
+                if inv is not None:
+                    del self.optimizer.grad_scale
             self.scheduler.step()
             self._net_accum = [None] * len(self._net_params)   # optimizer.zero_grad() (trainer.py:596-598)
 
@@ -723,7 +757,7 @@ class Stage3Trainer:
         m, c = self.model, self.cfg
         with torch.no_grad():
             self.wait_gradients()
-            self.clip_gradients(5.0)              # check_grad precedes the densification upstream (trainer.py:547)
+            self.clip_gradients(5.0, step)        # check_grad precedes the densification upstream (trainer.py:547)
             if step < c.densify_until_iter:
                 gen = None
                 if step > c.densify_from_iter and step % c.densification_interval == 0:
