@@ -844,9 +844,17 @@ def main():
             ach = launch_bytes / avg_s / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            # `traffic` and the SQ / TCC part of `limiter` are NOT measured by this run (counters need rocprofv3 passes of
+            # their own): they are REPLAYED from the committed summary of such passes, and the line says from which file,
+            # tree and day -- `achieved`, `avg_launch_ms` and `limiter.tile_walk` are this run's own
+            replayed_from = None
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                    pj = json.load(open(tpath))
+                    traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                    meta = pj.get("_meta", {})
+                    replayed_from = {"file": "profiles/pmc_traffic.json", "commit": meta.get("commit"), "date": meta.get("date"),
+                                     "command": meta.get("command"), "fields": ["roofline.traffic", "roofline.limiter (all but tile_walk)"]}
                 except Exception:
                     traffic = None
             # what actually limits the kernel (rocprofv3 SQ counters of this command, tools/profile_round.sh ->
@@ -859,7 +867,8 @@ def main():
             if walk:
                 limiter = dict(limiter, tile_walk=walk)
             out["roofline"] = {"bound": limiter.get("bound", "hbm"), "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "limiter": limiter,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "replayed_from": replayed_from,
+                               "limiter": limiter,
                                "avg_launch_ms": stages[dom]["ms_avg"],
                                "timing": "HIP events on the launch stream, %d extra steps before the warm-up / timed region"
                                          % min(args.steps, 20) +

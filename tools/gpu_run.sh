@@ -100,6 +100,7 @@ trace_gaps)
       FIT_OPTIM_WARP=1 FIT_STEP0=12001 FIT_OPTS="{\"captured_step\":$C}" FIT_K=40 FIT_NO_TORCH_PROF=1 rocprofv3 --kernel-trace -d $R/$O/gaps_$C -o trace --output-format csv -- python $R/tools/fit_profile.py > $R/$O/gaps_$C.log 2>&1
       f=$(find $R/$O/gaps_$C -name '*kernel_trace.csv' | head -1)
       echo "captured_step=$C $(grep FIT_STEP $R/$O/gaps_$C.log)"; python $R/tools/trace_gaps.py $f blend_bwd_kernel 20
+      python $R/tools/trace_gaps.py $f blend_bwd_kernel 20 --table > $R/$O/r06_fit_optim_warp_kernels_captured_$C.txt
       rm -rf $R/$O/gaps_$C
     done | tee $R/$O/r06_fit_optim_warp_gaps.txt
     cd $R

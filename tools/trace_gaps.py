@@ -8,6 +8,7 @@ from collections import Counter
 
 path, anchor = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+TABLE = "--table" in sys.argv
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
 rows.sort()
 marks = [i for i, r in enumerate(rows) if anchor in r[2]]
@@ -15,6 +16,7 @@ marks = marks[-(steps + 1):]
 tot = Counter()
 gaps = Counter()
 names = Counter()
+calls = Counter()
 for a, b in zip(marks[:-1], marks[1:]):
     seg = rows[a:b]
     span = rows[b][0] - seg[0][0]
@@ -29,6 +31,7 @@ for a, b in zip(marks[:-1], marks[1:]):
             busy += e - end
             end = e
         names[n[:70]] += e - s
+        calls[n[:70]] += 1
     if rows[b][0] > end:
         gaps["tail"] += rows[b][0] - end
     tot["launches"] += len(seg)
@@ -40,3 +43,7 @@ print(f"{n} steps: launches per step {tot['launches'] / n:.0f}, span {tot['span_
       f"{tot['kernel_sum_ns'] / n / 1e3:.0f} us, GPU busy (union) {tot['busy_ns'] / n / 1e3:.0f} us, idle {(tot['span_ns'] - tot['busy_ns']) / n / 1e3:.0f} us")
 print("idle time per step by gap size (us):", {k: round(v / n / 1e3, 1) for k, v in sorted(gaps.items())})
 print("largest kernels (us per step):", [(k, round(v / n / 1e3, 1)) for k, v in names.most_common(12)])
+if TABLE:
+    print("kernel, calls per step, us per step")
+    for k, v in names.most_common():
+        print(f"{k.replace(',', ' ')}, {calls[k] / n:.2f}, {v / n / 1e3:.1f}")
