@@ -918,3 +918,425 @@ void oracle_preprocess_backward(int P, int D, int M, const float* means3D, const
                         dL_dcolors + 3 * (size_t)idx, dmean, dL_dshs + (size_t)idx * M * 3);
     }
 }
+
+/* ================================================================================================================
+ * DECISION REPLAY (round 6; test infrastructure, like everything in this file).
+ *
+ * Two fp32 implementations of forward.cu:265-463 / backward.cu:143-449 that round differently -- the reference's own build,
+ * this oracle, the HIP product -- differ in two ways: by rounding (<= ~1e-5 of a tensor's scale) and by DECISIONS: each
+ * (pixel, list entry) pair passes threshold tests on an ill-conditioned cross product -- accept: depth >= 0.2, alpha >=
+ * 1/255 (forward.cu:385-395, backward.cu:351-353 recomputes them); the depth / gradient branch rho3d <= rho2d
+ * (forward.cu:379-383); the walk's end T (1 - alpha) < 1e-4 (:400-405) and the median sample T > 0.5 (:416-421) -- and a pair
+ * within rounding of a threshold falls on different sides in the two.  One such flip moves a pixel (and the gradient rows of
+ * the surfels involved) by up to a few per cent of scale: the "outliers" the parity tests budget.  The functions below let a
+ * test EXPLAIN those outliers instead of counting them: the blend is recomputed with given decisions FORCED --
+ *   forced_last / forced_median [H*W]  the other implementation's n_contrib (last contributor, median contributor) of a
+ *                                      pixel, 0xFFFFFFFF = decide as usual;
+ *   flips (pixel, pos, what), sorted   pair `pos` (1-based position in the pixel's tile list): bit 0 inverts the accept
+ *                                      decision, bit 1 the rho3d <= rho2d branch --
+ * and oracle_pixel_candidates lists the pairs of a pixel that sit within a given relative distance of a threshold: the only
+ * pairs a flip may be blamed on.  If, with a handful of such flips, EVERY entry of EVERY tensor agrees to 1e-4 of scale, the
+ * two implementations differ by threshold flips and rounding, and by nothing else.
+ * ================================================================================================================ */
+#define REPLAY_FREE 0xFFFFFFFFu
+
+typedef struct {
+    const uint32_t* forced_last;
+    const uint32_t* forced_median;
+    uint32_t n_flips;
+    const uint32_t* flip_pixel;
+    const uint32_t* flip_pos;
+    const uint32_t* flip_what;
+} replay_t;
+
+/* eval_pair without its early exits (a rejected pair may be forced in), the two decisions separated */
+static int eval_pair_replay(const float* Tu, const float* Tv, const float* Tw, const float* xy, float opacity, float pixx,
+                            float pixy, uint32_t what, pair_eval* e, int* use3d, float* margin_alpha, float* margin_rho)
+{
+    e->kx = fmaf(pixx, Tw[0], -Tu[0]);
+    e->ky = fmaf(pixx, Tw[1], -Tu[1]);
+    e->kz = fmaf(pixx, Tw[2], -Tu[2]);
+    e->lx = fmaf(pixy, Tw[0], -Tv[0]);
+    e->ly = fmaf(pixy, Tw[1], -Tv[1]);
+    e->lz = fmaf(pixy, Tw[2], -Tv[2]);
+    const float px = fmaf(e->ky, e->lz, -(e->kz * e->ly));
+    const float py = fmaf(e->kz, e->lx, -(e->kx * e->lz));
+    const float pz = fmaf(e->kx, e->ly, -(e->ky * e->lx));
+    if (pz == 0.0f) return 0;
+    e->pz = pz;
+    const float ipz = 1.0f / pz;
+    e->sx = px * ipz;
+    e->sy = py * ipz;
+    e->rho3d = fmaf(e->sx, e->sx, e->sy * e->sy);
+    e->dx = xy[0] - pixx;
+    e->dy = xy[1] - pixy;
+    e->rho2d = 2.0f * fmaf(e->dx, e->dx, e->dy * e->dy);
+    int b3d = e->rho3d <= e->rho2d;
+    if (what & 2u) b3d = !b3d;
+    *use3d = b3d;
+    const float rho = e->rho3d < e->rho2d ? e->rho3d : e->rho2d;
+    e->depth = b3d ? fmaf(e->sx, Tw[0], fmaf(e->sy, Tw[1], Tw[2])) : Tw[2];
+    const float power = -0.5f * rho;
+    e->G = expf(power);
+    const float a = opacity * e->G;
+    e->alpha = a < 0.99f ? a : 0.99f;
+    int accept = !(e->depth < NEAR_PLANE_F) && !(power > 0.0f) && !(e->alpha < 1.0f / 255.0f);
+    if (margin_alpha) {
+        const float ma = fabsf(e->alpha * 255.0f - 1.0f), md = fabsf(e->depth / NEAR_PLANE_F - 1.0f);
+        *margin_alpha = ma < md ? ma : md;
+    }
+    if (margin_rho) {
+        const float big = e->rho3d > e->rho2d ? e->rho3d : e->rho2d;
+        *margin_rho = big > 0.f ? fabsf(e->rho3d - e->rho2d) / big : 0.f;
+    }
+    if (what & 1u) accept = !accept;
+    return accept;
+}
+
+static uint32_t replay_what(const replay_t* r, uint32_t lo, uint32_t hi, uint32_t pos)
+{
+    for (uint32_t i = lo; i < hi; i++)
+        if (r->flip_pos[i] == pos) return r->flip_what[i];
+    return 0u;
+}
+
+static void replay_range(const replay_t* r, uint32_t pixel, uint32_t* lo, uint32_t* hi)
+{
+    uint32_t a = 0, b = r->n_flips;
+    while (a < b) {
+        const uint32_t m = (a + b) / 2;
+        if (r->flip_pixel[m] < pixel) a = m + 1; else b = m;
+    }
+    *lo = a;
+    while (a < r->n_flips && r->flip_pixel[a] == pixel) a++;
+    *hi = a;
+}
+
+/* one pixel of forward.cu:265-463 under forced decisions; out: color[3] | others[8] | T dist1 dist2 | last median */
+static void replay_pixel(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                         const float* features, const float* transMats, const float* normal_opacity, const float* bg,
+                         const replay_t* r, uint32_t pixel, uint32_t f_last, uint32_t f_med, float* out_color3,
+                         float* out_others8, float* out_T3, uint32_t* out_n2)
+{
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X;
+    const int pxi = (int)(pixel % (uint32_t)W), pyi = (int)(pixel / (uint32_t)W);
+    (void)H;
+    const int tile = (pyi / BLOCK_Y) * grid_x + pxi / BLOCK_X;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const float pixx = (float)pxi + 0.5f, pixy = (float)pyi + 0.5f;
+    uint32_t lo, hi;
+    replay_range(r, pixel, &lo, &hi);
+    float T = 1.0f;
+    uint32_t contributor = 0, last_contributor = 0, median_contributor = 0;
+    float C[3] = {0, 0, 0}, D = 0, N[3] = {0, 0, 0}, dist1 = 0, dist2 = 0, distortion = 0, median_depth = 0, median_weight = 0;
+    for (uint32_t i = r0; i < r1; i++) {
+        contributor++;
+        if (f_last != REPLAY_FREE && contributor > f_last) break;   /* the other implementation's walk ended here */
+        const uint32_t id = point_list[i];
+        const float* Tm = transMats + 9 * (size_t)id;
+        const float* no = normal_opacity + 4 * (size_t)id;
+        pair_eval e;
+        int use3d;
+        if (!eval_pair_replay(Tm, Tm + 3, Tm + 6, means2D + 2 * (size_t)id, no[3], pixx, pixy,
+                              replay_what(r, lo, hi, contributor), &e, &use3d, NULL, NULL))
+            continue;
+        const float alpha = e.alpha, depth = e.depth;
+        const float test_T = T * (1 - alpha);
+        if (f_last == REPLAY_FREE && test_T < 0.0001f) break;
+        const float A = 1 - T;
+        const float m = map_depth(depth);
+        const float error = m * m * A + dist2 - 2 * m * dist1;
+        distortion += error * alpha * T;
+        if (f_med == REPLAY_FREE ? (T > 0.5f) : (contributor == f_med)) {
+            median_depth = depth;
+            median_weight = alpha * T;
+            median_contributor = contributor;
+        }
+        for (int ch = 0; ch < 3; ch++) N[ch] += no[ch] * alpha * T;
+        D += depth * alpha * T;
+        dist1 += m * alpha * T;
+        dist2 += m * m * alpha * T;
+        for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * (size_t)id + ch] * alpha * T;
+        T = test_T;
+        last_contributor = contributor;
+    }
+    for (int ch = 0; ch < 3; ch++) out_color3[ch] = C[ch] + T * bg[ch];
+    out_others8[0] = D;
+    out_others8[1] = 1 - T;
+    for (int ch = 0; ch < 3; ch++) out_others8[2 + ch] = N[ch];
+    out_others8[5] = median_depth;
+    out_others8[6] = distortion;
+    out_others8[7] = median_weight;
+    out_T3[0] = T;
+    out_T3[1] = dist1;
+    out_T3[2] = dist2;
+    out_n2[0] = last_contributor;
+    out_n2[1] = median_contributor;
+}
+
+void oracle_replay_pixel(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                         const float* features, const float* transMats, const float* normal_opacity, const float* bg,
+                         uint32_t pixel, uint32_t forced_last, uint32_t forced_median, uint32_t n_flips,
+                         const uint32_t* flip_pos, const uint32_t* flip_what, float* out14, uint32_t* out_n2)
+{
+    uint32_t* pix = (uint32_t*)malloc(sizeof(uint32_t) * (n_flips ? n_flips : 1));
+    for (uint32_t i = 0; i < n_flips; i++) pix[i] = pixel;
+    const replay_t r = {NULL, NULL, n_flips, pix, flip_pos, flip_what};
+    replay_pixel(W, H, ranges, point_list, means2D, features, transMats, normal_opacity, bg, &r, pixel, forced_last,
+                 forced_median, out14, out14 + 3, out14 + 11, out_n2);
+    free(pix);
+}
+
+/* the pairs of a pixel, up to list position max_pos, within tol of a threshold: kind 1 = the accept test (alpha against
+ * 1/255, depth against the near plane), 2 = the rho3d <= rho2d branch; returns how many (at most max_out are written) */
+uint32_t oracle_pixel_candidates(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                                 const float* transMats, const float* normal_opacity, uint32_t pixel, uint32_t max_pos,
+                                 float tol_alpha, float tol_rho, uint32_t max_out, uint32_t* out_pos, uint32_t* out_kind,
+                                 float* out_margin)
+{
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X;
+    const int pxi = (int)(pixel % (uint32_t)W), pyi = (int)(pixel / (uint32_t)W);
+    (void)H;
+    const int tile = (pyi / BLOCK_Y) * grid_x + pxi / BLOCK_X;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const float pixx = (float)pxi + 0.5f, pixy = (float)pyi + 0.5f;
+    uint32_t n = 0, contributor = 0;
+    for (uint32_t i = r0; i < r1 && contributor < max_pos; i++) {
+        contributor++;
+        const uint32_t id = point_list[i];
+        const float* Tm = transMats + 9 * (size_t)id;
+        const float* no = normal_opacity + 4 * (size_t)id;
+        pair_eval e;
+        int use3d;
+        float ma = 1e30f, mr = 1e30f;
+        const int acc = eval_pair_replay(Tm, Tm + 3, Tm + 6, means2D + 2 * (size_t)id, no[3], pixx, pixy, 0u, &e, &use3d, &ma, &mr);
+        if (e.pz == 0.0f) continue;
+        if (ma <= tol_alpha) {
+            if (n < max_out) { out_pos[n] = contributor; out_kind[n] = 1u; out_margin[n] = ma; }
+            n++;
+        }
+        if (acc && mr <= tol_rho) {
+            if (n < max_out) { out_pos[n] = contributor; out_kind[n] = 2u; out_margin[n] = mr; }
+            n++;
+        }
+    }
+    return n;
+}
+
+/* forward.cu:265-463 for the whole image under forced decisions (oracle_render_forward's outputs) */
+void oracle_render_forward_replay(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                                  const float* features, const float* transMats, const float* normal_opacity,
+                                  const float* bg, const uint32_t* forced_last, const uint32_t* forced_median,
+                                  uint32_t n_flips, const uint32_t* flip_pixel, const uint32_t* flip_pos,
+                                  const uint32_t* flip_what, float* final_T, uint32_t* n_contrib, float* out_color,
+                                  float* out_others)
+{
+    const replay_t r = {forced_last, forced_median, n_flips, flip_pixel, flip_pos, flip_what};
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t p = 0; p < (int64_t)HW; p++) {
+        float c[3], o[8], t[3];
+        uint32_t n2[2];
+        replay_pixel(W, H, ranges, point_list, means2D, features, transMats, normal_opacity, bg, &r, (uint32_t)p,
+                     forced_last ? forced_last[p] : REPLAY_FREE, forced_median ? forced_median[p] : REPLAY_FREE, c, o, t, n2);
+        for (int ch = 0; ch < 3; ch++) out_color[ch * HW + p] = c[ch];
+        for (int k = 0; k < 8; k++) out_others[k * HW + p] = o[k];
+        for (int k = 0; k < 3; k++) final_T[k * HW + p] = t[k];
+        n_contrib[p] = n2[0];
+        n_contrib[HW + p] = n2[1];
+    }
+}
+
+/* backward.cu:143-449 under the same forced pair decisions (final_Ts / n_contrib: what the replayed forward left) */
+void oracle_render_backward_replay(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+                                   const float* means2D, const float* normal_opacity, const float* transMats,
+                                   const float* colors, const float* final_Ts, const uint32_t* n_contrib,
+                                   const float* dL_dpixels, const float* dL_depths, uint32_t n_flips,
+                                   const uint32_t* flip_pixel, const uint32_t* flip_pos, const uint32_t* flip_what,
+                                   double* dL_dtransMat, double* dL_dmean2D, double* dL_dnormal3D, double* dL_dopacity,
+                                   double* dL_dcolors)
+{
+    const replay_t r = {NULL, NULL, n_flips, flip_pixel, flip_pos, flip_what};
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < grid_x * grid_y; tile++) {
+        const int tx = tile % grid_x, ty = tile / grid_x;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        const uint32_t toDo = r1 - r0;
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                if (pxi >= W || pyi >= H) continue;
+                const size_t pix_id = (size_t)W * pyi + pxi;
+                const float pixx = (float)pxi + 0.5f, pixy = (float)pyi + 0.5f;
+                uint32_t flo, fhi;
+                replay_range(&r, (uint32_t)pix_id, &flo, &fhi);
+                const float T_final = final_Ts[pix_id];
+                float T = T_final;
+                uint32_t contributor = toDo;
+                const int last_contributor = (int)n_contrib[pix_id];
+                float accum_rec[3] = {0, 0, 0};
+                float dL_dpixel[3];
+                const float dL_ddepth = dL_depths[0 * HW + pix_id];
+                const float dL_daccum = dL_depths[1 * HW + pix_id];
+                const float dL_dreg = dL_depths[6 * HW + pix_id];
+                float dL_dnormal2D[3];
+                for (int i = 0; i < 3; i++) dL_dnormal2D[i] = dL_depths[(2 + i) * HW + pix_id];
+                const int median_contributor = (int)n_contrib[pix_id + HW];
+                const float dL_dmedian_depth = dL_depths[5 * HW + pix_id];
+                const float dL_dmax_dweight = dL_depths[7 * HW + pix_id];
+                float last_depth = 0, last_normal[3] = {0, 0, 0};
+                float accum_depth_rec = 0, accum_alpha_rec = 0, accum_normal_rec[3] = {0, 0, 0};
+                const float final_D = final_Ts[pix_id + HW];
+                const float final_D2 = final_Ts[pix_id + 2 * HW];
+                const float final_A = 1 - T_final;
+                float last_dL_dT = 0;
+                for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * HW + pix_id];
+                float last_alpha = 0, last_color[3] = {0, 0, 0};
+                float bg_dot_dpixel = 0;
+                for (int i = 0; i < 3; i++) bg_dot_dpixel += bg[i] * dL_dpixel[i];
+                for (uint32_t it = 0; it < toDo; it++) {
+                    contributor--;
+                    if ((int64_t)contributor >= (int64_t)last_contributor) continue;
+                    const uint32_t id = point_list[r1 - it - 1];
+                    const float* Tm = transMats + 9 * (size_t)id;
+                    const float* Tw = Tm + 6;
+                    const float* no = normal_opacity + 4 * (size_t)id;
+                    pair_eval e;
+                    int use3d;
+                    /* (`contributor` is 0-based here: list position contributor + 1) */
+                    if (!eval_pair_replay(Tm, Tm + 3, Tw, means2D + 2 * (size_t)id, no[3], pixx, pixy,
+                                          replay_what(&r, flo, fhi, contributor + 1u), &e, &use3d, NULL, NULL))
+                        continue;
+                    const float alpha = e.alpha, G = e.G, c_d = e.depth;
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float c = colors[3 * (size_t)id + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        const float dL_dchannel = dL_dpixel[ch];
+                        dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+#pragma omp atomic
+                        dL_dcolors[3 * (size_t)id + ch] += (double)(dchannel_dcolor * dL_dchannel);
+                    }
+                    float dL_dz = 0.0f;
+                    float dL_dweight = 0;
+                    const float m_d = map_depth(c_d);
+                    const float dmd_dd = (FAR_PLANE_F * NEAR_PLANE_F) / ((FAR_PLANE_F - NEAR_PLANE_F) * c_d * c_d);
+                    if ((int64_t)contributor == (int64_t)median_contributor - 1) {
+                        dL_dz += dL_dmedian_depth;
+                        dL_dweight += dL_dmax_dweight;
+                    }
+                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                    dL_dz += dL_dmd * dmd_dd;
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = c_d;
+                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                    for (int ch = 0; ch < 3; ch++) {
+                        accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                        last_normal[ch] = no[ch];
+                        dL_dalpha += (no[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
+#pragma omp atomic
+                        dL_dnormal3D[3 * (size_t)id + ch] += (double)(alpha * T * dL_dnormal2D[ch]);
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    const float dL_dG = no[3] * dL_dalpha;
+                    dL_dz += alpha * T * dL_ddepth;
+                    if (use3d) {
+                        const float dL_dsx = dL_dG * -G * e.sx + dL_dz * Tw[0];
+                        const float dL_dsy = dL_dG * -G * e.sy + dL_dz * Tw[1];
+                        const float dz_dTw[3] = {e.sx, e.sy, 1.0f};
+                        const float dsx_pz = dL_dsx / e.pz;
+                        const float dsy_pz = dL_dsy / e.pz;
+                        const float dp[3] = {dsx_pz, dsy_pz, -(dsx_pz * e.sx + dsy_pz * e.sy)};
+                        const float dk[3] = {e.ly * dp[2] - e.lz * dp[1], e.lz * dp[0] - e.lx * dp[2], e.lx * dp[1] - e.ly * dp[0]};
+                        const float dl[3] = {dp[1] * e.kz - dp[2] * e.ky, dp[2] * e.kx - dp[0] * e.kz, dp[0] * e.ky - dp[1] * e.kx};
+                        double* g = dL_dtransMat + 9 * (size_t)id;
+                        for (int c = 0; c < 3; c++) {
+                            const float dTw = pixx * dk[c] + pixy * dl[c] + dL_dz * dz_dTw[c];
+#pragma omp atomic
+                            g[c] += (double)(-dk[c]);
+#pragma omp atomic
+                            g[3 + c] += (double)(-dl[c]);
+#pragma omp atomic
+                            g[6 + c] += (double)dTw;
+                        }
+                    } else {
+                        const float dG_ddelx = -G * 2.0f * e.dx;
+                        const float dG_ddely = -G * 2.0f * e.dy;
+#pragma omp atomic
+                        dL_dmean2D[3 * (size_t)id + 0] += (double)(dL_dG * dG_ddelx);
+#pragma omp atomic
+                        dL_dmean2D[3 * (size_t)id + 1] += (double)(dL_dG * dG_ddely);
+#pragma omp atomic
+                        dL_dtransMat[9 * (size_t)id + 8] += (double)dL_dz;
+                    }
+#pragma omp atomic
+                    dL_dopacity[id] += (double)(G * dL_dalpha);
+                }
+            }
+    }
+}
+
+/* Plane 6 (distortion, forward.cu:411-428) in fp64 (round 6): the mathematical quantity
+ *     sum_i w_i sum_{j<i} w_j (m_i - m_j)^2,   w = alpha T,  m = mapped depth,
+ * from the SAME fp32 per-pair alpha / depth and the same walk as oracle_render_forward (decisions in fp32 as there), with
+ * everything behind them -- transmittance, weights, the mapped depth, the double sum in its direct pairwise-difference form via
+ * running moments ABOUT THE FIRST SAMPLE -- in double.  The reference's fp32 form m^2 A + M2 - 2 m M1 cancels three terms of size
+ * m^2 ~ 0.9 to (depth spread)^2; the product accumulates the moments about a per-tile reference depth instead.
+ * This is the yardstick a test holds both against. */
+void oracle_distortion_f64(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                           const float* transMats, const float* normal_opacity, double* out)
+{
+    const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < grid_x * grid_y; tile++) {
+        const int tx = tile % grid_x, ty = tile / grid_x;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                if (pxi >= W || pyi >= H) continue;
+                const size_t pix_id = (size_t)W * pyi + pxi;
+                const float pixx = (float)pxi + 0.5f, pixy = (float)pyi + 0.5f;
+                float Tf = 1.0f;              /* (the walk's own fp32 transmittance: decides where it ends, as the reference) */
+                double T = 1.0, A = 0.0, M1 = 0.0, M2 = 0.0, dist = 0.0, m0 = 0.0;
+                int first = 1;
+                for (uint32_t i = r0; i < r1; i++) {
+                    const uint32_t id = point_list[i];
+                    const float* Tm = transMats + 9 * (size_t)id;
+                    const float* no = normal_opacity + 4 * (size_t)id;
+                    pair_eval e;
+                    if (!eval_pair(Tm, Tm + 3, Tm + 6, means2D + 2 * (size_t)id, no[3], pixx, pixy, &e)) continue;
+                    const float test_T = Tf * (1 - e.alpha);
+                    if (test_T < 0.0001f) break;
+                    const double d = (double)e.depth, a = (double)e.alpha;
+                    double m = ((double)FAR_PLANE_F * d - (double)FAR_PLANE_F * (double)NEAR_PLANE_F) /
+                               (((double)FAR_PLANE_F - (double)NEAR_PLANE_F) * d);
+                    if (first) {
+                        m0 = m;
+                        first = 0;
+                    }
+                    m -= m0;
+                    const double w = a * T;
+                    dist += w * (m * m * A + M2 - 2.0 * m * M1);
+                    A += w;
+                    M1 += w * m;
+                    M2 += w * m * m;
+                    T *= 1.0 - a;
+                    Tf = test_T;
+                }
+                out[pix_id] = dist;
+            }
+    }
+}

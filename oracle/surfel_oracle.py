@@ -213,3 +213,12 @@ def mark_visible(means3D, viewmatrix):
     present = np.zeros(means3D.shape[0], np.uint8)
     lib().oracle_mark_visible(C.c_int(means3D.shape[0]), _p(means3D), _p(_f32(viewmatrix, (16,))), _p(present))
     return present.astype(bool)
+
+
+def distortion_f64(st):
+    """Plane 6 in fp64 from the oracle's own fp32 per-pair alpha / depth and walk (oracle_distortion_f64): the yardstick for
+    "which fp32 formulation of the distortion is closer to what it means" (tests/test_gpu_reference.py)."""
+    out = np.zeros((st["H"], st["W"]), np.float64)
+    lib().oracle_distortion_f64(C.c_int(st["W"]), C.c_int(st["H"]), _p(st["ranges"]), _p(st["point_list"]), _p(st["means2D"]),
+                                _p(st["transMat"]), _p(st["normal_opacity"]), _p(out))
+    return out

@@ -138,3 +138,34 @@ def test_reference_golden_fixtures_pin_the_oracle():
             assert_close(f"{f}:{k}", st[k], z[k], atol=2e-6, outlier_fraction=2e-3)
         for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh"):
             assert_close(f"{f}:{k}", g[k], z[k], outlier_fraction=2e-3)
+
+
+def test_decision_replay_explains_a_perturbed_run():
+    """oracle/decision_replay.py on the CPU: a second run of the oracle with every opacity 2e-5 larger differs from the first
+    by a few threshold flips (walk ends, median samples, accept decisions of pairs within rounding of 1/255) and by ~1e-5
+    otherwise; with those decisions forced into the first run every plane agrees to 1e-4 of scale.  And forcing NOTHING
+    reproduces the oracle bit for bit (the replay functions restate forward.cu:265-463 / backward.cu:143-449 a second time)."""
+    from oracle import decision_replay as dr
+    from vidu4d_amd.synthetic import make_scene, make_upstream_grads
+    sc = make_scene(12000, 112, 96, seed=5)
+
+    def fwd(opac):
+        return so.forward(sc.means3D, opac, sc.scales, sc.rotations, sc.viewmatrix, sc.projmatrix, sc.campos, sc.bg, sc.width,
+                          sc.height, sc.tanfovx, sc.tanfovy, sc.sh_degree, shs=sc.shs)
+    st = fwd(sc.opacities)
+    dc, do = make_upstream_grads(sc.width, sc.height)
+    g = so.backward(st, dc, do)
+    ex = dr.explain(st, st["color"], st["others"], st["n_contrib"])
+    assert ex["pixels"] == 0 and not ex["flips"]
+    out, g2 = dr.replay(st, ex, dc, do)
+    assert all(np.array_equal(out[k], st[k]) for k in ("color", "others", "final_T", "n_contrib"))
+    assert all(np.array_equal(g[k], g2[k]) for k in g)
+    other = fwd(sc.opacities * np.float32(1 + 2e-5))
+    ex = dr.explain(st, other["color"], other["others"], other["n_contrib"])
+    assert ex["pixels"] > 0 and not ex["unexplained"] and ex["max_margin"] <= 1e-4, ex
+    out, _ = dr.replay(st, ex, dc, do)
+    for k in ("color", "others"):
+        for a, b in zip(out[k], other[k]):
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + dr.DIST_ATOL
+    has = other["n_contrib"][0] > 0
+    assert np.array_equal(out["n_contrib"][0], other["n_contrib"][0]) and np.array_equal(out["n_contrib"][1][has], other["n_contrib"][1][has])
