@@ -40,8 +40,8 @@ PY
 
 case "$TASK" in
 tests)
-    ARGS=${*:-tests -m gpu -q}
-    timeout 2400 python -m pytest $ARGS --timeout=900 > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+    if [ $# -eq 0 ]; then set -- tests -m gpu -q; fi
+    timeout 2400 python -m pytest "$@" --timeout=900 > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
     grep -E "^(FAILED|ERROR)|passed|failed|rc " $O/pytest.log | tail -15
     ;;
 bench)
