@@ -30,7 +30,7 @@ def _u32(a):
     return np.ascontiguousarray(a, dtype=np.uint32)
 
 
-def _pixel_outputs(st, feats, bg, pixel, f_last, f_med, flips):
+def _pixel_outputs(st, feats, bg, pixel, f_last, f_med, flips, strict=0):
     L = so.lib()
     pos = _u32([f[0] for f in flips]) if flips else np.zeros(1, np.uint32)
     what = _u32([f[1] for f in flips]) if flips else np.zeros(1, np.uint32)
@@ -39,27 +39,30 @@ def _pixel_outputs(st, feats, bg, pixel, f_last, f_med, flips):
     L.oracle_replay_pixel(C.c_int(st["W"]), C.c_int(st["H"]), so._p(st["ranges"]), so._p(st["point_list"]), so._p(st["means2D"]),
                           so._p(feats), so._p(st["transMat"]), so._p(st["normal_opacity"]), so._p(bg), C.c_uint32(int(pixel)),
                           C.c_uint32(int(f_last)), C.c_uint32(int(f_med)), C.c_uint32(len(flips)), so._p(pos), so._p(what),
-                          so._p(out), so._p(n2))
+                          C.c_int(int(strict)), so._p(out), so._p(n2))
     return out, n2
 
 
-def _candidates(st, pixel, max_pos, cand_tol, max_out=64):
+def _candidates(st, pixel, max_pos, cand_tol, strict=0, max_out=64):
     L = so.lib()
     L.oracle_pixel_candidates.restype = C.c_uint32
     pos, kind, margin = np.zeros(max_out, np.uint32), np.zeros(max_out, np.uint32), np.zeros(max_out, np.float32)
     n = L.oracle_pixel_candidates(C.c_int(st["W"]), C.c_int(st["H"]), so._p(st["ranges"]), so._p(st["point_list"]),
                                   so._p(st["means2D"]), so._p(st["transMat"]), so._p(st["normal_opacity"]), C.c_uint32(int(pixel)),
-                                  C.c_uint32(int(max_pos)), C.c_float(cand_tol), C.c_float(cand_tol), C.c_uint32(max_out),
-                                  so._p(pos), so._p(kind), so._p(margin))
+                                  C.c_uint32(int(max_pos)), C.c_float(cand_tol), C.c_float(cand_tol), C.c_int(int(strict)),
+                                  C.c_uint32(max_out), so._p(pos), so._p(kind), so._p(margin))
     n = min(int(n), max_out)
     order = np.argsort(margin[:n])
     return [(int(pos[i]), int(kind[i]), float(margin[i])) for i in order]
 
 
-def explain(st, other_color, other_others, other_n_contrib, tol=1e-4, cand_tol=2e-3, max_flips=3, max_candidates=10):
+def explain(st, other_color, other_others, other_n_contrib, tol=1e-4, cand_tol=2e-3, max_flips=3, max_candidates=10, strict=0):
     """st: the oracle's forward state (surfel_oracle.forward); other_*: the other implementation's color (3,H,W), others
-    (8,H,W), n_contrib (2,H,W).  -> dict(pixels, explained, unexplained (list of pixel ids), flips [(pixel, pos, what)],
-    forced_last, forced_median, max_margin, by_kind)."""
+    (8,H,W), n_contrib (2,H,W).  strict: 1 when the other implementation evaluates the (pixel, surfel) pairs in the source's
+    unfused operation order (oracle/_ref's strict build) -- the oracle's side of the comparison is then ITS blend in that
+    order (oracle_render_forward_replay with nothing forced), not the explicit-FMA sequence it shares with the product.
+    -> dict(pixels, explained, unexplained (list of pixel ids), flips [(pixel, pos, what)], forced_last, forced_median,
+    max_margin, by_kind, strict)."""
     W, H = st["W"], st["H"]
     HW = W * H
     inp = st["_inputs"]
@@ -68,7 +71,11 @@ def explain(st, other_color, other_others, other_n_contrib, tol=1e-4, cand_tol=2
     oc = np.asarray(other_color, np.float32).reshape(3, HW)
     oo = np.asarray(other_others, np.float32).reshape(8, HW)
     on = np.asarray(other_n_contrib).astype(np.uint32).reshape(2, HW)
-    mc, mo, mn = st["color"].reshape(3, HW), st["others"].reshape(8, HW), st["n_contrib"].reshape(2, HW)
+    if strict:
+        base, _ = replay(st, dict(flips=[], forced_last=None, forced_median=None, strict=1), None, None)
+    else:
+        base = st
+    mc, mo, mn = base["color"].reshape(3, HW), base["others"].reshape(8, HW), base["n_contrib"].reshape(2, HW)
     s_color = float(np.abs(oc).max()) + 1e-30
     s_others = np.abs(oo).max(axis=1) + 1e-30
     tol_c = tol * s_color
@@ -89,18 +96,18 @@ def explain(st, other_color, other_others, other_n_contrib, tol=1e-4, cand_tol=2
         fl = int(on[0, p])
         fm = int(on[1, p]) if fl > 0 else 0
         forced_last[p], forced_median[p] = fl, fm
-        out, _ = _pixel_outputs(st, feats, bg, p, fl, fm, [])
+        out, _ = _pixel_outputs(st, feats, bg, p, fl, fm, [], strict)
         if matches(out, p):
             by_kind["walk_end_or_median_only"] += 1
             continue
-        cands = _candidates(st, p, max(fl, int(mn[0, p])) + 2, cand_tol)[:max_candidates]
+        cands = _candidates(st, p, max(fl, int(mn[0, p])) + 2, cand_tol, strict)[:max_candidates]
         found = None
         for k in range(1, max_flips + 1):
             for combo in itertools.combinations(cands, k):
                 fs = {}
                 for pos, kind, _m in combo:
                     fs[pos] = fs.get(pos, 0) | (1 if kind == 1 else 2)
-                out, _ = _pixel_outputs(st, feats, bg, p, fl, fm, sorted(fs.items()))
+                out, _ = _pixel_outputs(st, feats, bg, p, fl, fm, sorted(fs.items()), strict)
                 if matches(out, p):
                     found = (combo, fs)
                     break
@@ -118,11 +125,12 @@ def explain(st, other_color, other_others, other_n_contrib, tol=1e-4, cand_tol=2
             by_kind["accept" if kind == 1 else "branch"] += 1
     flips.sort()
     return dict(pixels=int(len(pixels)), explained=int(len(pixels) - len(unexplained)), unexplained=unexplained, flips=flips,
-                forced_last=forced_last, forced_median=forced_median, max_margin=max_margin, by_kind=by_kind)
+                forced_last=forced_last, forced_median=forced_median, max_margin=max_margin, by_kind=by_kind, strict=int(strict))
 
 
 def replay(st, ex, dL_dcolor, dL_dothers):
-    """The whole forward and backward of the oracle with the decisions of `ex` (explain()) forced.
+    """The whole forward and backward of the oracle with the decisions of `ex` (explain()) forced, in the operation order
+    `ex["strict"]` names.  dL_dcolor None: the forward only.
     -> (state dict with color / others / final_T / n_contrib replaced, gradient dict as surfel_oracle.backward)."""
     L = so.lib()
     W, H, P = st["W"], st["H"], st["P"]
@@ -140,8 +148,10 @@ def replay(st, ex, dL_dcolor, dL_dothers):
     L.oracle_render_forward_replay(C.c_int(W), C.c_int(H), so._p(st["ranges"]), so._p(st["point_list"]), so._p(st["means2D"]),
                                    so._p(feats), so._p(st["transMat"]), so._p(st["normal_opacity"]), so._p(inp["bg"]),
                                    so._p(ex["forced_last"]), so._p(ex["forced_median"]), C.c_uint32(nf), so._p(fp), so._p(fpos),
-                                   so._p(fwhat), so._p(out["final_T"]), so._p(out["n_contrib"]), so._p(out["color"]),
-                                   so._p(out["others"]))
+                                   so._p(fwhat), C.c_int(int(ex.get("strict", 0))), so._p(out["final_T"]), so._p(out["n_contrib"]),
+                                   so._p(out["color"]), so._p(out["others"]))
+    if dL_dcolor is None:
+        return out, None
     dL_dcolor = so._f32(dL_dcolor, (3, H, W))
     dL_dothers = so._f32(dL_dothers, (8, H, W))
     acc_T, acc_m2d = np.zeros((P, 9), np.float64), np.zeros((P, 3), np.float64)
@@ -149,8 +159,8 @@ def replay(st, ex, dL_dcolor, dL_dothers):
     L.oracle_render_backward_replay(C.c_int(W), C.c_int(H), so._p(st["ranges"]), so._p(st["point_list"]), so._p(inp["bg"]),
                                     so._p(st["means2D"]), so._p(st["normal_opacity"]), so._p(st["transMat"]), so._p(feats),
                                     so._p(out["final_T"]), so._p(out["n_contrib"]), so._p(dL_dcolor), so._p(dL_dothers),
-                                    C.c_uint32(nf), so._p(fp), so._p(fpos), so._p(fwhat), so._p(acc_T), so._p(acc_m2d),
-                                    so._p(acc_n), so._p(acc_o), so._p(acc_c))
+                                    C.c_uint32(nf), so._p(fp), so._p(fpos), so._p(fwhat), C.c_int(int(ex.get("strict", 0))), so._p(acc_T),
+                                    so._p(acc_m2d), so._p(acc_n), so._p(acc_o), so._p(acc_c))
     g = dict(dL_dtransMat=acc_T.astype(np.float32), dL_dmeans2D=acc_m2d.astype(np.float32), dL_dnormal=acc_n.astype(np.float32),
              dL_dopacity=acc_o.astype(np.float32).reshape(P, 1), dL_dcolors=acc_c.astype(np.float32))
     g["dL_dmeans2D_filter"] = g["dL_dmeans2D"].copy()

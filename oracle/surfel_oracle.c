@@ -947,35 +947,69 @@ typedef struct {
     const uint32_t* flip_pixel;
     const uint32_t* flip_pos;
     const uint32_t* flip_what;
+    int strict;   /* 1: the pair evaluation in the SOURCE's operation order without any fused multiply-add and with true
+                   * divisions (forward.cu:362-395 / backward.cu:287-325 under -ffp-contract=off: what oracle/_ref's strict build
+                   * executes), mapped depth in double as the source's double-typed macros force; 0: this oracle's explicit-FMA
+                   * sequence (eval_pair above; the product's).  The ray / splat intersection is a cross product of two nearly
+                   * parallel plane vectors: its two roundings differ by far more than 1e-4 on ill-conditioned pairs, which is
+                   * NOT a threshold flip -- a comparison with the strict build has to start from the strict build's order */
 } replay_t;
+
+static float map_depth_r(float depth, int strict)
+{
+    if (!strict) return map_depth(depth);
+    return (float)((100.0 * (double)depth - 100.0 * 0.2) / ((100.0 - 0.2) * (double)depth));
+}
 
 /* eval_pair without its early exits (a rejected pair may be forced in), the two decisions separated */
 static int eval_pair_replay(const float* Tu, const float* Tv, const float* Tw, const float* xy, float opacity, float pixx,
-                            float pixy, uint32_t what, pair_eval* e, int* use3d, float* margin_alpha, float* margin_rho)
+                            float pixy, uint32_t what, int strict, pair_eval* e, int* use3d, float* margin_alpha,
+                            float* margin_rho)
 {
-    e->kx = fmaf(pixx, Tw[0], -Tu[0]);
-    e->ky = fmaf(pixx, Tw[1], -Tu[1]);
-    e->kz = fmaf(pixx, Tw[2], -Tu[2]);
-    e->lx = fmaf(pixy, Tw[0], -Tv[0]);
-    e->ly = fmaf(pixy, Tw[1], -Tv[1]);
-    e->lz = fmaf(pixy, Tw[2], -Tv[2]);
-    const float px = fmaf(e->ky, e->lz, -(e->kz * e->ly));
-    const float py = fmaf(e->kz, e->lx, -(e->kx * e->lz));
-    const float pz = fmaf(e->kx, e->ly, -(e->ky * e->lx));
+    float px, py, pz;
+    if (strict) {   /* (this file is compiled with -ffp-contract=off: every operation below rounds on its own) */
+        e->kx = -Tu[0] + pixx * Tw[0];
+        e->ky = -Tu[1] + pixx * Tw[1];
+        e->kz = -Tu[2] + pixx * Tw[2];
+        e->lx = -Tv[0] + pixy * Tw[0];
+        e->ly = -Tv[1] + pixy * Tw[1];
+        e->lz = -Tv[2] + pixy * Tw[2];
+        px = e->ky * e->lz - e->kz * e->ly;   /* auxiliary.h:152-158 */
+        py = e->kz * e->lx - e->kx * e->lz;
+        pz = e->kx * e->ly - e->ky * e->lx;
+    } else {
+        e->kx = fmaf(pixx, Tw[0], -Tu[0]);
+        e->ky = fmaf(pixx, Tw[1], -Tu[1]);
+        e->kz = fmaf(pixx, Tw[2], -Tu[2]);
+        e->lx = fmaf(pixy, Tw[0], -Tv[0]);
+        e->ly = fmaf(pixy, Tw[1], -Tv[1]);
+        e->lz = fmaf(pixy, Tw[2], -Tv[2]);
+        px = fmaf(e->ky, e->lz, -(e->kz * e->ly));
+        py = fmaf(e->kz, e->lx, -(e->kx * e->lz));
+        pz = fmaf(e->kx, e->ly, -(e->ky * e->lx));
+    }
     if (pz == 0.0f) return 0;
     e->pz = pz;
-    const float ipz = 1.0f / pz;
-    e->sx = px * ipz;
-    e->sy = py * ipz;
-    e->rho3d = fmaf(e->sx, e->sx, e->sy * e->sy);
     e->dx = xy[0] - pixx;
     e->dy = xy[1] - pixy;
-    e->rho2d = 2.0f * fmaf(e->dx, e->dx, e->dy * e->dy);
+    if (strict) {
+        e->sx = px / pz;
+        e->sy = py / pz;
+        e->rho3d = e->sx * e->sx + e->sy * e->sy;
+        e->rho2d = 2.0f * (e->dx * e->dx + e->dy * e->dy);
+    } else {
+        const float ipz = 1.0f / pz;
+        e->sx = px * ipz;
+        e->sy = py * ipz;
+        e->rho3d = fmaf(e->sx, e->sx, e->sy * e->sy);
+        e->rho2d = 2.0f * fmaf(e->dx, e->dx, e->dy * e->dy);
+    }
     int b3d = e->rho3d <= e->rho2d;
     if (what & 2u) b3d = !b3d;
     *use3d = b3d;
     const float rho = e->rho3d < e->rho2d ? e->rho3d : e->rho2d;
-    e->depth = b3d ? fmaf(e->sx, Tw[0], fmaf(e->sy, Tw[1], Tw[2])) : Tw[2];
+    if (strict) e->depth = b3d ? (e->sx * Tw[0] + e->sy * Tw[1]) + Tw[2] : Tw[2];
+    else e->depth = b3d ? fmaf(e->sx, Tw[0], fmaf(e->sy, Tw[1], Tw[2])) : Tw[2];
     const float power = -0.5f * rho;
     e->G = expf(power);
     const float a = opacity * e->G;
@@ -1038,13 +1072,13 @@ static void replay_pixel(int W, int H, const uint32_t* ranges, const uint32_t* p
         pair_eval e;
         int use3d;
         if (!eval_pair_replay(Tm, Tm + 3, Tm + 6, means2D + 2 * (size_t)id, no[3], pixx, pixy,
-                              replay_what(r, lo, hi, contributor), &e, &use3d, NULL, NULL))
+                              replay_what(r, lo, hi, contributor), r->strict, &e, &use3d, NULL, NULL))
             continue;
         const float alpha = e.alpha, depth = e.depth;
         const float test_T = T * (1 - alpha);
         if (f_last == REPLAY_FREE && test_T < 0.0001f) break;
         const float A = 1 - T;
-        const float m = map_depth(depth);
+        const float m = map_depth_r(depth, r->strict);
         const float error = m * m * A + dist2 - 2 * m * dist1;
         distortion += error * alpha * T;
         if (f_med == REPLAY_FREE ? (T > 0.5f) : (contributor == f_med)) {
@@ -1077,11 +1111,11 @@ static void replay_pixel(int W, int H, const uint32_t* ranges, const uint32_t* p
 void oracle_replay_pixel(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
                          const float* features, const float* transMats, const float* normal_opacity, const float* bg,
                          uint32_t pixel, uint32_t forced_last, uint32_t forced_median, uint32_t n_flips,
-                         const uint32_t* flip_pos, const uint32_t* flip_what, float* out14, uint32_t* out_n2)
+                         const uint32_t* flip_pos, const uint32_t* flip_what, int strict, float* out14, uint32_t* out_n2)
 {
     uint32_t* pix = (uint32_t*)malloc(sizeof(uint32_t) * (n_flips ? n_flips : 1));
     for (uint32_t i = 0; i < n_flips; i++) pix[i] = pixel;
-    const replay_t r = {NULL, NULL, n_flips, pix, flip_pos, flip_what};
+    const replay_t r = {NULL, NULL, n_flips, pix, flip_pos, flip_what, strict};
     replay_pixel(W, H, ranges, point_list, means2D, features, transMats, normal_opacity, bg, &r, pixel, forced_last,
                  forced_median, out14, out14 + 3, out14 + 11, out_n2);
     free(pix);
@@ -1091,8 +1125,8 @@ void oracle_replay_pixel(int W, int H, const uint32_t* ranges, const uint32_t* p
  * 1/255, depth against the near plane), 2 = the rho3d <= rho2d branch; returns how many (at most max_out are written) */
 uint32_t oracle_pixel_candidates(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
                                  const float* transMats, const float* normal_opacity, uint32_t pixel, uint32_t max_pos,
-                                 float tol_alpha, float tol_rho, uint32_t max_out, uint32_t* out_pos, uint32_t* out_kind,
-                                 float* out_margin)
+                                 float tol_alpha, float tol_rho, int strict, uint32_t max_out, uint32_t* out_pos,
+                                 uint32_t* out_kind, float* out_margin)
 {
     const int grid_x = (W + BLOCK_X - 1) / BLOCK_X;
     const int pxi = (int)(pixel % (uint32_t)W), pyi = (int)(pixel / (uint32_t)W);
@@ -1109,7 +1143,7 @@ uint32_t oracle_pixel_candidates(int W, int H, const uint32_t* ranges, const uin
         pair_eval e;
         int use3d;
         float ma = 1e30f, mr = 1e30f;
-        const int acc = eval_pair_replay(Tm, Tm + 3, Tm + 6, means2D + 2 * (size_t)id, no[3], pixx, pixy, 0u, &e, &use3d, &ma, &mr);
+        const int acc = eval_pair_replay(Tm, Tm + 3, Tm + 6, means2D + 2 * (size_t)id, no[3], pixx, pixy, 0u, strict, &e, &use3d, &ma, &mr);
         if (e.pz == 0.0f) continue;
         if (ma <= tol_alpha) {
             if (n < max_out) { out_pos[n] = contributor; out_kind[n] = 1u; out_margin[n] = ma; }
@@ -1128,10 +1162,10 @@ void oracle_render_forward_replay(int W, int H, const uint32_t* ranges, const ui
                                   const float* features, const float* transMats, const float* normal_opacity,
                                   const float* bg, const uint32_t* forced_last, const uint32_t* forced_median,
                                   uint32_t n_flips, const uint32_t* flip_pixel, const uint32_t* flip_pos,
-                                  const uint32_t* flip_what, float* final_T, uint32_t* n_contrib, float* out_color,
-                                  float* out_others)
+                                  const uint32_t* flip_what, int strict, float* final_T, uint32_t* n_contrib,
+                                  float* out_color, float* out_others)
 {
-    const replay_t r = {forced_last, forced_median, n_flips, flip_pixel, flip_pos, flip_what};
+    const replay_t r = {forced_last, forced_median, n_flips, flip_pixel, flip_pos, flip_what, strict};
     const size_t HW = (size_t)H * W;
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t p = 0; p < (int64_t)HW; p++) {
@@ -1153,10 +1187,10 @@ void oracle_render_backward_replay(int W, int H, const uint32_t* ranges, const u
                                    const float* colors, const float* final_Ts, const uint32_t* n_contrib,
                                    const float* dL_dpixels, const float* dL_depths, uint32_t n_flips,
                                    const uint32_t* flip_pixel, const uint32_t* flip_pos, const uint32_t* flip_what,
-                                   double* dL_dtransMat, double* dL_dmean2D, double* dL_dnormal3D, double* dL_dopacity,
-                                   double* dL_dcolors)
+                                   int strict, double* dL_dtransMat, double* dL_dmean2D, double* dL_dnormal3D,
+                                   double* dL_dopacity, double* dL_dcolors)
 {
-    const replay_t r = {NULL, NULL, n_flips, flip_pixel, flip_pos, flip_what};
+    const replay_t r = {NULL, NULL, n_flips, flip_pixel, flip_pos, flip_what, strict};
     const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
     const size_t HW = (size_t)H * W;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -1207,7 +1241,7 @@ void oracle_render_backward_replay(int W, int H, const uint32_t* ranges, const u
                     int use3d;
                     /* (`contributor` is 0-based here: list position contributor + 1) */
                     if (!eval_pair_replay(Tm, Tm + 3, Tw, means2D + 2 * (size_t)id, no[3], pixx, pixy,
-                                          replay_what(&r, flo, fhi, contributor + 1u), &e, &use3d, NULL, NULL))
+                                          replay_what(&r, flo, fhi, contributor + 1u), strict, &e, &use3d, NULL, NULL))
                         continue;
                     const float alpha = e.alpha, G = e.G, c_d = e.depth;
                     T = T / (1.f - alpha);
@@ -1224,8 +1258,9 @@ void oracle_render_backward_replay(int W, int H, const uint32_t* ranges, const u
                     }
                     float dL_dz = 0.0f;
                     float dL_dweight = 0;
-                    const float m_d = map_depth(c_d);
-                    const float dmd_dd = (FAR_PLANE_F * NEAR_PLANE_F) / ((FAR_PLANE_F - NEAR_PLANE_F) * c_d * c_d);
+                    const float m_d = map_depth_r(c_d, strict);
+                    const float dmd_dd = strict ? (float)((100.0 * 0.2) / ((100.0 - 0.2) * (double)c_d * (double)c_d))
+                                                : (FAR_PLANE_F * NEAR_PLANE_F) / ((FAR_PLANE_F - NEAR_PLANE_F) * c_d * c_d);
                     if ((int64_t)contributor == (int64_t)median_contributor - 1) {
                         dL_dz += dL_dmedian_depth;
                         dL_dweight += dL_dmax_dweight;
