@@ -71,7 +71,11 @@ def test_captured_steps_follow_the_eager_trajectory(gpu_device, regime):
     for la, lb, lc in zip(out["captured"][0], out["eager"][0], out["eager2"][0]):
         for k in lb:
             noise = abs(lb[k] - lc[k])
-            assert abs(la[k] - lb[k]) <= max(2e-4 * abs(lb[k]), 4 * noise) + 1e-7, (k, la, lb, lc)
+            # (with networks that train AdamW's normalised updates turn the atomics' noise into +- lr steps of near-zero-gradient
+            # weights: two EAGER runs have been seen 2e-4 apart on a loss term after 14 steps, and a single pair of runs is a
+            # poor estimate of that spread)
+            rel = 1e-3 if regime == "networks_train" else 2e-4
+            assert abs(la[k] - lb[k]) <= max(rel * abs(lb[k]), 4 * noise) + 1e-7, (k, la, lb, lc)
     lrs = (5e-5, 2.5e-3, 2.5e-3 / 20, 0.05, 5e-3, 1e-3, 2.5e-3, 2.5e-3)
     for a, b, c, lr in zip(out["captured"][1], out["eager"][1], out["eager2"][1], lrs):
         d, noise = (a - b).abs(), (b - c).abs()
