@@ -105,6 +105,11 @@ trace_gaps)
     done | tee $R/$O/r06_fit_optim_warp_gaps.txt
     cd $R
     ;;
+ubench)
+    # a microbenchmark of tools/ubench (built here if the binary did not travel): ubench <name>
+    N=$1; [ -x tools/ubench/$N ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -o tools/ubench/$N tools/ubench/$N.hip
+    timeout 600 tools/ubench/$N | tee $O/r06_ubench_$N.txt
+    ;;
 matrix)
     timeout 1500 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log | tail -1 > $O/r06_bench_line_cfgB.json; line $O/r06_bench_line_cfgB.json
     timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver.log 2>&1; grep "^{" $O/bench_driver.log | tail -1 > $O/r06_bench_line_cfgB_driver_form.json; line $O/r06_bench_line_cfgB_driver_form.json
