@@ -17,7 +17,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 TAG=${TAG:-r06}
 O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 TASK=${1:-tests}; shift || true
-QUICK="--cpu-images 0 --torch-cpu-images 0 --fit-steps 0 --fit-densify-steps 0 --per-frame-surface 0 --host-probe 0 --fit-optim-warp 0"
+QUICK="--cpu-images 0 --torch-cpu-images 0 --fit-densify-steps 0 --per-frame-surface 0 --host-probe 0 --fit-optim-warp 0 --fit-steps 0"
 
 line() {  # prints the fields of a bench line that the A/B tables quote
 python - "$1" <<'PY'
@@ -109,6 +109,21 @@ ubench)
     # a microbenchmark of tools/ubench (built here if the binary did not travel): ubench <name>
     N=$1; [ -x tools/ubench/$N ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -o tools/ubench/$N tools/ubench/$N.hip
     timeout 600 tools/ubench/$N | tee $O/r06_ubench_$N.txt
+    ;;
+seg_variants)
+    # the segment-parallel path with 256-entry segments (a variant build) against the product's 512, on the fitting scene
+    cp vidu4d_amd/csrc/libvidu4d_surfel.so /tmp/product.so
+    {
+    for V in product seg256; do
+      if [ $V = seg256 ]; then cp variants/seg256.so vidu4d_amd/csrc/libvidu4d_surfel.so; export VIDU4D_SEG_LEN=256; else cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so; unset VIDU4D_SEG_LEN; fi
+      for SPLIT in auto 1; do for SG in 0 1; do
+        echo -n "$V split=$SPLIT spec_geom=$SG : "
+        VIDU4D_SURFEL_SPLIT=$SPLIT VIDU4D_SURFEL_SPEC_GEOM=$SG timeout 600 python bench.py $QUICK --fit-steps 60 --repeats 0 2>/dev/null | grep "^{" | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'fit', round(d['fit_step']['images_per_s']), round(d['fit_step']['ms_per_step'],3), 'geometry', round(d['fit_step_geometry']['images_per_s']), round(d['fit_step_geometry']['ms_per_step'],3))"
+      done; done
+    done
+    } | tee $O/r06_seg256_ab.txt
+    cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so
     ;;
 matrix)
     timeout 1500 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log | tail -1 > $O/r06_bench_line_cfgB.json; line $O/r06_bench_line_cfgB.json

@@ -45,6 +45,7 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = int(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_LEN", "2048"))
 SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU", "2.0"))
+SEG_LEN = int(os.environ.get("VIDU4D_SEG_LEN", "512"))   # csrc/surfel_state.h SEG_LEN (a variant build with another length says so here)
 MSD_SORT_FROM = int(os.environ.get("VIDU4D_MSD_SORT_FROM", "10000"))  # longest list from which the long lists are MSD-split
 # The segment-parallel alpha-only blend runs without its transmittance pre-pass (Vidu4dSurfelForwardArgs::
 # assume_unsaturated): segments are blended from T = 1 and scaled in the combine, which blends the one segment a pixel
@@ -443,7 +444,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             if ctx.unlimited.get(key, 0) > 0:
                 ctx.unlimited[key] -= 1
             else:
-                a.segment_split = max(2, (int(depth * 1.25) + 511) // 512 + 1)
+                a.segment_split = max(2, (int(depth * 1.25) + SEG_LEN - 1) // SEG_LEN + 1)
         if _deferred and not debug and hint is not None and not _EXACT:
             # (the header is read back after the blend anyway: the depth counter lives in it -- word 12, zeroed by the
             # projection kernel -- instead of in a tensor of its own that wants a reset and a copy per frame)
