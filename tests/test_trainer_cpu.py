@@ -92,3 +92,34 @@ def test_network_gradients_accumulate_within_a_round():
     assert not torch.equal(before, used.detach())
     assert torch.allclose(fake_step(5, 2.0), torch.full_like(used, 2.0))      # ... and zeroes what it consumed
     assert len(tr.optimizer.state[unused]) == 0                                 # never updated, no weight decay
+
+
+def test_which_steps_may_be_replayed_from_a_captured_graph():
+    """lab4d/captured_step.py replays PLAIN steps only -- the host decisions of the schedule (trainer.py:465-466 SH degree,
+    :549-591 densify / prune / opacity reset / outlier pass, :449 and :592-598 the networks' round and their AdamW) stay in the
+    eager loop.  The predicate, on the CPU (where nothing is ever captured: there is no CPU rasterizer)."""
+    import numpy as np
+    from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+    from vidu4d_amd.lab4d.stage3 import Stage3Trainer
+    rng = np.random.default_rng(0)
+
+    def trainer(**opts):
+        m = DeformableSurfels(dict(fg_motion="gs-bob", **opts), num_frames=4, device="cpu")
+        m.init_from_points(rng.normal(size=(50, 3)).astype(np.float32) * 0.1, rng.uniform(size=(50, 3)).astype(np.float32))
+        return m, Stage3Trainer(m, dict(m.opts))
+    m, tr = trainer()
+    assert tr.captured_step is False                      # (surfels on the CPU)
+    assert not tr._plain_step(0)                          # SH degree 0 -> 1, opacity reset
+    assert tr._plain_step(1) and tr._plain_step(499) and tr._plain_step(550)
+    assert not tr._plain_step(600)                        # densify (from 500, every 100)
+    assert not tr._plain_step(1000) and not tr._plain_step(3000)   # SH raise; opacity reset
+    m.active_sh_degree = m.max_sh_degree
+    assert tr._plain_step(4001)
+    assert not tr._plain_step(4000)                       # densify + the outlier pass (every 2000 from 500)
+    assert tr._plain_step(15000) and tr._plain_step(16000)   # past densify_until_iter: nothing but SH, which is at its maximum
+    m2, tr2 = trainer(gs_optim_warp=True, optim_warp_neus_iters=12000, iters_per_round=200, num_rounds=100)
+    m2.active_sh_degree = m2.max_sh_degree
+    assert tr2.optimizer is not None
+    assert not tr2._plain_step(11999)                     # the networks' gradients still accumulate over the round
+    assert not tr2._plain_step(12000) and not tr2._plain_step(12200)   # a round starts: accumulation reset
+    assert tr2._plain_step(12001) and not tr2._plain_step(12100)       # ... 12100 densifies

@@ -6,7 +6,8 @@ from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
 dev = torch.device("cuda:0")
 N, H, W, frames = 200000, 512, 512, 120
 rng = np.random.default_rng(0)
-m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0, fused_warp_trainable=os.environ.get("FUSED", "1") == "1"), num_frames=frames, device=dev)
+m = DeformableSurfels(dict(fg_motion="gs-bob", densify_until_iter=0, fused_warp_trainable=os.environ.get("FUSED", "1") == "1",
+                           captured_step=os.environ.get("CAPTURED", "0") == "1"), num_frames=frames, device=dev)   # (eager: the ops keep their names)
 d = rng.normal(size=(N, 3)).astype(np.float32)
 pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(N, 1)).astype(np.float32) ** (1 / 3)
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32))
@@ -25,4 +26,9 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for i in range(3): tr.train_step(batches[i % 4])
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=90))
+if os.environ.get("BY_STACK", "0") == "1":   # which lines of the host code the small launches come from
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], with_stack=True) as prof2:
+        for i in range(3): tr.train_step(batches[i % 4])
+        torch.cuda.synchronize()
+    print(prof2.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=60, max_src_column_width=110))
 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=20, max_name_column_width=70))
