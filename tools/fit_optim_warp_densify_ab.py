@@ -1,0 +1,24 @@
+import sys, time, os, numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from vidu4d_amd.lab4d.deformable_surfels import DeformableSurfels
+from vidu4d_amd.lab4d.stage3 import Stage3Trainer, synthetic_batch
+dev = torch.device("cuda:0")
+N, H, W, frames = 200000, 512, 512, 120
+rng = np.random.default_rng(0)
+for captured in ("auto", False):
+    torch.manual_seed(0)
+    m = DeformableSurfels(dict(fg_motion="gs-bob", captured_step=captured, densify_until_iter=15000), num_frames=frames, device=dev)
+    d = rng.normal(size=(N, 3)).astype(np.float32)
+    pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(N, 1)).astype(np.float32) ** (1 / 3)
+    m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32))
+    tr = Stage3Trainer(m, m.opts | dict(gs_optim_warp=True))
+    m.active_sh_degree = m.max_sh_degree
+    tr.current_steps = 12001
+    batches = [synthetic_batch(m, [(2 * i) % frames, (2 * i + 1) % frames], H, W, seed=i) for i in range(8)]
+    for i in range(20): tr.train_step(batches[i % 8])
+    tr.current_steps = 12021
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    K = 330
+    for i in range(K): tr.train_step(batches[i % 8])
+    tr.settle(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+    print(f"networks train + densify / prune every 100 steps, captured_step={captured}: {dt*1e3:.3f} ms/step over {K} steps, surfels {m._xyz.shape[0]}, stats {tr.captured_stats}")

@@ -698,8 +698,11 @@ class Stage3Trainer:
             from .captured_step import CapturedStep
             if len(self._captured) >= 4:
                 self._captured.clear()
+            import time as _time
+            t0 = _time.perf_counter()
             cs = self._captured[key] = CapturedStep(self, batch, step)
             self.captured_stats["captures"] += 1
+            self.captured_stats["capture_ms"] = self.captured_stats.get("capture_ms", 0.0) + 1e3 * (_time.perf_counter() - t0)
         losses = cs.replay(batch)
         self.captured_stats["replays"] += 1
         self._inflight = (cs, batch)
