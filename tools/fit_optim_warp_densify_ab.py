@@ -11,7 +11,7 @@ for captured in ("auto", False):
     d = rng.normal(size=(N, 3)).astype(np.float32)
     pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 1.0, size=(N, 1)).astype(np.float32) ** (1 / 3)
     m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32))
-    tr = Stage3Trainer(m, m.opts | dict(gs_optim_warp=True))
+    tr = Stage3Trainer(m, m.opts | dict(gs_optim_warp=True, num_rounds=100, iters_per_round=200))
     m.active_sh_degree = m.max_sh_degree
     tr.current_steps = 12001
     batches = [synthetic_batch(m, [(2 * i) % frames, (2 * i + 1) % frames], H, W, seed=i) for i in range(8)]
