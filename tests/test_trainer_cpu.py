@@ -107,7 +107,7 @@ def test_which_steps_may_be_replayed_from_a_captured_graph():
         m = DeformableSurfels(dict(fg_motion="gs-bob", **opts), num_frames=4, device="cpu")
         m.init_from_points(rng.normal(size=(50, 3)).astype(np.float32) * 0.1, rng.uniform(size=(50, 3)).astype(np.float32))
         return m, Stage3Trainer(m, dict(m.opts))
-    m, tr = trainer()
+    m, tr = trainer(captured_step=True)                   # (forced on: also inside the densification regime)
     assert tr.captured_step is False                      # (surfels on the CPU)
     assert not tr._plain_step(0)                          # SH degree 0 -> 1, opacity reset
     assert tr._plain_step(1) and tr._plain_step(499) and tr._plain_step(550)
@@ -117,7 +117,10 @@ def test_which_steps_may_be_replayed_from_a_captured_graph():
     assert tr._plain_step(4001)
     assert not tr._plain_step(4000)                       # densify + the outlier pass (every 2000 from 500)
     assert tr._plain_step(15000) and tr._plain_step(16000)   # past densify_until_iter: nothing but SH, which is at its maximum
-    m2, tr2 = trainer(gs_optim_warp=True, optim_warp_neus_iters=12000, iters_per_round=200, num_rounds=100)
+    m1, tr1 = trainer()                                   # "auto": the densification regime (steps 500 .. 15000) stays eager
+    m1.active_sh_degree = m1.max_sh_degree
+    assert tr1._plain_step(499) and not tr1._plain_step(550) and not tr1._plain_step(14999) and tr1._plain_step(15001)
+    m2, tr2 = trainer(gs_optim_warp=True, optim_warp_neus_iters=12000, iters_per_round=200, num_rounds=100, captured_step=True)
     m2.active_sh_degree = m2.max_sh_degree
     assert tr2.optimizer is not None
     assert not tr2._plain_step(11999)                     # the networks' gradients still accumulate over the round

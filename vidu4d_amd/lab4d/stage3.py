@@ -193,6 +193,12 @@ class Stage3Trainer:
         # box, 200 k surfels / 512^2: 3.01 -> 2.65 ms per step); with frozen networks the eager step is GPU-bound already and
         # a replayed graph costs ~1.5 us more per node on this runtime (1.10 -> 1.19 ms): eager stays (profiles/r06_graph_env_ab.txt)
         want = o.get("captured_step", "auto")
+        # ("auto" also keeps the densification regime eager: every densify / prune re-creates the surfel tensors, i.e. a new
+        # capture (14.6 ms each at 200 k surfels) every 100 steps plus a taken-back step whenever the pair count has outgrown
+        # the captured buffers -- measured with training networks, tools/fit_optim_warp_densify_ab.py: 3.33 ms per step
+        # captured against 2.59 eager.  In the reference's schedule the networks' optimizer starts at step 12 000 and
+        # densification ends at 15 000: the captured steps are the ones behind that.)
+        self._capture_while_densifying = want is True
         want = self.optimizer is not None if want == "auto" else bool(want)
         self.captured_step = want and m._xyz.is_cuda and self.world == 1
         self._captured, self._cap_stream, self._inflight, self._streak = {}, None, None, (None, 0)
@@ -610,6 +616,8 @@ class Stage3Trainer:
         if step % 1000 == 0 and m.active_sh_degree < m.max_sh_degree:
             return False
         if step < c.densify_until_iter:
+            if step > c.densify_from_iter and not self._capture_while_densifying:
+                return False          # ("auto": the densification regime stays eager, see __init__)
             if step > c.densify_from_iter and step % c.densification_interval == 0:
                 return False
             if step % c.opacity_reset_interval == 0:
