@@ -166,7 +166,10 @@ class Stage3Trainer:
             fused = on_gpu and o.get("fused_network_adamw", True)
             # (captured steps, lab4d/captured_step.py: the step counters and the learning rates live on the device -- torch's
             # capturable form of the same update; the scheduler below fills the rate tensors)
-            capt = fused and self.world == 1 and bool(o.get("captured_step", "auto"))
+            # (whether or not steps end up being replayed from a graph: torch's capturable form evaluates the bias corrections
+            # on the device in fp32, the other one on the host in double -- 1e-7 apart per step, which AdamW's normalised
+            # updates amplify; one form for both keeps the captured and the eager loop on ONE trajectory)
+            capt = fused and self.world == 1 and bool(o.get("capturable_network_adamw", True))
             self.optimizer = torch.optim.AdamW(groups, lr=torch.tensor(float(c.learning_rate), device=m._xyz.device) if capt
                                                else c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
                                                **({"fused": True} if fused else {}), **({"capturable": True} if capt else {}))
