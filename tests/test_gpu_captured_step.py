@@ -79,7 +79,11 @@ def test_captured_steps_follow_the_eager_trajectory(gpu_device, regime):
     lrs = (5e-5, 2.5e-3, 2.5e-3 / 20, 0.05, 5e-3, 1e-3, 2.5e-3, 2.5e-3)
     for a, b, c, lr in zip(out["captured"][1], out["eager"][1], out["eager2"][1], lrs):
         d, noise = (a - b).abs(), (b - c).abs()
-        assert float(d.median()) <= 4 * float(noise.median()) + 1e-6 + 1e-5 * float(b.abs().median()), (lr, float(d.median()))
+        # (networks that train: the run-to-run divergence sets in at a random step -- tools/captured_noise_probe.py: pairs of
+        # EAGER runs are 3e-7 .. 1e-5 apart in the median of xyz after 14 steps -- so the bound is a fraction of ONE Adam step:
+        # a replay that skipped an update, or ran it with another step's scalars, moves every entry by about lr)
+        slack = 0.5 * lr if regime == "networks_train" else 0.0
+        assert float(d.median()) <= 4 * float(noise.median()) + 1e-6 + 1e-5 * float(b.abs().median()) + slack, (lr, float(d.median()))
         assert float(d.max()) <= 8 * lr + 4 * float(noise.max()) + 1e-4 * float(b.abs().max()), (lr, float(d.max()))
     d, noise = (out["captured"][2] - out["eager"][2]).abs(), (out["eager"][2] - out["eager2"][2]).abs()
     if regime == "networks_train":
