@@ -530,3 +530,17 @@ def test_a_run_without_rgb_loss_only_does_not_silently_train_the_reduced_objecti
     opts, _ = train.parse_flags(["--rgb_loss_only"])
     train.check_loss_flags(opts)
     assert capsys.readouterr().out == ""
+
+
+def test_replayed_counters_carry_their_provenance():
+    """bench.py's `roofline.traffic` / `roofline.limiter` are not measured by the run that prints them: they are replayed from
+    profiles/pmc_traffic.json (rocprofv3 counter passes need runs of their own) and the line says so in `roofline.replayed_from`
+    -- which needs the file to carry the tree and the day it was measured on (tools/stamp_profiles.py)."""
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json"))).get("_meta")
+    assert meta and re.fullmatch(r"[0-9a-f]{7,40}", meta["commit"]) and re.fullmatch(r"\d{4}-\d{2}-\d{2}", meta["date"]), meta
+    src = open(os.path.join(root, "bench.py")).read()
+    assert '"replayed_from": replayed_from' in src and 'meta.get("commit")' in src
