@@ -52,7 +52,7 @@ extern "C" {
 #define VIDU4D_E_UNSUPPORTED (-4)  /* reference feature that is undefined upstream (see message) */
 
 /* ABI version of this header; bumped on any struct change. */
-#define VIDU4D_SURFEL_ABI 20
+#define VIDU4D_SURFEL_ABI 21
 int vidu4d_surfel_abi_version(void);
 const char* vidu4d_last_error(void);
 
@@ -192,6 +192,15 @@ typedef struct Vidu4dSurfelForwardArgs {
                                         * segments up in ONE launch that also blends the saturating segments of a tile again,
                                         * one after the other (rounds 3-4); default since round 5: three launches -- scan,
                                         * one workgroup per saturating (tile, segment), add up.  Same results. */
+#define VIDU4D_SCHED_PAIR(K) (((K) & 15) << 12)        /* (ABI 21, read by the forward with segment_split == 0; carried in debug_flags like
+                                        * VIDU4D_SCHED_XCD_BLOCK, which it excludes) the LONGEST tiles of the launch are blended
+                                        * by TWO workgroups each -- one per half of the tile's pixels, every wave on one 8x4 block
+                                        * with its two halves on consecutive list entries and the transmittance recurrence run
+                                        * over both -- so that a launch whose tiles all start at once does not wait for one
+                                        * workgroup's walk of its longest list.  K = 1..14: the tiles longer than about K / 4 x the
+                                        * mean list length of the launch (at most 1024 of them); 15: every tile (tests); 0: off.
+                                        * Same transmittances, contributor counts and median samples; colour / depth / normal /
+                                        * distortion sums of the paired tiles up to fp32 re-association. */
 #define VIDU4D_SCHED_XCD_BLOCK(B) (((B) & 15) << 8)   /* (ABI 20, read by the forward; not a debugging switch but carried in
                                         * debug_flags) the blend and sort launches' schedule as EIGHT longest-first queues,
                                         * one per XCD: the tiles of a BxB-tile block of a frame go to one XCD (workgroup b runs

@@ -34,7 +34,7 @@ def _run(sc, dev, dc, do, aux=0, flags=None, frames=None):
     W, H, P = d.width, d.height, d.num_surfels
     ncon = _C.read_state("n_contrib", None, geom, binning, img, P, W, H, torch.int32, 2 * W * H)
     fT = _C.read_state("final_T", None, geom, binning, img, P, W, H, torch.float32, 3 * W * H)
-    header = geom[:64].view(torch.int32).cpu()
+    header = geom[:256].view(torch.int32).cpu()   # (the 64 words of surfel_state.h Header)
     return dict(color=color, others=others, radii=radii, n_contrib=ncon, final_T=fT, grads=dict(zip(GRAD_NAMES, g)),
                 header=header, R=R)
 

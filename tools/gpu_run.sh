@@ -11,6 +11,7 @@
 #   xcd_ab                   item 1(i): the XCD-local schedule, block sizes 0 1 2 4 8, op-level + the TCC (L2) counters
 #   profile <tag> [args]     tools/profile_round.sh (kernel stats + FETCH / WRITE / SQ / TCC passes)
 #   fit_ab                   the fitting step's regimes (tools/fit_profile.py) with the schedule / graph switches
+#   pair_ab                  item 2: two workgroups for the longest tiles of the whole-tile forward, A/B at the headline and on the fit scenes
 #   matrix                   the final-tree measurement matrix: cfgA / cfgB (headline, default + driver form) / cfgE lines
 #   py <script> [args]       any tools/*.py under a timeout, output kept
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
@@ -123,6 +124,35 @@ import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'fit',
       done; done
     done
     } | tee $O/r06_seg256_ab.txt
+    cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so
+    ;;
+pair_ab)
+    # item 2: paired workgroups for the longest tiles of the whole-tile forward (VIDU4D_SURFEL_PAIR=K: the tiles above K / 4 x
+    # the mean list length) against one workgroup per tile: headline op level (full instance), the bench's fitting scene
+    # (colour + alpha / planes 0-4 instances), tools/fit_profile.py's dense ball.
+    # VARIANTS="product name ..." swaps variants/<name>.so in (tools/make_variants.sh); KS="0 4 8"; PROFILE=1 adds the kernel times.
+    cp vidu4d_amd/csrc/libvidu4d_surfel.so /tmp/product.so
+    for V in ${VARIANTS:-product}; do
+    if [ $V = product ]; then cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so; else cp variants/$V.so vidu4d_amd/csrc/libvidu4d_surfel.so; fi
+    for K in ${KS:-0 4 6 8 0}; do
+      echo -n "$V PAIR=$K bench: "
+      VIDU4D_SURFEL_PAIR=$K timeout 600 python bench.py $QUICK --fit-steps ${FIT_STEPS:-100} --repeats 3 "$@" 2>/dev/null | grep "^{" | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); st=d.get('stage_ms_avg',{}); print(round(d['value']), 'median', round(d.get('repeats',{}).get('median')), 'blend_fwd', st.get('blend_fwd'), 'blend_bwd', st.get('blend_bwd'), '| fit', round(d['fit_step']['images_per_s']), round(d['fit_step']['ms_per_step'],3), 'geometry', round(d['fit_step_geometry']['images_per_s']), round(d['fit_step_geometry']['ms_per_step'],3))"
+      for S0 in 0 8001; do
+        echo -n "$V PAIR=$K dense ball step0=$S0: "
+        VIDU4D_SURFEL_PAIR=$K FIT_STEP0=$S0 FIT_K=100 FIT_NO_TORCH_PROF=1 timeout 300 python tools/fit_profile.py 2>&1 | grep FIT_STEP | sed "s/.*step: //"
+      done
+      if [ "$PROFILE" = 1 ]; then
+        R=$(pwd); cd /tmp
+        for S0 in 0 8001; do
+          VIDU4D_SURFEL_PAIR=$K FIT_STEP0=$S0 FIT_K=30 FIT_NO_TORCH_PROF=1 rocprofv3 --kernel-trace --stats -d $R/$O/f8trace -o trace --output-format csv -- python $R/tools/fit_profile.py > $R/$O/f8trace.log 2>&1
+          f=$(find $R/$O/f8trace -name '*kernel_stats.csv' | head -1)
+          echo "$V PAIR=$K dense ball step0=$S0 kernels: $(python $R/tools/fit_kernel_stats.py $f 36 | grep 'blend_fwd\|blend_bwd' | sed 's/(int.*,\([0-9.]*\)$/ \1/; s/void surfel:://' | tr '\n' ' ')"
+          rm -rf $R/$O/f8trace
+        done
+        cd $R
+      fi
+    done; done | tee $O/r06_pair_ab.txt
     cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so
     ;;
 matrix)

@@ -69,6 +69,10 @@ DEBUG_FLAGS = ((_lib.DEBUG_NO_CULL if os.environ.get("VIDU4D_SURFEL_NO_CULL", "0
 # of a frame on one XCD (VIDU4D_SCHED_XCD_BLOCK, csrc/binning.hip grouped_order); 0 = one queue over all tiles (rounds 1-5).
 # The process-wide default; RasterContext.xcd_block overrides it for the calls made under a context.
 XCD_BLOCK = int(os.environ.get("VIDU4D_SURFEL_XCD_BLOCK", "0"))
+# Paired workgroups for the longest tiles of an unsplit forward (VIDU4D_SCHED_PAIR, csrc/blend.hip fwd_pair_walk): K > 0 = the
+# tiles longer than K / 4 x the mean list length of the launch are blended by two workgroups each (15: every tile), 0 = off.
+# The process-wide default; RasterContext.pair_k overrides it.  Not together with the XCD-local schedule.
+PAIR_K = int(os.environ.get("VIDU4D_SURFEL_PAIR", "0"))
 _cu_count: dict = {}
 
 
@@ -101,6 +105,7 @@ class RasterContext:
         self.grad_written = None
         self.debug_flags = None       # None: the process-wide DEBUG_FLAGS
         self.xcd_block = None         # None: the process-wide XCD_BLOCK
+        self.pair_k = None            # None: the process-wide PAIR_K
         self.walk_counters = None     # (device int64 tensor, one-shot): the next backward counts its tile walk
         self.capacity_hint: dict = {}
         self.depth_hint: dict = {}
@@ -123,7 +128,8 @@ class RasterContext:
 
     def flags(self) -> int:
         block = XCD_BLOCK if self.xcd_block is None else self.xcd_block
-        return int(DEBUG_FLAGS if self.debug_flags is None else self.debug_flags) | _lib.sched_xcd_block(block)
+        pair = 0 if block else (PAIR_K if self.pair_k is None else self.pair_k)
+        return int(DEBUG_FLAGS if self.debug_flags is None else self.debug_flags) | _lib.sched_xcd_block(block) | _lib.sched_pair(pair)
 
 
 _tls = threading.local()

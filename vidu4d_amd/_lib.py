@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvidu4d_surfel.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class ForwardArgs(C.Structure):
@@ -80,6 +80,12 @@ SKIN_FIELD = dict(width=64, in_max=96, out_max=32, max_hidden=4)
 AUX_ALPHA = 0x02  # VIDU4D_AUX_ALPHA
 AUX_GEOM = 0x1F   # VIDU4D_AUX_GEOM: planes 0-4 (depth, alpha, normal)
 DEBUG_NO_CULL, DEBUG_WHOLE_TILE_BACKWARD, DEBUG_SERIAL_REPAIR, DEBUG_POSITION_ORDER = 1, 2, 4, 8   # VIDU4D_DEBUG_*
+
+
+
+def sched_pair(k: int) -> int:
+    """VIDU4D_SCHED_PAIR(K) (ABI 21): two workgroups for the tiles longer than K / 4 x the mean list (15: every tile)"""
+    return (int(k) & 15) << 12
 
 
 def sched_xcd_block(block: int) -> int:

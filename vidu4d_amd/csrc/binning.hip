@@ -132,6 +132,8 @@ struct TileOrderShared {
     uint32_t max;
     uint32_t any;
     uint32_t n_long;
+    unsigned long long total_len;
+    uint32_t n_paired;
     // XCD-local schedule (grouped_order): one histogram / queue per XCD group
     uint32_t bin8[8][1024];
     uint32_t scan8[8][16];
@@ -235,20 +237,28 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
     s_bin[threadIdx.x] = 0;
     __syncthreads();
     uint32_t mx = 0, n_long = 0;
+    unsigned long long total = 0;
     for (int t = threadIdx.x; t < num_tiles; t += 1024) {
         const uint32_t len = img.ranges[2 * t + 1] - img.ranges[2 * t];
         mx = max(mx, len);
+        total += len;
         n_long += len > (uint32_t)SPLIT_MIN;
         img.seg_first[t] = SEG_NONE;
+        img.live_count[t] = 0;   // (by schedule position; the paired workgroups of a tile raise it with atomicMax, blend.hip)
     }
     for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     if (lane == 0) atomicMax(&s_max, mx);
     // (Header::num_long_tiles: tiles longer than SPLIT_MIN, whatever table this call builds -- the caller's split decision
     // reads THIS, not num_split_pos, whose meaning follows the mode of the call)
     for (int off = 32; off; off >>= 1) n_long += (uint32_t)__shfl_xor((int)n_long, off);
-    if (threadIdx.x == 0) sh.n_long = 0;
+    if (threadIdx.x == 0) {
+        sh.n_long = 0;
+        sh.total_len = 0;
+        sh.n_paired = 0;
+    }
     __syncthreads();
     if (lane == 0 && n_long) atomicAdd(&sh.n_long, n_long);
+    if (sp.pair_k && total) atomicAdd(&sh.total_len, total);
     __syncthreads();
     const uint32_t max_len = s_max;
     const uint64_t denom = (uint64_t)max_len + 1;
@@ -273,6 +283,22 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
         s_bin[threadIdx.x] = wbase + inc - c;  // exclusive start of this length class
         __syncthreads();
         for (int t = threadIdx.x; t < num_tiles; t += 1024) img.tile_order[atomicAdd(&s_bin[bucket(t)], 1u)] = (uint32_t)t;
+        if (sp.pair_k) {
+            // Paired workgroups (blend.hip fwd_pair_walk): the tiles whose length class lies above the class of pair_k / 4 x
+            // the mean list length -- a prefix of the schedule; s_bin[c] is now the END of class c, i.e. the number of tiles
+            // of the classes 0 .. c (the longer ones)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned long long thr = sh.total_len * (unsigned long long)sp.pair_k / (4ull * (unsigned long long)max(num_tiles, 1));
+                uint32_t n = 0;
+                if (sp.pair_k >= 15) n = (uint32_t)num_tiles;
+                else if (thr < (unsigned long long)max_len) {
+                    const uint32_t cls = 1023u - (uint32_t)((thr << 10) / denom);   // class of the threshold length: pair the classes in front of it
+                    n = cls > 0u ? s_bin[cls - 1u] : 0u;
+                }
+                sh.n_paired = min(n, (uint32_t)PAIR_MAX);
+            }
+        }
     }
     __syncthreads();  // tile_order is read back below (same workgroup: the barrier orders the global accesses)
 
@@ -360,6 +386,7 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
         g.hdr->truncated = 0;
         g.hdr->xcd_block = xcd ? (uint32_t)sp.xcd_block : 0u;
         g.hdr->live_xcd = 0;
+        g.hdr->num_paired = sh.n_paired;
     }
 }
 

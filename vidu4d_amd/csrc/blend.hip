@@ -205,7 +205,7 @@ __device__ __forceinline__ uint32_t search_positions_mod8(const uint32_t* __rest
 
 template <bool SPLIT>
 __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageState& img, int grid_x, int grid_y,
-                                              bool overflow)
+                                              bool overflow, uint32_t pos = blockIdx.x)
 {
     WorkItem w;
     w.seg = -1;
@@ -234,7 +234,7 @@ __device__ __forceinline__ WorkItem find_work(const Header* hdr, const ImageStat
             if (!overflow && img.seg_first[tile] != SEG_NONE) w.valid = false;  // blended by its segments
         }
     } else {
-        tile = (int)img.tile_order[blockIdx.x];
+        tile = (int)img.tile_order[pos];   // (an unsplit launch: the schedule position, blend_fwd_kernel's paired workgroups in front)
     }
     w.tc.tile = tile;
     w.tc.valid = true;
@@ -479,6 +479,283 @@ __device__ __forceinline__ void store_record(float* __restrict__ seg_data, uint3
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Long tiles on TWO workgroups ("paired workgroups", "two-entry walk").  A launch whose tiles all start at
+// once (the dense Stage-3 ball: fewer long tiles than the chip has workgroup slots) lasts as long as its longest list takes
+// ONE workgroup, and the second half of it runs on workgroups that are alone on their CU at one wave per SIMD
+// (tools/fwd_trace.py: 35 % of the CU-time with fewer than two workgroups resident).  Cutting the LIST needs the start
+// transmittance (a pre-pass, or speculation + repair walks: the segment-parallel instances); this cuts the PIXELS and
+// shortens the walk:
+//   * the tiles at the schedule positions [0, Header::num_paired) -- the longest, binning.hip tile_order -- get two
+//     workgroups each; workgroup `half` of the pair owns the blocks 4 half .. 4 half + 3 (publish_block_masks: 8x4 pixels
+//     each), stages every batch of the list itself and culls for its four blocks only.  Pixels are independent: the two
+//     never talk to each other;
+//   * wave w of such a workgroup owns ONE block and holds every pixel TWICE, in lane p and in lane p + 32;
+//   * the two halves of the wave take CONSECUTIVE entries of the block's culled list (two each per trip, as
+//     blend_fwd_kernel's halves): both evaluate their pair (forward.cu:358-399, independent of the transmittance), exchange
+//     alpha (and the mapped depth, full instance) with one v_permlane32_swap, and both run the transmittance recurrence
+//     over the two entries in list order -- T1 = T (1 - a1), T2 = T1 (1 - a2), the same two roundings per entry, an entry
+//     that was not accepted enters as alpha = 0 (T * 1 is exact) -- so T, the end of the walk (forward.cu:400-405) and, full
+//     instance, the moments in front of every entry (forward.cu:407-414) and the median sample (:416-421) are
+//     bit-identical to the one-entry walk;
+//   * each half accumulates ITS entries' colour / depth / normal / distortion sums; the halves are added when a recorded
+//     segment ends and when the walk ends -- these sums differ from the unpaired walk's by fp32 re-association (even
+//     entries + odd entries), the transmittance, contributor counts and median sample do not.
+// Per wave half the trips of the unpaired walk at ~1.2 x the instructions per entry (the exchange and the second
+// recurrence; measured with EVERY tile on eight waves: headline blend_fwd 148 -> 210 us, which is why only the tail's tiles
+// are paired) plus the second staging: the pair costs more VALU work than the one workgroup and ends in half the time --
+// where the launch waits for it.  Records, outputs, schedule otherwise as the unpaired walk.
+__device__ __forceinline__ void both_halves(float v, float& lo, float& hi)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]);   // what lane (L & 31) holds, in both halves
+    hi = __uint_as_float(r[1]);   // what lane (L & 31) + 32 holds
+}
+__device__ __forceinline__ void both_halves(uint32_t v, uint32_t& lo, uint32_t& hi)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    lo = r[0];
+    hi = r[1];
+}
+__device__ __forceinline__ float halves_sum(float v)
+{
+    float lo, hi;
+    both_halves(v, lo, hi);
+    return lo + hi;
+}
+
+// One entry per half: the lower half's is the earlier one in the list.
+template <int MODE>
+__device__ __forceinline__ void pair_step(FwdPixel& s, bool& done, bool upper, bool ok, const PairEval& e, const float4* r,
+                                          uint32_t key)
+{
+#pragma clang fp contract(off)
+    float a1, a2;
+    both_halves(ok ? e.alpha : 0.f, a1, a2);
+    const float T0 = s.T;
+    const float T1 = T0 * (1.0f - a1);   // THRESHOLD-EXACT (fwd_accumulate: the same two roundings per entry)
+    const float T2 = T1 * (1.0f - a2);
+    // (T >= T_EPS while a pixel is not done, so an entry that enters as alpha = 0 never stops the walk)
+    const bool stop1 = T1 < T_EPS, stop2 = T2 < T_EPS;
+    const float T_own = upper ? T1 : T0;
+    const bool live = ok && !done && !stop1 && !(upper && stop2);
+    float m = 0.f, M1a = 0.f, M2a = 0.f, m2 = 0.f;
+    if (MODE == BLEND_FULL) {
+        float m1;
+        m = ok ? map_depth(e.depth) - s.m0 : 0.f;
+        both_halves(m, m1, m2);
+        const bool first_live = a1 > 0.f && !stop1;
+        const float w1 = a1 * T0;
+        M1a = first_live ? fmaf(m1, w1, s.dist1) : s.dist1;   // the moments behind the first entry
+        M2a = first_live ? fmaf(m1 * m1, w1, s.dist2) : s.dist2;
+    }
+    if (live) {
+        const float4 q3 = r[3], q4 = r[4];
+        const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
+        const float w = e.alpha * T_own;
+        if (MODE == BLEND_FULL) {
+            const float A = 1.0f - T_own;
+            const float M1 = upper ? M1a : s.dist1, M2 = upper ? M2a : s.dist2;
+            const float error = fmaf(m * m, A, fmaf(-2.0f * m, M1, M2));
+            s.distortion = fmaf(error, w, s.distortion);
+            if (T_own > 0.5f) {
+                s.median_depth = e.depth;
+                s.median_weight = w;
+                s.median_contributor = key;
+            }
+        }
+        if (MODE != BLEND_LITE) {
+            for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(nrm[ch], w, s.N[ch]);
+            s.D = fmaf(e.depth, w, s.D);
+        }
+        for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(rgb[ch], w, s.C[ch]);
+        s.last_contributor = key;
+    }
+    if (!done) {
+        if (MODE == BLEND_FULL) {
+            const bool second_live = a2 > 0.f && !stop1 && !stop2;
+            const float w2 = a2 * T1;
+            s.dist1 = second_live ? fmaf(m2, w2, M1a) : M1a;
+            s.dist2 = second_live ? fmaf(m2 * m2, w2, M2a) : M2a;
+        }
+        s.T = stop1 ? T0 : (stop2 ? T1 : T2);
+        done = stop1 || stop2;
+    }
+}
+
+// The sums the two halves hold of one pixel, added: afterwards both halves hold the pixel's sums.
+template <int MODE>
+__device__ __forceinline__ void pair_add_halves(FwdPixel& s)
+{
+    for (int ch = 0; ch < 3; ch++) s.C[ch] = halves_sum(s.C[ch]);
+    if (MODE != BLEND_LITE) {
+        for (int ch = 0; ch < 3; ch++) s.N[ch] = halves_sum(s.N[ch]);
+        s.D = halves_sum(s.D);
+    }
+}
+
+// store_record for a pixel index that is not the thread index; the caller has added the halves.
+template <int MODE>
+__device__ __forceinline__ void pair_store_record(float* __restrict__ seg_data, uint32_t slot, int pix, bool write, FwdPixel& s,
+                                                  float first)
+{
+    float* d = seg_data + (size_t)slot * REC_REC_FLOATS * 256 + pix;
+    if (write) {
+        d[RS_T * 256] = first;
+        for (int ch = 0; ch < 3; ch++) d[(RS_C + ch) * 256] = s.C[ch];
+        if (MODE != BLEND_LITE) {
+            d[RS_D * 256] = s.D;
+            for (int ch = 0; ch < 3; ch++) d[(RS_N + ch) * 256] = s.N[ch];
+        }
+        if (MODE == BLEND_FULL) {
+            d[RS_M1 * 256] = s.dist1;
+            d[RS_M2 * 256] = s.dist2;
+        }
+    }
+    for (int ch = 0; ch < 3; ch++) s.C[ch] = 0.f;
+    if (MODE != BLEND_LITE) {
+        s.D = 0.f;
+        for (int ch = 0; ch < 3; ch++) s.N[ch] = 0.f;
+    }
+}
+
+// One workgroup of a pair: the blocks 4 half .. 4 half + 3 of the tile at schedule position `pos`.
+template <int MODE>
+__device__ __forceinline__ int fwd_pair_walk(int W, int H, int grid_x, int grid_y, Header* hdr, const ImageState& img,
+                                             const uint32_t* __restrict__ point_list, int64_t capacity,
+                                             const float* __restrict__ rec, const float* __restrict__ bg,
+                                             float* __restrict__ seg_data, float* __restrict__ out_color,
+                                             float* __restrict__ out_others, uint32_t* depth_used, int flags, int rec_len,
+                                             float4* s_rec, unsigned long long (*s_mask8)[FWD_BATCH / 64], uint32_t pos, int half)
+{
+    const bool overflow = (int64_t)hdr->num_rendered > capacity;
+    TileCoord tc;
+    tc.tile = (int)img.tile_order[pos];
+    tc.valid = true;
+    tc.tx = tc.tile % grid_x;
+    tc.ty = tc.tile / grid_x;
+    size_t plane;
+    const size_t frame_base = frame_of_tile(tc, W, H, grid_y, plane);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int block = 4 * half + wave;   // block 2q + h of publish_block_masks
+    const bool upper = lane >= 32;
+    const int p = lane & 31;
+    const int pix = block * 32 + p;      // the pixel's thread index in the unpaired walk (records, segment data)
+    const int px = tc.tx * TILE + ((block >> 1) & 1) * 8 + (p & 7);
+    const int py = tc.ty * TILE + (block >> 2) * 8 + (block & 1) * 4 + (p >> 3);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px + 0.5f, pixy = (float)py + 0.5f;
+    const uint32_t r0 = img.ranges[2 * tc.tile], r1 = img.ranges[2 * tc.tile + 1];
+    int todo = overflow ? 0 : (int)(r1 - r0);
+    const uint32_t rec_first = (rec_len && !overflow) ? img.seg_first[tc.tile] : SEG_NONE;
+    int rec_next = rec_len;
+    uint32_t rec_stop = 0;
+    int walked = 0;
+
+    FwdPixel s;
+    if (MODE == BLEND_FULL && todo > 0) {
+        s.m0 = map_depth(rec[(size_t)point_list[r0] * REC_FLOATS + R_DEPTH]);
+        if (threadIdx.x == 0 && half == 0) img.tile_m0[tc.tile] = s.m0;
+    }
+    bool done = !inside;
+    for (int base = 0; todo > 0; base += FWD_BATCH, todo -= FWD_BATCH) {
+        if (rec_first != SEG_NONE && base == rec_next) {  // (wave-uniform) entries [0, base) are behind us
+            rec_stop = (uint32_t)(base / rec_len);
+            pair_add_halves<MODE>(s);
+            pair_store_record<MODE>(seg_data, rec_first + rec_stop - 1u, pix, !upper, s, s.T);
+            rec_next += rec_len;
+        }
+        if (__syncthreads_count(done) == 256) break;
+        const int prio_len = (int)(r1 - r0);   // (issue priority by the fraction of the walk that is left: blend_fwd_kernel)
+        if (3 * todo > 2 * prio_len) __builtin_amdgcn_s_setprio(3);
+        else if (3 * todo > prio_len) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
+        walked = base + min(todo, FWD_BATCH);
+        const bool have = (int)threadIdx.x < todo;
+        FootprintTest foot = no_footprint();
+        if (have) foot = stage_record(s_rec, threadIdx.x, rec, point_list[r0 + base + threadIdx.x]);
+        if (half == 0)   // (workgroup-uniform: the four blocks of this half)
+            publish_block_masks<FWD_BATCH / 64, 4>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave, 0, lane, flags & FLAG_NO_CULL);
+        else
+            publish_block_masks<FWD_BATCH / 64, 4>(s_mask8, have, foot, tc.tx * TILE, tc.ty * TILE, wave, 4, lane, flags & FLAG_NO_CULL);
+        __syncthreads();
+        if (__all(done)) continue;
+        const int key_base = (base + 1) * 80;   // (keys: blend_fwd_kernel)
+#pragma unroll 1
+        for (int k = 0; k < FWD_BATCH / 64; k++) {
+            unsigned long long m = wave_any(!done) ? uniform_u64(s_mask8[block][k]) : 0ull;
+            while (m) {
+                const int o0 = (k * 64 + __builtin_ctzll(m)) * 80;
+                m &= m - 1;
+                const int o1 = (m ? k * 64 + __builtin_ctzll(m) : FWD_BATCH) * 80;
+                m &= m - 1;
+                const int o2 = (m ? k * 64 + __builtin_ctzll(m) : FWD_BATCH) * 80;
+                m &= m - 1;
+                const int o3 = (m ? k * 64 + __builtin_ctzll(m) : FWD_BATCH) * 80;
+                m &= m - 1;
+                const int oa = upper ? o1 : o0, ob = upper ? o3 : o2;
+                const float4* ra = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + oa);
+                const float4* rb = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + ob);
+                const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2];
+                const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2];
+                const float TuA[3] = {a0.x, a0.y, a0.z}, TvA[3] = {a0.w, a1.x, a1.y}, TwA[3] = {a1.z, a1.w, a2.x};
+                const float TuB[3] = {b0.x, b0.y, b0.z}, TvB[3] = {b0.w, b1.x, b1.y}, TwB[3] = {b1.z, b1.w, b2.x};
+                PairEval ea, eb;
+                const bool okA = eval_pair_flat(TuA, TvA, TwA, a2.y, a2.z, a2.w, pixx, pixy, ea);
+                const bool okB = eval_pair_flat(TuB, TvB, TwB, b2.y, b2.z, b2.w, pixx, pixy, eb);
+                pair_step<MODE>(s, done, upper, okA, ea, ra, (uint32_t)(key_base + oa));
+                pair_step<MODE>(s, done, upper, okB, eb, rb, (uint32_t)(key_base + ob));
+            }
+        }
+    }
+    // the halves' sums, added; the later of their last contributors and median samples
+    pair_add_halves<MODE>(s);
+    {
+        uint32_t lo, hi;
+        both_halves(s.last_contributor, lo, hi);
+        s.last_contributor = lo > hi ? lo : hi;
+    }
+    if (MODE == BLEND_FULL) {
+        s.distortion = halves_sum(s.distortion);
+        uint32_t lo, hi;
+        both_halves(s.median_contributor, lo, hi);
+        float d_lo, d_hi, w_lo, w_hi;
+        both_halves(s.median_depth, d_lo, d_hi);
+        both_halves(s.median_weight, w_lo, w_hi);
+        s.median_contributor = lo > hi ? lo : hi;
+        s.median_depth = lo > hi ? d_lo : d_hi;
+        s.median_weight = lo > hi ? w_lo : w_hi;
+    }
+    s.last_contributor /= 80u;
+    s.median_contributor /= 80u;
+    if (rec_first != SEG_NONE) {  // the final sums, in the slot of the tile's last segment (blend_fwd_kernel)
+        const uint32_t nseg = (r1 - r0 + (uint32_t)rec_len - 1u) / (uint32_t)rec_len;
+        if (!upper) seg_data[((size_t)(rec_first + nseg - 1u) * REC_REC_FLOATS + RS_STOP) * 256 + pix] = __uint_as_float(rec_stop);
+        pair_store_record<MODE>(seg_data, rec_first + nseg - 1u, pix, !upper, s, s.median_weight);
+        if (!upper) {
+            for (uint32_t k = 0; k <= rec_stop; k++) {
+                const uint32_t q = k < rec_stop ? k : nseg - 1u;
+                const float* e = seg_data + (size_t)(rec_first + q) * REC_REC_FLOATS * 256 + pix;
+                for (int ch = 0; ch < 3; ch++) s.C[ch] += e[(RS_C + ch) * 256];
+                if (MODE != BLEND_LITE) {
+                    for (int ch = 0; ch < 3; ch++) s.N[ch] += e[(RS_N + ch) * 256];
+                    s.D += e[RS_D * 256];
+                }
+            }
+        }
+    }
+    if (inside && !upper)
+        write_pixel(s, plane, frame_base + (size_t)py * W + px, bg, img.final_T, img.n_contrib, out_color, out_others);
+    report_depth(depth_used, s.last_contributor);
+    report_min_T(hdr, s.T, inside);
+    if (rec_len && threadIdx.x == 0 && rec_first != SEG_NONE) {
+        // the tile's live full segments: the farther of the two workgroups' walks (tile_order has zeroed the counts)
+        const uint32_t nseg = (r1 - r0 + (uint32_t)rec_len - 1u) / (uint32_t)rec_len;
+        atomicMax(&img.live_count[pos], rec_stop + 1u < nseg - 1u ? rec_stop + 1u : nseg - 1u);
+    }
+    return walked;
+}
+
 // The blend (pass 2 of the segment-parallel forward when SPLIT).  MODE (surfel_math.h): BLEND_LITE carries colour + alpha
 // plane only, BLEND_GEOM colour + planes 0-4 (fwd_accumulate<MODE>); what an instance does not carry comes out as zeros.
 //
@@ -506,7 +783,7 @@ namespace surfel {
 #endif
 template <bool SPLIT, int MODE>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu((!SPLIT && MODE == BLEND_FULL) ? SURFEL_FWD_WAVES_PER_EU : 1, (!SPLIT && MODE == BLEND_FULL) ? SURFEL_FWD_WAVES_PER_EU : 8)))
+__attribute__((amdgpu_waves_per_eu((!SPLIT && MODE != BLEND_LITE) ? SURFEL_FWD_WAVES_PER_EU : 1, (!SPLIT && MODE != BLEND_LITE) ? SURFEL_FWD_WAVES_PER_EU : 8)))
 void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
                                                        ImageState img, const uint32_t* __restrict__ point_list,
                                                        int64_t capacity, int max_seg, const float* __restrict__ rec,
@@ -538,10 +815,28 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
         hdr->split_used = !overflow && hdr->num_segments > 0;
     if (!SPLIT && rec_len && blockIdx.x == 0 && threadIdx.x == 0)
         hdr->split_used = (!overflow && hdr->num_segments > 0) ? 2u : 0u;
+    // Unsplit launch: the workgroups [0, 2 num_paired) are the pairs of the longest tiles (fwd_pair_walk), workgroup
+    // num_paired + p takes schedule position p >= num_paired; the host's grid is tiles + its bound on num_paired.
+    uint32_t pos = blockIdx.x;
+    if (!SPLIT) {
+        const uint32_t np = hdr->num_paired;
+        if (blockIdx.x < 2u * np) {
+            const int walked = fwd_pair_walk<MODE>(W, H, grid_x, grid_y, hdr, img, point_list, capacity, rec, bg, seg_data, out_color,
+                                                   out_others, depth_used, flags, rec_len, s_rec, s_mask8, blockIdx.x >> 1,
+                                                   (int)(blockIdx.x & 1u));
+#ifdef SURFEL_FWD_TRACE
+            trace_end.entries = walked;
+#endif
+            (void)walked;
+            return;
+        }
+        pos = blockIdx.x - np;
+        if (pos >= (uint32_t)(grid_x * grid_y)) return;
+    }
     // (SPLIT: full segments first, then the remainders and the unsplit tiles by descending size -- find_work_split_ordered;
     // until round 5 in schedule-position order, the unsplit tiles of up to SPLIT_MIN entries, twice a segment, last)
     const WorkItem wk = (SPLIT && !overflow && !(flags & FLAG_POSITION_ORDER)) ? find_work_split_ordered(hdr, img, grid_x, grid_y)
-                                                                              : find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow);
+                                                                              : find_work<SPLIT>(hdr, img, grid_x, grid_y, overflow, pos);
     if (!wk.valid || (SPLIT && wk.seg >= max_seg)) return;
     TileCoord tc = wk.tc;
     size_t plane;
@@ -715,7 +1010,7 @@ void blend_fwd_kernel(int W, int H, int grid_x, int grid_y, Header* hdr,
             const uint32_t nseg = (r1 - r0 + (uint32_t)rec_len - 1u) / (uint32_t)rec_len;
             live = rec_stop + 1u < nseg - 1u ? rec_stop + 1u : nseg - 1u;
         }
-        img.live_count[blockIdx.x] = live;
+        img.live_count[pos] = live;
     }
 }
 
@@ -1109,7 +1404,9 @@ void launch_blend_fwd(const CameraParams& cam, const GeomState& g, const ImageSt
     const uint32_t* point_list = capacity > 0 ? b.point_list : nullptr;
     if (!split || capacity <= 0) {
         const int rec_len = (record && capacity > 0) ? REC_SEG_LEN : 0;
-        hipLaunchKernelGGL(pick_fwd<false>(mode), dim3(tiles), dim3(256), fwd_pad_lds(), stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
+        // (paired workgroups for the longest tiles -- fwd_pair_walk; the device knows how many: Header::num_paired)
+        const int pair_cap = ((flags >> FLAG_PAIR_SHIFT) & 15) ? std::min(tiles, PAIR_MAX) : 0;
+        hipLaunchKernelGGL(pick_fwd<false>(mode), dim3(tiles + pair_cap), dim3(256), fwd_pad_lds(), stream, cam.W, cam.H, cam.grid_x, grid_y, g.hdr, img,
                            point_list, capacity, 0, g.rec, background, b.seg_data, out_color, out_others, depth_used, 0, flags,
                            rec_len);
         return;

@@ -210,7 +210,7 @@ static int blend_mode(int aux_planes)
 static int kernel_flags(int debug_flags)
 {
     return ((debug_flags & VIDU4D_DEBUG_NO_CULL) ? FLAG_NO_CULL : 0) | ((debug_flags & VIDU4D_DEBUG_SERIAL_REPAIR) ? FLAG_SERIAL_REPAIR : 0) |
-           ((debug_flags & VIDU4D_DEBUG_POSITION_ORDER) ? FLAG_POSITION_ORDER : 0);
+           ((debug_flags & VIDU4D_DEBUG_POSITION_ORDER) ? FLAG_POSITION_ORDER : 0) | (debug_flags & (15 << FLAG_PAIR_SHIFT));
 }
 // Does a whole-tile forward leave recorded segments for its backward (surfel_state.h)?  They pay by letting the dispatcher
 // balance the CUs when a launch has about as many tiles as the chip has workgroup slots (256 CUs x 6: the headline's 2048
@@ -353,7 +353,8 @@ extern "C" int vidu4d_surfel_forward_run(const Vidu4dSurfelForwardArgs* a, void*
     // schedule builder also orders the tails -- which the backward of a segment-parallel forward now dispatches by too)
     // (VIDU4D_SCHED_XCD_BLOCK(B) in debug_flags: the XCD-local longest-first schedule over BxB-tile blocks, binning.hip)
     const ScheduleParams sp = {record ? REC_SEG_LEN : SEG_LEN, record ? REC_MIN : SPLIT_MIN, 1,
-                               (a->debug_flags >> FLAG_XCD_SHIFT) & 15, cam.grid_x, cam.grid_x * cam.grid_y};
+                               (a->debug_flags >> FLAG_XCD_SHIFT) & 15, cam.grid_x, cam.grid_x * cam.grid_y,
+                               (a->segment_split == 0 && !((a->debug_flags >> FLAG_XCD_SHIFT) & 15)) ? (a->debug_flags >> FLAG_PAIR_SHIFT) & 15 : 0};
     {
         StageTimer t(ST_EMIT, stream);
         launch_emit_keys(cam, P, a->radii, g, img, b, capacity, use_grouped_binning(total_tiles(cam)), sp, stream);

@@ -103,6 +103,8 @@ inline size_t seg_data_floats(int64_t capacity)
 constexpr int FLAG_NO_CULL = 1;
 constexpr int FLAG_XCD_SHIFT = 8;      // bits 8-11: VIDU4D_SCHED_XCD_BLOCK(B) (read by the forward's schedule builder)
 constexpr int FLAG_POSITION_ORDER = 8;  // VIDU4D_DEBUG_POSITION_ORDER: the split backward's workgroups in schedule-position order (rounds 2-4)
+constexpr int FLAG_PAIR_SHIFT = 12;     // bits 12-15: VIDU4D_SCHED_PAIR(K) (read by the forward: its schedule builder and its whole-tile launch)
+constexpr int PAIR_MAX = 1024;          // at most this many tiles of a launch get a pair of workgroups (the host's grid bound)
 constexpr int FLAG_SERIAL_REPAIR = 4;   // VIDU4D_DEBUG_SERIAL_REPAIR: the speculated combine as ONE launch (rounds 3-4)
 
 struct Header {           // first 256 bytes of the geometry buffer
@@ -133,7 +135,9 @@ struct Header {           // first 256 bytes of the geometry buffer
     uint32_t live_xcd;       // word 16: 1 when the recorded backward numbers its live full segments per residue class of the
                              // schedule position (workgroup 8 i + g takes the i-th live segment of the positions = g mod 8, so a
                              // tile's segments stay on its XCD); written by the backward's preparation launch
-    uint32_t pad[47];
+    uint32_t num_paired;     // word 17 (ABI 21): the tiles at the schedule positions [0, num_paired) are blended by TWO workgroups
+                             // each in an unsplit forward (blend.hip fwd_pair_walk; binning.hip tile_order; ScheduleParams::pair_k)
+    uint32_t pad[46];
 };
 static_assert(sizeof(Header) == 256, "the header is the first 256 bytes of the geometry buffer");
 
@@ -347,6 +351,10 @@ struct ScheduleParams {
     // of a BxB-tile block of a frame share an XCD (workgroup b runs on XCD b mod 8: MI355X_MICROARCH.md, observed), i.e.
     // eight length-sorted queues interleaved over the schedule positions.  grid_x / frame_tiles: the tile grid of ONE frame.
     int xcd_block, grid_x, frame_tiles;
+    // Paired workgroups for the longest tiles of an unsplit forward (round 6, blend.hip fwd_pair_walk): 0 off; K = 1..14: the
+    // tiles whose length class lies above that of K / 4 x the mean list length of the launch; 15: every tile (tests).  At most
+    // PAIR_MAX tiles; not together with the XCD-local schedule.
+    int pair_k;
 };
 void launch_tile_order(const GeomState& g, const ImageState& img, int num_tiles, const ScheduleParams& sp, hipStream_t stream);
 void launch_emit_keys(const CameraParams& cam, int P, const int32_t* radii, const GeomState& g, const ImageState& img,
