@@ -563,6 +563,9 @@ def test_stacked_frames_equal_single_frame_calls(gpu_device, monkeypatch, F, spl
     from vidu4d_amd import _C
     from vidu4d_amd.synthetic import frame_motion
     monkeypatch.setattr(_C, "_SPLIT", split)
+    # (which tiles get two workgroups follows the LAUNCH's mean list length, and a pair re-associates its tile's sums: one
+    # workgroup per tile on both sides; the paired form of this test is in tests/test_gpu_paired_tiles.py)
+    monkeypatch.setattr(_C, "PAIR_K", 0)
     dev = gpu_device
     W, H, N = 176, 120, 6000   # (partial tiles in both directions)
     sc = make_scene(N, W, H, seed=21, sigma_px=6.0).to(dev)

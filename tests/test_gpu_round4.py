@@ -72,14 +72,17 @@ def _fuzz_scenes(n, seed, large=False):
 
 
 @pytest.mark.parametrize("seed,large,n", [(3, False, 24), (0, False, 12), (11, True, 8)])
-def test_footprint_cull_ab_on_the_device(gpu_device, seed, large, n):
+def test_footprint_cull_ab_on_the_device(gpu_device, monkeypatch, seed, large, n):
     """Forward planes, final_T, n_contrib bit-identical with and without the culls.  The gradient sums are float atomics
     whose order differs from run to run (screen-filling surfels add thousands of terms of both signs: the same kernel run
     twice differs by up to ~5e-6 of the tensor's scale on these scenes), so they are held to 1e-6 of scale plus four times
     the noise floor measured on the spot (culls on, twice) -- on the sums the blend kernel makes (BLEND_GRADS).  seed 3: the scenes whose footprints round 3's first conic test
     cut (huge, strongly foreshortened, near-plane surfels); `large`: image sizes up to 1920 x 1080."""
-    from vidu4d_amd import _lib
+    from vidu4d_amd import _C, _lib
     dev = gpu_device
+    # (one workgroup per tile: in a paired tile the culls decide which half of a wave takes an entry, i.e. the association of
+    # its sums -- tests/test_gpu_paired_tiles.py holds the paired walk to "stops where the culled walk stops")
+    monkeypatch.setattr(_C, "PAIR_K", 0)
     for sc, what in _fuzz_scenes(n, seed, large):
         dc, do = (t.to(dev) for t in make_upstream_grads(sc.width, sc.height))
         a = _run(sc, dev, dc, do, flags=0)
@@ -132,7 +135,8 @@ def test_recorded_segments_equal_the_whole_tile_backward(gpu_device, monkeypatch
         assert live == full, (live, full)          # nothing saturates: every walk reaches the end of its list
     for k in ("color", "others", "radii", "n_contrib", "final_T"):
         assert torch.equal(rec[k], whole[k]), k
-    _grads_close(rec, whole, 3e-6, which)
+    # (paired workgroups -- the object scene's long tiles -- leave records whose sums are even + odd entries: 9e-6 seen)
+    _grads_close(rec, whole, 1e-5 if int(rec["header"][17]) else 3e-6, which)
 
 
 @pytest.mark.parametrize("split", ["0", "1", "1-relative"])

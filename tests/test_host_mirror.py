@@ -471,7 +471,7 @@ def test_raster_contexts_do_not_share_state():
     module-level API acts on the calling thread's current one.  No GPU involved."""
     import threading
     import torch
-    from vidu4d_amd import _C
+    from vidu4d_amd import _C, _lib
     assert _C.current() is _C._default and _C._capacity_hint is _C._default.capacity_hint and _C._pending is _C._default.pending
     a, b = _C.RasterContext(), _C.RasterContext()
     key = ("ctx-test",)
@@ -488,7 +488,11 @@ def test_raster_contexts_do_not_share_state():
                 assert "dL_dopacity" in b.grad_out and not a.grad_out
             assert not b.grad_out and not b.deferred
             with _C.debug_flags(3):
-                assert b.flags() == 3 and a.flags() == int(_C.DEBUG_FLAGS)
+                sched = _lib.sched_pair(_C.PAIR_K) if not _C.XCD_BLOCK else _lib.sched_xcd_block(_C.XCD_BLOCK)   # (the schedule bits ride along)
+                assert b.flags() == 3 | sched and a.flags() == int(_C.DEBUG_FLAGS) | sched
+                b.pair_k = 0
+                assert b.flags() == 3 | (sched if _C.XCD_BLOCK else 0) and a.flags() == int(_C.DEBUG_FLAGS) | sched
+                b.pair_k = None
         assert _C.current() is a
     assert _C.current() is _C._default
     assert a.capacity_hint[key] >= 1000 and a.len_hint[key] == 77 and a.long_tiles_hint[key] == 5

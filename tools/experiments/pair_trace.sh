@@ -1,0 +1,7 @@
+# tools/fwd_trace.py on the dense ball (6-pixel footprints, initial opacity), colour + alpha instance, with and without pairs
+cp vidu4d_amd/csrc/libvidu4d_surfel.so /tmp/product.so; cp variants/ftrace.so vidu4d_amd/csrc/libvidu4d_surfel.so
+for K in ${KS:-0 6 8}; do
+  echo "#### PAIR=$K"
+  VIDU4D_SURFEL_PAIR=$K VIDU4D_SURFEL_SPLIT=0 TRACE_AUX=${TRACE_AUX:-alpha} TRACE_OBJECT_RADIUS=1.0 TRACE_SIGMA_PX=6 TRACE_OPACITY_MODE=init timeout 300 python tools/fwd_trace.py 2>&1 | grep -v amdgpu.ids
+done
+cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so

@@ -36,6 +36,7 @@ else:
 if os.environ.get("TRACE_SPLIT"):
     _C._SPLIT = os.environ["TRACE_SPLIT"]
 H = scene.height
+AUX = {"alpha": _lib.AUX_ALPHA, "geom": _lib.AUX_GEOM}.get(os.environ.get("TRACE_AUX", ""), 0)   # (TRACE_AUX=alpha / geom: that blend instance)
 dc, do = (t.to(dev) for t in make_upstream_grads(W, H))
 frames = [frame_motion(scene, f, 120) for f in range(8)]
 rs = dsr.GaussianRasterizationSettings(H, W, scene.tanfovx, scene.tanfovy, scene.bg, 1.0, scene.viewmatrix, scene.projmatrix,
@@ -51,7 +52,7 @@ def step(k):
     m = torch.stack([frames[i].means3D for i in ids])
     r = torch.stack([frames[i].rotations for i in ids])
     with torch.no_grad():
-        dsr.rasterize_frames(m, torch.zeros_like(m), scene.shs, scene.opacities, scene.scales, r, [rs] * F)
+        dsr.rasterize_frames(m, torch.zeros_like(m), scene.shs, scene.opacities, scene.scales, r, [rs] * F, aux_planes=AUX)
 
 
 for k in range(5):

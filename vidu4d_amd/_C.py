@@ -42,9 +42,15 @@ _EXACT = os.environ.get("VIDU4D_SURFEL_EXACT", "0") == "1"
 # 0.7 = 320: 1.25 / 1.05; 0.5 = 176: 1.52 / 1.02.  On the new count the threshold is 2.0 tiles per compute unit (512): radius
 # 0.85 and below split, radius 1.0 and bench.py's fitting scene (a filled unit ball: whole 0.98-1.01 ms / split 1.00-1.13,
 # three runs each, profiles/r05_split_rule.txt) walk whole tiles -- what round 4's rule did with its 2.5 on the other count.
+# Round 6: the whole-tile forward gives its longest tiles two workgroups each (PAIR_K below), which takes most of its tail away:
+# same scene (tools/experiments/pair_vs_split.sh, ms per step before / after step 8000): radius 1.0 whole + pairs 0.95 / 1.16
+# against split 1.00 / 1.26; 0.85: 0.95 / 1.15 against 1.00-1.04 / 1.23-1.26; 0.7: 0.98 / 1.17 against 0.97-1.01 / 1.16-1.18;
+# 0.5: 1.08 / 1.27 against 0.87-0.89 / 1.04-1.11.  The threshold moves to 1.25 tiles per compute unit (320): radius 0.85 now
+# walks whole tiles.  (Without pairs -- VIDU4D_SURFEL_PAIR=0 -- it is round 5's 2.0.)
 _SPLIT = os.environ.get("VIDU4D_SURFEL_SPLIT", "auto")
 SPLIT_AUTO_LEN = int(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_LEN", "2048"))
-SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU", "2.0"))
+SPLIT_AUTO_TILES_PER_CU = float(os.environ.get("VIDU4D_SURFEL_SPLIT_AUTO_TILES_PER_CU",
+                                               "1.25" if int(os.environ.get("VIDU4D_SURFEL_PAIR", "6")) > 0 else "2.0"))
 SEG_LEN = int(os.environ.get("VIDU4D_SEG_LEN", "512"))   # csrc/surfel_state.h SEG_LEN (a variant build with another length says so here)
 MSD_SORT_FROM = int(os.environ.get("VIDU4D_MSD_SORT_FROM", "10000"))  # longest list from which the long lists are MSD-split
 # The segment-parallel alpha-only blend runs without its transmittance pre-pass (Vidu4dSurfelForwardArgs::
@@ -72,7 +78,12 @@ XCD_BLOCK = int(os.environ.get("VIDU4D_SURFEL_XCD_BLOCK", "0"))
 # Paired workgroups for the longest tiles of an unsplit forward (VIDU4D_SCHED_PAIR, csrc/blend.hip fwd_pair_walk): K > 0 = the
 # tiles longer than K / 4 x the mean list length of the launch are blended by two workgroups each (15: every tile), 0 = off.
 # The process-wide default; RasterContext.pair_k overrides it.  Not together with the XCD-local schedule.
-PAIR_K = int(os.environ.get("VIDU4D_SURFEL_PAIR", "0"))
+# Default 6 (1.5 x the mean; tools/gpu_run.sh pair_ab, profiles/r06_pair_ab.txt): dense Stage-3 ball blend_fwd 348-390 -> 202 us
+# (colour + alpha instance) and 389-406 -> 223 us (planes 0-4), bench.py's fitting scene 231 -> 163 and 289 -> 212 us; a launch
+# of like lists (the headline scene) pairs nothing.  The rule goes by LIST length: where the long lists of a frame saturate
+# early and the long walks are elsewhere the pairs cost their ~1.3 x without shortening the launch (+2-5 % of the forward on
+# such a scene, tools/experiments/pair_cost.py).
+PAIR_K = int(os.environ.get("VIDU4D_SURFEL_PAIR", "6"))
 _cu_count: dict = {}
 
 

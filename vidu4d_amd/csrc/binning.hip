@@ -258,7 +258,13 @@ __device__ __forceinline__ void tile_order(GeomState g, ImageState img, int num_
     }
     __syncthreads();
     if (lane == 0 && n_long) atomicAdd(&sh.n_long, n_long);
-    if (sp.pair_k && total) atomicAdd(&sh.total_len, total);
+    if (sp.pair_k) {   // (the launch's pair count: one shared-memory atomic per wave)
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)total, off), hi = (uint32_t)__shfl_xor((int)(uint32_t)(total >> 32), off);
+            total += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0 && total) atomicAdd(&sh.total_len, total);
+    }
     __syncthreads();
     const uint32_t max_len = s_max;
     const uint64_t denom = (uint64_t)max_len + 1;

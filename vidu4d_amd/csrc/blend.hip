@@ -524,63 +524,71 @@ __device__ __forceinline__ float halves_sum(float v)
     return lo + hi;
 }
 
-// One entry per half: the lower half's is the earlier one in the list.
+// One entry per half: the lower half's is the earlier one in the list.  Branch-free in the sums: a sample that does not
+// count enters them with weight 0 (x * 0 + s == s bit for bit while x is finite: colours and normals of a record are, the
+// depth and the mapped depth of a pair that failed its tests are replaced by 0) -- written with `if (live) { ... }` the
+// compiler kept every running sum in two registers and copied them back and forth on both sides of the branch: 70 v_mov
+// per trip, 1.8 x the unpaired walk's instructions.  The one branch is wave-uniform and rare: "a pixel of this wave ends its
+// walk on this pair of entries" (once per pixel).
 template <int MODE>
 __device__ __forceinline__ void pair_step(FwdPixel& s, bool& done, bool upper, bool ok, const PairEval& e, const float4* r,
                                           uint32_t key)
 {
 #pragma clang fp contract(off)
+    // (a finished pixel's entries enter as alpha = 0 in both halves: its transmittance stays where the walk ended)
+    bool live = ok && !done;
+    const float a_own = live ? e.alpha : 0.f;
     float a1, a2;
-    both_halves(ok ? e.alpha : 0.f, a1, a2);
+    both_halves(a_own, a1, a2);
     const float T0 = s.T;
     const float T1 = T0 * (1.0f - a1);   // THRESHOLD-EXACT (fwd_accumulate: the same two roundings per entry)
     const float T2 = T1 * (1.0f - a2);
     // (T >= T_EPS while a pixel is not done, so an entry that enters as alpha = 0 never stops the walk)
     const bool stop1 = T1 < T_EPS, stop2 = T2 < T_EPS;
     const float T_own = upper ? T1 : T0;
-    const bool live = ok && !done && !stop1 && !(upper && stop2);
-    float m = 0.f, M1a = 0.f, M2a = 0.f, m2 = 0.f;
+    const float4 q3 = r[3], q4 = r[4];
+    float w = a_own * T_own;            // (0 for an entry that does not count: alpha * T otherwise, as fwd_accumulate)
+    float w1 = a1 * T0, w2 = a2 * T1;   // (full instance: the two entries' weights as both halves see them)
+    float Tn = T2;
+    if (wave_any(stop1 || stop2)) {   // the walk of a pixel ends here: the entry that would take T below T_EPS does not count
+        live = live && !stop1 && !(upper && stop2);
+        w = live ? w : 0.f;
+        w1 = stop1 ? 0.f : w1;
+        w2 = (stop1 || stop2) ? 0.f : w2;
+        Tn = stop1 ? T0 : (stop2 ? T1 : T2);
+        done = done || stop1 || stop2;
+    }
     if (MODE == BLEND_FULL) {
-        float m1;
-        m = ok ? map_depth(e.depth) - s.m0 : 0.f;
+        float m1, m2;
+        const float m = ok ? map_depth(e.depth) - s.m0 : 0.f;
         both_halves(m, m1, m2);
-        const bool first_live = a1 > 0.f && !stop1;
-        const float w1 = a1 * T0;
-        M1a = first_live ? fmaf(m1, w1, s.dist1) : s.dist1;   // the moments behind the first entry
-        M2a = first_live ? fmaf(m1 * m1, w1, s.dist2) : s.dist2;
+        // both halves carry the WHOLE moments: behind the first entry, then behind the second (forward.cu:413-414)
+        const float M1_0 = s.dist1, M2_0 = s.dist2;
+        const float M1a = fmaf(m1, w1, M1_0), M2a = fmaf(m1 * m1, w1, M2_0);
+        s.dist1 = fmaf(m2, w2, M1a);
+        s.dist2 = fmaf(m2 * m2, w2, M2a);
+        // the half's own entry against the moments in front of it (forward.cu:407-411), the median sample (:416-421)
+        const float A = 1.0f - T_own;
+        const float M1 = upper ? M1a : M1_0, M2 = upper ? M2a : M2_0;
+        const float error = fmaf(m * m, A, fmaf(-2.0f * m, M1, M2));
+        s.distortion = fmaf(error, w, s.distortion);
+        const bool med = live && T_own > 0.5f;
+        s.median_depth = med ? e.depth : s.median_depth;
+        s.median_weight = med ? w : s.median_weight;
+        s.median_contributor = med ? key : s.median_contributor;
     }
-    if (live) {
-        const float4 q3 = r[3], q4 = r[4];
-        const float nrm[3] = {q3.x, q3.y, q3.z}, rgb[3] = {q4.x, q4.y, q4.z};
-        const float w = e.alpha * T_own;
-        if (MODE == BLEND_FULL) {
-            const float A = 1.0f - T_own;
-            const float M1 = upper ? M1a : s.dist1, M2 = upper ? M2a : s.dist2;
-            const float error = fmaf(m * m, A, fmaf(-2.0f * m, M1, M2));
-            s.distortion = fmaf(error, w, s.distortion);
-            if (T_own > 0.5f) {
-                s.median_depth = e.depth;
-                s.median_weight = w;
-                s.median_contributor = key;
-            }
-        }
-        if (MODE != BLEND_LITE) {
-            for (int ch = 0; ch < 3; ch++) s.N[ch] = fmaf(nrm[ch], w, s.N[ch]);
-            s.D = fmaf(e.depth, w, s.D);
-        }
-        for (int ch = 0; ch < 3; ch++) s.C[ch] = fmaf(rgb[ch], w, s.C[ch]);
-        s.last_contributor = key;
+    if (MODE != BLEND_LITE) {
+        const float depth = live ? e.depth : 0.f;
+        s.N[0] = fmaf(q3.x, w, s.N[0]);
+        s.N[1] = fmaf(q3.y, w, s.N[1]);
+        s.N[2] = fmaf(q3.z, w, s.N[2]);
+        s.D = fmaf(depth, w, s.D);
     }
-    if (!done) {
-        if (MODE == BLEND_FULL) {
-            const bool second_live = a2 > 0.f && !stop1 && !stop2;
-            const float w2 = a2 * T1;
-            s.dist1 = second_live ? fmaf(m2, w2, M1a) : M1a;
-            s.dist2 = second_live ? fmaf(m2 * m2, w2, M2a) : M2a;
-        }
-        s.T = stop1 ? T0 : (stop2 ? T1 : T2);
-        done = stop1 || stop2;
-    }
+    s.C[0] = fmaf(q4.x, w, s.C[0]);
+    s.C[1] = fmaf(q4.y, w, s.C[1]);
+    s.C[2] = fmaf(q4.z, w, s.C[2]);
+    s.last_contributor = live ? key : s.last_contributor;
+    s.T = Tn;
 }
 
 // The sums the two halves hold of one pixel, added: afterwards both halves hold the pixel's sums.
