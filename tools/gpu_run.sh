@@ -12,6 +12,7 @@
 #   profile <tag> [args]     tools/profile_round.sh (kernel stats + FETCH / WRITE / SQ / TCC passes)
 #   fit_ab                   the fitting step's regimes (tools/fit_profile.py) with the schedule / graph switches
 #   pair_ab                  item 2: two workgroups for the longest tiles of the whole-tile forward, A/B at the headline and on the fit scenes
+#   pair_evidence            item 2: the A/B files behind DESIGN.md's paired-workgroup numbers
 #   matrix                   the final-tree measurement matrix: cfgA / cfgB (headline, default + driver form) / cfgE lines
 #   py <script> [args]       any tools/*.py under a timeout, output kept
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
@@ -154,6 +155,14 @@ import json,sys; d=json.loads(sys.stdin.read()); st=d.get('stage_ms_avg',{}); pr
       fi
     done; done | tee $O/r06_pair_ab.txt
     cp /tmp/product.so vidu4d_amd/csrc/libvidu4d_surfel.so
+    ;;
+pair_evidence)
+    # item 2, the files behind DESIGN.md's numbers: kernel times of bench.py's own fitting scene, whole tiles + pairs against
+    # the segment-parallel forward over object radii, what a pair costs per blend instance, the forward's workgroup trace
+    KS="0 4 6 8" bash tools/experiments/pair_bench_fit_kernels.sh 2>&1 | tee $O/r06_pair_bench_fit_kernels.txt
+    bash tools/experiments/pair_vs_split.sh 2>&1 | tee $O/r06_pair_vs_split.txt
+    python tools/experiments/pair_cost.py 2>&1 | grep -v amdgpu.ids | tee $O/r06_pair_cost.txt
+    [ -f variants/ftrace.so ] && KS="0 6" bash tools/experiments/pair_trace.sh 2>&1 | tee $O/r06_pair_fwd_trace.txt
     ;;
 matrix)
     timeout 1500 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log | tail -1 > $O/r06_bench_line_cfgB.json; line $O/r06_bench_line_cfgB.json

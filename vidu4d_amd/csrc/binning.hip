@@ -724,6 +724,9 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(const uint32_t* _
     const uint32_t start = ranges[2 * tile];
     const int n = (int)(ranges[2 * tile + 1] - start);
     if (n == 0 || n < min_len) return;
+#ifdef SURFEL_ABLATE_SORT_GLOBAL   // (timing experiment, results wrong: what do the lists beyond the LDS capacity cost?)
+    if (n > CAP) return;
+#endif
     // (take_long: this is the only sort launch -- a list beyond CAP goes through global memory here)
     if (IN_LDS ? ((skip_long || (CAP < TILE_SORT_CAP && !take_long)) && n > CAP) : n <= TILE_SORT_CAP) return;
     sort_one_list<WAVES, IN_LDS, CAP>(entries + start, start, n, 32, entries, scratch, point_list, id_bytes, s_buf, s_cnt,
@@ -900,6 +903,19 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const Header* hdr, int
     }
 }
 
+// Waves per workgroup of the in-LDS sort of the lists beyond 1024 entries (56 KiB of LDS: two workgroups per CU whatever
+// their size, so the waves per tile are the waves per CU, and a list's passes -- count, scan, scatter between barriers --
+// are a latency chain).  Dense Stage-3 ball (790 lists per frame beyond 320 entries, median 2 140, longest 5 240),
+// tools/experiments/sort_waves_ab.sh: 4 waves 69-70 us, 8 waves 46-47 us, 16 waves 56-58 us per launch; a third instance
+// for the lists of (1024, 2048] entries changed nothing (the launch lasts as long as its longest lists).  20 of the 46 us are
+// the ~10 % of those lists beyond TILE_SORT_CAP, which ping-pong through global memory (the SURFEL_ABLATE_SORT_GLOBAL build);
+// a 16-wave instance of their own on 128 KiB of launch-time LDS sorted them in 30 us -- one list's latency chain -- but as a
+// launch in front of this one, which then took 28: 58 us for the two.  Not kept.
+#ifndef SURFEL_SORT_LONG_WAVES
+#define SURFEL_SORT_LONG_WAVES 8
+#endif
+constexpr int SORT_LONG_WAVES = SURFEL_SORT_LONG_WAVES;
+
 void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState& b, int num_tiles, int num_surfels,
                       int64_t capacity, LongListSort mode, hipStream_t stream)
 {
@@ -928,7 +944,7 @@ void launch_tile_sort(const GeomState& g, const ImageState& img, const BinState&
             hipLaunchKernelGGL((tile_sort_kernel<16, false, 1>), dim3(num_tiles), dim3(1024), 0, stream, img.tile_order,
                                img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes, 0, 0, 0);
         if (mode != LongListSort::short_lists_expected)
-            hipLaunchKernelGGL((tile_sort_kernel<4, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(256), 0, stream, img.tile_order,
+            hipLaunchKernelGGL((tile_sort_kernel<SORT_LONG_WAVES, true, TILE_SORT_CAP>), dim3(num_tiles), dim3(SORT_LONG_WAVES * 64), 0, stream, img.tile_order,
                                img.ranges, &g.hdr->num_rendered, capacity, b.entries, b.scratch, b.point_list, id_bytes,
                                mode == LongListSort::one_workgroup ? 1 : 0, SMALL_CAP + 1, 0);
     }
