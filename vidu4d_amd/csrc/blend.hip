@@ -636,6 +636,10 @@ __device__ __forceinline__ int fwd_pair_walk(int W, int H, int grid_x, int grid_
                                              float* __restrict__ out_others, uint32_t* depth_used, int flags, int rec_len,
                                              float4* s_rec, unsigned long long (*s_mask8)[FWD_BATCH / 64], uint32_t pos, int half)
 {
+#ifndef SURFEL_PAIR_ENTRIES_CAPPED
+#define SURFEL_PAIR_ENTRIES_CAPPED 1
+#endif
+    constexpr int PAIR_ENTRIES = MODE == BLEND_LITE ? 2 : SURFEL_PAIR_ENTRIES_CAPPED;   // entries per half and trip
     const bool overflow = (int64_t)hdr->num_rendered > capacity;
     TileCoord tc;
     tc.tile = (int)img.tile_order[pos];
@@ -697,19 +701,25 @@ __device__ __forceinline__ int fwd_pair_walk(int W, int H, int grid_x, int grid_
                 m &= m - 1;
                 const int o1 = (m ? k * 64 + __builtin_ctzll(m) : FWD_BATCH) * 80;
                 m &= m - 1;
+                const int oa = upper ? o1 : o0;
+                const float4* ra = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + oa);
+                const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2];
+                const float TuA[3] = {a0.x, a0.y, a0.z}, TvA[3] = {a0.w, a1.x, a1.y}, TwA[3] = {a1.z, a1.w, a2.x};
+                PairEval ea;
+                const bool okA = eval_pair_flat(TuA, TvA, TwA, a2.y, a2.z, a2.w, pixx, pixy, ea);
+                if (PAIR_ENTRIES == 1) {   // (the instances held to 72 registers: one entry per half and trip)
+                    pair_step<MODE>(s, done, upper, okA, ea, ra, (uint32_t)(key_base + oa));
+                    continue;
+                }
                 const int o2 = (m ? k * 64 + __builtin_ctzll(m) : FWD_BATCH) * 80;
                 m &= m - 1;
                 const int o3 = (m ? k * 64 + __builtin_ctzll(m) : FWD_BATCH) * 80;
                 m &= m - 1;
-                const int oa = upper ? o1 : o0, ob = upper ? o3 : o2;
-                const float4* ra = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + oa);
+                const int ob = upper ? o3 : o2;
                 const float4* rb = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + ob);
-                const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2];
                 const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2];
-                const float TuA[3] = {a0.x, a0.y, a0.z}, TvA[3] = {a0.w, a1.x, a1.y}, TwA[3] = {a1.z, a1.w, a2.x};
                 const float TuB[3] = {b0.x, b0.y, b0.z}, TvB[3] = {b0.w, b1.x, b1.y}, TwB[3] = {b1.z, b1.w, b2.x};
-                PairEval ea, eb;
-                const bool okA = eval_pair_flat(TuA, TvA, TwA, a2.y, a2.z, a2.w, pixx, pixy, ea);
+                PairEval eb;
                 const bool okB = eval_pair_flat(TuB, TvB, TwB, b2.y, b2.z, b2.w, pixx, pixy, eb);
                 pair_step<MODE>(s, done, upper, okA, ea, ra, (uint32_t)(key_base + oa));
                 pair_step<MODE>(s, done, upper, okB, eb, rb, (uint32_t)(key_base + ob));
