@@ -781,7 +781,11 @@ def main():
                                                                 " all-reduce of surfel grads" if world > 1 else ""),
                    "frames_of_rank0": my_frames[:4] + ["..."],
                    "frames_of_a_step": "one stacked launch set" if args.stacked else
-                                       ("one call per frame, separate HIP streams" if args.frame_streams else "one call per frame")},
+                                       ("one call per frame, separate HIP streams" if args.frame_streams else "one call per frame"),
+                   # (the whole-tile forward's paired workgroups, VIDU4D_SCHED_PAIR: tiles longer than K / 4 x the launch's mean
+                   # list get two workgroups; this scene's lists are alike, so the op-level launch pairs none -- the fitting
+                   # steps' dense frames do)
+                   "sched_pair_k": int(native.PAIR_K)},
     }
     if rccl_check is not None:
         out["rccl"] = rccl_check

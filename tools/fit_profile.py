@@ -12,7 +12,7 @@ opts.update(__import__("json").loads(os.environ.get("FIT_OPTS", "{}")))  # e.g. 
 m = DeformableSurfels(opts, num_frames=frames, device=dev)
 pts = rng.normal(size=(N, 3)).astype(np.float32); pts = RADIUS * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 1.0, size=(N, 1)).astype(np.float32)
 m.init_from_points(pts, rng.uniform(size=(N, 3)).astype(np.float32), )
-with torch.no_grad(): m._scaling.add_(0.0)
+with torch.no_grad(): m._scaling.add_(0.0); m._opacity.add_(float(os.environ.get('FIT_OPACITY_SHIFT', '0')))   # (logits: +3 turns the initial 0.1 into 0.69 -- a trained, saturating cloud)
 if os.environ.get("FIT_OPTIM_WARP", "0") == "1":   # networks that train (--gs_optim_warp=True); FIT_STEP0=12001: AdamW stepping
     tr = Stage3Trainer(m, m.opts | dict(gs_optim_warp=True, num_rounds=120, iters_per_round=200))
 else:
