@@ -162,7 +162,8 @@ pair_evidence)
     KS="0 4 6 8" bash tools/experiments/pair_bench_fit_kernels.sh 2>&1 | tee $O/r06_pair_bench_fit_kernels.txt
     bash tools/experiments/pair_vs_split.sh 2>&1 | tee $O/r06_pair_vs_split.txt
     python tools/experiments/pair_cost.py 2>&1 | grep -v amdgpu.ids | tee $O/r06_pair_cost.txt
-    [ -f variants/ftrace.so ] && KS="0 6" bash tools/experiments/pair_trace.sh 2>&1 | tee $O/r06_pair_fwd_trace.txt
+    [ -f variants/ftrace.so ] && { bash tools/experiments/pair_trace2.sh; KS="0 6" bash tools/experiments/pair_trace.sh; } 2>&1 | tee $O/r06_pair_fwd_trace.txt
+    bash tools/experiments/pair_saturating.sh 2>&1 | tee $O/r06_pair_saturating.txt
     ;;
 matrix)
     timeout 1500 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log | tail -1 > $O/r06_bench_line_cfgB.json; line $O/r06_bench_line_cfgB.json
