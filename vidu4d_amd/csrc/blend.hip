@@ -27,6 +27,9 @@
 //     reduce-scatter (round 2): an LDS transposition, exact-f32 MFMA contraction of the pixel axis
 //     (tools/experiments/blend_bwd_mfma_contraction.hip.txt), per-lane LDS atomics for sparse entries, pair
 //     compaction, a 4x4-block row walk, a 2x2-block quad walk (round 3) -- none was faster;
+//   * the longest tiles of a whole-tile forward get TWO workgroups, one per half of the tile's pixels, whose waves run the
+//     transmittance recurrence over two consecutive entries per trip (fwd_pair_walk, round 6): the launch no longer waits
+//     for one workgroup's walk of its longest list;
 //   * long lists are blended segment-parallel (SPLIT instances: transmittance pre-pass, per-segment blend, in-order
 //     combine); callers that read only colour + alpha plane get the LITE instances (aux_planes), which carry
 //     nothing else and need no pre-pass: their segments are blended from T = 1 and the combine blends the one segment
@@ -491,8 +494,8 @@ __device__ __forceinline__ void store_record(float* __restrict__ seg_data, uint3
 //     each), stages every batch of the list itself and culls for its four blocks only.  Pixels are independent: the two
 //     never talk to each other;
 //   * wave w of such a workgroup owns ONE block and holds every pixel TWICE, in lane p and in lane p + 32;
-//   * the two halves of the wave take CONSECUTIVE entries of the block's culled list (two each per trip, as
-//     blend_fwd_kernel's halves): both evaluate their pair (forward.cu:358-399, independent of the transmittance), exchange
+//   * the two halves of the wave take CONSECUTIVE entries of the block's culled list (two each per trip in the colour +
+//     alpha instance, as blend_fwd_kernel's halves; one in the instances held to 72 registers): both evaluate their pair (forward.cu:358-399, independent of the transmittance), exchange
 //     alpha (and the mapped depth, full instance) with one v_permlane32_swap, and both run the transmittance recurrence
 //     over the two entries in list order -- T1 = T (1 - a1), T2 = T1 (1 - a2), the same two roundings per entry, an entry
 //     that was not accepted enters as alpha = 0 (T * 1 is exact) -- so T, the end of the walk (forward.cu:400-405) and, full
@@ -501,8 +504,8 @@ __device__ __forceinline__ void store_record(float* __restrict__ seg_data, uint3
 //   * each half accumulates ITS entries' colour / depth / normal / distortion sums; the halves are added when a recorded
 //     segment ends and when the walk ends -- these sums differ from the unpaired walk's by fp32 re-association (even
 //     entries + odd entries), the transmittance, contributor counts and median sample do not.
-// Per wave half the trips of the unpaired walk at ~1.2 x the instructions per entry (the exchange and the second
-// recurrence; measured with EVERY tile on eight waves: headline blend_fwd 148 -> 210 us, which is why only the tail's tiles
+// Per wave half the trips of the unpaired walk at ~1.3 x the instructions per entry (the exchange, the second recurrence,
+// the selects; measured with EVERY tile on eight waves: headline blend_fwd 148 -> 210 us, which is why only the tail's tiles
 // are paired) plus the second staging: the pair costs more VALU work than the one workgroup and ends in half the time --
 // where the launch waits for it.  Records, outputs, schedule otherwise as the unpaired walk.
 __device__ __forceinline__ void both_halves(float v, float& lo, float& hi)
