@@ -548,6 +548,13 @@ int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double beta1, doubl
  * it.  skip == NULL: vidu4d_adam_step. */
 int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
                              const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream);
+/* (ABI 21) AdamW for the warp / camera networks (reference: lab4d/engine/trainer.py:177-286, torch.optim.AdamW(betas (0.9,
+ * 0.999), weight_decay 1e-4) over 66 small tensors): the update above with p <- p - lr * weight_decay * p in front (torch's
+ * fused kernel, ATen/native/cuda/fused_adam_utils.cuh, ADAMW mode), n <= VIDU4D_ADAMW_MAX_TENSORS tensors per launch -- three
+ * launches for the bob networks where torch's fused capturable form takes seven of ~24 us each. */
+#define VIDU4D_ADAMW_MAX_TENSORS 32
+int vidu4d_adamw_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps, double weight_decay,
+                              const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream);
 
 /* ---- the gradient clip's norm and coefficient: torch.nn.utils.clip_grad_norm_(params, max_norm) as Trainer.check_grad
  *      calls it (lab4d/engine/trainer.py:861-869) is a norm per tensor, a stack, a norm, an add, a division, a clamp and

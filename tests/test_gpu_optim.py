@@ -272,3 +272,57 @@ def test_direct_gradient_outputs_into_the_flat_buffer(gpu_device):
         for t in (t1, t2):
             for p in t.surfel_params():
                 p.grad = None
+
+
+def test_network_adamw_equals_torch_adamw(gpu_device):
+    """gs/surfel_optim.NetworkAdamW (csrc/optim.hip adam_kernel with the decoupled decay, 32 tensors per launch) against
+    torch.optim.AdamW -- the reference's optimizer of the warp / camera networks (lab4d/engine/trainer.py:177-286): 70
+    tensors of odd sizes in two groups of different rates, one of them never given a gradient, rates changing per step as
+    the one-cycle schedule changes them, a clip coefficient riding along.  Parameters and both moments after 12 steps equal
+    to rounding (the two evaluate the bias corrections in double / in fp32)."""
+    from vidu4d_amd.gs.surfel_optim import NetworkAdamW
+    dev = gpu_device
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 1 + (i * 7) % 90) if i % 3 else (1 + i,) for i in range(70)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+
+    def make(cls, **kw):
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        groups = [{"params": ps[:40], "lr": 5e-4}, {"params": ps[40:], "lr": 5e-3}]
+        return ps, cls(groups, lr=5e-4, betas=(0.9, 0.999), weight_decay=1e-4, **kw)
+
+    pa, oa = make(NetworkAdamW)
+    pb, ob = make(torch.optim.AdamW)
+    for step in range(12):
+        coef = torch.tensor(1.0 if step % 2 else 0.37, device=dev)
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k == 13:
+                continue   # (never touched by autograd: skipped, weight decay included)
+            gr = torch.randn(a.shape, generator=g).to(dev) * (10.0 ** ((k % 5) - 3))
+            a.grad = gr.clone()
+            b.grad = gr * coef          # (torch's optimizer sees the clipped gradient; ours multiplies on the way in)
+        for grp_a, grp_b in zip(oa.param_groups, ob.param_groups):
+            grp_a["lr"] = grp_b["lr"] = grp_b["lr"] * (1.1 if step < 5 else 0.8)
+        oa.step(grad_scale=coef)
+        ob.step()
+    assert len(oa.state[pa[13]]) == 0 and torch.equal(pa[13], init[13].to(dev))
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        if k == 13:
+            continue
+        assert float(oa.state[a]["step"]) == 12.0
+        for x, y, what in ((a, b, "param"), (oa.state[a]["exp_avg"], ob.state[b]["exp_avg"], "exp_avg"),
+                           (oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], "exp_avg_sq")):
+            err = float((x - y).abs().max())
+            assert err <= 2e-6 * float(y.abs().max()) + 1e-12, (k, what, err, float(y.abs().max()))
+    # the checkpoint format is torch's: a state written by torch's AdamW (tensor step counts) loads and steps
+    oc_params, oc = make(NetworkAdamW)
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))   # (load_state_dict keeps tensors that already match: the two would share moments)
+    for a, b in zip(oc_params, pb):
+        a.data.copy_(b.data)
+        a.grad = torch.ones_like(a)
+        b.grad = torch.ones_like(b)
+    oc.step()
+    ob.step()
+    for k, (a, b) in enumerate(zip(oc_params, pb)):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12, k

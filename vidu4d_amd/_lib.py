@@ -95,6 +95,7 @@ def sched_xcd_block(block: int) -> int:
 
 BLEND_STATS = 11  # VIDU4D_BLEND_STATS (vidu4d_surfel_diag.h)
 ADAM_MAX_TENSORS = 8
+ADAMW_MAX_TENSORS = 32
 CLIP_MAX_TENSORS = 96
 CLIP_WORKSPACE_FLOATS = 1056
 DENSIFY_MAX_ATTRS = 8
@@ -181,6 +182,7 @@ SYMBOLS = {
     "vidu4d_stage3_loss_backward": (C.c_int, [C.POINTER(Stage3LossArgs), _P, C.POINTER(Stage3LossGrads), _P]),
     "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P]),
     "vidu4d_adam_step_guarded": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P, _P]),
+    "vidu4d_adamw_step_guarded": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_int, _P, _P]),
     "vidu4d_grad_clip_coef": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, _P, _P, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,

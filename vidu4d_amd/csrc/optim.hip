@@ -23,27 +23,44 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ Adam
-struct AdamLaunch {
-    Vidu4dAdamTensor t[VIDU4D_ADAM_MAX_TENSORS];
-    unsigned first_block[VIDU4D_ADAM_MAX_TENSORS + 1];
+template <int MAXT>
+struct AdamLaunchT {
+    Vidu4dAdamTensor t[MAXT];
+    unsigned first_block[MAXT + 1];
     int n;
     float beta2, one_minus_beta1, one_minus_beta2, eps;
+    float weight_decay;     // AdamW's decoupled decay (vidu4d_adamw_step_guarded); 0: Adam
     const float* grad_scale;
     int zero_grads;
     const uint32_t* skip;   // device word: non-zero = this launch changes nothing (vidu4d_adam_step_guarded)
 };
+using AdamLaunch = AdamLaunchT<VIDU4D_ADAM_MAX_TENSORS>;
 
 constexpr int ADAM_PER_THREAD = 4;
 constexpr int ADAM_PER_BLOCK = 256 * ADAM_PER_THREAD;
 
 // The update of torch's Adam (torch/optim/adam.py _single_tensor_adam, non-amsgrad, no weight decay):
 //   m <- lerp(m, g, 1 - beta1);  v <- beta2 v + (1 - beta2) g g;  p <- p - (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
-__global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
+// AdamW (vidu4d_adamw_step_guarded; torch's fused kernel, ATen/native/cuda/fused_adam_utils.cuh adam_math in ADAMW mode): the
+// same with p <- p - lr * weight_decay * p in front.  The networks of the warp / camera fields are 66 small tensors: their
+// launch struct holds 32.
+template <int MAXT>
+__global__ __launch_bounds__(256) void adam_kernel(AdamLaunchT<MAXT> a)
 {
     int k = 0;
+    if (MAXT <= 8) {
 #pragma unroll
-    for (int i = 1; i < VIDU4D_ADAM_MAX_TENSORS; i++)
-        if (i < a.n && blockIdx.x >= a.first_block[i]) k = i;
+        for (int i = 1; i < MAXT; i++)
+            if (i < a.n && blockIdx.x >= a.first_block[i]) k = i;
+    } else {   // (first_block ascends: bisection)
+        int lo = 0, hi = a.n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (blockIdx.x >= a.first_block[mid]) lo = mid;
+            else hi = mid;
+        }
+        k = lo;
+    }
     if (a.skip && *a.skip) return;   // (wave-uniform: the step's forward did not fit its buffers, its gradients are garbage)
     const Vidu4dAdamTensor t = a.t[k];
     // (captured launches read the step's scalars from device memory: same float values the host would have passed by value)
@@ -75,7 +92,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch a)
             if (a.zero_grads) t.grad[e] = 0.f;
             t.exp_avg[e] = mn;
             t.exp_avg_sq[e] = vn;
-            t.param[e] = p[j] - step_size * (mn / denom);
+            const float pd = a.weight_decay != 0.f ? p[j] - lr * a.weight_decay * p[j] : p[j];
+            t.param[e] = pd - step_size * (mn / denom);
         }
     }
 }
@@ -325,12 +343,14 @@ extern "C" int vidu4d_adam_step(int n, const Vidu4dAdamTensor* tensors, double b
     return vidu4d_adam_step_guarded(n, tensors, beta1, beta2, eps, grad_scale, zero_grads, nullptr, stream);
 }
 
-extern "C" int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
-                                        const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream)
+template <int MAXT>
+static int adam_launch(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps, double weight_decay,
+                       const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream)
 {
-    if (n < 0 || n > VIDU4D_ADAM_MAX_TENSORS || (n && !tensors)) return VIDU4D_E_INVALID;
-    AdamLaunch a;
+    if (n < 0 || n > MAXT || (n && !tensors)) return VIDU4D_E_INVALID;
+    AdamLaunchT<MAXT> a;
     a.n = 0;
+    a.weight_decay = (float)weight_decay;
     a.beta2 = (float)beta2;
     a.one_minus_beta1 = (float)(1.0 - beta1);
     a.one_minus_beta2 = (float)(1.0 - beta2);
@@ -352,8 +372,21 @@ extern "C" int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, 
     a.first_block[a.n] = blocks;
     if (!blocks) return VIDU4D_OK;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adam_kernel<MAXT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}
+
+extern "C" int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
+                                        const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream)
+{
+    return adam_launch<VIDU4D_ADAM_MAX_TENSORS>(n, tensors, beta1, beta2, eps, 0.0, grad_scale, zero_grads, skip, stream);
+}
+
+extern "C" int vidu4d_adamw_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps,
+                                         double weight_decay, const float* grad_scale, int zero_grads, const uint32_t* skip,
+                                         void* stream)
+{
+    return adam_launch<VIDU4D_ADAMW_MAX_TENSORS>(n, tensors, beta1, beta2, eps, weight_decay, grad_scale, zero_grads, skip, stream);
 }
 
 extern "C" int vidu4d_grad_clip_coef(int n, const float* const* grads, const int64_t* numel, float max_norm,

@@ -70,6 +70,61 @@ class SurfelAdam(torch.optim.Adam):
         return None
 
 
+class NetworkAdamW(torch.optim.AdamW):
+    """torch.optim.AdamW for the warp / camera networks (reference: lab4d/engine/trainer.py:177-286) -- same constructor,
+    param_groups, per-parameter state {"step", "exp_avg", "exp_avg_sq"}, so the one-cycle scheduler and the checkpoint
+    format are untouched -- whose step() is the surfel optimizer's kernel with the decoupled weight decay in front
+    (csrc/optim.hip adam_kernel, vidu4d_adamw_step_guarded): 32 tensors per launch, three launches for the bob networks'
+    66 tensors where torch's fused capturable form takes seven of ~24 us each (145 us of a 2.6 ms step).  `step` is kept
+    as a Python float in the state (a tensor found there -- a checkpoint written by torch's AdamW -- is converted on
+    first use).  grad_scale / zero_grads / captured: as SurfelAdam.step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False, fused=False)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=None, zero_grads=False, captured=None):
+        if closure is not None:
+            raise RuntimeError("NetworkAdamW: closures are not supported")
+        batches = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            lr = group["lr"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue   # (a parameter autograd never touched is skipped, weight decay included: as torch does)
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("NetworkAdamW: contiguous fp32 HIP parameters required")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0.0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                elif isinstance(st["step"], torch.Tensor):
+                    st["step"] = float(st["step"])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if captured is not None:
+                    rec = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                          p.numel(), 0.0, 0.0, 0.0, captured.row(group, p, st))
+                else:
+                    st["step"] += 1
+                    t = st["step"]
+                    rec = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                          p.numel(), float(lr), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), None)
+                batches.setdefault((p.device, b1, b2, group["eps"], group["weight_decay"]), []).append(rec)
+        lib = _lib.load()
+        skip = None if captured is None or captured.skip is None else captured.skip.data_ptr()
+        for (dev, b1, b2, eps, wd), items in batches.items():
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for i in range(0, len(items), _lib.ADAMW_MAX_TENSORS):
+                chunk = items[i:i + _lib.ADAMW_MAX_TENSORS]
+                arr = (_lib.AdamTensor * len(chunk))(*chunk)
+                _lib.check(lib.vidu4d_adamw_step_guarded(len(chunk), arr, b1, b2, eps, wd,
+                                                         None if grad_scale is None else grad_scale.data_ptr(),
+                                                         int(bool(zero_grads)), skip, stream), "adamw step")
+        return None
+
+
 class CapturedScalars:
     """The per-step scalars of a SurfelAdam launch that lives in a captured hipGraph: one device row {lr, 1 - beta1^t,
     sqrt(1 - beta2^t)} per parameter tensor, refreshed from the host's step counts by ONE small async copy in front of every
@@ -81,31 +136,40 @@ class CapturedScalars:
         self.dev = torch.zeros(self.MAX_ROWS, 4, dtype=torch.float32, device=device)
         self.host = torch.zeros(2, self.MAX_ROWS, 4, dtype=torch.float32).pin_memory()   # (two: the copy queued for the last
         self._flip = 0                                                                   # replay may not have run yet)
-        self.rows: list = []   # (group, state dict) per row, in the order the capture met them
+        self.rows: list = []   # (group, [state dicts]) per row, in the order the capture met them
+        self._row_of: dict = {}
         self.skip = skip
 
     def row(self, group, p, st) -> int:
-        if len(self.rows) >= self.MAX_ROWS:
-            raise RuntimeError("CapturedScalars: more parameter tensors than rows")
-        self.rows.append((group, st))
-        return self.dev[len(self.rows) - 1].data_ptr()
+        # (the tensors of one group at one step count share a row: the networks' 66 tensors are two rows)
+        key = (id(group), float(st["step"]))
+        i = self._row_of.get(key)
+        if i is None:
+            if len(self.rows) >= self.MAX_ROWS:
+                raise RuntimeError("CapturedScalars: more (group, step count) pairs than rows")
+            i = self._row_of[key] = len(self.rows)
+            self.rows.append((group, []))
+        self.rows[i][1].append(st)
+        return self.dev[i].data_ptr()
 
     def advance(self):
         """One optimizer step on the host's side of the books: every row's step count + 1, its scalars to the device (queued
         on the current stream, in front of the replay that reads them)."""
         self._flip ^= 1
         h = self.host[self._flip]
-        for i, (group, st) in enumerate(self.rows):
-            st["step"] += 1
-            t = float(st["step"])
+        for i, (group, states) in enumerate(self.rows):
+            for st in states:
+                st["step"] += 1
+            t = float(states[0]["step"])
             b1, b2 = group["betas"]
             h[i, 0], h[i, 1], h[i, 2] = float(group["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
         self.dev.copy_(h, non_blocking=True)
 
     def rewind(self, steps: int = 1):
         """The last `steps` replays changed nothing (their skip word was set): take their step counts back."""
-        for _, st in self.rows:
-            st["step"] -= steps
+        for _, states in self.rows:
+            for st in states:
+                st["step"] -= steps
 
 
 _clip_ws: dict = {}

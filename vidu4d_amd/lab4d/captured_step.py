@@ -46,6 +46,9 @@ class CapturedStep:
         self.skip_f = torch.zeros((), dtype=torch.float32, device=dev)    # ... as the fused AdamW's `found_inf` (0-dim, as its step counters)
         self.scalars = CapturedScalars(dev, skip=self.skip)
         self.adamw = tr.optimizer is not None and step >= tr.optim_warp_from
+        from ..gs.surfel_optim import NetworkAdamW
+        # (the networks' AdamW as the surfel optimizer's kernel: its scalars and skip word like the surfel Adam's)
+        self.net_scalars = CapturedScalars(dev, skip=self.skip) if self.adamw and isinstance(tr.optimizer, NetworkAdamW) else None
         self.replays = 0
         s = tr._step_stream()
         # what the step's launches create lazily PER STREAM must exist before the capture (made inside it, it would live in
@@ -109,8 +112,10 @@ class CapturedStep:
             whole = tr._flat is not None and all(p.grad is not None for p in tr.exchanged_params())
             tr.gs_optimizer.step(grad_scale=coef, zero_grads=whole, captured=self.scalars)
             self.leaves_flat_zero = whole
-            if self.adamw:
-                tr.optimizer.found_inf = self.skip_f    # (read by the fused step: nothing is updated, its step counter taken back)
+            if self.adamw and self.net_scalars is not None:
+                tr.optimizer.step(grad_scale=coef if inv is not None else None, captured=self.net_scalars)
+            elif self.adamw:
+                tr.optimizer.found_inf = self.skip_f    # (read by torch's fused step: nothing is updated, its step counter taken back)
                 if inv is not None:
                     tr.optimizer.grad_scale = inv       # (the clip, folded in: Stage3Trainer._fold_clip_into_both)
                 try:
@@ -129,6 +134,8 @@ class CapturedStep:
         for slot, _stat, _cap, _key in self.frames:
             slot[0] = SENTINEL
         self.scalars.advance()
+        if self.net_scalars is not None:
+            self.net_scalars.advance()
         self.graph.replay()
         if self.adamw:
             tr.scheduler.step()
@@ -155,6 +162,8 @@ class CapturedStep:
         tr = self.tr
         tr.__dict__.pop("_flat_is_zero", None)   # (the skipped Adam did not zero the flat gradient buffer)
         self.scalars.rewind(1)
+        if self.net_scalars is not None:
+            self.net_scalars.rewind(1)
         if self.adamw:
             tr.scheduler.last_epoch -= 2
             tr.scheduler.step()

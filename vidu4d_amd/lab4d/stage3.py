@@ -170,9 +170,17 @@ class Stage3Trainer:
             # on the device in fp32, the other one on the host in double -- 1e-7 apart per step, which AdamW's normalised
             # updates amplify; one form for both keeps the captured and the eager loop on ONE trajectory)
             capt = fused and self.world == 1 and bool(o.get("capturable_network_adamw", True))
-            self.optimizer = torch.optim.AdamW(groups, lr=torch.tensor(float(c.learning_rate), device=m._xyz.device) if capt
-                                               else c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
-                                               **({"fused": True} if fused else {}), **({"capturable": True} if capt else {}))
+            # Round 6: the same update from the surfel optimizer's kernel (gs/surfel_optim.NetworkAdamW: 32 tensors per
+            # launch -- three launches for the 66 tensors where torch's fused capturable form takes seven of ~24 us each,
+            # 145 us of a 2.6 ms step; scalars by value, or from device rows when the step is a captured graph's).
+            # `network_adamw: "torch"` restores torch's optimizer.
+            if on_gpu and o.get("network_adamw", "hip") == "hip":
+                from ..gs.surfel_optim import NetworkAdamW
+                self.optimizer = NetworkAdamW(groups, lr=c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4)
+            else:
+                self.optimizer = torch.optim.AdamW(groups, lr=torch.tensor(float(c.learning_rate), device=m._xyz.device) if capt
+                                                   else c.learning_rate, betas=(0.9, 0.999), weight_decay=1e-4,
+                                                   **({"fused": True} if fused else {}), **({"capturable": True} if capt else {}))
             # trainer.py:268-275: a resumed run starts the networks at the full rate and decays to lr / 5; a fresh one
             # warms up from lr / 25 over two rounds
             if self.is_resumed:
@@ -485,10 +493,10 @@ class Stage3Trainer:
         instead of clip_grad_norm_'s per-tensor norms, stack, norm, clamp and a multiply pass over 47 MB.  While the networks'
         gradients still ACCUMULATE over a round (before optim_warp_neus_iters) upstream's in-place clip scales what has
         accumulated, every step: that stays torch's clip_grad_norm_."""
-        from ..gs.surfel_optim import SurfelAdam
+        from ..gs.surfel_optim import NetworkAdamW, SurfelAdam
         return (self._adamw_steps(step) and isinstance(self.gs_optimizer, SurfelAdam) and self.world == 1
                 and bool(self.opts.get("fold_clip_into_optimizers", True))
-                and any(g.get("fused") for g in self.optimizer.param_groups))
+                and (isinstance(self.optimizer, NetworkAdamW) or any(g.get("fused") for g in self.optimizer.param_groups)))
 
     def clip_gradients(self, max_norm: float = 5.0, step: int | None = None):
         """clip_grad_norm_ over the parameters that have a gradient (trainer.py:861-869)."""
@@ -542,14 +550,19 @@ class Stage3Trainer:
         else:
             self.gs_optimizer.step()
         if self.optimizer is not None and step >= self.optim_warp_from:
+            from ..gs.surfel_optim import NetworkAdamW
             inv = self.__dict__.pop("_clip_inv", None)
-            if inv is not None:
-                self.optimizer.grad_scale = inv     # (the fused step divides the gradients by it: the clip, folded in)
-            try:
-                self.optimizer.step()
-            finally:
+            if isinstance(self.optimizer, NetworkAdamW):
+                # (the clip, folded in: this kernel multiplies by the coefficient, as the surfel Adam does)
+                self.optimizer.step(grad_scale=coef if inv is not None else None)
+            else:
                 if inv is not None:
-                    del self.optimizer.grad_scale
+                    self.optimizer.grad_scale = inv     # (torch's fused step divides the gradients by it)
+                try:
+                    self.optimizer.step()
+                finally:
+                    if inv is not None:
+                        del self.optimizer.grad_scale
             self.scheduler.step()
             self._net_accum = [None] * len(self._net_params)   # optimizer.zero_grad() (trainer.py:596-598)
 
