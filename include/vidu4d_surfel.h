@@ -556,6 +556,22 @@ int vidu4d_adam_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta
 int vidu4d_adamw_step_guarded(int n, const Vidu4dAdamTensor* tensors, double beta1, double beta2, double eps, double weight_decay,
                               const float* grad_scale, int zero_grads, const uint32_t* skip, void* stream);
 
+/* ---- (ABI 21) contractions over the surfels: out_j (rows_a x rows_b, row-major, ADDED to: the caller zero-fills) +=
+ *      sum_k a_j[r][k] * b_j[c][k] for up to VIDU4D_CONTRACT_MAX_JOBS pairs of strided (rows x K)
+ *      operands of at most 96 rows each, in ONE launch -- the weight gradients of the skinning field's layers when the networks
+ *      train (reference: autograd through lab4d/nnutils/skinning.py's delta MLP; here lab4d/lbs_fused._SkinFieldTrain.backward).
+ *      fp32 matrix cores (an fmaf chain); partial sums leave through float atomics: not a fixed summation order.  `jobs` is
+ *      a HOST array. ---- */
+#define VIDU4D_CONTRACT_MAX_JOBS 4
+typedef struct Vidu4dContractJob {
+    const float* a;   /* element (r, k) at a[r * lda + k * sa] */
+    const float* b;   /* element (c, k) at b[c * ldb + k * sb] (an (N, 4) array of points as four rows: ldb 1, sb 4) */
+    float* out;       /* (rows_a, rows_b) */
+    int rows_a, rows_b;
+    int64_t lda, ldb, sa, sb;
+} Vidu4dContractJob;
+int vidu4d_contract_rows(int n, const Vidu4dContractJob* jobs, int64_t K, void* stream);
+
 /* ---- the gradient clip's norm and coefficient: torch.nn.utils.clip_grad_norm_(params, max_norm) as Trainer.check_grad
  *      calls it (lab4d/engine/trainer.py:861-869) is a norm per tensor, a stack, a norm, an add, a division, a clamp and
  *      a multiply per tensor; here ONE launch reads the n gradient arrays (grads[i], numel[i]; HOST arrays, n <=

@@ -510,3 +510,25 @@ def test_camera_tail_kernel_matches_the_torch_ops(gpu_device):
             res[fused] = (out.detach(), a.grad, b.grad)
         for x, y in zip(res[True], res[False]):
             assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+
+
+def test_contractions_over_the_surfels_in_one_launch(gpu_device):
+    """lbs_fused.contract_pairs (csrc/contract.hip: the skinning field's weight gradients, fp32 matrix cores, one launch per
+    four contractions) against the products in float64: the shapes of the bob networks' step (75 x 4 against points stored
+    (N, 4), 64 x 76, 25 x 65, 64 x 65), N not a multiple of anything, rows that are strided views."""
+    from vidu4d_amd.lab4d.lbs_fused import contract_pairs
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    for N in (200_000, 175_366, 33, 4097):
+        pts = torch.randn(N, 4, generator=g).to(dev)
+        big = torch.randn(2, 64, N, generator=g).to(dev)
+        pairs = [(torch.randn(75, N, generator=g).to(dev), pts.t()),
+                 (big[0], torch.randn(76, N, generator=g).to(dev)),
+                 (torch.randn(25, N, generator=g).to(dev), torch.randn(66, N, generator=g).to(dev)[:65]),
+                 (big[1], torch.randn(65, N, generator=g).to(dev)),
+                 (torch.randn(96, N, generator=g).to(dev), torch.randn(1, N, generator=g).to(dev))]
+        outs = contract_pairs(pairs)
+        for (l, r), o in zip(pairs, outs):
+            ref = l.double() @ r.double().t()
+            err = float((o.double() - ref).abs().max())
+            assert o.shape == ref.shape and err <= 2e-6 * float(ref.abs().max()) * max(1.0, (N / 1e4) ** 0.5), (N, tuple(o.shape), err)

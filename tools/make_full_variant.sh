@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; flags=$2
 mkdir -p variants/obj_$name
 C=vidu4d_amd/csrc
-for f in preprocess binning blend quaternion lbs bone_tables dense_stack knn post optim skin_field loss capi; do
+for f in preprocess binning blend quaternion lbs bone_tables dense_stack knn post optim skin_field loss contract capi; do
   extra=""; [ $f = blend ] && extra="-fno-slp-vectorize"; [ $f = lbs ] && extra="-Wno-pass-failed"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-function -I include $extra $flags \
       -c $C/$f.hip -o variants/obj_$name/$f.o &

@@ -34,6 +34,12 @@ class ForwardArgs(C.Structure):
     ]
 
 
+class ContractJob(C.Structure):
+    """struct Vidu4dContractJob"""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("rows_a", C.c_int), ("rows_b", C.c_int),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("sa", C.c_int64), ("sb", C.c_int64)]
+
+
 class AdamTensor(C.Structure):
     """struct Vidu4dAdamTensor"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
@@ -96,6 +102,7 @@ def sched_xcd_block(block: int) -> int:
 BLEND_STATS = 11  # VIDU4D_BLEND_STATS (vidu4d_surfel_diag.h)
 ADAM_MAX_TENSORS = 8
 ADAMW_MAX_TENSORS = 32
+CONTRACT_MAX_JOBS = 4
 CLIP_MAX_TENSORS = 96
 CLIP_WORKSPACE_FLOATS = 1056
 DENSIFY_MAX_ATTRS = 8
@@ -183,6 +190,7 @@ SYMBOLS = {
     "vidu4d_adam_step": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P]),
     "vidu4d_adam_step_guarded": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P, _P]),
     "vidu4d_adamw_step_guarded": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_int, _P, _P]),
+    "vidu4d_contract_rows": (C.c_int, [C.c_int, C.POINTER(ContractJob), C.c_int64, _P]),
     "vidu4d_grad_clip_coef": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, _P, _P, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,

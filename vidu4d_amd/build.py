@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libvidu4d_surfel.so")
-SOURCES = ["preprocess.hip", "binning.hip", "blend.hip", "quaternion.hip", "lbs.hip", "bone_tables.hip", "dense_stack.hip", "knn.hip", "post.hip", "optim.hip", "skin_field.hip", "loss.hip", "capi.hip"]
+SOURCES = ["preprocess.hip", "binning.hip", "blend.hip", "quaternion.hip", "lbs.hip", "bone_tables.hip", "dense_stack.hip", "knn.hip", "post.hip", "optim.hip", "skin_field.hip", "loss.hip", "contract.hip", "capi.hip"]
 HEADERS = ["surfel_math.h", "surfel_state.h", "post_math.h", "wave_utils.h", "wave_reduce.h", "bone_tables_math.h",
            os.path.join(INCLUDE, "vidu4d_surfel.h"),
            os.path.join(INCLUDE, "vidu4d_surfel_diag.h")]

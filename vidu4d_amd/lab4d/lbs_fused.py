@@ -336,17 +336,45 @@ def _train_buffers(sm, dev, N, B, scratch=False):
         # values either way)
         return dict(bufs, N=N, gen=None, xb1=torch.empty(3 * B + 1, N, dtype=torch.float32, device=dev),
                     h1=torch.empty(D, W + 1, N, dtype=torch.float32, device=dev),
-                    xyz1=torch.empty(N, 4, dtype=torch.float32, device=dev))
+                    xyz1=torch.empty(4, N, dtype=torch.float32, device=dev))
     if bufs.get("N") != N:
         bufs["N"] = N
         xb1 = torch.empty(3 * B + 1, N, dtype=torch.float32, device=dev)
         xb1[3 * B] = 1.0
         h1 = torch.empty(D, W + 1, N, dtype=torch.float32, device=dev)
         h1[:, W] = 1.0
-        xyz1 = torch.ones(N, 4, dtype=torch.float32, device=dev)
+        xyz1 = torch.ones(4, N, dtype=torch.float32, device=dev)   # ([x; y; z; 1] feature-major, like the other right operands)
         bufs.update(xb1=xb1, h1=h1, xyz1=xyz1)
     bufs["gen"] = bufs.get("gen") or 0
     return bufs
+
+
+def contract_pairs(pairs):
+    """[(L (O, N), R (I, N)), ...] -> [L @ R^T (O, I), ...]: the contractions over the surfels of a step's weight gradients in
+    one launch per four of them (csrc/contract.hip; bob_warp.contract_over_columns is the library form: four launches
+    each).  Operands: fp32 HIP tensors whose rows are strided views (unit or constant stride along N), at most 96 rows."""
+    dev = pairs[0][0].device
+    sizes = [(int(l.shape[0]), int(r.shape[0])) for l, r in pairs]
+    flat = torch.zeros(sum(o * i for o, i in sizes), dtype=torch.float32, device=dev)   # (the kernel ADDS: one fill for all)
+    outs, off = [], 0
+    for o, i in sizes:
+        outs.append(flat[off:off + o * i].view(o, i))
+        off += o * i
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    N = int(pairs[0][0].shape[1])
+    for s0 in range(0, len(pairs), _lib.CONTRACT_MAX_JOBS):
+        chunk = list(zip(pairs, outs))[s0:s0 + _lib.CONTRACT_MAX_JOBS]
+        jobs = []
+        for (l, r), out in chunk:
+            if l.dtype != torch.float32 or r.dtype != torch.float32 or not l.is_cuda or int(l.shape[1]) != N or int(r.shape[1]) != N \
+                    or max(l.shape[0], r.shape[0]) > 96:
+                raise RuntimeError("contract_pairs: fp32 HIP operands over the same N, at most 96 rows each")
+            jobs.append(_lib.ContractJob(l.data_ptr(), r.data_ptr(), out.data_ptr(), int(l.shape[0]), int(r.shape[0]),
+                                         int(l.stride(0)), int(r.stride(0)), int(l.stride(1)), int(r.stride(1))))
+        arr = (_lib.ContractJob * len(jobs))(*jobs)
+        _lib.check(lib.vidu4d_contract_rows(len(jobs), arr, N, stream), "contract rows")
+    return outs
 
 
 class _SkinFieldTrain(Function):
@@ -365,7 +393,7 @@ class _SkinFieldTrain(Function):
             for i in range(D - 1):
                 sm_bufs["w_hid"][i].copy_(hidden[2 * i])
                 sm_bufs["b_hid"][i].copy_(hidden[2 * i + 1])
-            sm_bufs["xyz1"][:, :3].copy_(x)
+            sm_bufs["xyz1"][:3].copy_(x.t())
         tab = dict(B=B, D=D, bone_A=_c(A), bone_c=_c(c0), **{k: sm_bufs[k] for k in ("w_in", "w_out", "b_out", "w_hid", "b_hid")})
         dev = xyz.device
         xb1, h1 = sm_bufs["xb1"], sm_bufs["h1"]
@@ -409,19 +437,27 @@ class _SkinFieldTrain(Function):
         need = ctx.needs_input_grad
         # every contraction against [x; 1]: the last column is the bias gradient (the row sum of its left operand)
         g_A = g_c = g_w1 = g_b_in = g_wo = g_bo = None
+        pairs = []   # (left (O, N), right (I, N), what)
         if need[2] or need[3]:
-            t = contract_over_columns(gx, xyz1.t())            # (3B, 4)
-            g_A, g_c = t[:, :3], t[:, 3]
+            pairs.append((gx, xyz1, "A"))                      # (3B, 4)
         if need[4] or need[1]:
-            t = contract_over_columns(g[0], xb1)                # (W, 3B + 1)
-            g_w1, g_b_in = t[:, :3 * B], t[:, 3 * B]
+            pairs.append((g[0], xb1, "w1"))                    # (W, 3B + 1)
         if need[5] or need[6]:
-            t = contract_over_columns(g_rawT, h1[D - 1])        # (B, W + 1)
-            g_wo, g_bo = t[:, :W], t[:, W]
-        hidden = []
+            pairs.append((g_rawT, h1[D - 1], "wo"))            # (B, W + 1)
         for i in range(1, D):
-            t = contract_over_columns(g[i], h1[i - 1])          # (W, W + 1)
-            hidden += [t[:, :W], t[:, W]]
+            pairs.append((g[i], h1[i - 1], i))                 # (W, W + 1)
+        outs = contract_pairs([(l, r) for l, r, _ in pairs]) if ctx.bufs.get("fused_contractions", True) else \
+            [contract_over_columns(l, r) for l, r, _ in pairs]
+        hidden = []
+        for (_l, _r, what), t in zip(pairs, outs):
+            if what == "A":
+                g_A, g_c = t[:, :3], t[:, 3]
+            elif what == "w1":
+                g_w1, g_b_in = t[:, :3 * B], t[:, 3 * B]
+            elif what == "wo":
+                g_wo, g_bo = t[:, :W], t[:, W]
+            else:
+                hidden += [t[:, :W], t[:, W]]
         return (g_xyz if need[0] else None, g_b_in, g_A, g_c, g_w1, g_wo, g_bo, None, *hidden)
 
 
