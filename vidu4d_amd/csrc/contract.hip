@@ -23,6 +23,15 @@ constexpr int KS = 32;          // columns per stage
 constexpr int MAXR = 96;        // rows of either operand (three 32-row blocks)
 constexpr int LD = KS + 1;      // LDS row stride: rows 32 apart at one column fall into 32 different banks
 
+#ifndef CONTRACT_BUFS
+#define CONTRACT_BUFS 2
+#endif
+#ifndef CONTRACT_WAVES
+#define CONTRACT_WAVES 3
+#endif
+#ifndef CONTRACT_WG_PER_CU
+#define CONTRACT_WG_PER_CU 3
+#endif
 struct __attribute__((packed, aligned(4))) Quad {
     float x, y, z, w;
 };
@@ -40,9 +49,9 @@ struct ContractLaunch {
 // stage ahead, into registers (24 dwords in flight per thread).  Otherwise (an operand strided along k, e.g. an (N, 4) point
 // array read as four rows): four-byte loads straight into the other LDS buffer -- correct, not fast.
 template <bool WIDE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void contract_rows_kernel(ContractLaunch a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CONTRACT_WAVES, CONTRACT_WAVES))) void contract_rows_kernel(ContractLaunch a)
 {
-    __shared__ float s_a[2][MAXR * LD], s_b[2][MAXR * LD];
+    __shared__ float s_a[CONTRACT_BUFS][MAXR * LD], s_b[CONTRACT_BUFS][MAXR * LD];
     const Vidu4dContractJob job = a.j[blockIdx.y];
     const int M = job.rows_a, C = job.rows_b;
     const int MT = (M + 31) >> 5, NT = (C + 31) >> 5, tiles = MT * NT;
@@ -147,12 +156,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kp], pb[2 * kp], acc[i], 0, 0, 0);
             }
         }
+        if (CONTRACT_BUFS == 1) __syncthreads();          // (every wave is done reading the one buffer)
         if (more) {
-            if (WIDE) stash(buf ^ 1);
-            else stage_narrow(buf ^ 1, k0 + KS);
+            if (WIDE) stash(CONTRACT_BUFS == 1 ? 0 : buf ^ 1);
+            else stage_narrow(CONTRACT_BUFS == 1 ? 0 : buf ^ 1, k0 + KS);
         }
         __syncthreads();
-        buf ^= 1;
+        if (CONTRACT_BUFS == 2) buf ^= 1;
     }
     // C/D layout of the 32x32x2 MFMA: register v of lane l holds row (v & 3) + 8 (v >> 2) + 4 (l >> 5), column l & 31
 #pragma unroll
@@ -191,7 +201,7 @@ extern "C" int vidu4d_contract_rows(int n, const Vidu4dContractJob* jobs, int64_
     auto launch = [&](ContractLaunch& a, int count, bool is_wide) {
         if (!count) return;
         // three workgroups per compute unit over the contractions of the launch, at least eight stages each
-        const int64_t want = 768 / count;
+        const int64_t want = 256 * CONTRACT_WG_PER_CU / count;
         int64_t blocks = stages / 8 < want ? (stages / 8 > 0 ? stages / 8 : 1) : want;
         a.K = K;
         a.k_per_block = ((stages + blocks - 1) / blocks) * KS;
