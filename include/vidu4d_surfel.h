@@ -572,6 +572,17 @@ typedef struct Vidu4dContractJob {
 } Vidu4dContractJob;
 int vidu4d_contract_rows(int n, const Vidu4dContractJob* jobs, int64_t K, void* stream);
 
+/* ---- (ABI 21) up to VIDU4D_COPY_MAX_JOBS strided 2-D copies of fp32 in one launch: dst[r * dst_ld + c] = src[r * src_ld +
+ *      c * src_cs] for r < rows, c < cols (a transposing copy: src_ld 1, src_cs = the source's row length).  `jobs` is a HOST
+ *      array.  Used by the TRAIN skinning field to repack its weights and the surfel centres every step. ---- */
+#define VIDU4D_COPY_MAX_JOBS 8
+typedef struct Vidu4dCopyJob {
+    const float* src;
+    float* dst;
+    int64_t rows, cols, src_ld, src_cs, dst_ld;
+} Vidu4dCopyJob;
+int vidu4d_copy_strided(int n, const Vidu4dCopyJob* jobs, void* stream);
+
 /* ---- the gradient clip's norm and coefficient: torch.nn.utils.clip_grad_norm_(params, max_norm) as Trainer.check_grad
  *      calls it (lab4d/engine/trainer.py:861-869) is a norm per tensor, a stack, a norm, an add, a division, a clamp and
  *      a multiply per tensor; here ONE launch reads the n gradient arrays (grads[i], numel[i]; HOST arrays, n <=

@@ -532,3 +532,26 @@ def test_contractions_over_the_surfels_in_one_launch(gpu_device):
             ref = l.double() @ r.double().t()
             err = float((o.double() - ref).abs().max())
             assert o.shape == ref.shape and err <= 2e-6 * float(ref.abs().max()) * max(1.0, (N / 1e4) ** 0.5), (N, tuple(o.shape), err)
+
+
+def test_strided_copies_in_one_launch(gpu_device):
+    """lbs_fused.copy_strided: padded weight arrays, a row vector, a transposing copy of the centres -- what the TRAIN skinning
+    field repacks every step -- equal to Tensor.copy_ bit for bit."""
+    from vidu4d_amd.lab4d.lbs_fused import copy_strided
+    dev = gpu_device
+    g = torch.Generator().manual_seed(9)
+    N = 12_345
+    srcs = [torch.randn(64, 75, generator=g), torch.randn(25, 64, generator=g), torch.randn(1, 25, generator=g),
+            torch.randn(N, 3, generator=g).t(), torch.randn(64, 64, generator=g), torch.randn(1, 64, generator=g)] + \
+           [torch.randn(3, 5, generator=g) for _ in range(5)]
+    srcs = [s.to(dev) if s.is_contiguous() else s.t().contiguous().to(dev).t() for s in srcs]
+    bufs = [torch.zeros(64, 96, device=dev), torch.zeros(32, 64, device=dev), torch.zeros(1, 32, device=dev),
+            torch.ones(4, N, device=dev), torch.zeros(64, 64, device=dev), torch.zeros(1, 64, device=dev)] + \
+           [torch.zeros(4, 8, device=dev) for _ in range(5)]
+    want = [b.clone() for b in bufs]
+    views = lambda bs: [bs[0][:, :75], bs[1][:25], bs[2][:, :25], bs[3][:3], bs[4], bs[5]] + [b[:3, :5] for b in bs[6:]]  # noqa: E731
+    for s, d in zip(srcs, views(want)):
+        d.copy_(s)
+    copy_strided(list(zip(srcs, views(bufs))))
+    for a, b in zip(bufs, want):
+        assert torch.equal(a, b)

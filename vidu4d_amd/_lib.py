@@ -40,6 +40,12 @@ class ContractJob(C.Structure):
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("sa", C.c_int64), ("sb", C.c_int64)]
 
 
+class CopyJob(C.Structure):
+    """struct Vidu4dCopyJob"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("src_ld", C.c_int64),
+                ("src_cs", C.c_int64), ("dst_ld", C.c_int64)]
+
+
 class AdamTensor(C.Structure):
     """struct Vidu4dAdamTensor"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
@@ -103,6 +109,7 @@ BLEND_STATS = 11  # VIDU4D_BLEND_STATS (vidu4d_surfel_diag.h)
 ADAM_MAX_TENSORS = 8
 ADAMW_MAX_TENSORS = 32
 CONTRACT_MAX_JOBS = 4
+COPY_MAX_JOBS = 8
 CLIP_MAX_TENSORS = 96
 CLIP_WORKSPACE_FLOATS = 1056
 DENSIFY_MAX_ATTRS = 8
@@ -191,6 +198,7 @@ SYMBOLS = {
     "vidu4d_adam_step_guarded": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _P, C.c_int, _P, _P]),
     "vidu4d_adamw_step_guarded": (C.c_int, [C.c_int, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_int, _P, _P]),
     "vidu4d_contract_rows": (C.c_int, [C.c_int, C.POINTER(ContractJob), C.c_int64, _P]),
+    "vidu4d_copy_strided": (C.c_int, [C.c_int, C.POINTER(CopyJob), _P]),
     "vidu4d_grad_clip_coef": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, _P, _P, _P]),
     "vidu4d_densify_plan": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vidu4d_densify_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DensifyAttr), C.c_int,

@@ -215,3 +215,56 @@ extern "C" int vidu4d_contract_rows(int n, const Vidu4dContractJob* jobs, int64_
     launch(narrow, n_narrow, false);
     return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
 }
+
+// ---- several small strided 2-D copies in one launch: the TRAIN skinning field repacks its weights into the kernels' padded
+// arrays and the surfel centres into a feature-major array every step -- six copies of 64 bytes .. 2.4 MB, ~6 us each as
+// launches of their own (lab4d/lbs_fused._SkinFieldTrain.forward).
+namespace {
+struct CopyLaunch {
+    Vidu4dCopyJob j[VIDU4D_COPY_MAX_JOBS];
+    unsigned first_block[VIDU4D_COPY_MAX_JOBS + 1];
+    int n;
+};
+constexpr int COPY_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void copy_strided_kernel(CopyLaunch a)
+{
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < VIDU4D_COPY_MAX_JOBS; i++)
+        if (i < a.n && blockIdx.x >= a.first_block[i]) k = i;
+    const Vidu4dCopyJob job = a.j[k];
+    const int64_t total = (int64_t)job.rows * job.cols;
+    const int64_t base = (int64_t)(blockIdx.x - a.first_block[k]) * COPY_PER_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < COPY_PER_BLOCK / 256; i++) {
+        const int64_t e = base + 256 * i;
+        if (e < total) {
+            const int64_t r = e / job.cols, c = e - r * job.cols;
+            job.dst[r * job.dst_ld + c] = job.src[r * job.src_ld + c * job.src_cs];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vidu4d_copy_strided(int n, const Vidu4dCopyJob* jobs, void* stream)
+{
+    if (n < 0 || n > VIDU4D_COPY_MAX_JOBS || (n && !jobs)) return VIDU4D_E_INVALID;
+    CopyLaunch a;
+    a.n = 0;
+    unsigned blocks = 0;
+    for (int i = 0; i < n; i++) {
+        const Vidu4dCopyJob& j = jobs[i];
+        if (j.rows < 0 || j.cols < 0 || ((int64_t)j.rows * j.cols && (!j.src || !j.dst))) return VIDU4D_E_INVALID;
+        if ((int64_t)j.rows * j.cols == 0) continue;
+        a.j[a.n] = j;
+        a.first_block[a.n] = blocks;
+        blocks += (unsigned)(((int64_t)j.rows * j.cols + COPY_PER_BLOCK - 1) / COPY_PER_BLOCK);
+        a.n++;
+    }
+    a.first_block[a.n] = blocks;
+    if (!blocks) return VIDU4D_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(copy_strided_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? VIDU4D_OK : VIDU4D_E_HIP;
+}

@@ -349,6 +349,24 @@ def _train_buffers(sm, dev, N, B, scratch=False):
     return bufs
 
 
+def copy_strided(copies):
+    """[(src (R, C) view, dst (R, C) view with unit column stride), ...] -> dst[...] = src, one launch per eight copies
+    (csrc/contract.hip copy_strided_kernel); fp32 HIP tensors."""
+    lib = _lib.load()
+    dev = copies[0][1].device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for s0 in range(0, len(copies), _lib.COPY_MAX_JOBS):
+        jobs = []
+        for src, dst in copies[s0:s0 + _lib.COPY_MAX_JOBS]:
+            if src.shape != dst.shape or src.dim() != 2 or src.dtype != torch.float32 or dst.dtype != torch.float32 or \
+                    not dst.is_cuda or (dst.shape[1] > 1 and dst.stride(1) != 1):
+                raise RuntimeError("copy_strided: 2-D fp32 HIP views of equal shape, unit column stride on the destination")
+            jobs.append(_lib.CopyJob(src.data_ptr(), dst.data_ptr(), int(src.shape[0]), int(src.shape[1]), int(src.stride(0)),
+                                     int(src.stride(1)), int(dst.stride(0))))
+        arr = (_lib.CopyJob * len(jobs))(*jobs)
+        _lib.check(lib.vidu4d_copy_strided(len(jobs), arr, stream), "copy strided")
+
+
 def contract_pairs(pairs):
     """[(L (O, N), R (I, N)), ...] -> [L @ R^T (O, I), ...]: the contractions over the surfels of a step's weight gradients in
     one launch per four of them (csrc/contract.hip; bob_warp.contract_over_columns is the library form: four launches
@@ -387,13 +405,12 @@ class _SkinFieldTrain(Function):
         W = _lib.SKIN_FIELD["width"]
         x, b = _c(xyz), _c(b_in).reshape(-1)
         with torch.no_grad():
-            sm_bufs["w_in"][:, :3 * B].copy_(w1)
-            sm_bufs["w_out"][:B].copy_(w_out)
-            sm_bufs["b_out"][:B].copy_(b_out)
+            # the weights into the kernels' padded arrays, the centres into the feature-major [x; y; z; 1]: one launch
+            copies = [(w1, sm_bufs["w_in"][:, :3 * B]), (w_out, sm_bufs["w_out"][:B]), (b_out[None], sm_bufs["b_out"][None, :B]),
+                      (x.t(), sm_bufs["xyz1"][:3])]
             for i in range(D - 1):
-                sm_bufs["w_hid"][i].copy_(hidden[2 * i])
-                sm_bufs["b_hid"][i].copy_(hidden[2 * i + 1])
-            sm_bufs["xyz1"][:3].copy_(x.t())
+                copies += [(hidden[2 * i], sm_bufs["w_hid"][i]), (hidden[2 * i + 1][None], sm_bufs["b_hid"][i][None])]
+            copy_strided(copies)
         tab = dict(B=B, D=D, bone_A=_c(A), bone_c=_c(c0), **{k: sm_bufs[k] for k in ("w_in", "w_out", "b_out", "w_hid", "b_hid")})
         dev = xyz.device
         xb1, h1 = sm_bufs["xb1"], sm_bufs["h1"]
