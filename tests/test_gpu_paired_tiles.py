@@ -160,3 +160,38 @@ def test_paired_workgroups_stacked_frames_equal_per_frame_calls(gpu_device, monk
             for k in (1, 5, 7):
                 assert torch.equal(others[k, i], o1[k]), (i, k)
             assert float((color[:, i] - c1).abs().max()) <= 1e-6 and float((others[:, i] - o1).abs().max()) <= 1e-6 * (1 + float(o1.abs().max()))
+
+
+@pytest.mark.parametrize("which,k", [("concentrated", 6), ("concentrated_opaque", 15), ("mixed", 15), ("partial_tiles", 6)])
+def test_paired_workgroups_match_the_oracle(gpu_device, monkeypatch, which, k):
+    """The paired walk against the CPU ORACLE (forward.cu:265-463 / backward.cu:143-449 restated, oracle/surfel_oracle.c), not only
+    against the product's own one-workgroup walk: the scenes of the segment-parallel path's oracle tests (long lists, pixels
+    that saturate inside them, tiles at the image border), whole tiles, with the product's pairing rule (K = 6) and with
+    every tile paired.  Same checks as every forward / backward parity test: integers identical, floats within the usual
+    tolerance, the recorded backward fed from the paired forward included."""
+    import numpy as np
+    from tests.test_gpu_parity import _check_backward, _check_forward, _concentrated, _native_forward
+    from tests.util import oracle_forward
+    from vidu4d_amd import _C, _lib
+    monkeypatch.setattr(_C, "_SPLIT", "0")
+    monkeypatch.setattr(_C, "PAIR_K", k)
+    if which == "concentrated":
+        sc = _concentrated()
+    elif which == "concentrated_opaque":
+        sc = _concentrated(seed=92)
+        sc.opacities[:] = 0.6
+    elif which == "mixed":
+        sc = make_scene(60_000, 256, 192, seed=95, sigma_px=6.0)
+    else:
+        sc = make_scene(20_000, 150, 121, seed=96, sigma_px=1.0)
+        g = torch.Generator().manual_seed(96)
+        sc.means3D[:, 0] = (torch.rand(20_000, generator=g) - 0.2) * 0.5 * sc.means3D[:, 2]
+        sc.means3D[:, 1] = (torch.rand(20_000, generator=g) - 0.2) * 0.5 * sc.means3D[:, 2]
+        sc.opacities[:] = 0.15
+    st = oracle_forward(sc)
+    d, shs, cols, out = _native_forward(sc, gpu_device)
+    geom = out[4]
+    n_paired = int(geom[:256].view(torch.int32)[17])
+    assert n_paired > 0, "the scene does not exercise the pairs"
+    _check_forward(sc, st, out)
+    _check_backward(sc, st, d, shs, cols, out, gpu_device)
